@@ -1,0 +1,191 @@
+/*
+ * st2.h -- C ABI of libst2_hip.so, the MI355X (gfx950) kernel library behind the
+ * StyleTTS 2 text->waveform hot path (style-diffusion sampler, AdaIN acoustic decoder,
+ * iSTFTNet / HiFi-GAN vocoder).
+ *
+ * The reference (yl4579/StyleTTS2) has no FFI of its own: the hot path is a chain of
+ * torch ATen ops issued from nn.Module.forward.  Each entry point
+ * below therefore replaces one *class* of ATen calls; the reference call sites it stands
+ * in for are cited per function (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns
+ *     all memory; nothing is allocated or freed inside the library;
+ *   - tensors are row-major "NCL": element (b, c, l) of tensor t lives at
+ *     t + b * t_bs + c * t_cs + l   (strides in ELEMENTS; bs = batch, cs = channel);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
+ *     stream-ordered and asynchronous; no entry point synchronises;
+ *   - return value: 0 on success, non-zero on error; st2_last_error() gives the message
+ *     of the last failing call on this thread.  No C++ exception crosses the ABI.
+ */
+#ifndef ST2_H
+#define ST2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST2_ABI_VERSION 1
+
+/* ---- library ---------------------------------------------------------------------- */
+int st2_abi_version(void);
+const char* st2_last_error(void);
+/* Fills name (<= cap bytes) with the gcnArchName of device `dev`, returns CU count or <0. */
+int st2_device_info(int dev, char* name, int cap);
+
+/* ---- fused Conv1d (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32) ------------ *
+ * y[b,co,l] = epi( bias[co] + sum_{ci,t} W[co,ci,t] * pro(x)[b,ci, l + t*dil - pad_left] )
+ * with zero padding applied AFTER the prologue, stride 1.
+ * Replaces: F.conv1d behind every weight-normed nn.Conv1d on the path
+ *   Modules/istftnet.py:68-74 (AdaINResBlock1 convs1/convs2), :445-448 (AdainResBlk1d),
+ *   :319-322,364 (ConvTranspose1d via its polyphase form, see st2_convt_interleave),
+ *   :377 (conv_post), Modules/hifigan.py:65-74,292-294,344, models.py:255-263,
+ *   and nn.Linear / 1x1 Conv1d of the denoiser, Modules/diffusion/modules.py:256-261,
+ *   484-490,317-324 (tokens laid out channel-major so a Linear is a k=1 conv).
+ */
+enum st2_prologue {
+  ST2_PRO_NONE = 0,
+  ST2_PRO_LEAKY = 1,        /* x>=0 ? x : slope*x                       istftnet.py:360,376 */
+  ST2_PRO_ADAIN_LEAKY = 2,  /* leaky((1+g)*(x-mean)*rstd + b)           istftnet.py:441-447 */
+  ST2_PRO_ADAIN_SNAKE = 3,  /* u=(1+g)*(x-mean)*rstd+b; u+sin(a u)^2/a  istftnet.py:68-72   */
+  ST2_PRO_SNAKE = 4,        /* x + sin(a x)^2 / a                       hifigan.py:329,343  */
+  ST2_PRO_COLNORM = 5       /* (x-mean[b,l])*rstd[b,l]*G[b,c]+Bt[b,c]   modules.py:18-38,556 */
+};
+enum st2_epilogue_act {
+  ST2_ACT_NONE = 0,
+  ST2_ACT_GELU = 1,     /* exact erf GELU                                modules.py:484-490 */
+  ST2_ACT_EXP_SIN = 2,  /* rows < act_split: exp, rows >= act_split: sin istftnet.py:378-379 */
+  ST2_ACT_TANH = 3,     /*                                               hifigan.py:345     */
+  ST2_ACT_LEAKY = 4     /* leaky(act_slope)                                                  */
+};
+
+typedef struct st2_conv_desc {
+  /* geometry */
+  int32_t B, C_in, C_out, L_in, L_out, ks, dil, pad_left;
+  /* input */
+  const float* x; int64_t x_bs; int32_t x_cs;
+  /* weights packed K-major: wt[(ci*ks + t) * w_ld + co], w_ld >= C_out, w_ld % 4 == 0 */
+  const float* wt; int32_t w_ld;
+  const float* bias;                 /* [C_out] or NULL */
+  /* output */
+  float* y; int64_t y_bs; int32_t y_cs;
+  /* prologue */
+  int32_t pro;                       /* enum st2_prologue */
+  float slope;                       /* LEAKY / ADAIN_LEAKY */
+  const float* stats;                /* ADAIN_*: [B][C_in][2] = (mean, rstd); COLNORM: [B][L_in][2] */
+  const float* gamma; const float* beta;  /* ADAIN_*: gamma[b*gb_bs + c]; the kernel applies (1+gamma)
+                                             COLNORM: G = gamma[b*gb_bs+c] (+1 if gamma_plus_one) */
+  int64_t gb_bs; int32_t gamma_plus_one;
+  const float* alpha;                /* SNAKE modes: [C_in] */
+  /* epilogue: v = acc + bias; v += res; v += res2; v /= div; v = act(v) */
+  const float* res;  int64_t res_bs;  int32_t res_cs;  int32_t res_shift;  /* reads res[b,co,l>>res_shift] */
+  const float* res2; int64_t res2_bs; int32_t res2_cs;
+  float div;                         /* 1.0f = none */
+  int32_t act; int32_t act_split; float act_slope;
+} st2_conv_desc;
+
+int st2_conv1d(const st2_conv_desc* d, void* stream);
+/* sizeof(st2_conv_desc) as the library was compiled: lets a binding verify its struct mirror. */
+int st2_sizeof_conv_desc(void);
+
+/* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *
+ * y[b,co,l] = bias[co] + sum_{ci,t} w[co,ci,t] * x[b,ci, l*stride + t - pad]   (plain OIK weights)
+ * Replaces: Modules/istftnet.py:332-339,361 (noise_convs), :486-488,511-512 (F0_conv/N_conv),
+ *           Modules/hifigan.py:296-303,330, models.py:464-465 (F0_proj/N_proj).
+ */
+int st2_conv1d_direct(const float* x, int64_t x_bs, int32_t x_cs,
+                      const float* w, const float* bias,
+                      float* y, int64_t y_bs, int32_t y_cs,
+                      int32_t B, int32_t C_in, int32_t C_out, int32_t L_in, int32_t L_out,
+                      int32_t ks, int32_t stride, int32_t pad, void* stream);
+
+/* ---- InstanceNorm1d statistics ------------------------------------------------------ *
+ * stats[b][c] = (mean, 1/sqrt(biased_var + eps)) over l in [0,L).  fp64 accumulation in a
+ * fixed tree order (bitwise reproducible).  Replaces nn.InstanceNorm1d inside AdaIN1d,
+ * Modules/istftnet.py:15-25.
+ */
+int st2_instnorm_stats(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
+                       float eps, float* stats /* [B][C][2] */, void* stream);
+
+/* LayerNorm statistics over the CHANNEL axis of an NCL tensor: stats[b][l] = (mean, rstd) over c.
+ * Replaces F.layer_norm's reduction, Modules/diffusion/modules.py:18-38,556-557. */
+int st2_colnorm_stats(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
+                      float eps, float* stats /* [B][L][2] */, void* stream);
+
+/* ---- style FC: h[b][j] = act(bias[j] + sum_k s[b][k] * wt[k*J + j])  (all AdaIN fc's of a module
+ * concatenated along j; act is an st2_epilogue_act, NONE or GELU).  Replaces the per-AdaIN nn.Linear,
+ * Modules/istftnet.py:19,22-24, and the per-utterance mapping MLPs of the denoiser,
+ * Modules/diffusion/modules.py:333-357,363-384. */
+int st2_style_fc(const float* s, int32_t B, int32_t K, const float* wt, const float* bias,
+                 int32_t J, int32_t act, float* h, void* stream);
+
+/* ---- ConvTranspose1d finishing pass ------------------------------------------------- *
+ * phases[b][r*C + co][q] (q in [0,Lq)) is the polyphase GEMM output of st2_conv1d;
+ * out[b,co,l] = bias[co] + phases[b][((l+pad)%s)*C + co][(l+pad)/s] + add[b,co,l]
+ * for l in [0,L_raw); if reflect_left the result is shifted right by one sample and
+ * out[.,.,0] = value at raw index 1 (nn.ReflectionPad1d((1,0))).  L_out = L_raw + reflect_left.
+ * Replaces: Modules/istftnet.py:364-368 (ups[i], reflection_pad, + x_source),
+ *           Modules/hifigan.py:333-334.
+ */
+int st2_convt_interleave(const float* phases, int64_t p_bs, int32_t p_cs, int32_t Lq,
+                         const float* bias, const float* add, int64_t a_bs, int32_t a_cs,
+                         float* out, int64_t o_bs, int32_t o_cs,
+                         int32_t B, int32_t C, int32_t stride, int32_t pad, int32_t L_raw,
+                         int32_t reflect_left, void* stream);
+
+/* ---- AdaIN + LeakyReLU + depthwise ConvTranspose1d(k3,s2,p1,op1) ("pool") ------------ *
+ * Replaces Modules/istftnet.py:441-444 with upsample=True (weights w[c][3], bias[c]). */
+int st2_adain_leaky_pool(const float* x, int64_t x_bs, int32_t x_cs,
+                         const float* stats, const float* gamma, const float* beta, int64_t gb_bs,
+                         float slope, const float* w, const float* bias,
+                         float* y, int64_t y_bs, int32_t y_cs,
+                         int32_t B, int32_t C, int32_t L, void* stream);
+
+/* ---- harmonic source (SineGen + SourceModuleHnNSF) ---------------------------------- *
+ * f0 [B][F] frame-rate F0 (Hz), U samples per frame, H harmonics (9).
+ * noise [B][F*U][H] standard normal draws (the reference's randn_like, istftnet.py:242).
+ * lin_w [H], lin_b [1]: l_linear.  out [B][F*U] = tanh(linear(sine_waves)).
+ * phase_scratch: [B][H][F] floats.  Bit-faithful to ATen-CPU op order.
+ * Replaces Modules/istftnet.py:141-247,283-297,352-354 (identical code hifigan.py:112-268).
+ */
+int st2_har_source(const float* f0, int32_t B, int32_t F, int32_t U, int32_t H,
+                   const float* noise, const float* lin_w, const float* lin_b,
+                   float sine_amp, float noise_std, float voiced_threshold, float sample_rate,
+                   float* phase_scratch, float* out, void* stream);
+
+/* ---- STFT of the harmonic source (n_fft = win = N, hop, periodic Hann, center/reflect) *
+ * har[b][k][m] = |X_k|, har[b][N/2+1+k][m] = atan2(Im, Re), k in [0,N/2], m in [0, L/hop].
+ * Replaces Modules/istftnet.py:91-97,355-357. */
+int st2_stft_mag_phase(const float* x, int32_t B, int32_t L, int32_t n_fft, int32_t hop,
+                       float* har, int64_t har_bs, int32_t har_cs, void* stream);
+
+/* ---- iSTFT synthesis: spec/phase [B][N/2+1][M] each (spec = exp(.), phase = sin(.) already
+ * applied by the conv_post epilogue) -> wave [B][hop*(M-1)].
+ * Replaces Modules/istftnet.py:99-104,380. */
+int st2_istft(const float* sp, int64_t sp_bs, int32_t sp_cs, int32_t B, int32_t M,
+              int32_t n_fft, int32_t hop, float* wave, int64_t wave_bs, void* stream);
+
+/* ---- denoiser helpers (tokens channel-major: x[b][c][n]) ------------------------------ */
+/* Multi-head attention without mask: q,k,v [B][H*D][N] -> o [B][H*D][N], softmax(q^T k * scale) v.
+ * Replaces Modules/diffusion/modules.py:523-535. */
+int st2_attention(const float* q, const float* k, const float* v, int64_t bs, int32_t cs,
+                  float* o, int64_t o_bs, int32_t o_cs,
+                  int32_t B, int32_t H, int32_t D, int32_t N, float scale, void* stream);
+
+/* generic fused elementwise helpers used by the sampler / denoiser glue */
+/* y[b][c][n] = x[b][c][n] + v[b][c]  (x = x + mapping, modules.py:152,394) */
+int st2_add_chanvec(const float* x, int64_t x_bs, int32_t x_cs, const float* v, int64_t v_bs,
+                    float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C, int32_t N, void* stream);
+/* m[b][c] = mean_n x[b][c][n]  (modules.py:155,397) */
+int st2_mean_tokens(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_t m_bs,
+                    int32_t B, int32_t C, int32_t N, void* stream);
+/* out[i] = a*x[i] + b*y[i] + c*z[i] (z may be NULL): sampler updates, sampler.py:184-208,497-510 */
+int st2_axpbypcz(const float* x, float a, const float* y, float b, const float* z, float c,
+                 float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST2_H */

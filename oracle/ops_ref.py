@@ -1,0 +1,217 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+Per-kernel fp32 restatements, in plain PyTorch-CPU ops, of the contracts declared in
+include/st2.h.  Same call signatures as styletts2_amd.ops so that tests can (a) compare each
+HIP kernel against its contract on the GPU box and (b) run the host-side layer plans on CPU by
+substituting these functions for the HIP wrappers (plan / weight-packing check without a GPU).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
+ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY = range(5)
+
+
+def _snake(u, alpha):
+    a = alpha.view(1, -1, 1)
+    return u + (1.0 / a) * torch.sin(a * u) ** 2
+
+
+def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
+           pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
+           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
+    B, C_in, L_in = x.shape
+    if L_out is None:
+        L_out = L_in
+    u = x
+    if pro == PRO_LEAKY:
+        u = F.leaky_relu(x, slope)
+    elif pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE):
+        n = (x - stats[:, :, 0:1]) * stats[:, :, 1:2]
+        u = (1.0 + gamma.unsqueeze(-1)) * n + beta.unsqueeze(-1)
+        u = F.leaky_relu(u, slope) if pro == PRO_ADAIN_LEAKY else _snake(u, alpha)
+    elif pro == PRO_SNAKE:
+        u = _snake(x, alpha)
+    elif pro == PRO_COLNORM:
+        n = (x - stats[:, :, 0].unsqueeze(1)) * stats[:, :, 1].unsqueeze(1)
+        g = gamma.unsqueeze(-1)
+        if gamma_plus_one:
+            g = 1.0 + g
+        u = n * g + beta.unsqueeze(-1)
+    w = wt[:, :C_out].reshape(C_in, ks, C_out).permute(2, 0, 1).contiguous()
+    need = (L_out - 1) + (ks - 1) * dil + 1  # input span [ -pad_left, need - pad_left )
+    pad_right = max(0, need - pad_left - L_in)
+    up = F.pad(u, (pad_left, pad_right))
+    y = F.conv1d(up, w, None, dilation=dil)[:, :, :L_out]
+    if bias is not None:
+        y = y + bias.view(1, -1, 1)
+    if res is not None:
+        r = res
+        if res_shift:
+            r = res.repeat_interleave(1 << res_shift, dim=2)[:, :, :L_out]
+        y = y + r
+    if res2 is not None:
+        y = res2 + y
+    if div != 1.0:
+        y = y / div
+    if act == ACT_GELU:
+        y = F.gelu(y)
+    elif act == ACT_EXP_SIN:
+        y = torch.cat([torch.exp(y[:, :act_split]), torch.sin(y[:, act_split:])], dim=1)
+    elif act == ACT_TANH:
+        y = torch.tanh(y)
+    elif act == ACT_LEAKY:
+        y = F.leaky_relu(y, act_slope)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def conv1d_direct(x, w, bias, stride, pad, L_out=None, out=None):
+    y = F.conv1d(x, w, bias, stride=stride, padding=pad)
+    if L_out is not None:
+        y = y[:, :, :L_out]
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def instnorm_stats(x, eps=1e-5, out=None):
+    xd = x.double()
+    mean = xd.mean(dim=2)
+    var = xd.var(dim=2, unbiased=False)
+    st = torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).float()
+    if out is not None:
+        out.copy_(st)
+        return out
+    return st
+
+
+def colnorm_stats(x, eps=1e-5, out=None):
+    xd = x.double()
+    mean = xd.mean(dim=1)
+    var = xd.var(dim=1, unbiased=False)
+    st = torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).float()
+    if out is not None:
+        out.copy_(st)
+        return out
+    return st
+
+
+def style_fc(s, wt, bias, act=ACT_NONE, out=None):
+    h = s @ wt
+    if bias is not None:
+        h = h + bias
+    if act == ACT_GELU:
+        h = F.gelu(h)
+    if out is not None:
+        out.copy_(h)
+        return out
+    return h
+
+
+def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None):
+    B, RC, Lq = phases.shape
+    ph = phases.reshape(B, stride, C_out, Lq)
+    full = ph.permute(0, 2, 3, 1).reshape(B, C_out, Lq * stride)  # index q*stride + r
+    y = full[:, :, pad:pad + L_raw]
+    if bias is not None:
+        y = y + bias.view(1, -1, 1)
+    if reflect_left:
+        y = torch.cat([y[:, :, 1:2], y], dim=2)
+    if add is not None:
+        y = y + add
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def adain_leaky_pool(x, stats, gamma, beta, slope, w, bias, out=None):
+    n = (x - stats[:, :, 0:1]) * stats[:, :, 1:2]
+    u = F.leaky_relu((1.0 + gamma.unsqueeze(-1)) * n + beta.unsqueeze(-1), slope)
+    Cc = x.shape[1]
+    y = F.conv_transpose1d(u, w.view(Cc, 1, 3), bias, stride=2, padding=1, output_padding=1, groups=Cc)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def har_source(f0, U, noise, lin_w, lin_b, sine_amp=0.1, noise_std=0.003, voiced_threshold=10.0,
+               sample_rate=24000.0):
+    """Restates SineGen/SourceModuleHnNSF (Modules/istftnet.py:141-247,283-297) with torch ops in the
+    reference's own order (the frame-rate shortcut of SURVEY.md App. A.1 step 4 is NOT used here)."""
+    B, Fr = f0.shape
+    H = noise.shape[2]
+    f0u = f0[:, None].repeat_interleave(U, dim=2).transpose(1, 2)  # nearest x U  [B, L, 1]
+    fn = f0u * torch.arange(1, H + 1, dtype=torch.float32).view(1, 1, H)
+    rad = (fn / sample_rate) % 1
+    rad = F.interpolate(rad.transpose(1, 2), scale_factor=1 / U, mode="linear").transpose(1, 2)
+    phase = torch.cumsum(rad, dim=1) * 2 * math.pi
+    phase = F.interpolate(phase.transpose(1, 2) * U, scale_factor=U, mode="linear").transpose(1, 2)
+    sines = torch.sin(phase) * sine_amp
+    uv = (f0u > voiced_threshold).float()
+    noise_amp = uv * noise_std + (1 - uv) * sine_amp / 3
+    sw = sines * uv + noise_amp * noise
+    return torch.tanh(sw @ lin_w.view(H, 1) + lin_b.view(1)).squeeze(-1)
+
+
+def stft_mag_phase(x, n_fft, hop):
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
+    X = torch.stft(x, n_fft, hop, n_fft, window=win, return_complex=True)
+    return torch.cat([X.abs(), X.angle()], dim=1)
+
+
+def istft(sp, n_fft, hop):
+    nb = n_fft // 2 + 1
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
+    y = torch.istft(sp[:, :nb] * torch.exp(sp[:, nb:] * 1j), n_fft, hop, n_fft, window=win)
+    return y.unsqueeze(-2)
+
+
+def attention(q, k, v, heads, scale, out=None):
+    B, HD, N = q.shape
+    D = HD // heads
+    qh = q.reshape(B, heads, D, N)
+    kh = k.reshape(B, heads, D, N)
+    vh = v.reshape(B, heads, D, N)
+    sim = torch.einsum("bhdn,bhdm->bhnm", qh, kh) * scale
+    attn = sim.softmax(dim=-1)
+    o = torch.einsum("bhnm,bhdm->bhdn", attn, vh).reshape(B, HD, N)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def add_chanvec(x, v, out=None):
+    y = x + v.unsqueeze(-1)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def mean_tokens(x, out=None):
+    m = x.mean(dim=2)
+    if out is not None:
+        out.copy_(m)
+        return out
+    return m
+
+
+def axpbypcz(x, a, y=None, b=0.0, z=None, c=0.0, out=None):
+    r = a * x
+    if y is not None:
+        r = r + b * y
+    if z is not None:
+        r = r + c * z
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r

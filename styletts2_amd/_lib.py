@@ -1,0 +1,116 @@
+"""ctypes binding of libst2_hip.so (the C ABI declared in include/st2.h).
+
+There is no fallback: if the shared library is missing or does not match this binding the import
+of any compute entry point raises.  Build it with `python -m styletts2_amd._build`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
+ABI_VERSION = 1
+
+f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
+ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY = range(5)
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `st2_conv_desc` (include/st2.h); size is cross-checked at load time."""
+    _fields_ = [
+        ("B", C.c_int32), ("C_in", C.c_int32), ("C_out", C.c_int32), ("L_in", C.c_int32),
+        ("L_out", C.c_int32), ("ks", C.c_int32), ("dil", C.c_int32), ("pad_left", C.c_int32),
+        ("x", f32p), ("x_bs", C.c_int64), ("x_cs", C.c_int32),
+        ("wt", f32p), ("w_ld", C.c_int32),
+        ("bias", f32p),
+        ("y", f32p), ("y_bs", C.c_int64), ("y_cs", C.c_int32),
+        ("pro", C.c_int32),
+        ("slope", C.c_float),
+        ("stats", f32p),
+        ("gamma", f32p), ("beta", f32p),
+        ("gb_bs", C.c_int64), ("gamma_plus_one", C.c_int32),
+        ("alpha", f32p),
+        ("res", f32p), ("res_bs", C.c_int64), ("res_cs", C.c_int32), ("res_shift", C.c_int32),
+        ("res2", f32p), ("res2_bs", C.c_int64), ("res2_cs", C.c_int32),
+        ("div", C.c_float),
+        ("act", C.c_int32), ("act_split", C.c_int32), ("act_slope", C.c_float),
+    ]
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "st2_abi_version": (C.c_int, []),
+    "st2_last_error": (C.c_char_p, []),
+    "st2_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "st2_sizeof_conv_desc": (C.c_int, []),
+    "st2_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "st2_conv1d_direct": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p]),
+    "st2_instnorm_stats": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, f32p,
+                                     C.c_void_p]),
+    "st2_colnorm_stats": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, f32p,
+                                    C.c_void_p]),
+    "st2_style_fc": (C.c_int, [f32p, C.c_int32, C.c_int32, f32p, f32p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
+    "st2_convt_interleave": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, f32p, f32p, C.c_int64, C.c_int32,
+                                       f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "st2_adain_leaky_pool": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_float, f32p,
+                                       f32p, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p]),
+    "st2_har_source": (C.c_int, [f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
+    "st2_stft_mag_phase": (C.c_int, [f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p, C.c_int64, C.c_int32,
+                                     C.c_void_p]),
+    "st2_istft": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p, C.c_int64,
+                            C.c_void_p]),
+    "st2_attention": (C.c_int, [f32p, f32p, f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "st2_add_chanvec": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, f32p, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "st2_mean_tokens": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p]),
+    "st2_axpbypcz": (C.c_int, [f32p, C.c_float, f32p, C.c_float, f32p, C.c_float, f32p, C.c_int64, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+class St2Error(RuntimeError):
+    pass
+
+
+def load():
+    """Loads (once) and returns the ctypes handle; raises St2Error if the HIP library is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise St2Error("libst2_hip.so is not built (%s missing). Run `python -m styletts2_amd._build`; "
+                       "there is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise St2Error("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise St2Error("libst2_hip.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.st2_abi_version() != ABI_VERSION:
+        raise St2Error("ABI mismatch: library %d, binding %d" % (lib.st2_abi_version(), ABI_VERSION))
+    if lib.st2_sizeof_conv_desc() != C.sizeof(ConvDesc):
+        raise St2Error("st2_conv_desc layout mismatch: library %d B, binding %d B"
+                       % (lib.st2_sizeof_conv_desc(), C.sizeof(ConvDesc)))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().st2_last_error()
+        raise St2Error("%s failed: %s" % (what, msg.decode() if msg else "unknown error"))

@@ -1,0 +1,38 @@
+// Shared helpers for the libst2_hip kernels (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "st2.h"
+
+void st2_set_error(const char* fmt, ...);
+
+#define ST2_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      st2_set_error(__VA_ARGS__);         \
+      return 1;                           \
+    }                                     \
+  } while (0)
+
+#define ST2_CHECK_LAUNCH(name)                                   \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) {                                     \
+      st2_set_error("%s: %s", name, hipGetErrorString(e__));     \
+      return 1;                                                  \
+    }                                                            \
+  } while (0)
+
+static inline int st2_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// 64-lane butterfly-free tree (fixed order => bitwise reproducible).
+__device__ __forceinline__ double st2_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float st2_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}

@@ -1,0 +1,195 @@
+// Small HBM-bound kernels around the conv path: direct (strided / tiny-C_in) Conv1d, the
+// ConvTranspose1d polyphase interleave, AdaIN + LeakyReLU + depthwise up-pool, and the
+// per-token / per-vector glue used by the denoiser and the ADPM2 sampler.
+#include "st2_common.h"
+
+namespace {
+
+// thread = one output (b, co, l); lanes run along l (coalesced stores), co is workgroup-uniform
+// so weight reads are scalar broadcasts.
+__global__ __launch_bounds__(256) void conv1d_direct_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int64_t y_bs, int y_cs, int C_in, int L_in, int L_out,
+                                                            int ks, int stride, int pad) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  const int b = blockIdx.z;
+  if (l >= L_out) return;
+  const float* xb = x + (int64_t)b * x_bs;
+  const float* wc = w + (int64_t)co * C_in * ks;
+  float acc = 0.f;
+  const int base = l * stride - pad;
+  for (int ci = 0; ci < C_in; ++ci) {
+    const float* xr = xb + (int64_t)ci * x_cs;
+    for (int t = 0; t < ks; ++t) {
+      const int p = base + t;
+      if (p >= 0 && p < L_in) acc = fmaf(wc[ci * ks + t], xr[p], acc);
+    }
+  }
+  if (bias) acc += bias[co];
+  y[(int64_t)b * y_bs + (int64_t)co * y_cs + l] = acc;
+}
+
+__global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __restrict__ ph, int64_t p_bs, int p_cs,
+                                                               int Lq, const float* __restrict__ bias,
+                                                               const float* __restrict__ add, int64_t a_bs, int a_cs,
+                                                               float* __restrict__ out, int64_t o_bs, int o_cs, int C,
+                                                               int stride, int pad, int L_raw, int reflect_left) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  const int b = blockIdx.z;
+  const int L_out = L_raw + reflect_left;
+  if (o >= L_out) return;
+  int l = o;
+  if (reflect_left) l = (o == 0) ? 1 : o - 1;
+  const int lp = l + pad;
+  const int r = lp % stride;
+  const int q = lp / stride;
+  float v = 0.f;
+  if (q < Lq) v = ph[(int64_t)b * p_bs + (int64_t)(r * C + co) * p_cs + q];
+  if (bias) v += bias[co];
+  if (add) v += add[(int64_t)b * a_bs + (int64_t)co * a_cs + o];
+  out[(int64_t)b * o_bs + (int64_t)co * o_cs + o] = v;
+}
+
+__global__ __launch_bounds__(256) void adain_leaky_pool_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int64_t gb_bs,
+                                                               float slope, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int64_t y_bs, int y_cs, int C, int L) {
+  const int lo = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int b = blockIdx.z;
+  if (lo >= 2 * L) return;
+  const float mean = stats[((int64_t)b * C + c) * 2 + 0];
+  const float rstd = stats[((int64_t)b * C + c) * 2 + 1];
+  const float g = 1.0f + gamma[(int64_t)b * gb_bs + c];
+  const float be = beta[(int64_t)b * gb_bs + c];
+  const float* xr = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+  auto act = [&](int i) -> float {
+    float u = (xr[i] - mean) * rstd;
+    u = g * u + be;
+    return u >= 0.f ? u : u * slope;
+  };
+  const int j = lo >> 1;
+  float v;
+  if ((lo & 1) == 0) {
+    v = act(j) * w[c * 3 + 1];
+  } else {
+    v = act(j) * w[c * 3 + 2];
+    if (j + 1 < L) v += act(j + 1) * w[c * 3 + 0];
+  }
+  if (bias) v += bias[c];
+  y[(int64_t)b * y_bs + (int64_t)c * y_cs + lo] = v;
+}
+
+__global__ __launch_bounds__(256) void add_chanvec_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                          const float* __restrict__ v, int64_t v_bs,
+                                                          float* __restrict__ y, int64_t y_bs, int y_cs, int C,
+                                                          int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int b = blockIdx.z;
+  if (n >= N) return;
+  y[(int64_t)b * y_bs + (int64_t)c * y_cs + n] =
+      x[(int64_t)b * x_bs + (int64_t)c * x_cs + n] + v[(int64_t)b * v_bs + c];
+}
+
+// one wave per (b, c) row
+__global__ __launch_bounds__(64) void mean_tokens_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                         float* __restrict__ m, int64_t m_bs, int C, int N) {
+  const int c = blockIdx.x;
+  const int b = blockIdx.y;
+  const float* xr = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+  double s = 0.0;
+  for (int n = threadIdx.x; n < N; n += 64) s += (double)xr[n];
+  s = st2_wave_sum(s);
+  if (threadIdx.x == 0) m[(int64_t)b * m_bs + c] = (float)(s / (double)N);
+}
+
+__global__ __launch_bounds__(256) void axpbypcz_kernel(const float* __restrict__ x, float a,
+                                                       const float* __restrict__ y, float b,
+                                                       const float* __restrict__ z, float c, float* __restrict__ out,
+                                                       int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = a * x[i];
+  if (y) v += b * y[i];
+  if (z) v += c * z[i];
+  out[i] = v;
+}
+
+}  // namespace
+
+extern "C" int st2_conv1d_direct(const float* x, int64_t x_bs, int32_t x_cs, const float* w, const float* bias,
+                                 float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C_in, int32_t C_out,
+                                 int32_t L_in, int32_t L_out, int32_t ks, int32_t stride, int32_t pad,
+                                 void* stream) {
+  ST2_REQUIRE(x && w && y && B > 0 && C_in > 0 && C_out > 0 && L_in > 0 && L_out > 0 && ks > 0 && stride > 0,
+              "st2_conv1d_direct: bad arguments");
+  ST2_REQUIRE(C_out <= 65535 && B <= 65535, "st2_conv1d_direct: grid too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(conv1d_direct_kernel, dim3(st2_cdiv(L_out, 256), C_out, B), dim3(256), 0, s, x, x_bs, x_cs, w,
+                     bias, y, y_bs, y_cs, C_in, L_in, L_out, ks, stride, pad);
+  ST2_CHECK_LAUNCH("st2_conv1d_direct");
+  return 0;
+}
+
+extern "C" int st2_convt_interleave(const float* phases, int64_t p_bs, int32_t p_cs, int32_t Lq, const float* bias,
+                                    const float* add, int64_t a_bs, int32_t a_cs, float* out, int64_t o_bs,
+                                    int32_t o_cs, int32_t B, int32_t C, int32_t stride, int32_t pad, int32_t L_raw,
+                                    int32_t reflect_left, void* stream) {
+  ST2_REQUIRE(phases && out && B > 0 && C > 0 && stride > 0 && L_raw > 0 && Lq > 0,
+              "st2_convt_interleave: bad arguments");
+  ST2_REQUIRE(reflect_left == 0 || (reflect_left == 1 && L_raw >= 2), "st2_convt_interleave: bad reflect_left");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(convt_interleave_kernel, dim3(st2_cdiv(L_raw + reflect_left, 256), C, B), dim3(256), 0, s,
+                     phases, p_bs, p_cs, Lq, bias, add, a_bs, a_cs, out, o_bs, o_cs, C, stride, pad, L_raw,
+                     reflect_left);
+  ST2_CHECK_LAUNCH("st2_convt_interleave");
+  return 0;
+}
+
+extern "C" int st2_adain_leaky_pool(const float* x, int64_t x_bs, int32_t x_cs, const float* stats,
+                                    const float* gamma, const float* beta, int64_t gb_bs, float slope, const float* w,
+                                    const float* bias, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
+                                    int32_t L, void* stream) {
+  ST2_REQUIRE(x && stats && gamma && beta && w && y && B > 0 && C > 0 && L > 0,
+              "st2_adain_leaky_pool: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adain_leaky_pool_kernel, dim3(st2_cdiv(2 * L, 256), C, B), dim3(256), 0, s, x, x_bs, x_cs,
+                     stats, gamma, beta, gb_bs, slope, w, bias, y, y_bs, y_cs, C, L);
+  ST2_CHECK_LAUNCH("st2_adain_leaky_pool");
+  return 0;
+}
+
+extern "C" int st2_add_chanvec(const float* x, int64_t x_bs, int32_t x_cs, const float* v, int64_t v_bs, float* y,
+                               int64_t y_bs, int32_t y_cs, int32_t B, int32_t C, int32_t N, void* stream) {
+  ST2_REQUIRE(x && v && y && B > 0 && C > 0 && N > 0, "st2_add_chanvec: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(add_chanvec_kernel, dim3(st2_cdiv(N, 256), C, B), dim3(256), 0, s, x, x_bs, x_cs, v, v_bs, y,
+                     y_bs, y_cs, C, N);
+  ST2_CHECK_LAUNCH("st2_add_chanvec");
+  return 0;
+}
+
+extern "C" int st2_mean_tokens(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_t m_bs, int32_t B,
+                               int32_t C, int32_t N, void* stream) {
+  ST2_REQUIRE(x && m && B > 0 && C > 0 && N > 0, "st2_mean_tokens: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(C, B), dim3(64), 0, s, x, x_bs, x_cs, m, m_bs, C, N);
+  ST2_CHECK_LAUNCH("st2_mean_tokens");
+  return 0;
+}
+
+extern "C" int st2_axpbypcz(const float* x, float a, const float* y, float b, const float* z, float c, float* out,
+                            int64_t n, void* stream) {
+  ST2_REQUIRE(x && out && n > 0, "st2_axpbypcz: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(axpbypcz_kernel, dim3(st2_cdiv(n, 256)), dim3(256), 0, s, x, a, y, b, z, c, out, n);
+  ST2_CHECK_LAUNCH("st2_axpbypcz");
+  return 0;
+}

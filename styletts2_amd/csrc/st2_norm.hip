@@ -1,0 +1,136 @@
+// Normalisation statistics and the batched style FC.  All HBM-bound row/column reductions:
+// coalesced reads, fp64 partial sums, fixed shuffle-tree order (bitwise reproducible).
+#include "st2_common.h"
+
+namespace {
+
+// One workgroup per (b, c) row.  Rows are up to 48 001 samples (generator) or 400/800 (decoder front).
+template <int NT>
+__global__ __launch_bounds__(NT) void instnorm_stats_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                            int C, int L, float eps, float* __restrict__ stats) {
+  const int row = blockIdx.x;
+  const int b = row / C;
+  const int c = row % C;
+  const float* xr = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+  double s = 0.0, ss = 0.0;
+  for (int l = threadIdx.x; l < L; l += NT) {
+    const double v = (double)xr[l];
+    s += v;
+    ss += v * v;
+  }
+  s = st2_wave_sum(s);
+  ss = st2_wave_sum(ss);
+  __shared__ double red[2][NT / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tss = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+      ts += red[0][w];
+      tss += red[1][w];
+    }
+    const double mean = ts / (double)L;
+    double var = tss / (double)L - mean * mean;  // biased, InstanceNorm1d
+    if (var < 0.0) var = 0.0;
+    stats[(int64_t)row * 2 + 0] = (float)mean;
+    stats[(int64_t)row * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// LayerNorm over channels of an NCL tensor: one thread per (b, l) column, lanes along l (coalesced).
+__global__ __launch_bounds__(64) void colnorm_stats_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs, int C,
+                                                           int L, float eps, float* __restrict__ stats) {
+  const int l = blockIdx.x * 64 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (l >= L) return;
+  const float* xb = x + (int64_t)b * x_bs + l;
+  double s = 0.0, ss = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double v = (double)xb[(int64_t)c * x_cs];
+    s += v;
+    ss += v * v;
+  }
+  const double mean = s / (double)C;
+  double var = ss / (double)C - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float* o = stats + ((int64_t)b * L + l) * 2;
+  o[0] = (float)mean;
+  o[1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// h[b][j] = bias[j] + sum_k s[b][k] * wt[k*J + j]; one thread per j, all batch rows in registers
+// chunks of 8 (style vectors staged in LDS).
+constexpr int FC_BT = 8;
+__global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__ s, int B, int K,
+                                                       const float* __restrict__ wt, const float* __restrict__ bias,
+                                                       int J, int act, float* __restrict__ h) {
+  extern __shared__ float sl[];  // [FC_BT][K]
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * FC_BT;
+  const int nb = min(FC_BT, B - b0);
+  for (int e = threadIdx.x; e < FC_BT * K; e += 256) {
+    const int bb = e / K, k = e % K;
+    sl[e] = bb < nb ? s[(int64_t)(b0 + bb) * K + k] : 0.f;
+  }
+  __syncthreads();
+  if (j >= J) return;
+  float acc[FC_BT];
+#pragma unroll
+  for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = wt[(int64_t)k * J + j];
+#pragma unroll
+    for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sl[bb * K + k], w, acc[bb]);
+  }
+  const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+  for (int bb = 0; bb < FC_BT; ++bb)
+    if (bb < nb) {
+      float v = acc[bb] + bj;
+      if (act == ST2_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      h[(int64_t)(b0 + bb) * J + j] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int st2_instnorm_stats(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
+                                  float eps, float* stats, void* stream) {
+  ST2_REQUIRE(x && stats && B > 0 && C > 0 && L > 0, "st2_instnorm_stats: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rows = B * C;
+  if (L <= 2048)
+    hipLaunchKernelGGL((instnorm_stats_kernel<64>), dim3(rows), dim3(64), 0, s, x, x_bs, x_cs, C, L, eps, stats);
+  else
+    hipLaunchKernelGGL((instnorm_stats_kernel<256>), dim3(rows), dim3(256), 0, s, x, x_bs, x_cs, C, L, eps, stats);
+  ST2_CHECK_LAUNCH("st2_instnorm_stats");
+  return 0;
+}
+
+extern "C" int st2_colnorm_stats(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
+                                 float eps, float* stats, void* stream) {
+  ST2_REQUIRE(x && stats && B > 0 && C > 0 && L > 0, "st2_colnorm_stats: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colnorm_stats_kernel, dim3(st2_cdiv(L, 64), B), dim3(64), 0, s, x, x_bs, x_cs, C, L, eps,
+                     stats);
+  ST2_CHECK_LAUNCH("st2_colnorm_stats");
+  return 0;
+}
+
+extern "C" int st2_style_fc(const float* sv, int32_t B, int32_t K, const float* wt, const float* bias, int32_t J,
+                            int32_t act, float* h, void* stream) {
+  ST2_REQUIRE(sv && wt && h && B > 0 && K > 0 && J > 0, "st2_style_fc: bad arguments");
+  ST2_REQUIRE(K <= 2048, "st2_style_fc: K=%d too large", K);
+  ST2_REQUIRE(act == ST2_ACT_NONE || act == ST2_ACT_GELU, "st2_style_fc: act must be NONE or GELU");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = (size_t)FC_BT * K * sizeof(float);
+  hipLaunchKernelGGL(style_fc_kernel, dim3(st2_cdiv(J, 256), st2_cdiv(B, FC_BT)), dim3(256), smem, s, sv, B, K, wt,
+                     bias, J, act, h);
+  ST2_CHECK_LAUNCH("st2_style_fc");
+  return 0;
+}

@@ -1,0 +1,294 @@
+"""Tensor-level wrappers over the C ABI (include/st2.h).
+
+Every function takes PyTorch-ROCm tensors (fp32, device memory, unit stride along the last axis),
+forwards raw pointers + strides to libst2_hip.so on torch's current HIP stream and returns torch
+tensors.  PyTorch is plumbing here (allocation, streams); all arithmetic happens in the HIP kernels.
+There is no CPU path: a tensor that is not on a HIP device raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_EXP_SIN, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_TANH, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE,  # noqa: F401
+                   PRO_COLNORM, PRO_LEAKY, PRO_NONE, PRO_SNAKE, ConvDesc)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, ndim=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.St2Error("%s must live on a HIP device (got %s); the engine has no CPU path" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise _lib.St2Error("%s must be float32 (got %s)" % (name, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise _lib.St2Error("%s must be %d-D (got shape %s)" % (name, ndim, tuple(t.shape)))
+    if t.dim() > 0 and t.shape[-1] > 1 and t.stride(-1) != 1:
+        raise _lib.St2Error("%s must have unit stride along its last axis" % name)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _bs_cs(t):
+    """(batch stride, channel stride) of an NCL view."""
+    return t.stride(0), t.stride(1)
+
+
+def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
+           pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
+           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
+    """Fused Conv1d, see `st2_conv1d` in include/st2.h.  wt is the packed K-major weight
+    [C_in*ks, w_ld] produced by weights.pack_conv()."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(wt, "wt", 2)
+    B, C_in, L_in = x.shape
+    if wt.shape[0] != C_in * ks or not wt.is_contiguous():
+        raise _lib.St2Error("packed weight has shape %s, expected [%d, >=%d]" % (tuple(wt.shape), C_in * ks, C_out))
+    if L_out is None:
+        L_out = L_in
+    if out is None:
+        out = torch.empty((B, C_out, L_out), device=x.device, dtype=torch.float32)
+    _chk(out, "out", 3)
+    assert out.shape == (B, C_out, L_out), (out.shape, (B, C_out, L_out))
+    d = ConvDesc()
+    d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil, d.pad_left = B, C_in, C_out, L_in, L_out, ks, dil, pad_left
+    d.x, d.x_bs, d.x_cs = x.data_ptr(), x.stride(0), x.stride(1)
+    d.wt, d.w_ld = wt.data_ptr(), wt.shape[1]
+    _chk(bias, "bias", 1)
+    d.bias = _ptr(bias)
+    d.y, d.y_bs, d.y_cs = out.data_ptr(), out.stride(0), out.stride(1)
+    d.pro, d.slope = pro, slope
+    if pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_COLNORM):
+        _chk(stats, "stats", 3)
+        _chk(gamma, "gamma", 2)
+        _chk(beta, "beta", 2)
+        want = (B, L_in, 2) if pro == PRO_COLNORM else (B, C_in, 2)
+        assert tuple(stats.shape) == want and stats.is_contiguous(), (stats.shape, want)
+        assert gamma.shape[1] == C_in and beta.shape[1] == C_in
+        gbs = gamma.stride(0) if gamma.shape[0] > 1 else 0
+        bbs = beta.stride(0) if beta.shape[0] > 1 else 0
+        assert gamma.shape[0] in (1, B) and beta.shape[0] == gamma.shape[0] and (gbs == bbs)
+        d.stats, d.gamma, d.beta, d.gb_bs = stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), gbs
+        d.gamma_plus_one = 1 if gamma_plus_one else 0
+    if pro in (PRO_ADAIN_SNAKE, PRO_SNAKE):
+        _chk(alpha, "alpha", 1)
+        assert alpha.numel() == C_in and alpha.is_contiguous()
+        d.alpha = alpha.data_ptr()
+    if res is not None:
+        _chk(res, "res", 3)
+        assert res.shape[0] == B and res.shape[1] == C_out and res.shape[2] == (L_out + (1 << res_shift) - 1 >> res_shift)
+        d.res, d.res_bs, d.res_cs, d.res_shift = res.data_ptr(), res.stride(0), res.stride(1), res_shift
+    if res2 is not None:
+        _chk(res2, "res2", 3)
+        assert res2.shape == (B, C_out, L_out)
+        d.res2, d.res2_bs, d.res2_cs = res2.data_ptr(), res2.stride(0), res2.stride(1)
+    d.div = div
+    d.act, d.act_split, d.act_slope = act, act_split, act_slope
+    _lib.check(lib.st2_conv1d(C.byref(d), _stream()), "st2_conv1d")
+    return out
+
+
+def conv1d_direct(x, w, bias, stride, pad, L_out=None, out=None):
+    """Plain-weight ([C_out, C_in, ks]) direct conv for strided / tiny-C_in layers (`st2_conv1d_direct`)."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(w, "w", 3)
+    _chk(bias, "bias", 1)
+    assert w.is_contiguous()
+    B, C_in, L_in = x.shape
+    C_out, C_in_w, ks = w.shape
+    assert C_in_w == C_in
+    if L_out is None:
+        L_out = (L_in + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = torch.empty((B, C_out, L_out), device=x.device, dtype=torch.float32)
+    _chk(out, "out", 3)
+    _lib.check(lib.st2_conv1d_direct(x.data_ptr(), x.stride(0), x.stride(1), w.data_ptr(), _ptr(bias),
+                                     out.data_ptr(), out.stride(0), out.stride(1), B, C_in, C_out, L_in, L_out,
+                                     ks, stride, pad, _stream()), "st2_conv1d_direct")
+    return out
+
+
+def instnorm_stats(x, eps=1e-5, out=None):
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    B, Cc, L = x.shape
+    if out is None:
+        out = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_instnorm_stats(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, eps, out.data_ptr(),
+                                      _stream()), "st2_instnorm_stats")
+    return out
+
+
+def colnorm_stats(x, eps=1e-5, out=None):
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    B, Cc, L = x.shape
+    if out is None:
+        out = torch.empty((B, L, 2), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_colnorm_stats(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, eps, out.data_ptr(),
+                                     _stream()), "st2_colnorm_stats")
+    return out
+
+
+def style_fc(s, wt, bias, act=ACT_NONE, out=None):
+    """h = act(s @ wt + bias); wt is [K, J] (already transposed at pack time)."""
+    lib = _lib.load()
+    _chk(s, "s", 2)
+    _chk(wt, "wt", 2)
+    _chk(bias, "bias", 1)
+    assert s.is_contiguous() and wt.is_contiguous()
+    B, K = s.shape
+    assert wt.shape[0] == K
+    J = wt.shape[1]
+    if out is None:
+        out = torch.empty((B, J), device=s.device, dtype=torch.float32)
+    _lib.check(lib.st2_style_fc(s.data_ptr(), B, K, wt.data_ptr(), _ptr(bias), J, act, out.data_ptr(), _stream()),
+               "st2_style_fc")
+    return out
+
+
+def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None):
+    lib = _lib.load()
+    _chk(phases, "phases", 3)
+    _chk(bias, "bias", 1)
+    _chk(add, "add", 3)
+    B, RC, Lq = phases.shape
+    assert RC == stride * C_out
+    L_out = L_raw + (1 if reflect_left else 0)
+    if out is None:
+        out = torch.empty((B, C_out, L_out), device=phases.device, dtype=torch.float32)
+    if add is not None:
+        assert add.shape == (B, C_out, L_out), (add.shape, (B, C_out, L_out))
+    a_bs, a_cs = (add.stride(0), add.stride(1)) if add is not None else (0, 0)
+    _lib.check(lib.st2_convt_interleave(phases.data_ptr(), phases.stride(0), phases.stride(1), Lq, _ptr(bias),
+                                        _ptr(add), a_bs, a_cs, out.data_ptr(), out.stride(0), out.stride(1), B,
+                                        C_out, stride, pad, L_raw, 1 if reflect_left else 0, _stream()),
+               "st2_convt_interleave")
+    return out
+
+
+def adain_leaky_pool(x, stats, gamma, beta, slope, w, bias, out=None):
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(stats, "stats", 3)
+    _chk(gamma, "gamma", 2)
+    _chk(beta, "beta", 2)
+    _chk(w, "w", 2)
+    _chk(bias, "bias", 1)
+    B, Cc, L = x.shape
+    assert w.shape == (Cc, 3) and w.is_contiguous() and gamma.stride(0) == beta.stride(0)
+    if out is None:
+        out = torch.empty((B, Cc, 2 * L), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_adain_leaky_pool(x.data_ptr(), x.stride(0), x.stride(1), stats.data_ptr(), gamma.data_ptr(),
+                                        beta.data_ptr(), gamma.stride(0), slope, w.data_ptr(), _ptr(bias),
+                                        out.data_ptr(), out.stride(0), out.stride(1), B, Cc, L, _stream()),
+               "st2_adain_leaky_pool")
+    return out
+
+
+def har_source(f0, U, noise, lin_w, lin_b, sine_amp=0.1, noise_std=0.003, voiced_threshold=10.0,
+               sample_rate=24000.0):
+    """f0 [B, F] -> har_source [B, F*U]; noise [B, F*U, H] standard-normal draws."""
+    lib = _lib.load()
+    _chk(f0, "f0", 2)
+    _chk(noise, "noise", 3)
+    _chk(lin_w, "lin_w")
+    _chk(lin_b, "lin_b")
+    B, F = f0.shape
+    H = noise.shape[2]
+    assert f0.is_contiguous() and noise.is_contiguous() and noise.shape == (B, F * U, H)
+    assert lin_w.numel() == H and lin_w.is_contiguous()
+    scratch = torch.empty((B, H, F), device=f0.device, dtype=torch.float32)
+    out = torch.empty((B, F * U), device=f0.device, dtype=torch.float32)
+    _lib.check(lib.st2_har_source(f0.data_ptr(), B, F, U, H, noise.data_ptr(), lin_w.data_ptr(), lin_b.data_ptr(),
+                                  sine_amp, noise_std, voiced_threshold, sample_rate, scratch.data_ptr(),
+                                  out.data_ptr(), _stream()), "st2_har_source")
+    return out
+
+
+def stft_mag_phase(x, n_fft, hop):
+    lib = _lib.load()
+    _chk(x, "x", 2)
+    assert x.is_contiguous()
+    B, L = x.shape
+    M = L // hop + 1
+    har = torch.empty((B, n_fft + 2, M), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_stft_mag_phase(x.data_ptr(), B, L, n_fft, hop, har.data_ptr(), har.stride(0), har.stride(1),
+                                      _stream()), "st2_stft_mag_phase")
+    return har
+
+
+def istft(sp, n_fft, hop):
+    """sp [B, n_fft+2, M] = cat(spec, phase) -> wave [B, 1, hop*(M-1)]."""
+    lib = _lib.load()
+    _chk(sp, "sp", 3)
+    B, Cc, M = sp.shape
+    assert Cc == n_fft + 2
+    wave = torch.empty((B, 1, hop * (M - 1)), device=sp.device, dtype=torch.float32)
+    _lib.check(lib.st2_istft(sp.data_ptr(), sp.stride(0), sp.stride(1), B, M, n_fft, hop, wave.data_ptr(),
+                             wave.stride(0), _stream()), "st2_istft")
+    return wave
+
+
+def attention(q, k, v, heads, scale, out=None):
+    """q, k, v: [B, heads*D, N] views with identical strides -> [B, heads*D, N]."""
+    lib = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n, 3)
+    B, HD, N = q.shape
+    D = HD // heads
+    assert k.shape == q.shape and v.shape == q.shape
+    assert _bs_cs(q) == _bs_cs(k) == _bs_cs(v)
+    if out is None:
+        out = torch.empty((B, HD, N), device=q.device, dtype=torch.float32)
+    _lib.check(lib.st2_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), out.data_ptr(),
+                                 out.stride(0), out.stride(1), B, heads, D, N, scale, _stream()), "st2_attention")
+    return out
+
+
+def add_chanvec(x, v, out=None):
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(v, "v", 2)
+    B, Cc, N = x.shape
+    assert v.shape == (B, Cc)
+    if out is None:
+        out = torch.empty((B, Cc, N), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_add_chanvec(x.data_ptr(), x.stride(0), x.stride(1), v.data_ptr(), v.stride(0), out.data_ptr(),
+                                   out.stride(0), out.stride(1), B, Cc, N, _stream()), "st2_add_chanvec")
+    return out
+
+
+def mean_tokens(x, out=None):
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    B, Cc, N = x.shape
+    if out is None:
+        out = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_mean_tokens(x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0), B, Cc, N,
+                                   _stream()), "st2_mean_tokens")
+    return out
+
+
+def axpbypcz(x, a, y=None, b=0.0, z=None, c=0.0, out=None):
+    """out = a*x + b*y + c*z (flat, contiguous)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    assert x.is_contiguous()
+    for t in (y, z):
+        if t is not None:
+            _chk(t, "operand")
+            assert t.is_contiguous() and t.numel() == x.numel()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.st2_axpbypcz(x.data_ptr(), a, _ptr(y), b, _ptr(z), c, out.data_ptr(), x.numel(), _stream()),
+               "st2_axpbypcz")
+    return out

@@ -1,0 +1,257 @@
+"""Per-kernel parity: every C-ABI entry point (through styletts2_amd.ops) against its fp32
+PyTorch-CPU contract in oracle/ops_ref.py, on seeded random data.  Tolerances are written per test;
+they are fp32 round-off class (different summation order), not a precision downgrade."""
+import math
+
+import pytest
+import torch
+
+from oracle import ops_ref as R
+from styletts2_amd import ops, weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def g(t):
+    return None if t is None else t.to(DEV)
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def make_conv_case(seed, B, C_in, C_out, L, ks, dil, pro, act=R.ACT_NONE, res=False, res2=False, res_shift=0,
+                   div=1.0, pad_left=None, L_out=None, bias=True, sliced=False):
+    gen = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    x = r(B, C_in, L) * 1.5 + 0.3
+    w = r(C_out, C_in, ks) / math.sqrt(C_in * ks)
+    kw = dict(dil=dil, pad_left=(ks - 1) * dil // 2 if pad_left is None else pad_left, L_out=L_out,
+              bias=r(C_out) if bias else None, pro=pro, div=div, act=act)
+    Lo = L if L_out is None else L_out
+    if pro in (R.PRO_LEAKY, R.PRO_ADAIN_LEAKY):
+        kw["slope"] = 0.2
+    if pro in (R.PRO_ADAIN_LEAKY, R.PRO_ADAIN_SNAKE):
+        kw["stats"] = R.instnorm_stats(x)
+        h = r(B, 2 * C_in + 3) * 0.5
+        kw["gamma"], kw["beta"] = h[:, 1:1 + C_in], h[:, 1 + C_in:1 + 2 * C_in]
+    if pro == R.PRO_COLNORM:
+        kw["stats"] = R.colnorm_stats(x)
+        kw["gamma"], kw["beta"] = r(1, C_in), r(1, C_in)
+    if pro in (R.PRO_ADAIN_SNAKE, R.PRO_SNAKE):
+        kw["alpha"] = torch.rand(C_in, generator=gen) + 0.5
+    if res:
+        kw["res"] = r(B, C_out, (Lo + (1 << res_shift) - 1) >> res_shift)
+        kw["res_shift"] = res_shift
+    if res2:
+        kw["res2"] = r(B, C_out, Lo)
+    if act == R.ACT_EXP_SIN:
+        kw["act_split"] = C_out // 2
+    if act == R.ACT_LEAKY:
+        kw["act_slope"] = 0.1
+    return x, w, kw
+
+
+CONV_CASES = [
+    # B, C_in, C_out, L, ks, dil, pro, extra
+    dict(B=2, C_in=8, C_out=32, L=64, ks=3, dil=1, pro=R.PRO_NONE),
+    dict(B=1, C_in=128, C_out=128, L=300, ks=3, dil=1, pro=R.PRO_ADAIN_SNAKE, res=True),
+    dict(B=2, C_in=128, C_out=128, L=1001, ks=7, dil=3, pro=R.PRO_ADAIN_SNAKE, res=True, res2=True, div=3.0),
+    dict(B=1, C_in=128, C_out=128, L=777, ks=11, dil=5, pro=R.PRO_ADAIN_SNAKE),
+    dict(B=1, C_in=256, C_out=256, L=500, ks=11, dil=1, pro=R.PRO_ADAIN_SNAKE, res=True),
+    dict(B=2, C_in=66, C_out=40, L=130, ks=3, dil=1, pro=R.PRO_ADAIN_LEAKY, res=True, res_shift=1,
+         div=math.sqrt(2)),
+    dict(B=1, C_in=1090, C_out=1024, L=100, ks=3, dil=1, pro=R.PRO_ADAIN_LEAKY),
+    dict(B=2, C_in=130, C_out=70, L=90, ks=1, dil=1, pro=R.PRO_NONE, bias=False),
+    dict(B=2, C_in=1024, C_out=512, L=100, ks=1, dil=1, pro=R.PRO_COLNORM, act=R.ACT_GELU),
+    dict(B=1, C_in=128, C_out=22, L=481, ks=7, dil=1, pro=R.PRO_LEAKY, act=R.ACT_EXP_SIN),
+    dict(B=1, C_in=32, C_out=1, L=300, ks=7, dil=1, pro=R.PRO_SNAKE, act=R.ACT_TANH),
+    dict(B=2, C_in=64, C_out=60, L=50, ks=2, dil=1, pro=R.PRO_LEAKY, pad_left=1, L_out=51),
+    dict(B=1, C_in=512, C_out=512, L=37, ks=5, dil=1, pro=R.PRO_NONE, act=R.ACT_LEAKY),
+    dict(B=3, C_in=2, C_out=3, L=5, ks=3, dil=1, pro=R.PRO_NONE),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "ci%d_co%d_L%d_k%d_d%d_p%d" % (
+    c["C_in"], c["C_out"], c["L"], c["ks"], c["dil"], c["pro"]))
+def test_conv1d_matches_contract(case):
+    x, w, kw = make_conv_case(seed=1234, **case)
+    wt = weights.pack_conv(w)
+    C_out, ks = w.shape[0], w.shape[2]
+    ref = R.conv1d(x, wt, C_out, ks, **kw)
+    kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    out = ops.conv1d(g(x), g(wt), C_out, ks, **kwg)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    e = rel_err(out, ref)
+    assert e < 2e-5, "rel err %g" % e
+
+
+def test_conv1d_writes_into_channel_slice():
+    """Producers write straight into the [x | asr_res | F0 | N] concat buffer (Modules/istftnet.py:522)."""
+    x, w, kw = make_conv_case(seed=7, B=2, C_in=16, C_out=24, L=70, ks=3, dil=1, pro=R.PRO_NONE)
+    wt = weights.pack_conv(w)
+    ref = R.conv1d(x, wt, 24, 3, **kw)
+    big_in = torch.full((2, 40, 70), 7.0, device=DEV)
+    big_in[:, 5:21] = g(x)
+    big_out = torch.full((2, 50, 70), -3.0, device=DEV)
+    kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    ops.conv1d(big_in[:, 5:21], g(wt), 24, 3, out=big_out[:, 10:34], **kwg)
+    torch.cuda.synchronize()
+    assert rel_err(big_out[:, 10:34], ref) < 2e-5
+    assert (big_out[:, :10] == -3.0).all() and (big_out[:, 34:] == -3.0).all()
+
+
+def test_conv1d_rejects_bad_arguments():
+    from styletts2_amd._lib import St2Error
+    x = torch.randn(1, 4, 8, device=DEV)
+    wt = weights.pack_conv(torch.randn(4, 4, 4)).to(DEV)
+    with pytest.raises(St2Error):
+        ops.conv1d(x, wt, 4, 4)  # unsupported kernel size
+    with pytest.raises(St2Error):
+        ops.conv1d(x.cpu(), wt, 4, 4)  # no CPU path
+
+
+@pytest.mark.parametrize("B,C,L", [(2, 5, 7), (3, 66, 400), (2, 128, 48001), (1, 3, 2049)])
+def test_instnorm_stats(B, C, L):
+    gen = torch.Generator().manual_seed(L)
+    x = torch.randn(B, C, L, generator=gen) * 2.0 + 5.0
+    ref = R.instnorm_stats(x)
+    out = ops.instnorm_stats(g(x))
+    assert rel_err(out[..., 0], ref[..., 0]) < 1e-6
+    assert rel_err(out[..., 1], ref[..., 1]) < 1e-5
+    out2 = ops.instnorm_stats(g(x))
+    assert torch.equal(out, out2), "reduction must be bitwise reproducible"
+
+
+def test_colnorm_stats():
+    x = torch.randn(3, 1024, 100) + 0.5
+    ref = R.colnorm_stats(x)
+    out = ops.colnorm_stats(g(x))
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,K,J,act", [(1, 128, 300, R.ACT_NONE), (32, 128, 4100, R.ACT_NONE),
+                                       (9, 257, 1024, R.ACT_GELU), (3, 1024, 1024, R.ACT_GELU)])
+def test_style_fc(B, K, J, act):
+    gen = torch.Generator().manual_seed(J)
+    s = torch.randn(B, K, generator=gen)
+    wt = torch.randn(K, J, generator=gen) / math.sqrt(K)
+    bias = torch.randn(J, generator=gen)
+    ref = R.style_fc(s, wt, bias, act)
+    out = ops.style_fc(g(s), g(wt), g(bias), act)
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("C_in,C_out,s,p,op,L,reflect", [(16, 8, 10, 5, 0, 33, False), (12, 6, 6, 3, 0, 50, True),
+                                                        (8, 8, 5, 3, 1, 21, False), (8, 4, 3, 2, 1, 19, False),
+                                                        (6, 4, 2, 1, 0, 40, False)])
+def test_conv_transpose_polyphase(C_in, C_out, s, p, op, L, reflect):
+    """ups[i] of both vocoders: polyphase GEMM + interleave == ConvTranspose1d (+ ReflectionPad1d((1,0)))."""
+    gen = torch.Generator().manual_seed(s)
+    x = torch.randn(2, C_in, L, generator=gen)
+    w = torch.randn(C_in, C_out, 2 * s, generator=gen) * 0.1
+    b = torch.randn(C_out, generator=gen)
+    ref = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x, 0.1), w, b, stride=s, padding=p,
+                                               output_padding=op)
+    L_raw = ref.shape[2]
+    if reflect:
+        ref = torch.nn.functional.pad(ref, (1, 0), mode="reflect")
+    add = torch.randn(ref.shape, generator=gen)
+    ref = ref + add
+    wt = weights.pack_conv(weights.polyphase_convt(w, s))
+    Y = ops.conv1d(g(x), g(wt), s * C_out, 2, pad_left=1, L_out=L + 1, pro=R.PRO_LEAKY, slope=0.1)
+    out = ops.convt_interleave(Y, C_out, s, p, L_raw, bias=g(b), add=g(add), reflect_left=reflect)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-5
+
+
+def test_conv1d_direct():
+    gen = torch.Generator().manual_seed(3)
+    for (C_in, C_out, ks, st, pad, L) in [(22, 16, 12, 6, 3, 481), (22, 8, 1, 1, 0, 100), (1, 1, 3, 2, 1, 80),
+                                          (1, 8, 60, 30, 15, 3000), (256, 1, 1, 1, 0, 55)]:
+        x = torch.randn(2, C_in, L, generator=gen)
+        w = torch.randn(C_out, C_in, ks, generator=gen) * 0.2
+        b = torch.randn(C_out, generator=gen)
+        ref = R.conv1d_direct(x, w, b, st, pad)
+        out = ops.conv1d_direct(g(x), g(w), g(b), st, pad)
+        assert out.shape == ref.shape
+        assert rel_err(out, ref) < 1e-5
+
+
+def test_adain_leaky_pool():
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 70, 33, generator=gen) + 1.0
+    st = R.instnorm_stats(x)
+    h = torch.randn(2, 140, generator=gen) * 0.3
+    w = torch.randn(70, 3, generator=gen)
+    b = torch.randn(70, generator=gen)
+    ref = R.adain_leaky_pool(x, st, h[:, :70], h[:, 70:], 0.2, w, b)
+    hg = g(h)
+    out = ops.adain_leaky_pool(g(x), g(st), hg[:, :70], hg[:, 70:], 0.2, g(w), g(b))
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("F,U", [(16, 300), (800, 300)])
+def test_har_source_bit_faithful_phase(F, U):
+    """SineGen phases reach ~1e5 rad; one fp32 ulp there moves sin() by ~8e-3, so this passes only if the
+    cumsum/interp op order matches ATen-CPU.  Includes unvoiced and negative F0."""
+    gen = torch.Generator().manual_seed(F)
+    B, H = 2, 9
+    f0 = torch.rand(B, F, generator=gen) * 300.0 + 80.0
+    f0[0, : F // 4] = 0.0
+    f0[1, F // 2: F // 2 + 3] = -40.0
+    noise = torch.randn(B, F * U, H, generator=gen)
+    lw = torch.randn(H, generator=gen) * 0.5
+    lb = torch.randn(1, generator=gen) * 0.1
+    ref = R.har_source(f0, U, noise, lw, lb)
+    out = ops.har_source(g(f0), U, g(noise), g(lw), g(lb)).cpu()
+    diff = (out - ref).abs()
+    assert diff.max().item() < 2e-5, "max %g, frac>1e-4: %g" % (diff.max().item(), (diff > 1e-4).float().mean().item())
+
+
+def test_stft_mag_and_phase_mod_2pi():
+    gen = torch.Generator().manual_seed(11)
+    x = torch.tanh(torch.randn(2, 4000, generator=gen))
+    ref = R.stft_mag_phase(x, 20, 5)
+    out = ops.stft_mag_phase(g(x), 20, 5).cpu()
+    assert out.shape == ref.shape
+    assert (out[:, :11] - ref[:, :11]).abs().max().item() < 2e-5
+    # phase is ill-conditioned where |X| ~ 0 and wraps at +-pi: compare on the unit circle, weighted by magnitude
+    d = torch.remainder(out[:, 11:] - ref[:, 11:] + math.pi, 2 * math.pi) - math.pi
+    assert (d.abs() * ref[:, :11]).max().item() < 5e-5
+
+
+def test_istft():
+    gen = torch.Generator().manual_seed(13)
+    M = 801
+    sp = torch.cat([torch.exp(torch.randn(2, 11, M, generator=gen)), torch.sin(torch.randn(2, 11, M, generator=gen) * 3)], 1)
+    ref = R.istft(sp, 20, 5)
+    out = ops.istft(g(sp), 20, 5).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("B,N", [(2, 100), (1, 5), (2, 190), (1, 512)])
+def test_attention(B, N):
+    gen = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, 3 * 512, N, generator=gen)
+    q, k, v = qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:]
+    ref = R.attention(q, k, v, 8, 64 ** -0.5)
+    t = g(qkv)
+    out = ops.attention(t[:, :512], t[:, 512:1024], t[:, 1024:], 8, 64 ** -0.5)
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_token_glue():
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(3, 40, 101, generator=gen)
+    v = torch.randn(3, 40, generator=gen)
+    assert rel_err(ops.add_chanvec(g(x), g(v)), R.add_chanvec(x, v)) < 1e-6
+    assert rel_err(ops.mean_tokens(g(x)), R.mean_tokens(x)) < 1e-6
+    y, z = torch.randn(3, 40, 101, generator=gen), torch.randn(3, 40, 101, generator=gen)
+    assert rel_err(ops.axpbypcz(g(x), 0.3, g(y), -1.2, g(z), 2.0), R.axpbypcz(x, 0.3, y, -1.2, z, 2.0)) < 1e-6
+    assert rel_err(ops.axpbypcz(g(x), 0.3, g(y), -1.2), R.axpbypcz(x, 0.3, y, -1.2)) < 1e-6
