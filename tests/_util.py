@@ -1,0 +1,39 @@
+"""Shared helpers for the parity tests."""
+import json
+import math
+import os
+
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Parity bars from BASELINE.json's north_star: "within 1e-3 mel L1 and 1e-4 waveform RMS".
+WAVE_RMS_TOL = 1e-4
+MEL_L1_TOL = 1e-3
+
+
+def manifest(tag):
+    with open(os.path.join(GOLDEN, "manifest_%s.json" % tag)) as f:
+        return json.load(f)
+
+
+def decoder_kwargs(dc, hidden=512, style_dim=128, n_mels=80):
+    kw = dict(dim_in=hidden, style_dim=style_dim, dim_out=n_mels,
+              resblock_kernel_sizes=dc["resblock_kernel_sizes"], upsample_rates=dc["upsample_rates"],
+              upsample_initial_channel=dc["upsample_initial_channel"],
+              resblock_dilation_sizes=dc["resblock_dilation_sizes"],
+              upsample_kernel_sizes=dc["upsample_kernel_sizes"], kind=dc["type"])
+    if dc["type"] == "istftnet":
+        kw.update(gen_istft_n_fft=dc["gen_istft_n_fft"], gen_istft_hop_size=dc["gen_istft_hop_size"])
+    return kw
+
+
+def rms(x):
+    return x.detach().double().pow(2).mean().sqrt().item()
+
+
+def phase_err_weighted(har_a, har_b, nb):
+    """|wrap(phase_a - phase_b)| * |X|: the harmonic-STFT phase is ill-conditioned where |X| ~ 0 and wraps at
+    +-pi, so it is compared on the unit circle weighted by the magnitude."""
+    d = torch.remainder(har_a[:, nb:] - har_b[:, nb:] + math.pi, 2 * math.pi) - math.pi
+    return (d.abs() * har_b[:, :nb]).max().item()
