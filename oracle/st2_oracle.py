@@ -234,3 +234,243 @@ def decoder(sd, cfg, asr, F0_curve, N, s, noise=None, har=None, taps=None):
     gsd = sub(sd, "generator")
     gen = generator_istftnet if cfg["type"] == "istftnet" else generator_hifigan
     return gen(gsd, cfg, x, s, F0_curve, noise=noise, har=har, taps=taps)
+
+
+# ------------------------------------------------------------------------------------------------
+# style-diffusion sampler (Modules/diffusion/{sampler,modules}.py)
+# ------------------------------------------------------------------------------------------------
+def _ada_layer_norm(sd, prefix, x, s):
+    """AdaLayerNorm.forward, Modules/diffusion/modules.py:26-38 (x [B,N,C], s [B,style])."""
+    h = F.linear(s, sd[prefix + ".fc.weight"], sd[prefix + ".fc.bias"])
+    gamma, beta = torch.chunk(h.unsqueeze(1), 2, dim=-1)
+    C = x.shape[-1]
+    return (1 + gamma) * F.layer_norm(x, (C,), eps=1e-5) + beta
+
+
+def _attention_base(sd, prefix, q, k, v, heads):
+    """AttentionBase.forward, Modules/diffusion/modules.py:523-535 (no mask, no rel-pos)."""
+    B, N, HD = q.shape
+    D = HD // heads
+    qh, kh, vh = (t.reshape(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
+    sim = torch.einsum("bhnd,bhmd->bhnm", qh, kh) * (D ** -0.5)
+    attn = sim.softmax(dim=-1)
+    out = torch.einsum("bhnm,bhmd->bhnd", attn, vh).transpose(1, 2).reshape(B, N, HD)
+    return F.linear(out, sd[prefix + ".to_out.weight"], sd[prefix + ".to_out.bias"])
+
+
+def _transformer_block(sd, prefix, x, heads, features=None):
+    """TransformerBlock / StyleTransformerBlock.forward, modules.py:630-635 / 230-235 (self-attention only)."""
+    a = prefix + ".attention"
+    if features is None:  # Attention.forward, modules.py:575-584 (nn.LayerNorm)
+        C = x.shape[-1]
+        xn = F.layer_norm(x, (C,), sd[a + ".norm.weight"], sd[a + ".norm.bias"], 1e-5)
+        cn = F.layer_norm(x, (C,), sd[a + ".norm_context.weight"], sd[a + ".norm_context.bias"], 1e-5)
+    else:  # StyleAttention.forward, modules.py:269-281
+        xn = _ada_layer_norm(sd, a + ".norm", x, features)
+        cn = _ada_layer_norm(sd, a + ".norm_context", x, features)
+    q = F.linear(xn, sd[a + ".to_q.weight"])
+    k, v = torch.chunk(F.linear(cn, sd[a + ".to_kv.weight"]), 2, dim=-1)
+    x = _attention_base(sd, a + ".attention", q, k, v, heads) + x
+    f = prefix + ".feed_forward"
+    y = F.linear(F.gelu(F.linear(x, sd[f + ".0.weight"], sd[f + ".0.bias"])), sd[f + ".2.weight"], sd[f + ".2.bias"])
+    return y + x
+
+
+def denoiser_net(sd, x, time, embedding, features=None, embedding_scale=1.0, heads=8, num_layers=3):
+    """Transformer1d.forward (modules.py:402-425) / StyleTransformer1d.forward (modules.py:160-183).
+    `sd` holds the net's own keys (the `diffusion.net.` / `unet.` prefix stripped).  multispeaker <=> features."""
+    multispeaker = "to_features.0.weight" in sd
+
+    def mapping():
+        t = time.reshape(-1, 1)
+        freqs = t * sd["to_time.0.0.weights"].reshape(1, -1) * 2 * math.pi  # modules.py:666-671
+        four = torch.cat([t, freqs.sin(), freqs.cos()], dim=-1)
+        m = F.gelu(F.linear(four, sd["to_time.0.1.weight"], sd["to_time.0.1.bias"]))
+        if multispeaker:
+            m = m + F.gelu(F.linear(features, sd["to_features.0.weight"], sd["to_features.0.bias"]))
+        m = F.gelu(F.linear(m, sd["to_mapping.0.weight"], sd["to_mapping.0.bias"]))
+        return F.gelu(F.linear(m, sd["to_mapping.2.weight"], sd["to_mapping.2.bias"]))
+
+    def run(emb):
+        m = mapping().unsqueeze(1)
+        h = torch.cat([x.expand(-1, emb.size(1), -1), emb], dim=-1)
+        for i in range(num_layers):
+            h = h + m
+            h = _transformer_block(sd, "blocks.%d" % i, h, heads, features if multispeaker else None)
+        h = h.mean(dim=1).unsqueeze(1)  # no mask: padded positions are averaged too (modules.py:155,397)
+        h = F.conv1d(h.transpose(1, 2), sd["to_out.1.weight"], sd["to_out.1.bias"])
+        return h.transpose(-1, -2)
+
+    if embedding_scale != 1.0:  # classifier-free guidance, modules.py:418-423
+        N = embedding.shape[1]
+        fixed = sd["fixed_embedding.embedding.weight"][:N].unsqueeze(0).expand(embedding.shape[0], -1, -1)
+        out, out_masked = run(embedding), run(fixed)
+        return out_masked + (out - out_masked) * embedding_scale
+    return run(embedding)
+
+
+def kdiffusion_denoise(sd, x_noisy, sigma, sigma_data, **kw):
+    """KDiffusion.denoise_fn + get_scale_weights, Modules/diffusion/sampler.py:184-208."""
+    B = x_noisy.shape[0]
+    sigmas = torch.full((B,), float(sigma), dtype=torch.float32) if not torch.is_tensor(sigma) else \
+        sigma.reshape(1).expand(B).float()
+    c_noise = torch.log(sigmas) * 0.25
+    sg = sigmas.reshape(B, 1, 1)
+    c_skip = (sigma_data ** 2) / (sg ** 2 + sigma_data ** 2)
+    c_out = sg * sigma_data * (sigma_data ** 2 + sg ** 2) ** -0.5
+    c_in = (sg ** 2 + sigma_data ** 2) ** -0.5
+    x_pred = denoiser_net(sd, c_in * x_noisy, c_noise, **kw)
+    return c_skip * x_noisy + c_out * x_pred
+
+
+def karras_schedule(num_steps, sigma_min=1e-4, sigma_max=3.0, rho=9.0):
+    """KarrasSchedule.forward, sampler.py:328-337."""
+    rho_inv = 1.0 / rho
+    steps = torch.arange(num_steps, dtype=torch.float32)
+    sigmas = (sigma_max ** rho_inv + (steps / (num_steps - 1)) * (sigma_min ** rho_inv - sigma_max ** rho_inv)) ** rho
+    return F.pad(sigmas, pad=(0, 1), value=0.0)
+
+
+def adpm2_sigmas(sigma, sigma_next):
+    """ADPM2Sampler.get_sigmas with rho=1, sampler.py:490-495 (math.sqrt on 0-dim fp32 tensors -> python floats)."""
+    sigma_up = math.sqrt(sigma_next ** 2 * (sigma ** 2 - sigma_next ** 2) / sigma ** 2)
+    sigma_down = math.sqrt(sigma_next ** 2 - sigma_up ** 2)
+    sigma_mid = ((sigma ** 1.0 + sigma_down ** 1.0) / 2) ** 1.0
+    return sigma_up, sigma_down, sigma_mid
+
+
+def sample_style(sd, noise, embedding, num_steps, step_noise, sigma_data=0.2, features=None, embedding_scale=1.0,
+                 taps=None):
+    """DiffusionSampler.forward + ADPM2Sampler.forward/step (sampler.py:573-586, 497-519), clamp=False.
+    `step_noise` [num_steps-1, B, 1, C] replays the per-step randn_like draws (sampler.py:509)."""
+    sigmas = karras_schedule(num_steps)
+    kw = dict(embedding=embedding, features=features, embedding_scale=embedding_scale)
+    fn = lambda xx, sg: kdiffusion_denoise(sd, xx, sg, sigma_data, **kw)
+    x = sigmas[0] * noise
+    for i in range(num_steps - 1):
+        sigma, sigma_next = sigmas[i], sigmas[i + 1]
+        s_up, s_down, s_mid = adpm2_sigmas(sigma, sigma_next)
+        d = (x - fn(x, sigma)) / sigma
+        x_mid = x + d * (s_mid - sigma)
+        d_mid = (x_mid - fn(x_mid, s_mid)) / s_mid
+        x = x + d_mid * (s_down - sigma)
+        x = x + step_noise[i] * s_up
+        if taps is not None:
+            taps["step%d" % i] = x
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# text encoder, PL-BERT, prosody predictor, and the notebook glue
+# ------------------------------------------------------------------------------------------------
+def _lstm(sd, prefix, x, lengths=None):
+    """nn.LSTM(bidirectional, batch_first) with pack/pad (models.py:314-327,545-566)."""
+    w_ih = sd[prefix + ".weight_ih_l0"]
+    lstm = torch.nn.LSTM(w_ih.shape[1], w_ih.shape[0] // 4, 1, batch_first=True, bidirectional=True)
+    lstm.load_state_dict(sub(sd, prefix))
+    if lengths is None or bool((lengths == x.shape[1]).all()):
+        return lstm(x)[0]
+    total = x.shape[1]
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths.cpu(), batch_first=True, enforce_sorted=False)
+    y, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(packed)[0], batch_first=True, total_length=total)
+    return y
+
+
+def text_encoder(sd, tokens, lengths, mask):
+    """TextEncoder.forward, models.py:302-331."""
+    x = F.embedding(tokens, sd["embedding.weight"]).transpose(1, 2)
+    m = mask.unsqueeze(1)
+    x = x.masked_fill(m, 0.0)
+    i = 0
+    while ("cnn.%d.0.weight_g" % i) in sd:
+        x = F.conv1d(x, wn(sd, "cnn.%d.0" % i), sd["cnn.%d.0.bias" % i], padding=2)
+        x = F.layer_norm(x.transpose(1, -1), (x.shape[1],), sd["cnn.%d.1.gamma" % i], sd["cnn.%d.1.beta" % i],
+                         1e-5).transpose(1, -1)
+        x = F.leaky_relu(x, 0.2)
+        x = x.masked_fill(m, 0.0)
+        i += 1
+    y = _lstm(sd, "lstm", x.transpose(1, 2), lengths).transpose(-1, -2)
+    return y.masked_fill(m, 0.0)
+
+
+def duration_encoder(sd, x, style, lengths, mask):
+    """DurationEncoder.forward, models.py:536-569 (sd = predictor.text_encoder.*)."""
+    N = x.shape[2]
+    s = style.unsqueeze(1).expand(-1, N, -1)
+    h = torch.cat([x.transpose(1, 2), s], dim=-1).masked_fill(mask.unsqueeze(-1), 0.0)
+    i = 0
+    while ("lstms.%d.weight_ih_l0" % i) in sd:
+        h = _lstm(sd, "lstms.%d" % i, h, lengths)
+        fc = F.linear(style, sd["lstms.%d.fc.weight" % (i + 1)], sd["lstms.%d.fc.bias" % (i + 1)])
+        gamma, beta = torch.chunk(fc.unsqueeze(1), 2, dim=-1)
+        h = (1 + gamma) * F.layer_norm(h, (h.shape[-1],), eps=1e-5) + beta
+        h = torch.cat([h, s], dim=-1).masked_fill(mask.unsqueeze(-1), 0.0)
+        i += 2
+    return h
+
+
+def f0n_train(sd, x, s):
+    """ProsodyPredictor.F0Ntrain, models.py:497-510 (sd = predictor.*)."""
+    y = _lstm(sd, "shared", x.transpose(-1, -2)).transpose(-1, -2)
+    outs = []
+    for name in ("F0", "N"):
+        t = y
+        for i in range(3):
+            t = adain_resblk1d(sd, "%s.%d" % (name, i), t, s)
+        outs.append(F.conv1d(t, sd[name + "_proj.weight"], sd[name + "_proj.bias"]).squeeze(1))
+    return outs[0], outs[1]
+
+
+def plbert(sd, plbert_params, tokens, attention_mask):
+    """CustomAlbert.forward, Utils/PLBERT/util.py:6-12 (HF transformers AlbertModel; third-party, unpinned)."""
+    from transformers import AlbertConfig, AlbertModel
+    m = AlbertModel(AlbertConfig(**plbert_params)).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        return m(tokens, attention_mask=attention_mask).last_hidden_state
+
+
+def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_noise, diffusion_steps=5,
+              embedding_scale=1.0, ref_s=None, alpha=0.3, beta=0.7, durations=None, taps=None):
+    """The notebook `inference` cell (Demo/Inference_LJSpeech.ipynb:268-315; Demo/Inference_LibriTTS.ipynb:258-325),
+    batched over equal-length utterances.  `sds` maps module name -> reference-layout state_dict; cfg =
+    config['model_params']."""
+    B, N = tokens.shape
+    mask = torch.gt(torch.arange(N).unsqueeze(0).expand(B, -1) + 1, lengths.unsqueeze(1))  # utils.py:42-46
+    multispeaker = ref_s is not None
+    t_en = text_encoder(sds["text_encoder"], tokens, lengths, mask)
+    bert_dur = plbert(sds["bert"], plbert_params, tokens, (~mask).int())
+    d_en = F.linear(bert_dur, sds["bert_encoder"]["weight"], sds["bert_encoder"]["bias"]).transpose(-1, -2)
+    s_pred = sample_style(sub(sds["diffusion"], "unet"), noise, bert_dur, diffusion_steps, step_noise,
+                          sigma_data=cfg["diffusion"]["dist"]["sigma_data"], features=ref_s,
+                          embedding_scale=embedding_scale).squeeze(1)
+    s, ref = s_pred[:, 128:], s_pred[:, :128]
+    if multispeaker:
+        ref = alpha * ref + (1 - alpha) * ref_s[:, :128]
+        s = beta * s + (1 - beta) * ref_s[:, 128:]
+    psd = sds["predictor"]
+    d = duration_encoder(sub(psd, "text_encoder"), d_en, s, lengths, mask)
+    if durations is None:
+        x = _lstm(psd, "lstm", d)
+        dur = torch.sigmoid(F.linear(x, psd["duration_proj.linear_layer.weight"],
+                                     psd["duration_proj.linear_layer.bias"])).sum(dim=-1)
+        durations = torch.round(dur).clamp(min=1).long()
+        if not multispeaker:
+            durations[:, -1] += 5
+    T = int(durations[0].sum())
+    aln = torch.zeros(B, N, T)
+    for b in range(B):  # the notebook's one-hot alignment loop, ipynb:303-307
+        c = 0
+        for i in range(N):
+            aln[b, i, c:c + int(durations[b, i])] = 1
+            c += int(durations[b, i])
+    en = d.transpose(-1, -2) @ aln
+    asr = t_en @ aln
+    if cfg["decoder"]["type"] == "hifigan":
+        en = torch.cat([en[:, :, :1], en[:, :, :-1]], dim=2)
+        asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
+    F0_pred, N_pred = f0n_train(psd, en, s)
+    if taps is not None:
+        taps.update(s_pred=s_pred, durations=durations, F0=F0_pred, N=N_pred, asr=asr, en=en, t_en=t_en, d=d,
+                    bert_dur=bert_dur)
+    return decoder(sds["decoder"], cfg["decoder"], asr, F0_pred, N_pred, ref, noise=sine_noise, taps=taps)

@@ -83,10 +83,12 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
                                                    float* __restrict__ har, int64_t har_bs, int har_cs) {
   __shared__ float tw_c[MAXN], tw_s[MAXN], win[MAXN];
   if (threadIdx.x < N) {
-    const double a = 2.0 * 3.14159265358979323846 * (double)threadIdx.x / (double)N;
-    tw_c[threadIdx.x] = (float)cos(a);
-    tw_s[threadIdx.x] = (float)sin(a);
-    win[threadIdx.x] = (float)(0.5 - 0.5 * cos(a));  // periodic Hann, scipy get_window(fftbins=True)
+    // cospi/sinpi are exact at multiples of 1/2: the DC and Nyquist bins then have an exactly zero
+    // imaginary part, as a real FFT gives, so atan2 returns +pi (not a random +-pi) when Re < 0.
+    const double a = 2.0 * (double)threadIdx.x / (double)N;
+    tw_c[threadIdx.x] = (float)cospi(a);
+    tw_s[threadIdx.x] = (float)sinpi(a);
+    win[threadIdx.x] = (float)(0.5 - 0.5 * cospi(a));
   }
   __syncthreads();
   const int M = L / hop + 1;
@@ -131,10 +133,12 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
                                                     int N, int hop, float* __restrict__ wave, int64_t wave_bs) {
   __shared__ float tw_c[MAXN], tw_s[MAXN], win[MAXN];
   if (threadIdx.x < N) {
-    const double a = 2.0 * 3.14159265358979323846 * (double)threadIdx.x / (double)N;
-    tw_c[threadIdx.x] = (float)cos(a);
-    tw_s[threadIdx.x] = (float)sin(a);
-    win[threadIdx.x] = (float)(0.5 - 0.5 * cos(a));
+    // cospi/sinpi are exact at multiples of 1/2: the DC and Nyquist bins then have an exactly zero
+    // imaginary part, as a real FFT gives, so atan2 returns +pi (not a random +-pi) when Re < 0.
+    const double a = 2.0 * (double)threadIdx.x / (double)N;
+    tw_c[threadIdx.x] = (float)cospi(a);
+    tw_s[threadIdx.x] = (float)sinpi(a);
+    win[threadIdx.x] = (float)(0.5 - 0.5 * cospi(a));
   }
   __syncthreads();
   const int Lw = hop * (M - 1);

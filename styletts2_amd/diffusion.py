@@ -1,0 +1,371 @@
+"""Style-diffusion sampler engine: drop-in for the reference classes used at inference
+(Modules/diffusion/sampler.py: KarrasSchedule :319-337, ADPM2Sampler :481-519, KDiffusion :165-208,
+DiffusionSampler :550-586; Modules/diffusion/modules.py: Transformer1d :283-427, StyleTransformer1d :40-185;
+Modules/diffusion/diffusion.py: AudioDiffusionConditional shell, re-wired by models.py:653-669).
+
+    sampler = DiffusionSampler(model.diffusion.diffusion, sampler=ADPM2Sampler(),
+                               sigma_schedule=KarrasSchedule(sigma_min=1e-4, sigma_max=3.0, rho=9.0), clamp=False)
+    s_pred = sampler(noise[B,1,256], embedding=bert_dur[B,N,768], embedding_scale=1.0, num_steps=5[, features=ref_s])
+
+MI355X design: tokens are kept CHANNEL-MAJOR ([B, C, N]) for the whole denoiser so that every Linear is a k=1
+`st2_conv1d` on the fp32 matrix pipe with LayerNorm/AdaLayerNorm applied in the conv prologue, GELU / residual in
+its epilogue; attention is one HIP kernel; the per-utterance mapping MLP is `st2_style_fc`.  Everything the ADPM2
+loop needs from the host (sigma schedule, sigma_up/down/mid, EDM scale weights) is input-independent and is
+computed once on the host in the reference's own arithmetic (fp32 tensors + python floats), so the loop issues
+kernels back to back with no device->host synchronisation (the reference syncs every step, sampler.py:490-495).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import weights as W
+from .layers import PlainConv1d, PlainLinear
+
+
+# ---------------------------------------------------------------------------------------------------
+# schedule / sampler / diffusion wrappers (host-side, reference API)
+# ---------------------------------------------------------------------------------------------------
+class KarrasSchedule(nn.Module):
+    """sampler.py:319-337."""
+
+    def __init__(self, sigma_min: float, sigma_max: float, rho: float = 7.0):
+        super().__init__()
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def forward(self, num_steps: int, device=None):
+        rho_inv = 1.0 / self.rho
+        steps = torch.arange(num_steps, dtype=torch.float32)  # host: the schedule is input independent
+        sigmas = (self.sigma_max ** rho_inv +
+                  (steps / (num_steps - 1)) * (self.sigma_min ** rho_inv - self.sigma_max ** rho_inv)) ** self.rho
+        return torch.nn.functional.pad(sigmas, pad=(0, 1), value=0.0)
+
+
+class ADPM2Sampler(nn.Module):
+    """sampler.py:481-519 (second-order ancestral DPM step)."""
+
+    def __init__(self, rho: float = 1.0):
+        super().__init__()
+        self.rho = rho
+
+    def get_sigmas(self, sigma, sigma_next):
+        """Same expressions on the same types as the reference (0-dim fp32 tensors -> python floats)."""
+        r = self.rho
+        sigma_up = math.sqrt(sigma_next ** 2 * (sigma ** 2 - sigma_next ** 2) / sigma ** 2)
+        sigma_down = math.sqrt(sigma_next ** 2 - sigma_up ** 2)
+        sigma_mid = ((sigma ** (1 / r) + sigma_down ** (1 / r)) / 2) ** r
+        return float(sigma_up), float(sigma_down), float(sigma_mid)
+
+
+class KDiffusion(nn.Module):
+    """EDM pre-conditioning around the denoiser, sampler.py:165-208.  `sigma_data` is a plain mutable float
+    (models.py:665, train_second.py:317), not part of the state_dict."""
+
+    alias = "k"
+
+    def __init__(self, net, *, sigma_data: float, sigma_distribution=None, dynamic_threshold: float = 0.0):
+        super().__init__()
+        self.net = net
+        self.sigma_data = sigma_data
+        self.sigma_distribution = sigma_distribution
+        self.dynamic_threshold = dynamic_threshold
+
+    def get_scale_weights(self, sigma: float):
+        """sampler.py:184-191, evaluated in fp32 like the reference's tensor arithmetic."""
+        sd = self.sigma_data
+        s = torch.tensor(float(sigma), dtype=torch.float32)
+        c_noise = torch.log(s) * 0.25
+        c_skip = (sd ** 2) / (s ** 2 + sd ** 2)
+        c_out = s * sd * (sd ** 2 + s ** 2) ** -0.5
+        c_in = (s ** 2 + sd ** 2) ** -0.5
+        return float(c_skip), float(c_out), float(c_in), float(c_noise)
+
+    @torch.no_grad()
+    def denoise_fn(self, x_noisy, sigmas=None, sigma=None, _session=None, **kwargs):
+        if sigma is None:
+            if sigmas is None:
+                raise ValueError("denoise_fn needs sigma or sigmas")
+            sv = sigmas.reshape(-1)
+            if sv.numel() > 1 and not bool((sv == sv[0]).all()):
+                raise NotImplementedError("per-item sigmas are a training-time feature (sampler.py:223)")
+            sigma = float(sv[0])
+        c_skip, c_out, c_in, c_noise = self.get_scale_weights(float(sigma))
+        sess = _session if _session is not None else self.net.open_session(x_noisy, **kwargs)
+        x_in = ops.axpbypcz(x_noisy.contiguous(), c_in)
+        x_pred = self.net.run_session(sess, x_in, c_noise)
+        return ops.axpbypcz(x_noisy.contiguous(), c_skip, x_pred, c_out)
+
+
+class DiffusionSampler(nn.Module):
+    """sampler.py:550-586."""
+
+    def __init__(self, diffusion, *, sampler, sigma_schedule, num_steps=None, clamp=True):
+        super().__init__()
+        assert getattr(diffusion, "alias", None) == "k", "ADPM2Sampler incompatible with %s" % type(diffusion).__name__
+        self.diffusion = diffusion
+        self.denoise_fn = diffusion.denoise_fn
+        self.sampler = sampler
+        self.sigma_schedule = sigma_schedule
+        self.num_steps = num_steps
+        self.clamp = clamp
+
+    @torch.no_grad()
+    def forward(self, noise, num_steps=None, step_noise=None, taps=None, **kwargs):
+        """`step_noise` [num_steps-1, B, 1, C] (optional) replays the per-step randn_like draws of sampler.py:509."""
+        num_steps = num_steps if num_steps is not None else self.num_steps
+        assert num_steps is not None, "Parameter `num_steps` must be provided"
+        sigmas = self.sigma_schedule(num_steps, noise.device)
+        noise = noise.float().contiguous()
+        sess = self.diffusion.net.open_session(noise, **kwargs)
+        fn = lambda xx, sg: self.diffusion.denoise_fn(xx, sigma=sg, _session=sess)
+        x = ops.axpbypcz(noise, float(sigmas[0]))
+        for i in range(num_steps - 1):
+            sigma, sigma_next = sigmas[i], sigmas[i + 1]
+            s_up, s_down, s_mid = self.sampler.get_sigmas(sigma, sigma_next)
+            sg = float(sigma)
+            # d = (x - fn(x, sigma)) / sigma ; x_mid = x + d * (sigma_mid - sigma)
+            k = (s_mid - sg) / sg
+            x_mid = ops.axpbypcz(x, 1.0 + k, fn(x, sg), -k)
+            # d_mid = (x_mid - fn(x_mid, sigma_mid)) / sigma_mid ; x = x + d_mid * (sigma_down - sigma) + eps * s_up
+            k2 = (s_down - sg) / s_mid
+            eps = step_noise[i].float().contiguous() if step_noise is not None else torch.randn_like(x)
+            den_mid = fn(x_mid, s_mid)
+            d_mid = ops.axpbypcz(x_mid, k2, den_mid, -k2)
+            x = ops.axpbypcz(x, 1.0, d_mid, 1.0, eps, s_up)
+            if taps is not None:
+                taps["step%d" % i] = x
+        return x.clamp(-1.0, 1.0) if self.clamp else x
+
+
+# ---------------------------------------------------------------------------------------------------
+# denoiser parameter holders (state_dict layout of modules.py) + engine
+# ---------------------------------------------------------------------------------------------------
+class _LearnedPositionalEmbedding(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
+class _FixedEmbedding(nn.Module):
+    def __init__(self, max_length, features):
+        super().__init__()
+        self.max_length = max_length
+        self.embedding = nn.Embedding(max_length, features)
+
+
+class _AdaLNParams(nn.Module):
+    def __init__(self, style_dim, channels):
+        super().__init__()
+        self.fc = PlainLinear(style_dim, 2 * channels)
+
+
+class _AttnOut(nn.Module):
+    def __init__(self, mid, features):
+        super().__init__()
+        self.to_out = PlainLinear(mid, features)
+
+
+class _Attention(nn.Module):
+    def __init__(self, features, mid, style_dim=None):
+        super().__init__()
+        if style_dim is None:
+            self.norm = nn.LayerNorm(features)
+            self.norm_context = nn.LayerNorm(features)
+        else:
+            self.norm = _AdaLNParams(style_dim, features)
+            self.norm_context = _AdaLNParams(style_dim, features)
+        self.to_q = PlainLinear(features, mid, bias=False)
+        self.to_kv = PlainLinear(features, 2 * mid, bias=False)
+        self.attention = _AttnOut(mid, features)
+
+
+class _Block(nn.Module):
+    def __init__(self, features, mid, multiplier, style_dim=None):
+        super().__init__()
+        self.attention = _Attention(features, mid, style_dim)
+        self.feed_forward = nn.Sequential(PlainLinear(features, features * multiplier), nn.Identity(),
+                                          PlainLinear(features * multiplier, features))
+
+
+class _Transformer(nn.Module):
+    multispeaker = False
+
+    def __init__(self, num_layers, channels, num_heads, head_features, multiplier, context_embedding_features,
+                 context_features=None, embedding_max_length=512, **_unused):
+        super().__init__()
+        self.channels, self.heads, self.head_features = channels, num_heads, head_features
+        self.features = channels + context_embedding_features
+        self.emb_features = context_embedding_features
+        mid = num_heads * head_features
+        style = context_features if self.multispeaker else None
+        self.blocks = nn.ModuleList([_Block(self.features, mid, multiplier, style) for _ in range(num_layers)])
+        self.to_out = nn.Sequential(nn.Identity(), PlainConv1d(self.features, channels, 1))
+        F_ = self.features
+        self.to_mapping = nn.Sequential(PlainLinear(F_, F_), nn.Identity(), PlainLinear(F_, F_), nn.Identity())
+        self.to_time = nn.Sequential(nn.Sequential(_LearnedPositionalEmbedding(channels), PlainLinear(channels + 1, F_)),
+                                     nn.Identity())
+        if self.multispeaker:
+            self.to_features = nn.Sequential(PlainLinear(context_features, F_), nn.Identity())
+        self.fixed_embedding = _FixedEmbedding(embedding_max_length, context_embedding_features)
+        self._pk = None
+
+    # -- packed weights --------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._pk = None
+        return super().load_state_dict(W.strip_module_prefix(state_dict), *a, **k)
+
+    def refresh(self):
+        self._pk = None
+
+    def _prepare(self, device):
+        d = lambda t: t.detach().float().contiguous().to(device)
+        lin_t = lambda l: d(l.weight.detach().t())  # [in, out] for st2_style_fc
+        pk = type("PackedDenoiser", (), {})()
+        pk.device = device
+        pk.time_w = d(self.to_time[0][0].weights)
+        pk.time_lin, pk.time_b = lin_t(self.to_time[0][1]), d(self.to_time[0][1].bias)
+        pk.map0, pk.map0_b = lin_t(self.to_mapping[0]), d(self.to_mapping[0].bias)
+        pk.map2, pk.map2_b = lin_t(self.to_mapping[2]), d(self.to_mapping[2].bias)
+        if self.multispeaker:
+            pk.feat, pk.feat_b = lin_t(self.to_features[0]), d(self.to_features[0].bias)
+            # every AdaLayerNorm fc of the net in one [style, J] matrix (they all consume `features`)
+            fcs = [m for blk in self.blocks for m in (blk.attention.norm, blk.attention.norm_context)]
+            pk.ada_wt = torch.cat([d(m.fc.weight).t() for m in fcs], dim=1).contiguous()
+            pk.ada_b = torch.cat([d(m.fc.bias) for m in fcs]).contiguous()
+        pk.blocks = []
+        for blk in self.blocks:
+            b = type("PackedBlock", (), {})()
+            a = blk.attention
+            if not self.multispeaker:
+                b.n_w, b.n_b = d(a.norm.weight).reshape(1, -1), d(a.norm.bias).reshape(1, -1)
+                b.nc_w, b.nc_b = d(a.norm_context.weight).reshape(1, -1), d(a.norm_context.bias).reshape(1, -1)
+            b.q = W.pack_linear(a.to_q.weight.detach().float()).to(device)
+            b.kv = W.pack_linear(a.to_kv.weight.detach().float()).to(device)
+            b.o, b.o_b = W.pack_linear(a.attention.to_out.weight.detach().float()).to(device), d(a.attention.to_out.bias)
+            b.f1, b.f1_b = W.pack_linear(blk.feed_forward[0].weight.detach().float()).to(device), d(blk.feed_forward[0].bias)
+            b.f2, b.f2_b = W.pack_linear(blk.feed_forward[2].weight.detach().float()).to(device), d(blk.feed_forward[2].bias)
+            pk.blocks.append(b)
+        pk.out_t = d(self.to_out[1].weight.detach().reshape(self.channels, self.features).t())
+        pk.out_b = d(self.to_out[1].bias)
+        pk.fixed = d(self.fixed_embedding.embedding.weight)
+        self._pk = pk
+        return pk
+
+    # -- sessions: everything constant across the 2*(steps-1) net calls of one sampler run -------------
+    def open_session(self, x, embedding=None, features=None, embedding_scale=1.0, embedding_mask_proba=0.0):
+        assert embedding is not None, "the denoiser is conditional: `embedding` is required (modules.py:410)"
+        dev = x.device
+        pk = self._pk if (self._pk is not None and self._pk.device == dev) else self._prepare(dev)
+        B, N, E = embedding.shape
+        assert N <= self.fixed_embedding.max_length, "Input sequence length must be <= max_length"
+        assert E == self.emb_features
+        s = type("DenoiserSession", (), {})()
+        s.pk, s.B, s.N, s.scale = pk, B, N, float(embedding_scale)
+        embedding = embedding.float()
+        fixed = pk.fixed[:N].unsqueeze(0).expand(B, -1, -1)
+        if embedding_mask_proba > 0.0:  # modules.py:412-416 (classifier-free-guidance dropout; off at inference)
+            mask = torch.rand(B, 1, 1, device=dev) < embedding_mask_proba
+            embedding = torch.where(mask, fixed, embedding)
+        C = self.channels
+
+        def base(e):  # channel-major [x | embedding] buffer; rows < C are rewritten on every net call
+            buf = torch.empty((B, self.features, N), device=dev, dtype=torch.float32)
+            buf[:, C:].copy_(e.transpose(1, 2))
+            return buf
+
+        s.bases = [base(embedding)]
+        if s.scale != 1.0:
+            s.bases.append(base(fixed))
+        s.feat_map, s.ada = None, None
+        if self.multispeaker:
+            assert features is not None, "context_features exists but no features provided"
+            f = features.float().contiguous()
+            s.feat_map = ops.style_fc(f, pk.feat, pk.feat_b, ops.ACT_GELU)
+            s.ada = ops.style_fc(f, pk.ada_wt, pk.ada_b)
+        return s
+
+    def _mapping(self, s, c_noise):
+        pk = s.pk
+        t = torch.full((s.B, 1), c_noise, device=pk.device, dtype=torch.float32)
+        freqs = t * pk.time_w.view(1, -1) * 2 * math.pi  # modules.py:666-671
+        four = torch.cat([t, freqs.sin(), freqs.cos()], dim=-1).contiguous()
+        m = ops.style_fc(four, pk.time_lin, pk.time_b, ops.ACT_GELU)
+        if s.feat_map is not None:
+            m = m + s.feat_map  # reduce(stack(items), 'sum'), modules.py:140
+        m = ops.style_fc(m, pk.map0, pk.map0_b, ops.ACT_GELU)
+        return ops.style_fc(m, pk.map2, pk.map2_b, ops.ACT_GELU)
+
+    def _run(self, s, base, x, m):
+        pk = s.pk
+        B, N, Fz, C = s.B, s.N, self.features, self.channels
+        mid = self.heads * self.head_features
+        base[:, :C].copy_(x.reshape(B, C, 1).expand(B, C, N))
+        X = ops.add_chanvec(base, m)
+        nblk = len(pk.blocks)
+        for i, b in enumerate(pk.blocks):
+            st = ops.colnorm_stats(X)
+            qkv = torch.empty((B, 3 * mid, N), device=X.device, dtype=torch.float32)
+            if self.multispeaker:
+                o = 4 * Fz * i
+                g1, b1 = s.ada[:, o:o + Fz], s.ada[:, o + Fz:o + 2 * Fz]
+                g2, b2 = s.ada[:, o + 2 * Fz:o + 3 * Fz], s.ada[:, o + 3 * Fz:o + 4 * Fz]
+                kw1 = dict(gamma=g1, beta=b1, gamma_plus_one=True)
+                kw2 = dict(gamma=g2, beta=b2, gamma_plus_one=True)
+            else:
+                kw1 = dict(gamma=b.n_w, beta=b.n_b)
+                kw2 = dict(gamma=b.nc_w, beta=b.nc_b)
+            ops.conv1d(X, b.q, mid, 1, pro=ops.PRO_COLNORM, stats=st, out=qkv[:, :mid], **kw1)
+            ops.conv1d(X, b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=st, out=qkv[:, mid:], **kw2)
+            att = ops.attention(qkv[:, :mid], qkv[:, mid:2 * mid], qkv[:, 2 * mid:], self.heads,
+                                self.head_features ** -0.5)
+            X1 = ops.conv1d(att, b.o, Fz, 1, bias=b.o_b, res=X)
+            hmid = ops.conv1d(X1, b.f1, b.f1.shape[1], 1, bias=b.f1_b, act=ops.ACT_GELU)
+            X2 = ops.conv1d(hmid, b.f2, Fz, 1, bias=b.f2_b, res=X1)
+            X = ops.add_chanvec(X2, m) if i + 1 < nblk else X2
+        mean = ops.mean_tokens(X)  # unmasked mean over tokens, modules.py:155,397
+        return ops.style_fc(mean, pk.out_t, pk.out_b).reshape(B, 1, C)
+
+    def run_session(self, s, x, c_noise):
+        m = self._mapping(s, c_noise)
+        out = self._run(s, s.bases[0], x, m)
+        if s.scale != 1.0:  # classifier-free guidance, modules.py:418-423
+            out_masked = self._run(s, s.bases[1], x, m)
+            return ops.axpbypcz(out_masked, 1.0 - s.scale, out, s.scale)
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, time, embedding_mask_proba=0.0, embedding=None, features=None, embedding_scale=1.0):
+        """Reference call signature (modules.py:402-407).  `time` must be batch-uniform (it is c_noise of a
+        scalar sigma at inference)."""
+        tv = time.reshape(-1)
+        if tv.numel() > 1 and not bool((tv == tv[0]).all()):
+            raise NotImplementedError("per-item time embeddings are a training-time feature")
+        s = self.open_session(x, embedding=embedding, features=features, embedding_scale=embedding_scale,
+                              embedding_mask_proba=embedding_mask_proba)
+        return self.run_session(s, x.float().contiguous(), float(tv[0]))
+
+
+class Transformer1d(_Transformer):
+    """Single-speaker denoiser (modules.py:283-427): nn.LayerNorm before q / kv."""
+    multispeaker = False
+
+
+class StyleTransformer1d(_Transformer):
+    """Multi-speaker denoiser (modules.py:40-185): AdaLayerNorm conditioned on `features`."""
+    multispeaker = True
+
+
+class AudioDiffusionConditional(nn.Module):
+    """Shell that exposes the denoiser under both `diffusion.net.*` and `unet.*` state_dict prefixes
+    (Modules/diffusion/diffusion.py + models.py:653-669)."""
+
+    def __init__(self, transformer, sigma_data, embedding_mask_proba=0.1):
+        super().__init__()
+        self.diffusion = KDiffusion(net=transformer, sigma_data=sigma_data)
+        self.unet = transformer
+        self.embedding_mask_proba = embedding_mask_proba

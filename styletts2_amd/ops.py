@@ -18,6 +18,29 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class ConvTimer:
+    """Optional per-launch HIP-event timing of one st2_conv1d shape class (bench.py's roofline leg).  Events are
+    recorded on the launch stream around matching launches only and resolved after the caller synchronises."""
+
+    def __init__(self, ks, C_in, C_out, L_out):
+        self.key = (ks, C_in, C_out, L_out)
+        self.pairs = []
+
+    def matches(self, d):
+        return (d.ks, d.C_in, d.C_out, d.L_out) == self.key
+
+    def durations_ms(self):
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+_conv_timer = None
+
+
+def set_conv_timer(timer):
+    global _conv_timer
+    _conv_timer = timer
+
+
 def _chk(t, name, ndim=None):
     if t is None:
         return
@@ -91,6 +114,13 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         d.res2, d.res2_bs, d.res2_cs = res2.data_ptr(), res2.stride(0), res2.stride(1)
     d.div = div
     d.act, d.act_split, d.act_slope = act, act_split, act_slope
+    if _conv_timer is not None and _conv_timer.matches(d):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.st2_conv1d(C.byref(d), _stream()), "st2_conv1d")
+        e1.record()
+        _conv_timer.pairs.append((e0, e1))
+        return out
     _lib.check(lib.st2_conv1d(C.byref(d), _stream()), "st2_conv1d")
     return out
 

@@ -1,0 +1,99 @@
+"""Text -> waveform inference glue: the logic that in the reference exists
+only inside notebook cells (Demo/Inference_LJSpeech.ipynb:268-315, Demo/Inference_LibriTTS.ipynb:258-325),
+batched over utterances and kept on the device.
+
+Differences from the notebooks, all host-side:
+  * a batch of B utterances instead of one;
+  * the duration -> alignment step is an index gather (`expand_by_durations`) instead of a Python loop building a
+    dense one-hot matrix followed by a matmul (`t_en @ pred_aln_trg`); the result is bit-identical because the
+    matmul only ever adds zeros;
+  * optional `durations=` forces the per-phoneme durations (throughput runs use 4 frames / phoneme so that
+    every utterance is exactly 10 s) and removes the only data-dependent host sync.
+"""
+import torch
+
+from .utils import length_to_mask
+
+
+def expand_by_durations(x, dur, T):
+    """x [B, C, N], dur [B, N] (int64, every row sums to T) -> [B, C, T] with frame t taking phoneme idx[t]
+    (== x @ one_hot alignment, Demo/Inference_LJSpeech.ipynb:303-312)."""
+    B, C, N = x.shape
+    ar = torch.arange(N, device=x.device)
+    idx = torch.stack([torch.repeat_interleave(ar, dur[b], output_size=T) for b in range(B)])  # [B, T]
+    return torch.gather(x, 2, idx.unsqueeze(1).expand(B, C, T))
+
+
+def predict_durations(model, d, lj_tail=False):
+    """ipynb:296-301: duration LSTM -> projection -> sum of sigmoids -> round, clamp(min=1)."""
+    model.predictor.lstm.flatten_parameters()
+    x, _ = model.predictor.lstm(d)
+    duration = model.predictor.duration_proj(x)
+    duration = torch.sigmoid(duration).sum(dim=-1)
+    pred_dur = torch.round(duration).clamp(min=1).long()
+    if lj_tail:
+        pred_dur[:, -1] += 5  # LJSpeech notebook only (ipynb:301)
+    return pred_dur
+
+
+@torch.no_grad()
+def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
+              ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
+              taps=None):
+    """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
+
+    Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
+    (Demo/Inference_LibriTTS.ipynb:285-286).  All utterances of one call must expand to the same number of
+    frames (the decoder's InstanceNorm spans the whole utterance, so padding would change results: section 7.3-6);
+    callers bucket by length or pass `durations`.
+    """
+    dev = tokens.device
+    B, N = tokens.shape
+    if input_lengths is None:
+        input_lengths = torch.full((B,), N, dtype=torch.long)
+    text_mask = length_to_mask(input_lengths).to(dev)
+    multispeaker = ref_s is not None
+    hifigan = model.decoder.kind == "hifigan"
+    if lj_tail is None:
+        lj_tail = not multispeaker
+    if noise is None:
+        noise = torch.randn(B, 1, 256, device=dev)
+
+    t_en = model.text_encoder(tokens, input_lengths, text_mask)                      # [B, 512, N]
+    bert_dur = model.bert(tokens, attention_mask=(~text_mask).int())                 # [B, N, 768]
+    d_en = model.bert_encoder(bert_dur).transpose(-1, -2)                            # [B, 512, N]
+
+    kw = dict(embedding=bert_dur, embedding_scale=embedding_scale, num_steps=diffusion_steps, step_noise=step_noise)
+    if multispeaker:
+        kw["features"] = ref_s
+    s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
+    if taps is not None:
+        taps["s_pred"] = s_pred
+    s = s_pred[:, 128:]
+    ref = s_pred[:, :128]
+    if multispeaker:
+        ref = alpha * ref + (1 - alpha) * ref_s[:, :128]
+        s = beta * s + (1 - beta) * ref_s[:, 128:]
+    s, ref = s.contiguous(), ref.contiguous()
+
+    d = model.predictor.text_encoder(d_en, s, input_lengths, text_mask)              # [B, N, 640]
+    if durations is None:
+        durations = predict_durations(model, d, lj_tail=lj_tail)
+        tot = durations.sum(dim=1)
+        if not bool((tot == tot[0]).all()):
+            raise ValueError("utterances of one call must have equal total duration; bucket them or pass "
+                             "`durations` (frames per utterance: %s)" % tot.tolist())
+    T = int(durations[0].sum())  # host value when `durations` was given on the host: no device sync
+    durations = durations.to(dev)
+    if taps is not None:
+        taps["durations"] = durations
+
+    en = expand_by_durations(d.transpose(-1, -2).contiguous(), durations, T)          # [B, 640, T]
+    asr = expand_by_durations(t_en, durations, T)                                      # [B, 512, T]
+    if hifigan:  # one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
+        en = torch.cat([en[:, :, :1], en[:, :, :-1]], dim=2)
+        asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
+    F0_pred, N_pred = model.predictor.F0Ntrain(en.contiguous(), s)
+    if taps is not None:
+        taps.update(F0=F0_pred, N=N_pred, asr=asr, en=en)
+    return model.decoder(asr.contiguous(), F0_pred, N_pred, ref, noise=sine_noise)
