@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the start-up weight broadcast and the static utterance
+sharding (the data path itself has no collective)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from styletts2_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, lr, w = parallel.init_distributed(backend="gloo")
+    from styletts2_amd.layers import AdaINResBlock1Params
+    torch.manual_seed(100 + rank)  # ranks start from different weights
+    blk = AdaINResBlock1Params(8, 3, (1, 3), 16)
+    before = torch.cat([p.detach().reshape(-1) for p in blk.parameters()]).clone()
+    nbytes = parallel.broadcast_module_weights(blk, src=0)
+    after = torch.cat([p.detach().reshape(-1) for p in blk.parameters()])
+    gathered = [torch.zeros_like(after) for _ in range(w)]
+    dist.all_gather(gathered, after)
+    lo, hi = parallel.shard_range(7, r, w)
+    t = parallel.max_over_ranks(float(rank + 1), "cpu")
+    parallel.barrier()
+    q.put((rank, nbytes, bool(torch.equal(gathered[0], gathered[1])), bool(torch.equal(before, after)), (lo, hi), t))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, same0, unchanged0, sh0, t0), (r1, n1, same1, unchanged1, sh1, t1) = res
+    assert n0 == n1 > 0 and same0 and same1
+    assert unchanged0 and not unchanged1  # rank 0 is the source; rank 1 was overwritten
+    assert sh0 == (0, 4) and sh1 == (4, 7)
+    assert t0 == t1 == 2.0
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 256):
+        for w in (1, 2, 4, 8):
+            spans = [parallel.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
