@@ -174,6 +174,16 @@ int st2_attention(const float* q, const float* k, const float* v, int64_t bs, in
                   float* o, int64_t o_bs, int32_t o_cs,
                   int32_t B, int32_t H, int32_t D, int32_t N, float scale, void* stream);
 
+/* ---- bidirectional LSTM recurrence (hidden size H = 256) ------------------------------------- *
+ * G [B][2*4H][N]: input projections W_ih x_t + b_ih + b_hh for both directions (rows 0..4H-1 forward,
+ * 4H..8H-1 reverse; PyTorch gate order i,f,g,o), produced by st2_conv1d (k=1).  whh_t [2][H][4H] is
+ * W_hh transposed per direction.  lengths [B] int32 (NULL = all N): packed-sequence semantics, outputs
+ * beyond the length are zero.  Y [B][2H][N] (rows 0..H-1 forward h_t, H..2H-1 reverse).
+ * Replaces nn.LSTM(bidirectional=True) + pack/pad: models.py:300,314-327 (TextEncoder),
+ * :450,523-528,545-566 (duration LSTM / DurationEncoder), :453,498 (shared F0/N LSTM). */
+int st2_lstm_bidir(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
+                   int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* stream);
+
 /* generic fused elementwise helpers used by the sampler / denoiser glue */
 /* y[b][c][n] = x[b][c][n] + v[b][c]  (x = x + mapping, modules.py:152,394) */
 int st2_add_chanvec(const float* x, int64_t x_bs, int32_t x_cs, const float* v, int64_t v_bs,

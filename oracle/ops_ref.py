@@ -189,6 +189,31 @@ def attention(q, k, v, heads, scale, out=None):
     return o
 
 
+def lstm_bidir(G, whh_t, lengths=None, out=None):
+    """Restates the bidirectional LSTM recurrence with packed-sequence semantics (PyTorch gate order i,f,g,o)."""
+    B, R, N = G.shape
+    H = R // 8
+    Y = torch.zeros(B, 2 * H, N)
+    for b in range(B):
+        n = N if lengths is None else int(lengths[b])
+        for d in range(2):
+            Wt = whh_t[d]  # [H, 4H]
+            h = torch.zeros(H)
+            c = torch.zeros(H)
+            order = range(n) if d == 0 else range(n - 1, -1, -1)
+            for t in order:
+                g = G[b, d * 4 * H:(d + 1) * 4 * H, t] + h @ Wt
+                i, f, gg, o = torch.sigmoid(g[:H]), torch.sigmoid(g[H:2 * H]), torch.tanh(g[2 * H:3 * H]), \
+                    torch.sigmoid(g[3 * H:])
+                c = f * c + i * gg
+                h = o * torch.tanh(c)
+                Y[b, d * H:(d + 1) * H, t] = h
+    if out is not None:
+        out.copy_(Y)
+        return out
+    return Y
+
+
 def add_chanvec(x, v, out=None):
     y = x + v.unsqueeze(-1)
     if out is not None:

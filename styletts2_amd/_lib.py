@@ -6,6 +6,12 @@ of any compute entry point raises.  Build it with `python -m styletts2_amd._buil
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).  It must be the
+# first HIP runtime mapped into the process so that libst2_hip.so binds to the SAME runtime instance torch uses
+# (streams and device pointers are shared); loading ours first makes two HSA runtimes fight over the device
+# ("no ROCm-capable device is detected").
+import torch  # noqa: F401,E402  (deliberately before the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
 ABI_VERSION = 1
@@ -67,6 +73,8 @@ _SIGNATURES = {
                             C.c_void_p]),
     "st2_attention": (C.c_int, [f32p, f32p, f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "st2_lstm_bidir": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, f32p,
+                                 C.c_int64, C.c_int32, C.c_void_p]),
     "st2_add_chanvec": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, f32p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "st2_mean_tokens": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

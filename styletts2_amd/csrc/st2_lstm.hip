@@ -1,0 +1,95 @@
+// Bidirectional LSTM recurrence (H = 256) for the text / prosody encoders.
+//
+// The input projection  W_ih x_t + b_ih + b_hh  for ALL time steps is one k=1 st2_conv1d on the
+// matrix pipe (tokens are channel-major), so only the sequential part lives here:
+//     g_t = G[:, t] + W_hh h_{t-1};  i,f,o = sigmoid(.), g = tanh(.);  c_t = f c_{t-1} + i g;  h_t = o tanh(c_t)
+//
+// Design for MI355X: batch is small (32) and the chain is N = 100..400 steps long, so the step is
+// latency / L2-bandwidth bound, not FLOP bound.  One workgroup per (utterance, direction) keeps the
+// whole recurrence on one CU -- no inter-workgroup synchronisation per step -- with thread j owning
+// hidden unit j (its 4 gate rows, its cell state).  h_{t-1} is broadcast from LDS; W_hh is stored
+// K-major ([H][4H]) so that every k-step is four fully coalesced 1 KB wave loads served from L2
+// (1 MB per direction, resident).  The next step's input-projection column is prefetched before the
+// W_hh sweep.  Packed-sequence semantics (models.py:314-327): steps >= length are skipped and their
+// outputs are zero; the reverse direction starts at t = length-1.
+#include "st2_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int H>
+__global__ __launch_bounds__(H) void lstm_recurrence_kernel(const float* __restrict__ G, int64_t g_bs, int g_cs,
+                                                            const float* __restrict__ whh_t,  // [2][H][4H]
+                                                            const int* __restrict__ lengths, int N,
+                                                            float* __restrict__ Y, int64_t y_bs, int y_cs) {
+  __shared__ float hs[2][H];
+  const int j = threadIdx.x;
+  const int b = blockIdx.x;
+  const int dir = blockIdx.y;
+  const int len = lengths ? min(lengths[b], N) : N;
+  const float* Gb = G + (int64_t)b * g_bs + (int64_t)(dir * 4 * H) * g_cs;
+  const float* W = whh_t + (int64_t)dir * H * 4 * H;
+  float* Yb = Y + (int64_t)b * y_bs + (int64_t)(dir * H + j) * y_cs;
+
+  // zero the padded tail (pad_packed_sequence)
+  for (int t = len; t < N; ++t) Yb[t] = 0.f;
+  if (len <= 0) return;
+
+  float c = 0.f;
+  hs[0][j] = 0.f;
+  __syncthreads();
+  int t = dir == 0 ? 0 : len - 1;
+  const int dt = dir == 0 ? 1 : -1;
+  float gi = Gb[(int64_t)(0 * H + j) * g_cs + t];
+  float gf = Gb[(int64_t)(1 * H + j) * g_cs + t];
+  float gg = Gb[(int64_t)(2 * H + j) * g_cs + t];
+  float go = Gb[(int64_t)(3 * H + j) * g_cs + t];
+  for (int s = 0; s < len; ++s) {
+    const float* hp = hs[s & 1];
+    // prefetch the next step's projected inputs
+    const int tn = t + dt;
+    float ni = 0.f, nf = 0.f, ng = 0.f, no = 0.f;
+    if (s + 1 < len) {
+      ni = Gb[(int64_t)(0 * H + j) * g_cs + tn];
+      nf = Gb[(int64_t)(1 * H + j) * g_cs + tn];
+      ng = Gb[(int64_t)(2 * H + j) * g_cs + tn];
+      no = Gb[(int64_t)(3 * H + j) * g_cs + tn];
+    }
+    float ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) {
+      const float hk = hp[k];
+      const float* wk = W + (int64_t)k * 4 * H + j;
+      ai = fmaf(wk[0], hk, ai);
+      af = fmaf(wk[H], hk, af);
+      ag = fmaf(wk[2 * H], hk, ag);
+      ao = fmaf(wk[3 * H], hk, ao);
+    }
+    const float iv = sigmoidf_(gi + ai);
+    const float fv = sigmoidf_(gf + af);
+    const float gv = tanhf(gg + ag);
+    const float ov = sigmoidf_(go + ao);
+    c = fv * c + iv * gv;
+    const float h = ov * tanhf(c);
+    Yb[t] = h;
+    hs[(s + 1) & 1][j] = h;
+    __syncthreads();
+    gi = ni; gf = nf; gg = ng; go = no;
+    t = tn;
+  }
+}
+
+}  // namespace
+
+extern "C" int st2_lstm_bidir(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
+                              int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* stream) {
+  ST2_REQUIRE(G && whh_t && Y && B > 0 && N > 0, "st2_lstm_bidir: bad arguments");
+  ST2_REQUIRE(H == 256, "st2_lstm_bidir: hidden size %d unsupported (built for 256)", H);
+  ST2_REQUIRE(B <= 65535, "st2_lstm_bidir: batch too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((lstm_recurrence_kernel<256>), dim3(B, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t,
+                     reinterpret_cast<const int*>(lengths), N, Y, y_bs, y_cs);
+  ST2_CHECK_LAUNCH("st2_lstm_bidir");
+  return 0;
+}

@@ -284,6 +284,24 @@ def attention(q, k, v, heads, scale, out=None):
     return out
 
 
+def lstm_bidir(G, whh_t, lengths=None, out=None):
+    """G [B, 8H, N] projected inputs (both directions) -> Y [B, 2H, N]; lengths: int32 [B] on the device or None."""
+    lib = _lib.load()
+    _chk(G, "G", 3)
+    _chk(whh_t, "whh_t", 3)
+    B, R, N = G.shape
+    H = R // 8
+    assert whh_t.shape == (2, H, 4 * H) and whh_t.is_contiguous()
+    if lengths is not None:
+        assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.numel() == B and lengths.is_contiguous()
+    if out is None:
+        out = torch.empty((B, 2 * H, N), device=G.device, dtype=torch.float32)
+    _lib.check(lib.st2_lstm_bidir(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(),
+                                  0 if lengths is None else lengths.data_ptr(), B, H, N, out.data_ptr(),
+                                  out.stride(0), out.stride(1), _stream()), "st2_lstm_bidir")
+    return out
+
+
 def add_chanvec(x, v, out=None):
     lib = _lib.load()
     _chk(x, "x", 3)

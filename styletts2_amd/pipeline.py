@@ -26,7 +26,6 @@ def expand_by_durations(x, dur, T):
 
 def predict_durations(model, d, lj_tail=False):
     """ipynb:296-301: duration LSTM -> projection -> sum of sigmoids -> round, clamp(min=1)."""
-    model.predictor.lstm.flatten_parameters()
     x, _ = model.predictor.lstm(d)
     duration = model.predictor.duration_proj(x)
     duration = torch.sigmoid(duration).sum(dim=-1)

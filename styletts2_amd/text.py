@@ -1,10 +1,10 @@
 """Text side of the path: TextEncoder (models.py:284-345), PL-BERT wrapper (Utils/PLBERT/util.py:6-12) and the
 ProsodyPredictor with its DurationEncoder (models.py:440-582).
 
-Scope note: the recurrent cells (BiLSTM, H=256) and the ALBERT encoder run through
-PyTorch-ROCm (MIOpen RNN / hipBLASLt) this round -- they are ~7 % of the path's time.  Everything conv-shaped
-here (TextEncoder k=5 convs, the F0/N AdainResBlk1d stacks) already runs on the HIP kernels.  State_dict layouts
-are the reference's, key for key.
+Every conv and every BiLSTM here runs on the HIP kernels (TextEncoder k=5 convs and F0/N AdainResBlk1d stacks on
+`st2_conv1d`; LSTM input projections on `st2_conv1d`, recurrences on `st2_lstm_bidir`).  The small per-token
+LayerNorm / LeakyReLU / masking glue and the ALBERT encoder (HF transformers on hipBLASLt) are PyTorch-ROCm
+plumbing this round.  State_dict layouts are the reference's, key for key.
 """
 import torch
 import torch.nn as nn
@@ -16,23 +16,61 @@ from .decoder import StyleBank, _PackedAdainResBlk, _PackedConv, run_adain_resbl
 from .layers import AdainResBlk1dParams, PlainConv1d, PlainLinear, WNConv1d
 
 
-def _all_full(lengths, n):
-    """True when no sequence is padded; decided on the host copy of `lengths` (kept on CPU by the caller)."""
-    return bool((lengths == n).all())
+def _device_lengths(lengths, n, device):
+    """int32 device copy of `lengths`, or None when no sequence is padded (decided on the host copy the caller
+    already holds -- the reference reads `input_lengths.cpu()` at the same place, models.py:314)."""
+    if lengths is None:
+        return None
+    lc = lengths.detach().cpu()
+    if bool((lc == n).all()):
+        return None
+    return lc.to(torch.int32).to(device)
 
 
-def _bilstm(lstm, x, lengths, total):
-    """Batch-first BiLSTM with the reference's pack/pad semantics (models.py:314-327): padded steps are skipped
-    by the recurrence and come out as zeros."""
-    lstm.flatten_parameters()
-    lens_cpu = lengths.detach().cpu()
-    if _all_full(lens_cpu, x.shape[1]):
-        y, _ = lstm(x)
-        return y
-    packed = nn.utils.rnn.pack_padded_sequence(x, lens_cpu, batch_first=True, enforce_sorted=False)
-    y, _ = lstm(packed)
-    y, _ = nn.utils.rnn.pad_packed_sequence(y, batch_first=True, total_length=total)
-    return y
+class EngineLSTM(nn.LSTM):
+    """nn.LSTM(1 layer, bidirectional, batch_first) parameter holder -- same state_dict keys as the reference's
+    nn.LSTM -- whose arithmetic runs on the HIP kernels: the input projection of every time step is one k=1
+    `st2_conv1d` (channel-major tokens), the recurrence is `st2_lstm_bidir`.  Pack/pad semantics of
+    models.py:314-327 are reproduced through `lengths` (outputs past a sequence's end are zero)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__(input_size, hidden_size, 1, batch_first=True, bidirectional=True)
+        self._pk = None
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._pk = None
+        return super().load_state_dict(state_dict, *a, **k)
+
+    def _packed(self, device):
+        if self._pk is None or self._pk.device != device:
+            d = lambda t: t.detach().float().contiguous().to(device)
+            pk = type("PackedLSTM", (), {})()
+            pk.device = device
+            w_ih = torch.cat([self.weight_ih_l0.detach(), self.weight_ih_l0_reverse.detach()], dim=0).float()
+            pk.w_ih = W.pack_linear(w_ih).to(device)                                  # [I, 8H]
+            pk.bias = d(torch.cat([self.bias_ih_l0.detach() + self.bias_hh_l0.detach(),
+                                   self.bias_ih_l0_reverse.detach() + self.bias_hh_l0_reverse.detach()]))
+            pk.whh_t = d(torch.stack([self.weight_hh_l0.detach().t(), self.weight_hh_l0_reverse.detach().t()]))
+            self._pk = pk
+        return self._pk
+
+    def forward_cm(self, x_cm, lengths=None):
+        """x_cm [B, I, N] channel-major -> [B, 2H, N]; lengths: int32 device tensor or None."""
+        pk = self._packed(x_cm.device)
+        G = ops.conv1d(x_cm, pk.w_ih, 8 * self.hidden_size, 1, bias=pk.bias)
+        return ops.lstm_bidir(G, pk.whh_t, lengths)
+
+    @torch.no_grad()
+    def forward(self, x, hx=None):
+        """Reference call form `y, _ = lstm(x)` with x [B, N, I] (Demo/Inference_LJSpeech.ipynb:296)."""
+        if hx is not None or not torch.is_tensor(x):
+            raise NotImplementedError("EngineLSTM takes a padded [B, N, I] tensor; pass lengths via forward_cm")
+        y = self.forward_cm(x.transpose(1, 2).contiguous().float())
+        return y.transpose(1, 2), None
 
 
 class _ChannelLayerNorm(nn.Module):
@@ -77,7 +115,7 @@ class TextEncoder(_PackedCache, nn.Module):
         self.kernel_size = kernel_size
         self.cnn = nn.ModuleList([nn.Sequential(WNConv1d(channels, channels, kernel_size), _ChannelLayerNorm(channels))
                                   for _ in range(depth)])
-        self.lstm = nn.LSTM(channels, channels // 2, 1, batch_first=True, bidirectional=True)
+        self.lstm = EngineLSTM(channels, channels // 2)
         self._pk = None
 
     def _prepare(self, device):
@@ -96,8 +134,7 @@ class TextEncoder(_PackedCache, nn.Module):
             h = F.layer_norm(h.transpose(1, 2), (c[1].channels,), c[1].gamma, c[1].beta, c[1].eps).transpose(1, 2)
             h = F.leaky_relu(h, 0.2).contiguous()
             h.masked_fill_(mk, 0.0)
-        y = _bilstm(self.lstm, h.transpose(1, 2), input_lengths, m.shape[-1])
-        y = y.transpose(-1, -2).contiguous()
+        y = self.lstm.forward_cm(h, _device_lengths(input_lengths, h.shape[2], h.device))  # [B, C, N]
         y.masked_fill_(mk, 0.0)
         return y
 
@@ -123,8 +160,7 @@ class DurationEncoder(nn.Module):
         super().__init__()
         self.lstms = nn.ModuleList()
         for _ in range(nlayers):
-            self.lstms.append(nn.LSTM(d_model + sty_dim, d_model // 2, num_layers=1, batch_first=True,
-                                      bidirectional=True))
+            self.lstms.append(EngineLSTM(d_model + sty_dim, d_model // 2))
             self.lstms.append(_AdaLayerNorm(sty_dim, d_model))
         self.d_model, self.sty_dim = d_model, sty_dim
 
@@ -133,6 +169,7 @@ class DurationEncoder(nn.Module):
         """x [B, d_model, N], style [B, sty] -> [B, N, d_model + sty]."""
         mk = m.to(x.device)
         N = x.shape[2]
+        lens = _device_lengths(text_lengths, N, x.device)
         s = style.unsqueeze(1).expand(-1, N, -1)
         h = torch.cat([x.transpose(1, 2), s], dim=-1)
         h = h.masked_fill(mk.unsqueeze(-1), 0.0)
@@ -142,7 +179,7 @@ class DurationEncoder(nn.Module):
                 h = torch.cat([h, s], dim=-1)
                 h = h.masked_fill(mk.unsqueeze(-1), 0.0)
             else:
-                h = _bilstm(block, h, text_lengths, m.shape[-1])
+                h = block.forward_cm(h.transpose(1, 2).contiguous(), lens).transpose(1, 2)
         return h
 
 
@@ -164,9 +201,9 @@ class ProsodyPredictor(_PackedCache, nn.Module):
     def __init__(self, style_dim, d_hid, nlayers, max_dur=50, dropout=0.1):
         super().__init__()
         self.text_encoder = DurationEncoder(sty_dim=style_dim, d_model=d_hid, nlayers=nlayers, dropout=dropout)
-        self.lstm = nn.LSTM(d_hid + style_dim, d_hid // 2, 1, batch_first=True, bidirectional=True)
+        self.lstm = EngineLSTM(d_hid + style_dim, d_hid // 2)
         self.duration_proj = _LinearNorm(d_hid, max_dur)
-        self.shared = nn.LSTM(d_hid + style_dim, d_hid // 2, 1, batch_first=True, bidirectional=True)
+        self.shared = EngineLSTM(d_hid + style_dim, d_hid // 2)
         mk = lambda: nn.ModuleList([AdainResBlk1dParams(d_hid, d_hid, style_dim),
                                     AdainResBlk1dParams(d_hid, d_hid // 2, style_dim, upsample=True),
                                     AdainResBlk1dParams(d_hid // 2, d_hid // 2, style_dim)])
@@ -194,9 +231,7 @@ class ProsodyPredictor(_PackedCache, nn.Module):
     def F0Ntrain(self, x, s):
         """x [B, d_hid+sty, T] -> (F0 [B, 2T], N [B, 2T]); models.py:497-510."""
         pk = self._packed(x.device)
-        self.shared.flatten_parameters()
-        y, _ = self.shared(x.transpose(-1, -2))
-        y = y.transpose(-1, -2).contiguous()
+        y = self.shared.forward_cm(x.float().contiguous())  # [B, d_hid, T]
         h = pk.bank.run(s.float())
         outs = []
         for blocks, (pw, pb) in ((pk.F0, (pk.f0p_w, pk.f0p_b)), (pk.N, (pk.np_w, pk.np_b))):

@@ -255,3 +255,26 @@ def test_token_glue():
     y, z = torch.randn(3, 40, 101, generator=gen), torch.randn(3, 40, 101, generator=gen)
     assert rel_err(ops.axpbypcz(g(x), 0.3, g(y), -1.2, g(z), 2.0), R.axpbypcz(x, 0.3, y, -1.2, z, 2.0)) < 1e-6
     assert rel_err(ops.axpbypcz(g(x), 0.3, g(y), -1.2), R.axpbypcz(x, 0.3, y, -1.2)) < 1e-6
+
+
+@pytest.mark.parametrize("B,N,ragged", [(2, 17, False), (3, 40, True)])
+def test_lstm_bidir_matches_torch_lstm(B, N, ragged):
+    """Input projection on st2_conv1d + st2_lstm_bidir == nn.LSTM(bidirectional) with pack/pad semantics."""
+    from styletts2_amd.text import EngineLSTM
+    torch.manual_seed(N)
+    lstm = EngineLSTM(640, 256)
+    ref_lstm = torch.nn.LSTM(640, 256, 1, batch_first=True, bidirectional=True)
+    ref_lstm.load_state_dict(lstm.state_dict())
+    x = torch.randn(B, N, 640)
+    lengths = torch.tensor([N, N - 7, 5][:B]) if ragged else torch.full((B,), N)
+    with torch.no_grad():
+        packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, batch_first=True, enforce_sorted=False)
+        ref, _ = torch.nn.utils.rnn.pad_packed_sequence(ref_lstm(packed)[0], batch_first=True, total_length=N)
+    lstm = lstm.to(DEV)
+    lens = lengths.to(torch.int32).to(DEV) if ragged else None
+    out = lstm.forward_cm(g(x).transpose(1, 2).contiguous(), lens).transpose(1, 2)
+    assert out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    if not ragged:
+        y, _ = lstm(g(x))
+        assert torch.equal(y, out)
