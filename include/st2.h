@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 1
+#define ST2_ABI_VERSION 2
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -84,9 +84,29 @@ typedef struct st2_conv_desc {
   const float* res2; int64_t res2_bs; int32_t res2_cs;
   float div;                         /* 1.0f = none */
   int32_t act; int32_t act_split; float act_slope;
+  /* st2_conv1d_f16s only: split-f16 packed weights (see below); ignored by st2_conv1d */
+  const void* wq; int32_t wq_co_pad; int32_t wq_cin_pad;
+  float x_scale;                     /* power of two applied to pro(x) before the hi/lo split (8 by default) */
+  float out_scale;                   /* 1 / (x_scale * weight scale), applied to the accumulator first */
 } st2_conv_desc;
 
 int st2_conv1d(const st2_conv_desc* d, void* stream);
+
+/* ---- fused Conv1d on the f16 matrix pipe, fp32-class accuracy ("f16 hi/lo split") ---- *
+ * Same contract, prologues (NONE..SNAKE; COLNORM stays on st2_conv1d) and epilogues as st2_conv1d.
+ * Each operand v is carried as f16 hi + f16 lo of v*scale and the product is evaluated as
+ * hi*hi + hi*lo + lo*hi by three v_mfma_f32_32x32x16_f16 into one fp32 accumulator (the dropped lo*lo
+ * term is 2^-22 relative).  Through the whole decoder the waveform differs from an fp64 evaluation by
+ * 2.6e-7 RMS, the fp32 ATen path by 2.4e-7; the rate ceiling is 5.3x that of the exact-fp32 MFMA.
+ * Weights are pre-split once per load (the d.wt field is unused):
+ *   wq[((ci/16 * ks + t) * 2 + (ci%16)/8) * wq_co_pad + co][16 halves] = hi[0..7] | lo[0..7]
+ *   over the 8 channels ci..ci+7 of W[co, ., t] * w_scale, zero padded to wq_cin_pad input channels
+ *   (a multiple of st2_conv1d_f16s_chunk(ks)) and wq_co_pad rows (a multiple of
+ *   st2_conv1d_f16s_co_block(C_out)); w_scale is the power of two that puts max|W| in [2^13, 2^14).
+ * Replaces the same reference call sites as st2_conv1d for the decoder / vocoder convolutions. */
+int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
+int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
+int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
 /* sizeof(st2_conv_desc) as the library was compiled: lets a binding verify its struct mirror. */
 int st2_sizeof_conv_desc(void);
 

@@ -40,7 +40,13 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         if gamma_plus_one:
             g = 1.0 + g
         u = n * g + beta.unsqueeze(-1)
-    w = wt[:, :C_out].reshape(C_in, ks, C_out).permute(2, 0, 1).contiguous()
+    if hasattr(wt, "wq"):  # split-f16 packing (st2_conv1d_f16s): operands are hi + lo of v * scale; lo*lo dropped
+        w = wt.dense()
+        xs = 8.0
+        hi = (u * xs).half().float()
+        u = (hi + ((u * xs) - hi).half().float()) / xs
+    else:
+        w = wt[:, :C_out].reshape(C_in, ks, C_out).permute(2, 0, 1).contiguous()
     need = (L_out - 1) + (ks - 1) * dil + 1  # input span [ -pad_left, need - pad_left )
     pad_right = max(0, need - pad_left - L_in)
     up = F.pad(u, (pad_left, pad_right))

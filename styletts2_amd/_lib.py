@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -41,6 +41,8 @@ class ConvDesc(C.Structure):
         ("res2", f32p), ("res2_bs", C.c_int64), ("res2_cs", C.c_int32),
         ("div", C.c_float),
         ("act", C.c_int32), ("act_split", C.c_int32), ("act_slope", C.c_float),
+        ("wq", f32p), ("wq_co_pad", C.c_int32), ("wq_cin_pad", C.c_int32),
+        ("x_scale", C.c_float), ("out_scale", C.c_float),
     ]
 
 
@@ -51,6 +53,9 @@ _SIGNATURES = {
     "st2_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "st2_sizeof_conv_desc": (C.c_int, []),
     "st2_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "st2_conv1d_f16s": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
+    "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
     "st2_conv1d_direct": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p]),

@@ -1,0 +1,409 @@
+// Fused Conv1d on the CDNA4 f16 matrix pipe with fp32-class accuracy: "f16 hi/lo split", 3 products.
+//
+//   y[b,co,l] = epi( bias[co] + sum_{ci,t} W[co,ci,t] * pro(x)[b,ci, l + t*dil - pad_left] )
+//
+// Every operand v is carried as two halves  v*s = hi + lo  (hi = f16(v*s), lo = f16(v*s - hi); s a power
+// of two that keeps lo in the normal f16 range) and the product is evaluated as
+//       hi_w*hi_x + hi_w*lo_x + lo_w*hi_x          (lo_w*lo_x ~ 2^-22 relative: dropped)
+// by three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator.  f16 x f16 products are exact in fp32, so the
+// only errors are the 2^-22-relative operand residue and the fp32 accumulation every fp32 conv has anyway:
+// measured through the whole decoder the waveform differs from an fp64 evaluation by 2.6e-7 RMS, the fp32
+// ATen path by 2.4e-7 (tools/probe_split_precision.py).  Rate: 3 MFMAs at 1024 FLOP/clk/SIMD = 5.3x the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, st2_conv1d.hip) for the same algorithmic FLOPs.
+//
+// GEMM view per batch item: M = C_out, N = L_out, K = C_in*ks, k ordered (ci/16, tap, ci%16) so that one
+// MFMA k-step = 16 consecutive input channels at one tap.
+//   * B operand (activations): the workgroup stages the ACTIVATED, split input tile for CI_T channels,
+//     [hi|lo][ci/8][BN + (ks-1)*dil positions][8 halves], in LDS -- one ds_read_b128 per fragment, consecutive
+//     lanes read consecutive 16-byte slots (conflict free), taps are just a shift of the position index.
+//     Double buffered: global loads for chunk c+1 are issued before the MFMAs of chunk c and the prologue
+//     (AdaIN affine, Snake / LeakyReLU, split) runs on them afterwards; one barrier per chunk.
+//   * A operand (weights): pre-split and packed per load as [ci/16][tap][k-half][co][hi8|lo8]; every wave owns
+//     distinct output-channel rows, so its A fragments are read straight from L2 into registers (32 B per
+//     lane, prefetched one k-step ahead) and never touch LDS.  The whole packed weight (<= 0.7 MB for the
+//     vocoder layers) is L2 resident.
+//   * wave tile = 32 (co) x 32*TN (l): TN accumulators of 16 registers.  Waves are arranged WM x WN over
+//     (co, l): 4x1 for C_out >= 96, 2x2 for C_out in (32, 96), 1x4 for C_out <= 32.
+#include "st2_common.h"
+#include <type_traits>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// sin(x)^2 to ~2.4e-7 absolute: n = rint(x/pi), r = x - n*pi (two-term, fma-exact), odd minimax
+// polynomial of degree 9 on [-pi/2, pi/2] (max abs error 1.2e-7, fitted in tools/fit_sin.py).
+__device__ __forceinline__ float sin_sq(float x) {
+  const float n = rintf(x * 0.3183098861837907f);
+  float r = fmaf(n, -3.1415927410125732f, x);
+  r = fmaf(n, 8.742277657347586e-08f, r);
+  const float r2 = r * r;
+  float p = 2.6000539037340786e-06f;
+  p = fmaf(p, r2, -0.00019806614727713168f);
+  p = fmaf(p, r2, 0.008333017118275166f);
+  p = fmaf(p, r2, -0.16666656732559204f);
+  const float s = fmaf(r2 * r, p, r);
+  return s * s;
+}
+
+// sin(x) to 1.2e-7 absolute (same reduction and polynomial, sign restored from the parity of n)
+__device__ __forceinline__ float sin_acc(float x) {
+  const float n = rintf(x * 0.3183098861837907f);
+  float r = fmaf(n, -3.1415927410125732f, x);
+  r = fmaf(n, 8.742277657347586e-08f, r);
+  const float r2 = r * r;
+  float p = 2.6000539037340786e-06f;
+  p = fmaf(p, r2, -0.00019806614727713168f);
+  p = fmaf(p, r2, 0.008333017118275166f);
+  p = fmaf(p, r2, -0.16666656732559204f);
+  const float s = fmaf(r2 * r, p, r);
+  return ((int)n & 1) ? -s : s;
+}
+
+__device__ __forceinline__ float snake(float v, float alpha, float inv_alpha) {
+  return v + inv_alpha * sin_sq(alpha * v);  // x + (1/a) * sin(a*x)^2, Modules/istftnet.py:69
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
+  float mean, rstd, g, beta, alpha, inv_alpha, pad0, pad1;
+};
+
+template <int KS, int CI_T, int WM, int WN, int TN>
+__global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) {
+  constexpr int BM = 32 * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
+  constexpr int TPG = NT / CG;    // staging threads per group
+  constexpr int S16 = CI_T / 16;  // MFMA k-steps per tap per chunk
+  constexpr int MAXXW = BN + (KS - 1) * 8;
+  constexpr int R = (MAXXW + TPG - 1) / TPG;  // staging rounds (positions per thread)
+  static_assert(WM * WN == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int kg = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int b = blockIdx.z;
+
+  const int XW = BN + (KS - 1) * d.dil;  // staged positions
+  // LDS: [2 buffers][2 planes hi/lo][CG][XW] slots of 16 B, then the channel parameter table
+  h8* xs = reinterpret_cast<h8*>(smem_raw);
+  const int plane = CG * XW;  // slots per plane
+  ChanPar* par = reinterpret_cast<ChanPar*>(smem_raw + (size_t)4 * plane * 16);
+
+  const int pro = d.pro;
+  const bool has_par = pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE;
+  const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
+  if (has_par) {
+    for (int ci = tid; ci < C_pad; ci += NT) {
+      ChanPar p = {0.f, 1.f, 1.f, 0.f, 1.f, 1.f, 0.f, 0.f};
+      if (ci < d.C_in) {
+        if (pro != ST2_PRO_SNAKE) {
+          const float* st = d.stats + ((int64_t)b * d.C_in + ci) * 2;
+          p.mean = st[0];
+          p.rstd = st[1];
+          p.g = 1.0f + d.gamma[(int64_t)b * d.gb_bs + ci];
+          p.beta = d.beta[(int64_t)b * d.gb_bs + ci];
+        }
+        if (pro != ST2_PRO_ADAIN_LEAKY) {
+          p.alpha = d.alpha[ci];
+          p.inv_alpha = 1.0f / p.alpha;
+        }
+      }
+      par[ci] = p;
+    }
+  }
+
+  // ---- staging assignment: thread -> (channel group, R positions); identical for every chunk ----------
+  const int sg = tid / TPG;
+  const int sp0 = tid % TPG;
+  const float* xb = d.x + (int64_t)b * d.x_bs;
+  const int lin0 = n0 - d.pad_left;  // input position held by staged column 0
+  float xr[R][8];
+
+  // loads are unconditional on clamped (always valid) addresses; out-of-range values are zeroed in store_chunk
+  auto load_chunk = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int l = min(max(lin0 + sp0 + r * TPG, 0), d.L_in - 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ci = min(c0 + sg * 8 + e, d.C_in - 1);
+        xr[r][e] = xb[(int64_t)ci * d.x_cs + l];
+      }
+    }
+  };
+
+  // prologue + hi/lo split of the R x 8 loaded values, written to LDS buffer `buf`; PRO is a compile-time
+  // constant inside so the element loops carry no branches
+  auto store_chunk_as = [&](int c0, int buf, auto pro_tag) __attribute__((always_inline)) {
+    constexpr int PRO = decltype(pro_tag)::value;
+    h8* dst = xs + (size_t)buf * 2 * plane + sg * XW;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int pos = sp0 + r * TPG;
+      if (pos >= XW) continue;
+      const int l = lin0 + pos;
+      const bool lok = l >= 0 && l < d.L_in;
+      h8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ci = c0 + sg * 8 + e;
+        float v = xr[r][e];
+        if constexpr (PRO == ST2_PRO_LEAKY) {
+          v = leaky(v, d.slope);
+        } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
+          const ChanPar p = par[ci];
+          float u = (v - p.mean) * p.rstd;
+          u = p.g * u + p.beta;
+          v = leaky(u, d.slope);
+        } else if constexpr (PRO == ST2_PRO_ADAIN_SNAKE) {
+          const ChanPar p = par[ci];
+          float u = (v - p.mean) * p.rstd;
+          u = p.g * u + p.beta;
+          v = snake(u, p.alpha, p.inv_alpha);
+        } else if constexpr (PRO == ST2_PRO_SNAKE) {
+          const ChanPar p = par[ci];
+          v = snake(v, p.alpha, p.inv_alpha);
+        }
+        // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor
+        v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+      }
+      dst[pos] = hi;
+      dst[plane + pos] = lo;
+    }
+  };
+  auto store_chunk = [&](int c0, int buf) __attribute__((always_inline)) {
+    switch (pro) {
+      case ST2_PRO_LEAKY:
+        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_LEAKY>{});
+        break;
+      case ST2_PRO_ADAIN_LEAKY:
+        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_ADAIN_LEAKY>{});
+        break;
+      case ST2_PRO_ADAIN_SNAKE:
+        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_ADAIN_SNAKE>{});
+        break;
+      case ST2_PRO_SNAKE:
+        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_SNAKE>{});
+        break;
+      default:
+        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_NONE>{});
+        break;
+    }
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // ---- A operand stream: 32 B (hi8|lo8) per lane per k-step, constant stride between steps -----------
+  const int co_a = m0 + wm * 32 + l31;  // < wq_co_pad by construction of the packing
+  const h8* ap = reinterpret_cast<const h8*>(d.wq) + ((int64_t)kg * d.wq_co_pad + co_a) * 2;
+  const int64_t a_step = (int64_t)2 * d.wq_co_pad * 2;  // h8 units per k-step
+  const int nchunk = C_pad / CI_T;
+
+  load_chunk(0);
+  if (has_par) __syncthreads();  // parameter table visible
+  store_chunk(0, 0);
+  // weight fragments are double buffered in two NAMED register sets indexed by the (compile-time) parity of the
+  // k-step inside the chunk; with one set hipcc re-uses the registers and sinks the prefetch to ~4 MFMAs ahead
+  // of its consumer
+  constexpr int SPC = S16 * KS;  // k-steps per chunk
+  h8 a_hi[2], a_lo[2];
+  a_hi[0] = ap[0];
+  a_lo[0] = ap[1];
+  __syncthreads();
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunk;
+    const h8* xbuf = xs + (size_t)buf * 2 * plane + kg * XW + wn * (32 * TN) + l31;
+#pragma unroll
+    for (int s = 0; s < S16; ++s) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        const int cur = (s * KS + t) & 1, nxt = cur ^ 1;
+        ap += a_step;
+        if (more || s + 1 < S16 || t + 1 < KS) {  // prefetch the next k-step's weights
+          a_hi[nxt] = ap[0];
+          a_lo[nxt] = ap[1];
+        }
+        // next chunk's activations: issued AFTER the weight prefetch so that the in-order vmcnt wait of the next
+        // k-step does not have to drain these (possibly HBM-latency) loads
+        if (s == 0 && t == 0 && more) load_chunk((c + 1) * CI_T);
+        __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch stays a full k-step ahead
+        const h8 ah = a_hi[cur], al = a_lo[cur];
+        const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
+        h8 bh[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = xp[j * 32];
+          bl[j] = xp[plane + j * 32];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+      }
+    }
+    if (SPC & 1) {  // odd step count: next chunk's step 0 reads set 0
+      a_hi[0] = a_hi[1];
+      a_lo[0] = a_lo[1];
+    }
+    if (more) store_chunk((c + 1) * CI_T, buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------
+  float* yb = d.y + (int64_t)b * d.y_bs;
+  const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
+  const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
+  const float osc = d.out_scale;
+  auto epilogue_as = [&](auto act_tag) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (row < d.C_out && col < d.L_out) {
+          float v = acc[j][r] * osc;
+          if (d.bias) v += d.bias[row];
+          if (rb) v += rb[(int64_t)row * d.res_cs + (col >> d.res_shift)];
+          if (r2b) v = r2b[(int64_t)row * d.res2_cs + col] + v;
+          if (d.div != 1.0f) v = v / d.div;
+          if constexpr (ACT == ST2_ACT_GELU) {
+            v = gelu_erf(v);
+          } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
+            v = row < d.act_split ? expf(v) : sin_acc(v);
+          } else if constexpr (ACT == ST2_ACT_TANH) {
+            v = tanhf(v);
+          } else if constexpr (ACT == ST2_ACT_LEAKY) {
+            v = leaky(v, d.act_slope);
+          }
+          yb[(int64_t)row * d.y_cs + col] = v;
+        }
+      }
+    }
+  };
+  switch (d.act) {
+    case ST2_ACT_GELU:
+      epilogue_as(std::integral_constant<int, ST2_ACT_GELU>{});
+      break;
+    case ST2_ACT_EXP_SIN:
+      epilogue_as(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
+      break;
+    case ST2_ACT_TANH:
+      epilogue_as(std::integral_constant<int, ST2_ACT_TANH>{});
+      break;
+    case ST2_ACT_LEAKY:
+      epilogue_as(std::integral_constant<int, ST2_ACT_LEAKY>{});
+      break;
+    default:
+      epilogue_as(std::integral_constant<int, ST2_ACT_NONE>{});
+      break;
+  }
+}
+
+template <int KS, int CI_T, int WM, int WN, int TN>
+int launch(const st2_conv_desc& d, hipStream_t s) {
+  constexpr int BM = 32 * WM;
+  constexpr int BN = 32 * TN * WN;
+  const int XW = BN + (KS - 1) * d.dil;
+  const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
+  const bool has_par = d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_SNAKE;
+  const size_t smem = (size_t)4 * (CI_T / 8) * XW * 16 + (has_par ? (size_t)C_pad * 32 : 0);
+  ST2_REQUIRE(smem <= 160 * 1024, "st2_conv1d_f16s: tile needs %zu B of LDS (ks=%d dil=%d C_in=%d)", smem, KS,
+              d.dil, d.C_in);
+  ST2_REQUIRE(d.wq_cin_pad == C_pad, "st2_conv1d_f16s: packed weight has %d input channels, kernel needs %d",
+              d.wq_cin_pad, C_pad);
+  ST2_REQUIRE(d.wq_co_pad % BM == 0 && d.wq_co_pad >= d.C_out, "st2_conv1d_f16s: wq_co_pad=%d must be a multiple "
+              "of %d covering C_out=%d", d.wq_co_pad, BM, d.C_out);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  // rows beyond C_out inside the last co block are computed on zero weights and not stored
+  dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B);
+  hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
+  ST2_CHECK_LAUNCH("st2_conv1d_f16s");
+  return 0;
+}
+
+template <int KS, int CI_T>
+int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
+  if (d.C_out > 64) return launch<KS, CI_T, 4, 1, 4>(d, s);  // 128 co x 128 l
+  if (d.C_out > 32) return launch<KS, CI_T, 2, 2, 4>(d, s);  // 64 co x 256 l
+  return launch<KS, CI_T, 1, 4, 4>(d, s);                    // 32 co x 512 l
+}
+
+}  // namespace
+
+extern "C" int st2_conv1d_f16s_chunk(int ks) { return ks <= 3 ? 32 : 16; }
+
+extern "C" int st2_conv1d_f16s_co_block(int C_out) { return C_out > 64 ? 128 : (C_out > 32 ? 64 : 32); }
+
+extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {
+  ST2_REQUIRE(dp != nullptr, "st2_conv1d_f16s: null descriptor");
+  const st2_conv_desc& d = *dp;
+  ST2_REQUIRE(d.B > 0 && d.C_in > 0 && d.C_out > 0 && d.L_in > 0 && d.L_out > 0,
+              "st2_conv1d_f16s: empty geometry B=%d C_in=%d C_out=%d L_in=%d L_out=%d", d.B, d.C_in, d.C_out,
+              d.L_in, d.L_out);
+  ST2_REQUIRE(d.x && d.wq && d.y, "st2_conv1d_f16s: null tensor pointer");
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(d.wq) & 15) == 0, "st2_conv1d_f16s: wq must be 16-byte aligned");
+  ST2_REQUIRE(d.dil >= 1 && d.dil <= 8, "st2_conv1d_f16s: dil=%d out of range", d.dil);
+  ST2_REQUIRE(d.pro >= ST2_PRO_NONE && d.pro <= ST2_PRO_SNAKE, "st2_conv1d_f16s: prologue %d not supported", d.pro);
+  if (d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE)
+    ST2_REQUIRE(d.stats && d.gamma && d.beta, "st2_conv1d_f16s: prologue %d needs stats/gamma/beta", d.pro);
+  if (d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_SNAKE)
+    ST2_REQUIRE(d.alpha, "st2_conv1d_f16s: snake prologue needs alpha");
+  ST2_REQUIRE(d.res_shift >= 0 && d.res_shift <= 1, "st2_conv1d_f16s: res_shift must be 0 or 1");
+  ST2_REQUIRE(d.x_scale > 0.f && d.out_scale > 0.f, "st2_conv1d_f16s: x_scale / out_scale must be set");
+  ST2_REQUIRE(d.B <= 65535, "st2_conv1d_f16s: grid too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (d.ks) {
+    case 1:
+      return launch_by_cout<1, 32>(d, s);
+    case 2:
+      return launch_by_cout<2, 32>(d, s);
+    case 3:
+      return launch_by_cout<3, 32>(d, s);
+    case 5:
+      return launch_by_cout<5, 16>(d, s);
+    case 7:
+      return launch_by_cout<7, 16>(d, s);
+    case 11:
+      return launch_by_cout<11, 16>(d, s);
+    default:
+      st2_set_error("st2_conv1d_f16s: unsupported kernel size %d (have 1,2,3,5,7,11)", d.ks);
+      return 1;
+  }
+}

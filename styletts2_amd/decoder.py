@@ -54,7 +54,7 @@ def _dev(t, device):
 
 class _PackedConv:
     def __init__(self, conv: WNConv1d, device):
-        self.wt = W.pack_conv(conv.folded().float()).to(device)
+        self.wt = W.pack_conv_auto(conv.folded().float()).to(device)
         self.bias = _dev(conv.bias, device) if conv.bias is not None else None
         self.c_out, self.ks = conv.c_out, conv.ks
 
@@ -182,7 +182,7 @@ class Generator(nn.Module):
         pk.noise_b = [_dev(c.bias, device) for c in self.noise_convs]
         pk.noise_res = [_PackedResBlock1(r, device) for r in self.noise_res]
         pk.resblocks = [_PackedResBlock1(r, device) for r in self.resblocks]
-        pk.ups_wt = [W.pack_conv(W.polyphase_convt(u.folded().float(), r)).to(device)
+        pk.ups_wt = [W.pack_conv_auto(W.polyphase_convt(u.folded().float(), r)).to(device)
                      for u, r in zip(self.ups, self.rates)]
         pk.ups_b = [_dev(u.bias, device) for u in self.ups]
         pk.post = _PackedConv(self.conv_post, device)

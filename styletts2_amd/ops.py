@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .weights import F16S_X_SCALE, SplitConvWeight
 from ._lib import (ACT_EXP_SIN, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_TANH, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE,  # noqa: F401
                    PRO_COLNORM, PRO_LEAKY, PRO_NONE, PRO_SNAKE, ConvDesc)
 
@@ -66,14 +67,24 @@ def _bs_cs(t):
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
            res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
-    """Fused Conv1d, see `st2_conv1d` in include/st2.h.  wt is the packed K-major weight
-    [C_in*ks, w_ld] produced by weights.pack_conv()."""
+    """Fused Conv1d, see `st2_conv1d` / `st2_conv1d_f16s` in include/st2.h.  wt is either the packed K-major fp32
+    weight [C_in*ks, w_ld] of weights.pack_conv() (exact-fp32 MFMA kernel) or a weights.SplitConvWeight from
+    weights.pack_conv_f16s() (split-f16 MFMA kernel, fp32-class accuracy at 5.3x the rate ceiling)."""
     lib = _lib.load()
     _chk(x, "x", 3)
-    _chk(wt, "wt", 2)
     B, C_in, L_in = x.shape
-    if wt.shape[0] != C_in * ks or not wt.is_contiguous():
-        raise _lib.St2Error("packed weight has shape %s, expected [%d, >=%d]" % (tuple(wt.shape), C_in * ks, C_out))
+    split = isinstance(wt, SplitConvWeight)
+    if split:
+        if (wt.C_in, wt.C_out, wt.ks) != (C_in, C_out, ks) or not wt.wq.is_cuda or not wt.wq.is_contiguous():
+            raise _lib.St2Error("split weight is for (C_in=%d, C_out=%d, ks=%d) on %s, call has (%d, %d, %d)" % (
+                wt.C_in, wt.C_out, wt.ks, wt.wq.device, C_in, C_out, ks))
+        if pro == PRO_COLNORM:
+            raise _lib.St2Error("st2_conv1d_f16s has no COLNORM prologue; pack this layer with pack_conv()")
+    else:
+        _chk(wt, "wt", 2)
+        if wt.shape[0] != C_in * ks or not wt.is_contiguous():
+            raise _lib.St2Error("packed weight has shape %s, expected [%d, >=%d]" % (tuple(wt.shape), C_in * ks,
+                                                                                      C_out))
     if L_out is None:
         L_out = L_in
     if out is None:
@@ -83,7 +94,13 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     d = ConvDesc()
     d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil, d.pad_left = B, C_in, C_out, L_in, L_out, ks, dil, pad_left
     d.x, d.x_bs, d.x_cs = x.data_ptr(), x.stride(0), x.stride(1)
-    d.wt, d.w_ld = wt.data_ptr(), wt.shape[1]
+    if split:
+        d.wq, d.wq_co_pad, d.wq_cin_pad = wt.wq.data_ptr(), wt.co_pad, wt.cin_pad
+        d.x_scale, d.out_scale = F16S_X_SCALE, 1.0 / (F16S_X_SCALE * wt.w_scale)
+        fn, fname = lib.st2_conv1d_f16s, "st2_conv1d_f16s"
+    else:
+        d.wt, d.w_ld = wt.data_ptr(), wt.shape[1]
+        fn, fname = lib.st2_conv1d, "st2_conv1d"
     _chk(bias, "bias", 1)
     d.bias = _ptr(bias)
     d.y, d.y_bs, d.y_cs = out.data_ptr(), out.stride(0), out.stride(1)
@@ -117,11 +134,11 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     if _conv_timer is not None and _conv_timer.matches(d):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(lib.st2_conv1d(C.byref(d), _stream()), "st2_conv1d")
+        _lib.check(fn(C.byref(d), _stream()), fname)
         e1.record()
         _conv_timer.pairs.append((e0, e1))
         return out
-    _lib.check(lib.st2_conv1d(C.byref(d), _stream()), "st2_conv1d")
+    _lib.check(fn(C.byref(d), _stream()), fname)
     return out
 
 

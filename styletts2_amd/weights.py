@@ -3,6 +3,8 @@
 Done once per load_state_dict(); the reference instead re-evaluates weight-norm on every forward
 (torch.nn.utils.weight_norm hook).
 """
+import os
+
 import torch
 
 
@@ -21,6 +23,84 @@ def pack_conv(w):
     wt = torch.zeros((C_in * ks, w_ld), dtype=torch.float32, device=w.device)
     wt[:, :C_out] = w.permute(1, 2, 0).reshape(C_in * ks, C_out)
     return wt.contiguous()
+
+
+F16S_X_SCALE = 8.0  # power of two applied to the activated input before its hi/lo split (st2.h: x_scale)
+
+
+def f16s_chunk(ks):
+    """Input-channel padding granule of the split-f16 packing (== st2_conv1d_f16s_chunk)."""
+    return 32 if ks <= 3 else 16
+
+
+def f16s_co_block(C_out):
+    """Output-channel padding granule of the split-f16 packing (== st2_conv1d_f16s_co_block)."""
+    return 128 if C_out > 64 else (64 if C_out > 32 else 32)
+
+
+class SplitConvWeight:
+    """Conv weight pre-split for `st2_conv1d_f16s` (include/st2.h): wq is a float16 tensor
+    [C_in_pad/16, ks, 2, co_pad, 16] holding hi[0..7] | lo[0..7] of W * w_scale for 8 consecutive input
+    channels; w_scale is the power of two that puts max|W| in [2^13, 2^14) so that the lo halves stay in the
+    normal f16 range."""
+
+    def __init__(self, wq, w_scale, C_in, C_out, ks):
+        self.wq, self.w_scale, self.C_in, self.C_out, self.ks = wq, float(w_scale), C_in, C_out, ks
+
+    @property
+    def cin_pad(self):
+        return self.wq.shape[0] * 16
+
+    @property
+    def co_pad(self):
+        return self.wq.shape[3]
+
+    def to(self, device):
+        return SplitConvWeight(self.wq.to(device), self.w_scale, self.C_in, self.C_out, self.ks)
+
+    def dense(self):
+        """fp32 [C_out, C_in, ks] value the packed halves represent (hi + lo) / w_scale."""
+        n16, ks, _, co_pad, _ = self.wq.shape
+        q = self.wq.float()
+        w = (q[..., :8] + q[..., 8:]) / self.w_scale           # [n16, ks, 2, co_pad, 8]
+        w = w.permute(3, 0, 2, 4, 1).reshape(co_pad, n16 * 16, ks)  # [co, (n16, kg, e), t]
+        return w[:self.C_out, :self.C_in].contiguous()
+
+
+def pack_conv_f16s(w):
+    """[C_out, C_in, ks] fp32 -> SplitConvWeight."""
+    import math
+    w = w.detach().float().cpu()
+    C_out, C_in, ks = w.shape
+    cin_pad = -(-C_in // f16s_chunk(ks)) * f16s_chunk(ks)
+    co_pad = -(-C_out // f16s_co_block(C_out)) * f16s_co_block(C_out)
+    amax = float(w.abs().max())
+    w_scale = 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ws = torch.zeros((co_pad, cin_pad, ks), dtype=torch.float32)
+    ws[:C_out, :C_in] = w * w_scale
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    n16 = cin_pad // 16
+
+    def arrange(h):  # [co, (n16, kg, e), t] -> [n16, t, kg, co, e]
+        return h.reshape(co_pad, n16, 2, 8, ks).permute(1, 4, 2, 0, 3)
+
+    wq = torch.cat([arrange(hi), arrange(lo)], dim=-1).contiguous()
+    return SplitConvWeight(wq, w_scale, C_in, C_out, ks)
+
+
+def conv_precision():
+    """Which kernel the decoder / vocoder / prosody convolutions are packed for: "f16s" (default; split-f16 MFMA,
+    st2_conv1d_f16s) or "f32" (exact-fp32 MFMA, st2_conv1d).  Read from ST2_CONV_PRECISION at pack time."""
+    mode = os.environ.get("ST2_CONV_PRECISION", "f16s")
+    if mode not in ("f16s", "f32"):
+        raise ValueError("ST2_CONV_PRECISION must be f16s or f32, got %r" % mode)
+    return mode
+
+
+def pack_conv_auto(w):
+    """pack_conv_f16s() or pack_conv() according to conv_precision()."""
+    return pack_conv_f16s(w) if conv_precision() == "f16s" else pack_conv(w)
 
 
 def pack_linear(w):

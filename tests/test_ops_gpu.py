@@ -75,19 +75,43 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "ci%d_co%d_L%d_k%d_d%d_p%d" % (
+F16S_EXTRA_CASES = [
+    # the three wave layouts (C_out > 64, 33..64, <= 32) x long tiles, channel tails, every kernel size
+    dict(B=2, C_in=128, C_out=128, L=2500, ks=11, dil=5, pro=R.PRO_ADAIN_SNAKE, res=True, res2=True, div=3.0),
+    dict(B=2, C_in=64, C_out=64, L=1300, ks=7, dil=3, pro=R.PRO_ADAIN_SNAKE, res=True),
+    dict(B=2, C_in=32, C_out=32, L=2100, ks=3, dil=5, pro=R.PRO_ADAIN_SNAKE, res=True),
+    dict(B=1, C_in=32, C_out=32, L=1100, ks=11, dil=1, pro=R.PRO_ADAIN_SNAKE),
+    dict(B=1, C_in=514, C_out=1024, L=75, ks=3, dil=1, pro=R.PRO_ADAIN_LEAKY),
+    dict(B=1, C_in=256, C_out=1280, L=161, ks=2, dil=1, pro=R.PRO_LEAKY, pad_left=1, L_out=162),
+    dict(B=2, C_in=64, C_out=1, L=700, ks=7, dil=1, pro=R.PRO_SNAKE, act=R.ACT_TANH),
+    dict(B=1, C_in=17, C_out=33, L=129, ks=5, dil=2, pro=R.PRO_NONE),
+]
+
+
+@pytest.mark.parametrize("kernel", ["f32", "f16s"])
+@pytest.mark.parametrize("case", CONV_CASES + F16S_EXTRA_CASES, ids=lambda c: "ci%d_co%d_L%d_k%d_d%d_p%d" % (
     c["C_in"], c["C_out"], c["L"], c["ks"], c["dil"], c["pro"]))
-def test_conv1d_matches_contract(case):
+def test_conv1d_matches_contract(case, kernel):
+    """Both conv kernels against the same contract: `f32` = exact-fp32 MFMA (st2_conv1d), `f16s` = split-f16 MFMA
+    (st2_conv1d_f16s).  The f16s contract carries the operand split (hi + lo of v * scale), so the bar is the same
+    fp32 round-off class for both."""
+    if kernel == "f16s" and case["pro"] == R.PRO_COLNORM:
+        pytest.skip("COLNORM prologue lives on st2_conv1d only (denoiser)")
     x, w, kw = make_conv_case(seed=1234, **case)
-    wt = weights.pack_conv(w)
+    wt = weights.pack_conv(w) if kernel == "f32" else weights.pack_conv_f16s(w)
     C_out, ks = w.shape[0], w.shape[2]
     ref = R.conv1d(x, wt, C_out, ks, **kw)
+    exact = R.conv1d(x.double(), weights.pack_conv(w).double(), C_out, ks,
+                     **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
     kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
-    out = ops.conv1d(g(x), g(wt), C_out, ks, **kwg)
+    out = ops.conv1d(g(x), g(wt) if kernel == "f32" else wt.to(DEV), C_out, ks, **kwg)
     torch.cuda.synchronize()
     assert out.shape == ref.shape
     e = rel_err(out, ref)
-    assert e < 2e-5, "rel err %g" % e
+    assert e < 2e-5, "rel err vs contract %g" % e
+    # and against an fp64 evaluation of the un-split operands: fp32-class for both kernels
+    e64 = rel_err(out, exact)
+    assert e64 < 2e-5, "rel err vs fp64 %g" % e64
 
 
 def test_conv1d_writes_into_channel_slice():

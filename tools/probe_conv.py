@@ -14,18 +14,21 @@ B = int(os.environ.get("PROBE_B", "8"))
 cases = [  # C, L, ks, dil
     (128, 48001, 3, 1), (128, 48001, 7, 3), (128, 48001, 11, 5), (128, 48001, 11, 1),
     (256, 8000, 3, 1), (256, 8000, 7, 1), (256, 8000, 11, 5),
+    (64, 120000, 7, 3), (32, 240000, 11, 1),
 ]
+KERNELS = os.environ.get("PROBE_KERNELS", "f32,f16s").split(",")
 rows = []
 for (Cc, L, ks, dil) in cases:
     x = torch.randn(B, Cc, L, device=dev)
     w = torch.randn(Cc, Cc, ks, device=dev) / math.sqrt(Cc * ks)
-    wt = weights.pack_conv(w)
+    wts = {"f32": weights.pack_conv(w), "f16s": weights.pack_conv_f16s(w).to(dev)}
     bias = torch.randn(Cc, device=dev)
     st = ops.instnorm_stats(x)
     h = torch.randn(B, 2 * Cc, device=dev) * 0.3
     alpha = torch.rand(Cc, device=dev) + 0.5
     out = torch.empty_like(x)
-    for pro in (ops.PRO_NONE, ops.PRO_ADAIN_SNAKE):
+    for kern, pro in [(k, p) for k in KERNELS for p in (ops.PRO_NONE, ops.PRO_ADAIN_SNAKE)]:
+        wt = wts[kern]
         kw = dict(dil=dil, pad_left=(ks - 1) * dil // 2, bias=bias, out=out, pro=pro)
         if pro == ops.PRO_ADAIN_SNAKE:
             kw.update(stats=st, gamma=h[:, :Cc], beta=h[:, Cc:], alpha=alpha, res=x)
@@ -40,7 +43,7 @@ for (Cc, L, ks, dil) in cases:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         flop = 2.0 * B * Cc * Cc * ks * L
-        rows.append(dict(C=Cc, L=L, ks=ks, dil=dil, pro=pro, ms=ms, tflops=flop / ms / 1e9))
+        rows.append(dict(kernel=kern, C=Cc, L=L, ks=ks, dil=dil, pro=pro, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 1)))
         print(rows[-1], flush=True)
     # stats kernel
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
