@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 2
+#define ST2_ABI_VERSION 3
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -93,7 +93,7 @@ typedef struct st2_conv_desc {
 int st2_conv1d(const st2_conv_desc* d, void* stream);
 
 /* ---- fused Conv1d on the f16 matrix pipe, fp32-class accuracy ("f16 hi/lo split") ---- *
- * Same contract, prologues (NONE..SNAKE; COLNORM stays on st2_conv1d) and epilogues as st2_conv1d.
+ * Same contract, prologues and epilogues as st2_conv1d.
  * Each operand v is carried as f16 hi + f16 lo of v*scale and the product is evaluated as
  * hi*hi + hi*lo + lo*hi by three v_mfma_f32_32x32x16_f16 into one fp32 accumulator (the dropped lo*lo
  * term is 2^-22 relative).  Through the whole decoder the waveform differs from an fp64 evaluation by
@@ -103,7 +103,7 @@ int st2_conv1d(const st2_conv_desc* d, void* stream);
  *   over the 8 channels ci..ci+7 of W[co, ., t] * w_scale, zero padded to wq_cin_pad input channels
  *   (a multiple of st2_conv1d_f16s_chunk(ks)) and wq_co_pad rows (a multiple of
  *   st2_conv1d_f16s_co_block(C_out)); w_scale is the power of two that puts max|W| in [2^13, 2^14).
- * Replaces the same reference call sites as st2_conv1d for the decoder / vocoder convolutions. */
+ * Replaces the same reference call sites as st2_conv1d (decoder / vocoder convolutions, denoiser Linears). */
 int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
 int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
 int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
@@ -120,6 +120,14 @@ int st2_conv1d_direct(const float* x, int64_t x_bs, int32_t x_cs,
                       float* y, int64_t y_bs, int32_t y_cs,
                       int32_t B, int32_t C_in, int32_t C_out, int32_t L_in, int32_t L_out,
                       int32_t ks, int32_t stride, int32_t pad, void* stream);
+
+/* ---- polyphase split of a strided Conv1d input (kernel = 2*stride, the noise_convs of both vocoders) -------- *
+ * xp[b][ci*stride + r][u] = x[b][ci][u*stride + r - pad]  for u in [0,Lu), r in [0,stride); 0 outside [0,L_in).
+ * With weights.polyphase_strided_conv() the strided conv becomes a stride-1, k=2 st2_conv1d over C*stride
+ * channels (L_out = Lu - 1) on the matrix pipe.
+ * Replaces the im2col inside F.conv1d(stride=s): Modules/istftnet.py:332-336,361, Modules/hifigan.py:296-300,330. */
+int st2_phase_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L_in,
+                    int32_t stride, int32_t pad, float* xp, int64_t p_bs, int32_t p_cs, int32_t Lu, void* stream);
 
 /* ---- InstanceNorm1d statistics ------------------------------------------------------ *
  * stats[b][c] = (mean, 1/sqrt(biased_var + eps)) over l in [0,L).  fp64 accumulation in a

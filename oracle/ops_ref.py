@@ -86,6 +86,13 @@ def conv1d_direct(x, w, bias, stride, pad, L_out=None, out=None):
     return y
 
 
+def phase_split(x, stride, pad, Lu):
+    B, Cc, L = x.shape
+    need = Lu * stride
+    xpad = F.pad(x, (pad, max(0, need - pad - L)))[:, :, :need]
+    return xpad.reshape(B, Cc, Lu, stride).permute(0, 1, 3, 2).reshape(B, Cc * stride, Lu).contiguous()
+
+
 def instnorm_stats(x, eps=1e-5, out=None):
     xd = x.double()
     mean = xd.mean(dim=2)

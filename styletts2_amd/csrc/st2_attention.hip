@@ -1,63 +1,126 @@
-// Unmasked multi-head attention for the style-diffusion denoiser (N <= 512 tokens, 8 heads x 64).
-// Tensors are channel-major ([B][H*D][N]) so the q/k/v projections are k=1 convs on the MFMA path.
-// ~0.1 % of the path's FLOPs: a VALU kernel, one query per lane, K/V tiles broadcast from LDS,
-// online softmax in fp32.
+// Unmasked multi-head attention for the style-diffusion denoiser (N <= 512 tokens, 8 heads x 64), exact fp32 on
+// the matrix pipe (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain).
+// Tensors are channel-major ([B][H*D][N]): exactly the operand layout the 32x32x2 MFMA wants, so neither Q, K
+// nor V is ever transposed.
+//
+//   S^T tile [32 keys x 32 queries] = K_tile . Q_tile^T      A = K[d][m] (LDS), B = Q[d][q] (registers)
+//   O^T tile [32 d    x 32 queries] += V[d][m] . P^T[m][q]   A = V[d][m] (LDS), B = the lane's own P registers
+//
+// The C/D layout of S^T puts query (lane & 31) in every lane with 16 of the 32 keys in its registers -- keys
+// (r&3)+8(r>>2)+4(lane>>5) -- which is exactly the (k = lane>>5) operand split the next MFMA needs for P^T, so
+// softmax probabilities feed the PV product without leaving their registers.  The online-softmax state is
+// per query: the running max is shared between lanes l and l^32 with one shuffle per key tile.
 #include "st2_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int AD = 64;   // head features (fixed by the reference config)
-constexpr int AKT = 64;  // keys per LDS tile
+constexpr int AD = 64;         // head features (fixed by the reference config)
+constexpr int AKT = 128;       // keys per LDS chunk
+constexpr int ALD = AKT + 1;   // LDS row stride (odd: the V^T reads walk d across lanes)
+constexpr int AQB = 128;       // queries per workgroup (4 waves x 32)
 
-__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v, int64_t bs, int cs,
-                                                       float* __restrict__ o, int64_t o_bs, int o_cs, int N,
-                                                       float scale) {
-  __shared__ float ks[AD][AKT];
-  __shared__ float vs[AD][AKT];
-  const int n = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, int64_t bs, int cs,
+                                                        float* __restrict__ o, int64_t o_bs, int o_cs, int N,
+                                                        float scale) {
+  extern __shared__ __attribute__((aligned(16))) float att_smem[];  // 2 x 64 x 129 floats = 66 KB (dynamic: > 64 KB)
+  float* ks = att_smem;
+  float* vs = att_smem + AD * ALD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
   const int h = blockIdx.y;
   const int b = blockIdx.z;
-  const bool live = n < N;
+  const int q0 = blockIdx.x * AQB + wave * 32;
   const int64_t base = (int64_t)b * bs + (int64_t)h * AD * cs;
+  const int nq = q0 + l31;
+  const bool wave_live = q0 < N;  // a wave whose 32 queries are all out of range still helps staging
 
-  float qr[AD];
+  // B operand of the QK product: Q[d = 2i + half][q0 + l31], pre-multiplied by nothing (scale is applied to S)
+  float qr[AD / 2];
 #pragma unroll
-  for (int d = 0; d < AD; ++d) qr[d] = live ? q[base + (int64_t)d * cs + n] : 0.f;
-  float acc[AD];
+  for (int i = 0; i < AD / 2; ++i)
+    qr[i] = (wave_live && nq < N) ? q[base + (int64_t)(2 * i + half) * cs + nq] : 0.f;
+
+  f32x16 oacc[2];
 #pragma unroll
-  for (int d = 0; d < AD; ++d) acc[d] = 0.f;
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
   float mx = -INFINITY, den = 0.f;
 
-  for (int m0 = 0; m0 < N; m0 += AKT) {
-    const int mt = min(AKT, N - m0);
+  for (int c0 = 0; c0 < N; c0 += AKT) {
+    const int ct = min(AKT, N - c0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AD * AKT; e += 64) {
+    for (int e = tid; e < AD * AKT; e += 256) {
       const int d = e / AKT, mm = e % AKT;
-      const bool ok = mm < mt;
-      ks[d][mm] = ok ? k[base + (int64_t)d * cs + m0 + mm] : 0.f;
-      vs[d][mm] = ok ? v[base + (int64_t)d * cs + m0 + mm] : 0.f;
+      const bool ok = mm < ct;
+      ks[d * ALD + mm] = ok ? k[base + (int64_t)d * cs + c0 + mm] : 0.f;
+      vs[d * ALD + mm] = ok ? v[base + (int64_t)d * cs + c0 + mm] : 0.f;
     }
     __syncthreads();
-    for (int mm = 0; mm < mt; ++mm) {
-      float s = 0.f;
+    if (!wave_live) continue;
+    for (int m0 = 0; m0 < ct; m0 += 32) {
+      // ---- S^T = K . Q^T -------------------------------------------------------------------------------
+      f32x16 s;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) s = fmaf(qr[d], ks[d][mm], s);
-      s *= scale;
-      const float nmx = fmaxf(mx, s);
-      const float corr = expf(mx - nmx);
-      const float p = expf(s - nmx);
-      den = den * corr + p;
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-      for (int d = 0; d < AD; ++d) acc[d] = fmaf(p, vs[d][mm], acc[d] * corr);
+      for (int i = 0; i < AD / 2; ++i) {
+        const float a = ks[(2 * i + half) * ALD + m0 + l31];
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qr[i], s, 0, 0, 0);
+      }
+      // ---- online softmax over this tile's keys (rows), per query (column) -------------------------------
+      float tmx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        s[r] = key < ct ? s[r] * scale : -INFINITY;
+        tmx = fmaxf(tmx, s[r]);
+      }
+      tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));  // key m0 is always in range: tmx is finite
+      const float nmx = fmaxf(mx, tmx);
+      const float corr = expf(mx - nmx);  // 0 on the first tile (mx = -inf)
       mx = nmx;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = expf(s[r] - nmx);
+        psum += s[r];
+      }
+      den = den * corr + psum;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
+      // ---- O^T += V . P^T: k-step r pairs key (r&3)+8(r>>2) (lanes < 32) with the same +4 (lanes >= 32) ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float a = vs[(t * 32 + l31) * ALD + key];
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], oacc[t], 0, 0, 0);
+        }
+      }
     }
   }
-  if (live) {
+  if (!wave_live) return;
+  den += __shfl_xor(den, 32, 64);
+  if (nq < N) {
     const float inv = 1.0f / den;
     const int64_t ob = (int64_t)b * o_bs + (int64_t)h * AD * o_cs;
 #pragma unroll
-    for (int d = 0; d < AD; ++d) o[ob + (int64_t)d * o_cs + n] = acc[d] * inv;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        o[ob + (int64_t)d * o_cs + nq] = oacc[t][r] * inv;
+      }
   }
 }
 
@@ -68,9 +131,17 @@ extern "C" int st2_attention(const float* q, const float* k, const float* v, int
                              void* stream) {
   ST2_REQUIRE(q && k && v && o && B > 0 && H > 0 && N > 0, "st2_attention: bad arguments");
   ST2_REQUIRE(D == AD, "st2_attention: head_features=%d unsupported (built for %d)", D, AD);
+  ST2_REQUIRE(B <= 65535 && H <= 65535, "st2_attention: grid too large");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(attention_kernel, dim3(st2_cdiv(N, 64), H, B), dim3(64), 0, s, q, k, v, bs, cs, o, o_bs, o_cs,
-                     N, scale);
+  constexpr size_t smem = (size_t)2 * AD * ALD * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(attention_kernel, dim3(st2_cdiv(N, AQB), H, B), dim3(256), smem, s, q, k, v, bs, cs, o, o_bs,
+                     o_cs, N, scale);
   ST2_CHECK_LAUNCH("st2_attention");
   return 0;
 }

@@ -109,20 +109,25 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
   ChanPar* par = reinterpret_cast<ChanPar*>(smem_raw + (size_t)4 * plane * 16);
 
   const int pro = d.pro;
-  const bool has_par = pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE;
+  const bool has_par = pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE ||
+                       pro == ST2_PRO_COLNORM;
   const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
   if (has_par) {
     for (int ci = tid; ci < C_pad; ci += NT) {
       ChanPar p = {0.f, 1.f, 1.f, 0.f, 1.f, 1.f, 0.f, 0.f};
       if (ci < d.C_in) {
-        if (pro != ST2_PRO_SNAKE) {
+        if (pro == ST2_PRO_COLNORM) {  // per-channel affine of a LayerNorm over channels (statistics are per position)
+          const float g = d.gamma[(int64_t)b * d.gb_bs + ci];
+          p.g = d.gamma_plus_one ? 1.0f + g : g;
+          p.beta = d.beta[(int64_t)b * d.gb_bs + ci];
+        } else if (pro != ST2_PRO_SNAKE) {
           const float* st = d.stats + ((int64_t)b * d.C_in + ci) * 2;
           p.mean = st[0];
           p.rstd = st[1];
           p.g = 1.0f + d.gamma[(int64_t)b * d.gb_bs + ci];
           p.beta = d.beta[(int64_t)b * d.gb_bs + ci];
         }
-        if (pro != ST2_PRO_ADAIN_LEAKY) {
+        if (pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE) {
           p.alpha = d.alpha[ci];
           p.inv_alpha = 1.0f / p.alpha;
         }
@@ -162,6 +167,12 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
       if (pos >= XW) continue;
       const int l = lin0 + pos;
       const bool lok = l >= 0 && l < d.L_in;
+      float cmean = 0.f, crstd = 1.f;
+      if constexpr (PRO == ST2_PRO_COLNORM) {
+        const float* st = d.stats + ((int64_t)b * d.L_in + min(max(l, 0), d.L_in - 1)) * 2;
+        cmean = st[0];
+        crstd = st[1];
+      }
       h8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -182,6 +193,10 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
         } else if constexpr (PRO == ST2_PRO_SNAKE) {
           const ChanPar p = par[ci];
           v = snake(v, p.alpha, p.inv_alpha);
+        } else if constexpr (PRO == ST2_PRO_COLNORM) {
+          const ChanPar p = par[ci];
+          const float u = (v - cmean) * crstd;
+          v = u * p.g + p.beta;
         }
         // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor
         v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
@@ -206,6 +221,9 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
         break;
       case ST2_PRO_SNAKE:
         store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_SNAKE>{});
+        break;
+      case ST2_PRO_COLNORM:
+        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_COLNORM>{});
         break;
       default:
         store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_NONE>{});
@@ -337,7 +355,8 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   constexpr int BN = 32 * TN * WN;
   const int XW = BN + (KS - 1) * d.dil;
   const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
-  const bool has_par = d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_SNAKE;
+  const bool has_par = d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_SNAKE ||
+                       d.pro == ST2_PRO_COLNORM;
   const size_t smem = (size_t)4 * (CI_T / 8) * XW * 16 + (has_par ? (size_t)C_pad * 32 : 0);
   ST2_REQUIRE(smem <= 160 * 1024, "st2_conv1d_f16s: tile needs %zu B of LDS (ks=%d dil=%d C_in=%d)", smem, KS,
               d.dil, d.C_in);
@@ -380,8 +399,8 @@ extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(d.x && d.wq && d.y, "st2_conv1d_f16s: null tensor pointer");
   ST2_REQUIRE((reinterpret_cast<uintptr_t>(d.wq) & 15) == 0, "st2_conv1d_f16s: wq must be 16-byte aligned");
   ST2_REQUIRE(d.dil >= 1 && d.dil <= 8, "st2_conv1d_f16s: dil=%d out of range", d.dil);
-  ST2_REQUIRE(d.pro >= ST2_PRO_NONE && d.pro <= ST2_PRO_SNAKE, "st2_conv1d_f16s: prologue %d not supported", d.pro);
-  if (d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE)
+  ST2_REQUIRE(d.pro >= ST2_PRO_NONE && d.pro <= ST2_PRO_COLNORM, "st2_conv1d_f16s: prologue %d not supported", d.pro);
+  if (d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_COLNORM)
     ST2_REQUIRE(d.stats && d.gamma && d.beta, "st2_conv1d_f16s: prologue %d needs stats/gamma/beta", d.pro);
   if (d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_SNAKE)
     ST2_REQUIRE(d.alpha, "st2_conv1d_f16s: snake prologue needs alpha");

@@ -31,6 +31,23 @@ __global__ __launch_bounds__(256) void conv1d_direct_kernel(const float* __restr
   y[(int64_t)b * y_bs + (int64_t)co * y_cs + l] = acc;
 }
 
+// Polyphase split of a strided conv's input: xp[b][ci*stride + r][u] = x[b][ci][u*stride + r - pad] (0 outside).
+// Lanes run along the INPUT position p (coalesced reads); a wave's 64 positions scatter to `stride` output rows in
+// runs of 64/stride consecutive u.
+__global__ __launch_bounds__(256) void phase_split_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs, int L_in,
+                                                          float* __restrict__ xp, int64_t p_bs, int p_cs, int Lu,
+                                                          int stride, int pad) {
+  const int pp = blockIdx.x * 256 + threadIdx.x;  // shifted position p + pad = u*stride + r, in [0, Lu*stride)
+  const int ci = blockIdx.y;
+  const int b = blockIdx.z;
+  if (pp >= Lu * stride) return;
+  const int u = pp / stride;
+  const int r = pp - u * stride;
+  const int p = pp - pad;
+  const float v = (p >= 0 && p < L_in) ? x[(int64_t)b * x_bs + (int64_t)ci * x_cs + p] : 0.f;
+  xp[(int64_t)b * p_bs + (int64_t)(ci * stride + r) * p_cs + u] = v;
+}
+
 __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __restrict__ ph, int64_t p_bs, int p_cs,
                                                                int Lq, const float* __restrict__ bias,
                                                                const float* __restrict__ add, int64_t a_bs, int a_cs,
@@ -135,6 +152,19 @@ extern "C" int st2_conv1d_direct(const float* x, int64_t x_bs, int32_t x_cs, con
   hipLaunchKernelGGL(conv1d_direct_kernel, dim3(st2_cdiv(L_out, 256), C_out, B), dim3(256), 0, s, x, x_bs, x_cs, w,
                      bias, y, y_bs, y_cs, C_in, L_in, L_out, ks, stride, pad);
   ST2_CHECK_LAUNCH("st2_conv1d_direct");
+  return 0;
+}
+
+extern "C" int st2_phase_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L_in,
+                               int32_t stride, int32_t pad, float* xp, int64_t p_bs, int32_t p_cs, int32_t Lu,
+                               void* stream) {
+  ST2_REQUIRE(x && xp && B > 0 && C > 0 && L_in > 0 && stride > 0 && pad >= 0 && Lu > 0,
+              "st2_phase_split: bad arguments");
+  ST2_REQUIRE(C <= 65535 && B <= 65535 && (int64_t)Lu * stride < (int64_t)1 << 31, "st2_phase_split: grid too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(phase_split_kernel, dim3(st2_cdiv((int64_t)Lu * stride, 256), C, B), dim3(256), 0, s, x, x_bs,
+                     x_cs, L_in, xp, p_bs, p_cs, Lu, stride, pad);
+  ST2_CHECK_LAUNCH("st2_phase_split");
   return 0;
 }
 

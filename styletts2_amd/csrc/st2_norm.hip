@@ -42,25 +42,54 @@ __global__ __launch_bounds__(NT) void instnorm_stats_kernel(const float* __restr
   }
 }
 
-// LayerNorm over channels of an NCL tensor: one thread per (b, l) column, lanes along l (coalesced).
-__global__ __launch_bounds__(64) void colnorm_stats_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs, int C,
-                                                           int L, float eps, float* __restrict__ stats) {
-  const int l = blockIdx.x * 64 + threadIdx.x;
+// LayerNorm over channels of an NCL tensor.  Workgroup = 64 positions x CW channel slices: lanes run along l
+// (coalesced 256-byte rows), wave w sums channels w, w+CW, ... in fp64 with 8 independent loads in flight, and
+// the CW partials are combined through LDS in a fixed order (bitwise reproducible).
+constexpr int CW = 16;
+__global__ __launch_bounds__(64 * CW) void colnorm_stats_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                                int C, int L, float eps, float* __restrict__ stats) {
+  __shared__ double red[2][CW][64];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int l = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  if (l >= L) return;
-  const float* xb = x + (int64_t)b * x_bs + l;
+  const bool live = l < L;
+  const float* xb = x + (int64_t)b * x_bs + (live ? l : 0);
   double s = 0.0, ss = 0.0;
-  for (int c = 0; c < C; ++c) {
-    const double v = (double)xb[(int64_t)c * x_cs];
-    s += v;
-    ss += v * v;
+  int c = w;
+  for (; c + 7 * CW < C; c += 8 * CW) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)(c + u * CW) * x_cs];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double dv = (double)v[u];
+      s += dv;
+      ss += dv * dv;
+    }
   }
-  const double mean = s / (double)C;
-  double var = ss / (double)C - mean * mean;
-  if (var < 0.0) var = 0.0;
-  float* o = stats + ((int64_t)b * L + l) * 2;
-  o[0] = (float)mean;
-  o[1] = (float)(1.0 / sqrt(var + (double)eps));
+  for (; c < C; c += CW) {
+    const double dv = (double)xb[(int64_t)c * x_cs];
+    s += dv;
+    ss += dv * dv;
+  }
+  red[0][w][lane] = s;
+  red[1][w][lane] = ss;
+  __syncthreads();
+  if (w == 0 && live) {
+    double ts = 0.0, tss = 0.0;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+      ts += red[0][i][lane];
+      tss += red[1][i][lane];
+    }
+    const double mean = ts / (double)C;
+    double var = tss / (double)C - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* o = stats + ((int64_t)b * L + l) * 2;
+    o[0] = (float)mean;
+    o[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // h[b][j] = bias[j] + sum_k s[b][k] * wt[k*J + j]; one thread per j, all batch rows in registers
@@ -116,7 +145,7 @@ extern "C" int st2_colnorm_stats(const float* x, int64_t x_bs, int32_t x_cs, int
                                  float eps, float* stats, void* stream) {
   ST2_REQUIRE(x && stats && B > 0 && C > 0 && L > 0, "st2_colnorm_stats: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(colnorm_stats_kernel, dim3(st2_cdiv(L, 64), B), dim3(64), 0, s, x, x_bs, x_cs, C, L, eps,
+  hipLaunchKernelGGL(colnorm_stats_kernel, dim3(st2_cdiv(L, 64), B), dim3(64 * CW), 0, s, x, x_bs, x_cs, C, L, eps,
                      stats);
   ST2_CHECK_LAUNCH("st2_colnorm_stats");
   return 0;

@@ -178,7 +178,15 @@ class Generator(nn.Module):
         pk = type("PackedGenerator", (), {})()
         pk.lin_w = _dev(self.m_source.l_linear.weight.reshape(-1), device)
         pk.lin_b = _dev(self.m_source.l_linear.bias.reshape(-1), device)
-        pk.noise_w = [_dev(c.weight, device) for c in self.noise_convs]
+        # noise_convs (istftnet.py:332-339): kernel = 2*stride -> polyphase k=2 conv on the matrix pipe; last one is k=1
+        pk.noise_wt, pk.noise_stride = [], []
+        for i, c in enumerate(self.noise_convs):
+            stride_f0 = int(math.prod(self.rates[i + 1:])) if i + 1 < self.num_upsamples else 1
+            w = c.weight.detach().float()
+            if stride_f0 > 1:
+                w = W.polyphase_strided_conv(w, stride_f0)
+            pk.noise_wt.append(W.pack_conv_auto(w).to(device))
+            pk.noise_stride.append(stride_f0)
         pk.noise_b = [_dev(c.bias, device) for c in self.noise_convs]
         pk.noise_res = [_PackedResBlock1(r, device) for r in self.noise_res]
         pk.resblocks = [_PackedResBlock1(r, device) for r in self.resblocks]
@@ -208,11 +216,14 @@ class Generator(nn.Module):
             u, k, C = self.rates[i], self.up_ks[i], self.channels[i]
             last = i == self.num_upsamples - 1
             # harmonic-source branch (istftnet.py:361-362 / hifigan.py:330-331)
-            if not last:
-                stride_f0 = int(math.prod(self.rates[i + 1:]))
-                xs = ops.conv1d_direct(har, pk.noise_w[i], pk.noise_b[i], stride_f0, (stride_f0 + 1) // 2)
+            stride_f0 = pk.noise_stride[i]
+            if stride_f0 > 1:
+                pad_f0 = (stride_f0 + 1) // 2
+                L_ns = (har.shape[2] + 2 * pad_f0 - 2 * stride_f0) // stride_f0 + 1
+                harp = ops.phase_split(har, stride_f0, pad_f0, L_ns + 1)
+                xs = ops.conv1d(harp, pk.noise_wt[i], C, 2, pad_left=0, L_out=L_ns, bias=pk.noise_b[i])
             else:
-                xs = ops.conv1d_direct(har, pk.noise_w[i], pk.noise_b[i], 1, 0)
+                xs = ops.conv1d(har, pk.noise_wt[i], C, 1, bias=pk.noise_b[i])
             xs = run_resblock1(pk.noise_res[i], bank, h, xs)
             # up-sampling ConvTranspose1d as polyphase GEMM + interleave (istftnet.py:360,364-368)
             L_in = x.shape[2]

@@ -8,8 +8,9 @@ Modules/diffusion/diffusion.py: AudioDiffusionConditional shell, re-wired by mod
     s_pred = sampler(noise[B,1,256], embedding=bert_dur[B,N,768], embedding_scale=1.0, num_steps=5[, features=ref_s])
 
 MI355X design: tokens are kept CHANNEL-MAJOR ([B, C, N]) for the whole denoiser so that every Linear is a k=1
-`st2_conv1d` on the fp32 matrix pipe with LayerNorm/AdaLayerNorm applied in the conv prologue, GELU / residual in
-its epilogue; attention is one HIP kernel; the per-utterance mapping MLP is `st2_style_fc`.  Everything the ADPM2
+conv on the matrix pipe (`st2_conv1d_f16s`: split-f16 MFMA, fp32-class accuracy; `st2_conv1d` exact fp32 under
+ST2_CONV_PRECISION=f32) with LayerNorm/AdaLayerNorm applied in the conv prologue, GELU / residual in its epilogue;
+attention is one fp32-MFMA HIP kernel; the per-utterance mapping MLP is `st2_style_fc`.  Everything the ADPM2
 loop needs from the host (sigma schedule, sigma_up/down/mid, EDM scale weights) is input-independent and is
 computed once on the host in the reference's own arithmetic (fp32 tensors + python floats), so the loop issues
 kernels back to back with no device->host synchronisation (the reference syncs every step, sampler.py:490-495).
@@ -244,11 +245,12 @@ class _Transformer(nn.Module):
             if not self.multispeaker:
                 b.n_w, b.n_b = d(a.norm.weight).reshape(1, -1), d(a.norm.bias).reshape(1, -1)
                 b.nc_w, b.nc_b = d(a.norm_context.weight).reshape(1, -1), d(a.norm_context.bias).reshape(1, -1)
-            b.q = W.pack_linear(a.to_q.weight.detach().float()).to(device)
-            b.kv = W.pack_linear(a.to_kv.weight.detach().float()).to(device)
-            b.o, b.o_b = W.pack_linear(a.attention.to_out.weight.detach().float()).to(device), d(a.attention.to_out.bias)
-            b.f1, b.f1_b = W.pack_linear(blk.feed_forward[0].weight.detach().float()).to(device), d(blk.feed_forward[0].bias)
-            b.f2, b.f2_b = W.pack_linear(blk.feed_forward[2].weight.detach().float()).to(device), d(blk.feed_forward[2].bias)
+            b.q = W.pack_linear_auto(a.to_q.weight.detach().float()).to(device)
+            b.kv = W.pack_linear_auto(a.to_kv.weight.detach().float()).to(device)
+            b.o, b.o_b = W.pack_linear_auto(a.attention.to_out.weight.detach().float()).to(device), d(a.attention.to_out.bias)
+            b.f1, b.f1_b = W.pack_linear_auto(blk.feed_forward[0].weight.detach().float()).to(device), d(blk.feed_forward[0].bias)
+            b.f1_out = blk.feed_forward[0].weight.shape[0]
+            b.f2, b.f2_b = W.pack_linear_auto(blk.feed_forward[2].weight.detach().float()).to(device), d(blk.feed_forward[2].bias)
             pk.blocks.append(b)
         pk.out_t = d(self.to_out[1].weight.detach().reshape(self.channels, self.features).t())
         pk.out_b = d(self.to_out[1].bias)
@@ -324,7 +326,7 @@ class _Transformer(nn.Module):
             att = ops.attention(qkv[:, :mid], qkv[:, mid:2 * mid], qkv[:, 2 * mid:], self.heads,
                                 self.head_features ** -0.5)
             X1 = ops.conv1d(att, b.o, Fz, 1, bias=b.o_b, res=X)
-            hmid = ops.conv1d(X1, b.f1, b.f1.shape[1], 1, bias=b.f1_b, act=ops.ACT_GELU)
+            hmid = ops.conv1d(X1, b.f1, b.f1_out, 1, bias=b.f1_b, act=ops.ACT_GELU)
             X2 = ops.conv1d(hmid, b.f2, Fz, 1, bias=b.f2_b, res=X1)
             X = ops.add_chanvec(X2, m) if i + 1 < nblk else X2
         mean = ops.mean_tokens(X)  # unmasked mean over tokens, modules.py:155,397

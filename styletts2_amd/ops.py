@@ -78,8 +78,6 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         if (wt.C_in, wt.C_out, wt.ks) != (C_in, C_out, ks) or not wt.wq.is_cuda or not wt.wq.is_contiguous():
             raise _lib.St2Error("split weight is for (C_in=%d, C_out=%d, ks=%d) on %s, call has (%d, %d, %d)" % (
                 wt.C_in, wt.C_out, wt.ks, wt.wq.device, C_in, C_out, ks))
-        if pro == PRO_COLNORM:
-            raise _lib.St2Error("st2_conv1d_f16s has no COLNORM prologue; pack this layer with pack_conv()")
     else:
         _chk(wt, "wt", 2)
         if wt.shape[0] != C_in * ks or not wt.is_contiguous():
@@ -161,6 +159,17 @@ def conv1d_direct(x, w, bias, stride, pad, L_out=None, out=None):
                                      out.data_ptr(), out.stride(0), out.stride(1), B, C_in, C_out, L_in, L_out,
                                      ks, stride, pad, _stream()), "st2_conv1d_direct")
     return out
+
+
+def phase_split(x, stride, pad, Lu):
+    """x [B, C, L] -> xp [B, C*stride, Lu], xp[b, c*stride + r, u] = x[b, c, u*stride + r - pad] (`st2_phase_split`)."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    B, Cc, L = x.shape
+    xp = torch.empty((B, Cc * stride, Lu), device=x.device, dtype=torch.float32)
+    _lib.check(lib.st2_phase_split(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, stride, pad, xp.data_ptr(),
+                                   xp.stride(0), xp.stride(1), Lu, _stream()), "st2_phase_split")
+    return xp
 
 
 def instnorm_stats(x, eps=1e-5, out=None):

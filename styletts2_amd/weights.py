@@ -108,6 +108,21 @@ def pack_linear(w):
     return pack_conv(w.unsqueeze(-1))
 
 
+def pack_linear_auto(w):
+    """nn.Linear weight [out, in] packed as a k=1 conv for the kernel conv_precision() selects."""
+    return pack_conv_auto(w.unsqueeze(-1))
+
+
+def polyphase_strided_conv(w, stride):
+    """Strided Conv1d weight [C_out, C_in, K] with K == 2*stride -> the stride-1 Conv1d weight [C_out, C_in*stride, 2]
+    that acts on the de-interleaved input  xp[ci*stride + r][u] = x[ci][u*stride + r - pad]  (st2_phase_split):
+        y[co][q] = sum_{ci,r,j} w[co][ci][j*stride + r] * xp[ci*stride + r][q + j],  j in {0, 1}
+    (noise_convs of both vocoders: Modules/istftnet.py:332-336, Modules/hifigan.py:296-300)."""
+    C_out, C_in, K = w.shape
+    assert K == 2 * stride, "polyphase form implemented for kernel = 2*stride (all reference configs)"
+    return w.reshape(C_out, C_in, 2, stride).permute(0, 1, 3, 2).reshape(C_out, C_in * stride, 2).contiguous()
+
+
 def polyphase_convt(w, stride):
     """ConvTranspose1d weight [C_in, C_out, K] with K == 2*stride -> equivalent Conv1d weight
     [stride*C_out, C_in, 2] (pad_left = 1, L_out = L_in + 1):

@@ -95,8 +95,6 @@ def test_conv1d_matches_contract(case, kernel):
     """Both conv kernels against the same contract: `f32` = exact-fp32 MFMA (st2_conv1d), `f16s` = split-f16 MFMA
     (st2_conv1d_f16s).  The f16s contract carries the operand split (hi + lo of v * scale), so the bar is the same
     fp32 round-off class for both."""
-    if kernel == "f16s" and case["pro"] == R.PRO_COLNORM:
-        pytest.skip("COLNORM prologue lives on st2_conv1d only (denoiser)")
     x, w, kw = make_conv_case(seed=1234, **case)
     wt = weights.pack_conv(w) if kernel == "f32" else weights.pack_conv_f16s(w)
     C_out, ks = w.shape[0], w.shape[2]
@@ -204,6 +202,27 @@ def test_conv1d_direct():
         out = ops.conv1d_direct(g(x), g(w), g(b), st, pad)
         assert out.shape == ref.shape
         assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("kernel", ["f32", "f16s"])
+@pytest.mark.parametrize("C_in,C_out,stride,L", [(22, 256, 6, 4801), (1, 40, 30, 6000), (1, 64, 2, 301), (3, 8, 5, 77)])
+def test_strided_conv_as_phase_split_plus_k2_conv(C_in, C_out, stride, L, kernel):
+    """noise_convs of both vocoders (kernel = 2*stride, padding = (stride+1)//2): st2_phase_split + a stride-1 k=2
+    conv over C_in*stride channels == F.conv1d(stride=stride) (Modules/istftnet.py:332-336,361)."""
+    gen = torch.Generator().manual_seed(stride)
+    x = torch.randn(2, C_in, L, generator=gen)
+    w = torch.randn(C_out, C_in, 2 * stride, generator=gen) * 0.2
+    b = torch.randn(C_out, generator=gen)
+    pad = (stride + 1) // 2
+    ref = torch.nn.functional.conv1d(x, w, b, stride=stride, padding=pad)
+    L_out = ref.shape[2]
+    xp = ops.phase_split(g(x), stride, pad, L_out + 1)
+    assert torch.equal(xp.cpu(), R.phase_split(x, stride, pad, L_out + 1))
+    w2 = weights.polyphase_strided_conv(w, stride)
+    wt = g(weights.pack_conv(w2)) if kernel == "f32" else weights.pack_conv_f16s(w2).to(DEV)
+    out = ops.conv1d(xp, wt, C_out, 2, pad_left=0, L_out=L_out, bias=g(b))
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-5
 
 
 def test_adain_leaky_pool():
