@@ -30,7 +30,12 @@ N_PHONEMES = 100
 FRAMES_PER_PHONEME = 4
 DIFFUSION_STEPS = 5
 AUDIO_S_PER_UTT = N_PHONEMES * FRAMES_PER_PHONEME * 600 / 24000.0  # 10.0
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+# MI355X_MICROARCH.md: dense f16/bf16 MFMA peak ~2.5 PFLOP/s (v_mfma_f32_32x32x16_f16, 1024 FLOP/clk/SIMD).  The
+# dominant kernel evaluates every fp32-class multiply as THREE f16 MFMA products (hi*hi + hi*lo + lo*hi, fp32
+# accumulate), so the roof for ALGORITHMIC conv FLOPs is a third of that.
+F16_MFMA_PEAK_TFLOPS = 2500.0
+F16S_PRODUCTS = 3
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_dominant.json")  # written by tools/pmc_summary.py --json (rocprofv3 --pmc passes)
 KEYS = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]
 
 
@@ -84,6 +89,31 @@ def cpu_baseline(man, sds):
     return {"value": AUDIO_S_PER_UTT / best, "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 utterance x 10 s (100 phonemes, 5 diffusion steps, iSTFTNet), best of 3 after 1 warm-up, "
                       "%.2f s wall" % best}
+
+
+def roofline(ach, durs, avg_ms, flop, B, L_dom):
+    """Dominant kernel class = the k=11, C=128, L=48001 resblock convs of the last generator stage (12 launches per
+    decoder call).  `achieved` = algorithmic conv FLOPs (2*B*C_in*C_out*ks*L) / mean launch time measured with HIP
+    events on the launch stream inside the timed region; `peak` = dense f16 MFMA peak / 3 products (see above), so
+    `frac` is also (f16 MFMA FLOPs executed / s) / 2.5 PFLOP/s.  `traffic` = HBM bytes per launch from rocprofv3 PMC
+    passes (FETCH_SIZE x2 per the gfx950 correction in MI355X_MICROARCH.md + WRITE_SIZE), read from the committed
+    profiles/pmc_dominant.json; the HBM-side view (algorithmic bytes / s vs 8 TB/s) is reported beside it."""
+    peak = F16_MFMA_PEAK_TFLOPS / F16S_PRODUCTS
+    # every launch reads x and writes y (fp32); every second one (convs2) also reads the residual; weights are L2 resident
+    alg_bytes = 2.5 * B * 128 * L_dom * 4
+    traffic, note = None, "no PMC summary committed"
+    if os.path.exists(PMC_FILE):
+        pm = json.load(open(PMC_FILE))
+        traffic, note = pm.get("hbm_bytes_per_launch"), pm.get("note")
+    return {"bound": "mfma", "kernel": "conv1d_f16s_kernel<11,16,4,1,4> (C=128, L=48001, B=32, k=11; AdaIN+Snake "
+                                       "prologue, bias/residual epilogue)",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
+            "traffic": traffic, "traffic_note": note,
+            "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 products per fp32-class multiply",
+            "mfma_tflops_executed": (ach * F16S_PRODUCTS) if ach else None,
+            "launches_timed": len(durs), "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "hbm_view": {"achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if durs else None, "peak_GBps": 8000.0}}
 
 
 def main():
@@ -159,18 +189,13 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (convs/linears: f16 hi/lo split, 3 MFMA products, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "LJSpeech single-speaker, batch=32x10 s synthetic phoneme seqs per GPU, iSTFTNet, "
                                    "5 diffusion steps, 1xMI355X per rank (BASELINE.json configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "phonemes": N_PHONEMES,
                        "audio_s_per_utt": AUDIO_S_PER_UTT, "parallelism": "utterance-sharded x%d" % world,
                        "weights": "seeded random init, broadcast %d B from rank 0" % nbytes},
-            "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_kernel<11,8> (C=128, L=48001, B=32, AdaIN+Snake "
-                                                    "prologue, residual epilogue)",
-                         "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / FP32_MFMA_PEAK_TFLOPS) if ach else None, "traffic": None,
-                         "launches_timed": len(durs), "avg_launch_ms": avg_ms,
-                         "algorithmic_flop_per_launch": flop},
+            "roofline": roofline(ach, durs, avg_ms, flop, B, L_dom),
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(man, sds)
