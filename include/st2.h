@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 3
+#define ST2_ABI_VERSION 4
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -88,6 +88,11 @@ typedef struct st2_conv_desc {
   const void* wq; int32_t wq_co_pad; int32_t wq_cin_pad;
   float x_scale;                     /* power of two applied to pro(x) before the hi/lo split (8 by default) */
   float out_scale;                   /* 1 / (x_scale * weight scale), applied to the accumulator first */
+  /* st2_conv1d_xs only: pre-activated, pre-split input planes written by st2_act_split (x/pro/stats/... unused) */
+  const void* xs; int32_t xs_cg; int32_t xs_lp; int32_t xs_halo;
+  /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
+     part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) over the 128 columns of that tile */
+  float* part; int32_t part_nt;
 } st2_conv_desc;
 
 int st2_conv1d(const st2_conv_desc* d, void* stream);
@@ -109,6 +114,30 @@ int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of th
 int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
 /* sizeof(st2_conv_desc) as the library was compiled: lets a binding verify its struct mirror. */
 int st2_sizeof_conv_desc(void);
+
+/* ---- activation pass + pure MFMA conv ("xs" path) -------------------------------------------------------------- *
+ * The fused prologue of st2_conv1d_f16s costs ~40 VALU instructions per staged element inside the MFMA kernel.  The
+ * xs path runs it ONCE per element in an HBM-bound pass instead and hands the conv pre-split f16 operands:
+ *
+ *   st2_act_split:  xs[b][plane][cg][pos][e] (f16; plane 0 = hi, 1 = lo; 16-byte slots of 8 channels) =
+ *                   split( x_scale * pro(x)[b][cg*8 + e][pos - halo] ),  zero for pos - halo outside [0, L) and for
+ *                   channels >= C.  Same prologue arithmetic (op for op) as st2_conv1d_f16s.  cg in [0, xs_cg),
+ *                   pos in [0, Lp); xs_cg*8 >= C rounded up to st2_conv1d_f16s_chunk(ks) of the consuming conv.
+ *   st2_conv1d_xs:  same GEMM, weights (d.wq ...) and epilogue as st2_conv1d_f16s on those planes: chunks are staged
+ *                   global -> LDS as plain 16-byte copies, no per-element arithmetic in the MFMA kernel.  Requires
+ *                   pad_left <= xs_halo and Lp large enough for the last tile (checked).  If d.part != NULL the
+ *                   epilogue also emits per-128-column partial (sum, sumsq) of the stored output so the next
+ *                   layer's InstanceNorm statistics need no extra read of the tensor:
+ *   st2_stats_finalize: stats[row] = (mean, 1/sqrt(var+eps)) from part[row][nt][2] (fp64, fixed order), rows = B*C.
+ * Replaces the same reference call sites as st2_conv1d_f16s + st2_instnorm_stats. */
+int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
+                  int32_t pro, float slope, const float* stats, const float* gamma, const float* beta, int64_t gb_bs,
+                  int32_t gamma_plus_one, const float* alpha, float x_scale,
+                  void* xs, int32_t xs_cg, int32_t Lp, int32_t halo, void* stream);
+int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
+/* Tuning knob (process-wide): build of the 128-output-row variants held to 2 or 3 workgroups per CU (default 3). */
+int st2_conv1d_xs_set_occupancy(int wg_per_cu);
+int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *
  * y[b,co,l] = bias[co] + sum_{ci,t} w[co,ci,t] * x[b,ci, l*stride + t - pad]   (plain OIK weights)

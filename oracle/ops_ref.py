@@ -21,10 +21,15 @@ def _snake(u, alpha):
 
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
-    B, C_in, L_in = x.shape
-    if L_out is None:
-        L_out = L_in
+           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False):
+    y = _conv1d(x, wt, C_out, ks, dil=dil, pad_left=pad_left, L_out=L_out, bias=bias, out=out, pro=pro, slope=slope,
+                stats=stats, gamma=gamma, beta=beta, gamma_plus_one=gamma_plus_one, alpha=alpha, res=res,
+                res_shift=res_shift, res2=res2, div=div, act=act, act_split=act_split, act_slope=act_slope)
+    return (y, instnorm_stats(y)) if want_stats else y
+
+
+def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None):
+    """pro(x): the prologue of the conv contract = what st2_act_split materialises (before the x8 scale + hi/lo split)."""
     u = x
     if pro == PRO_LEAKY:
         u = F.leaky_relu(x, slope)
@@ -40,6 +45,17 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         if gamma_plus_one:
             g = 1.0 + g
         u = n * g + beta.unsqueeze(-1)
+    return u
+
+
+def _conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
+            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
+            res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
+    B, C_in, L_in = x.shape
+    if L_out is None:
+        L_out = L_in
+    u = activate(x, pro=pro, slope=slope, stats=stats, gamma=gamma, beta=beta, gamma_plus_one=gamma_plus_one,
+                 alpha=alpha)
     if hasattr(wt, "wq"):  # split-f16 packing (st2_conv1d_f16s): operands are hi + lo of v * scale; lo*lo dropped
         w = wt.dense()
         xs = 8.0

@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -43,6 +43,8 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("act_split", C.c_int32), ("act_slope", C.c_float),
         ("wq", f32p), ("wq_co_pad", C.c_int32), ("wq_cin_pad", C.c_int32),
         ("x_scale", C.c_float), ("out_scale", C.c_float),
+        ("xs", f32p), ("xs_cg", C.c_int32), ("xs_lp", C.c_int32), ("xs_halo", C.c_int32),
+        ("part", f32p), ("part_nt", C.c_int32),
     ]
 
 
@@ -56,6 +58,12 @@ _SIGNATURES = {
     "st2_conv1d_f16s": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
+    "st2_conv1d_xs": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "st2_conv1d_xs_set_occupancy": (C.c_int, [C.c_int]),
+    "st2_act_split": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                f32p, f32p, f32p, C.c_int64, C.c_int32, f32p, C.c_float, f32p, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_void_p]),
+    "st2_stats_finalize": (C.c_int, [f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, f32p, C.c_void_p]),
     "st2_conv1d_direct": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p]),

@@ -1,0 +1,162 @@
+// Activation pass of the "xs" conv path and the InstanceNorm statistics finaliser.
+//
+//   st2_act_split: xs[b][plane][cg][pos][e] = split_f16( x_scale * pro(x)[b][cg*8+e][pos-halo] )
+//
+// One pass over the tensor: every element is read once (fp32, 4 B) and written once (f16 hi + f16 lo, 4 B), so the
+// kernel is HBM-bound: 8 B per element.  A thread owns one position and the 8 channels of one 16-byte slot: its 8
+// loads are each coalesced across the wave (lanes run along l), its two 16-byte stores are contiguous 1 KB per wave.
+// The per-channel parameters (mean, rstd, gamma, beta, alpha) are wave-uniform and come through the scalar cache.
+// Zero padding of the conv (halo columns, the tail up to Lp, channel padding) is materialised here, AFTER the
+// activation as F.conv1d pads the activated tensor, so the MFMA kernel never tests a boundary.
+// Arithmetic is op for op that of the fused prologue in st2_conv1d_f16s.hip (same helpers, st2_act.h).
+#include "st2_common.h"
+#include "st2_act.h"
+#include <type_traits>
+
+namespace {
+
+struct ActArgs {
+  const float* x; int64_t x_bs; int x_cs;
+  int C, L;
+  float slope;
+  const float* stats; const float* gamma; const float* beta; int64_t gb_bs; int gamma_plus_one;
+  const float* alpha;
+  float x_scale;
+  st2_h8* xs; int xs_cg, Lp, halo;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= a.Lp) return;
+  const int cg = blockIdx.y;
+  const int b = blockIdx.z;
+  const int l = pos - a.halo;
+  const bool lok = l >= 0 && l < a.L;
+  const int lc = min(max(l, 0), a.L - 1);
+  const float* xb = a.x + (int64_t)b * a.x_bs + lc;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = min(cg * 8 + e, a.C - 1);
+    v[e] = xb[(int64_t)ci * a.x_cs];
+  }
+  float cmean = 0.f, crstd = 1.f;
+  if constexpr (PRO == ST2_PRO_COLNORM) {
+    const float* st = a.stats + ((int64_t)b * a.L + lc) * 2;
+    cmean = st[0];
+    crstd = st[1];
+  }
+  st2_h8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = cg * 8 + e;
+    const int cc = min(ci, a.C - 1);  // wave-uniform -> scalar loads
+    float u = v[e];
+    if constexpr (PRO == ST2_PRO_LEAKY) {
+      u = leaky(u, a.slope);
+    } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE) {
+      const float* st = a.stats + ((int64_t)b * a.C + cc) * 2;
+      const float g = 1.0f + a.gamma[(int64_t)b * a.gb_bs + cc];
+      const float bt = a.beta[(int64_t)b * a.gb_bs + cc];
+      float w = (u - st[0]) * st[1];
+      w = g * w + bt;
+      if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
+        u = leaky(w, a.slope);
+      } else {
+        const float al = a.alpha[cc];
+        u = snake(w, al, 1.0f / al);
+      }
+    } else if constexpr (PRO == ST2_PRO_SNAKE) {
+      const float al = a.alpha[cc];
+      u = snake(u, al, 1.0f / al);
+    } else if constexpr (PRO == ST2_PRO_COLNORM) {
+      const float g0 = a.gamma[(int64_t)b * a.gb_bs + cc];
+      const float g = a.gamma_plus_one ? 1.0f + g0 : g0;
+      const float bt = a.beta[(int64_t)b * a.gb_bs + cc];
+      const float w = (u - cmean) * crstd;
+      u = w * g + bt;
+    }
+    u = (lok && ci < a.C) ? u * a.x_scale : 0.f;
+    const _Float16 h = (_Float16)u;
+    hi[e] = h;
+    lo[e] = (_Float16)(u - (float)h);
+  }
+  const int64_t plane = (int64_t)a.xs_cg * a.Lp;
+  st2_h8* dst = a.xs + ((int64_t)b * 2 * a.xs_cg + cg) * a.Lp + pos;
+  dst[0] = hi;
+  dst[plane] = lo;
+}
+
+// stats[row] = (mean, rstd) from per-tile partial (sum, sumsq); one wave per row, fp64, fixed order.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, int rows, int nt, int L,
+                                                             float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(part) + (int64_t)row * nt;
+  double s = 0.0, ss = 0.0;
+  for (int i = lane; i < nt; i += 64) {
+    const float2 v = p[i];
+    s += (double)v.x;
+    ss += (double)v.y;
+  }
+  s = st2_wave_sum(s);
+  ss = st2_wave_sum(ss);
+  if (lane == 0) {
+    const double mean = s / (double)L;
+    double var = ss / (double)L - mean * mean;  // biased, InstanceNorm1d
+    if (var < 0.0) var = 0.0;
+    stats[(int64_t)row * 2 + 0] = (float)mean;
+    stats[(int64_t)row * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <int PRO>
+void launch_act(const ActArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL((act_split_kernel<PRO>), dim3(st2_cdiv(a.Lp, 256), a.xs_cg, B), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, int32_t pro,
+                             float slope, const float* stats, const float* gamma, const float* beta, int64_t gb_bs,
+                             int32_t gamma_plus_one, const float* alpha, float x_scale, void* xs, int32_t xs_cg,
+                             int32_t Lp, int32_t halo, void* stream) {
+  ST2_REQUIRE(x && xs && B > 0 && C > 0 && L > 0, "st2_act_split: bad arguments");
+  ST2_REQUIRE(B <= 65535 && xs_cg <= 65535, "st2_act_split: grid too large");
+  ST2_REQUIRE(xs_cg * 8 >= C, "st2_act_split: xs_cg=%d groups cannot hold C=%d channels", xs_cg, C);
+  ST2_REQUIRE(halo >= 0 && Lp >= L + halo, "st2_act_split: Lp=%d too small for L=%d + halo=%d", Lp, L, halo);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0, "st2_act_split: xs must be 16-byte aligned");
+  ST2_REQUIRE(pro >= ST2_PRO_NONE && pro <= ST2_PRO_COLNORM, "st2_act_split: prologue %d not supported", pro);
+  if (pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_COLNORM)
+    ST2_REQUIRE(stats && gamma && beta, "st2_act_split: prologue %d needs stats/gamma/beta", pro);
+  if (pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE) ST2_REQUIRE(alpha, "st2_act_split: snake needs alpha");
+  ST2_REQUIRE(x_scale > 0.f, "st2_act_split: x_scale must be set");
+  ActArgs a;
+  a.x = x; a.x_bs = x_bs; a.x_cs = x_cs; a.C = C; a.L = L; a.slope = slope;
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.gb_bs = gb_bs; a.gamma_plus_one = gamma_plus_one;
+  a.alpha = alpha; a.x_scale = x_scale;
+  a.xs = reinterpret_cast<st2_h8*>(xs); a.xs_cg = xs_cg; a.Lp = Lp; a.halo = halo;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (pro) {
+    case ST2_PRO_LEAKY: launch_act<ST2_PRO_LEAKY>(a, B, s); break;
+    case ST2_PRO_ADAIN_LEAKY: launch_act<ST2_PRO_ADAIN_LEAKY>(a, B, s); break;
+    case ST2_PRO_ADAIN_SNAKE: launch_act<ST2_PRO_ADAIN_SNAKE>(a, B, s); break;
+    case ST2_PRO_SNAKE: launch_act<ST2_PRO_SNAKE>(a, B, s); break;
+    case ST2_PRO_COLNORM: launch_act<ST2_PRO_COLNORM>(a, B, s); break;
+    default: launch_act<ST2_PRO_NONE>(a, B, s); break;
+  }
+  ST2_CHECK_LAUNCH("st2_act_split");
+  return 0;
+}
+
+extern "C" int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats,
+                                  void* stream) {
+  ST2_REQUIRE(part && stats && rows > 0 && nt > 0 && L > 0, "st2_stats_finalize: bad arguments");
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, "st2_stats_finalize: part must be 8-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(st2_cdiv(rows, 4)), dim3(256), 0, s, part, rows, nt, L, eps, stats);
+  ST2_CHECK_LAUNCH("st2_stats_finalize");
+  return 0;
+}

@@ -25,6 +25,7 @@
 //   * wave tile = 32 (co) x 32*TN (l): TN accumulators of 16 registers.  Waves are arranged WM x WN over
 //     (co, l): 4x1 for C_out >= 96, 2x2 for C_out in (32, 96), 1x4 for C_out <= 32.
 #include "st2_common.h"
+#include "st2_act.h"
 #include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -34,45 +35,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NT = 256;
-
-__device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
-
-// sin(x)^2 to ~2.4e-7 absolute: n = rint(x/pi), r = x - n*pi (two-term, fma-exact), odd minimax
-// polynomial of degree 9 on [-pi/2, pi/2] (max abs error 1.2e-7, fitted in tools/fit_sin.py).
-__device__ __forceinline__ float sin_sq(float x) {
-  const float n = rintf(x * 0.3183098861837907f);
-  float r = fmaf(n, -3.1415927410125732f, x);
-  r = fmaf(n, 8.742277657347586e-08f, r);
-  const float r2 = r * r;
-  float p = 2.6000539037340786e-06f;
-  p = fmaf(p, r2, -0.00019806614727713168f);
-  p = fmaf(p, r2, 0.008333017118275166f);
-  p = fmaf(p, r2, -0.16666656732559204f);
-  const float s = fmaf(r2 * r, p, r);
-  return s * s;
-}
-
-// sin(x) to 1.2e-7 absolute (same reduction and polynomial, sign restored from the parity of n)
-__device__ __forceinline__ float sin_acc(float x) {
-  const float n = rintf(x * 0.3183098861837907f);
-  float r = fmaf(n, -3.1415927410125732f, x);
-  r = fmaf(n, 8.742277657347586e-08f, r);
-  const float r2 = r * r;
-  float p = 2.6000539037340786e-06f;
-  p = fmaf(p, r2, -0.00019806614727713168f);
-  p = fmaf(p, r2, 0.008333017118275166f);
-  p = fmaf(p, r2, -0.16666656732559204f);
-  const float s = fmaf(r2 * r, p, r);
-  return ((int)n & 1) ? -s : s;
-}
-
-__device__ __forceinline__ float snake(float v, float alpha, float inv_alpha) {
-  return v + inv_alpha * sin_sq(alpha * v);  // x + (1/a) * sin(a*x)^2, Modules/istftnet.py:69
-}
-
-__device__ __forceinline__ float gelu_erf(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
 
 struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
   float mean, rstd, g, beta, alpha, inv_alpha, pad0, pad1;

@@ -75,18 +75,20 @@ def run_resblock1(pk: _PackedResBlock1, bank: StyleBank, h, x, x_stats=None, mrf
     p = pk.p
     C, ks = p.channels, p.ks
     nsteps = len(p.dilation)
+    st = x_stats if x_stats is not None else ops.instnorm_stats(x)
     for i, d in enumerate(p.dilation):
-        st = x_stats if (i == 0 and x_stats is not None) else ops.instnorm_stats(x)
         g1, b1 = bank.gb(h, p.adain1[i])
-        xt = ops.conv1d(x, pk.c1[i].wt, C, ks, dil=d, pad_left=(ks * d - d) // 2, bias=pk.c1[i].bias,
-                        pro=ops.PRO_ADAIN_SNAKE, stats=st, gamma=g1, beta=b1, alpha=pk.a1[i])
-        st2 = ops.instnorm_stats(xt)
+        # the InstanceNorm statistics each AdaIN needs come out of the producing conv's epilogue (want_stats)
+        xt, st2 = ops.conv1d(x, pk.c1[i].wt, C, ks, dil=d, pad_left=(ks * d - d) // 2, bias=pk.c1[i].bias,
+                             pro=ops.PRO_ADAIN_SNAKE, stats=st, gamma=g1, beta=b1, alpha=pk.a1[i], want_stats=True)
         g2, b2 = bank.gb(h, p.adain2[i])
         last = i == nsteps - 1
-        x = ops.conv1d(xt, pk.c2[i].wt, C, ks, dil=1, pad_left=(ks - 1) // 2, bias=pk.c2[i].bias,
-                       pro=ops.PRO_ADAIN_SNAKE, stats=st2, gamma=g2, beta=b2, alpha=pk.a2[i], res=x,
-                       res2=mrf_acc if last else None, div=float(n_mrf) if (last and mrf_last) else 1.0,
-                       out=out if last else None)
+        kw = dict(dil=1, pad_left=(ks - 1) // 2, bias=pk.c2[i].bias, pro=ops.PRO_ADAIN_SNAKE, stats=st2, gamma=g2,
+                  beta=b2, alpha=pk.a2[i], res=x)
+        if last:
+            x = ops.conv1d(xt, pk.c2[i].wt, C, ks, res2=mrf_acc, div=float(n_mrf) if mrf_last else 1.0, out=out, **kw)
+        else:
+            x, st = ops.conv1d(xt, pk.c2[i].wt, C, ks, want_stats=True, **kw)
     return x
 
 
@@ -110,11 +112,10 @@ def run_adain_resblk(pk: _PackedAdainResBlk, bank: StyleBank, h, x, out=None):
     g1, b1 = bank.gb(h, p.norm1)
     if p.upsample:
         u = ops.adain_leaky_pool(x, st1, g1, b1, 0.2, pk.pool_w, pk.pool_b)
-        t1 = ops.conv1d(u, pk.conv1.wt, p.dim_out, 3, pad_left=1, bias=pk.conv1.bias)
+        t1, st2 = ops.conv1d(u, pk.conv1.wt, p.dim_out, 3, pad_left=1, bias=pk.conv1.bias, want_stats=True)
     else:
-        t1 = ops.conv1d(x, pk.conv1.wt, p.dim_out, 3, pad_left=1, bias=pk.conv1.bias, pro=ops.PRO_ADAIN_LEAKY,
-                        slope=0.2, stats=st1, gamma=g1, beta=b1)
-    st2 = ops.instnorm_stats(t1)
+        t1, st2 = ops.conv1d(x, pk.conv1.wt, p.dim_out, 3, pad_left=1, bias=pk.conv1.bias, pro=ops.PRO_ADAIN_LEAKY,
+                             slope=0.2, stats=st1, gamma=g1, beta=b1, want_stats=True)
     g2, b2 = bank.gb(h, p.norm2)
     sc = ops.conv1d(x, pk.sc.wt, p.dim_out, 1) if pk.sc is not None else x
     return ops.conv1d(t1, pk.conv2.wt, p.dim_out, 3, pad_left=1, bias=pk.conv2.bias, pro=ops.PRO_ADAIN_LEAKY,

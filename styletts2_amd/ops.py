@@ -6,6 +6,7 @@ tensors.  PyTorch is plumbing here (allocation, streams); all arithmetic happens
 There is no CPU path: a tensor that is not on a HIP device raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -64,16 +65,162 @@ def _bs_cs(t):
     return t.stride(0), t.stride(1)
 
 
+XS_HALO = 32  # zero columns in front of every xs row (>= the largest pad_left on the path: 25)
+XS_MIN_L = 256  # shorter rows (the denoiser's 100 tokens) stay on the fused kernel: an xs row is >= 640 slots
+
+
+def conv_path():
+    """How convs with a prologue over split-f16 weights are issued: "xs" (default) = st2_act_split + st2_conv1d_xs
+    (activation in an HBM-bound pass of its own, pure MFMA conv, InstanceNorm partial sums from the conv epilogue);
+    "fused" = st2_conv1d_f16s with the prologue inside the MFMA kernel.  Read from ST2_CONV_PATH at call time."""
+    mode = os.environ.get("ST2_CONV_PATH", "xs")
+    if mode not in ("xs", "fused"):
+        raise ValueError("ST2_CONV_PATH must be xs or fused, got %r" % mode)
+    return mode
+
+
+class XsTensor:
+    """Pre-activated, pre-split conv operand written by `activate`: `data` is float16 [B, 2, cg, Lp, 8]
+    (plane 0 = hi, 1 = lo; 16-byte slots of 8 channels), logical shape [B, C, L], `halo` zero columns in front."""
+
+    def __init__(self, data, C, L, halo):
+        self.data, self.C, self.L, self.halo = data, C, L, halo
+
+    @property
+    def cg(self):
+        return self.data.shape[2]
+
+    @property
+    def Lp(self):
+        return self.data.shape[3]
+
+
+def xs_row_slots(L):
+    """Slots per xs row for a tensor of length L: halo + L rounded up to the widest conv tile (512) + room for the
+    last tile's taps (checked again inside st2_conv1d_xs)."""
+    return XS_HALO + (max(L, 1) + 1 + 511) // 512 * 512 + 96
+
+
+def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
+              c_pad=32):
+    """`st2_act_split`: x [B, C, L] fp32 -> XsTensor holding split_f16(8 * pro(x)) with the conv's zero padding."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    B, Cc, L = x.shape
+    cg = (Cc + c_pad - 1) // c_pad * c_pad // 8
+    Lp = xs_row_slots(L)
+    data = torch.empty((B, 2, cg, Lp, 8), device=x.device, dtype=torch.float16)
+    gbs = 0
+    if pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_COLNORM):
+        _chk(stats, "stats", 3)
+        _chk(gamma, "gamma", 2)
+        _chk(beta, "beta", 2)
+        want = (B, L, 2) if pro == PRO_COLNORM else (B, Cc, 2)
+        assert tuple(stats.shape) == want and stats.is_contiguous(), (stats.shape, want)
+        assert gamma.shape[1] == Cc and beta.shape[1] == Cc
+        gbs = gamma.stride(0) if gamma.shape[0] > 1 else 0
+        bbs = beta.stride(0) if beta.shape[0] > 1 else 0
+        assert gamma.shape[0] in (1, B) and beta.shape[0] == gamma.shape[0] and gbs == bbs
+    if pro in (PRO_ADAIN_SNAKE, PRO_SNAKE):
+        _chk(alpha, "alpha", 1)
+        assert alpha.numel() == Cc and alpha.is_contiguous()
+    _lib.check(lib.st2_act_split(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, pro, slope, _ptr(stats),
+                                 _ptr(gamma), _ptr(beta), gbs, 1 if gamma_plus_one else 0, _ptr(alpha), F16S_X_SCALE,
+                                 data.data_ptr(), cg, Lp, XS_HALO, _stream()), "st2_act_split")
+    return XsTensor(data, Cc, L, XS_HALO)
+
+
+def stats_finalize(part, L, eps=1e-5, out=None):
+    """`st2_stats_finalize`: part [B, C, nt, 2] (sum, sumsq per 128-column tile) -> stats [B, C, 2] (mean, rstd)."""
+    lib = _lib.load()
+    _chk(part, "part", 4)
+    B, Cc, nt, two = part.shape
+    assert two == 2 and part.is_contiguous()
+    if out is None:
+        out = torch.empty((B, Cc, 2), device=part.device, dtype=torch.float32)
+    _lib.check(lib.st2_stats_finalize(part.data_ptr(), B * Cc, nt, L, eps, out.data_ptr(), _stream()),
+               "st2_stats_finalize")
+    return out
+
+
+def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None, res=None, res_shift=0,
+              res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False):
+    """`st2_conv1d_xs` on an XsTensor; with want_stats returns (out, stats [B, C_out, 2]) where the InstanceNorm
+    statistics of `out` come from the conv epilogue's per-tile partial sums + `st2_stats_finalize`."""
+    lib = _lib.load()
+    assert isinstance(xs, XsTensor) and isinstance(wt, SplitConvWeight)
+    B, C_in, L_in = xs.data.shape[0], xs.C, xs.L
+    if (wt.C_in, wt.C_out, wt.ks) != (C_in, C_out, ks) or not wt.wq.is_cuda or not wt.wq.is_contiguous():
+        raise _lib.St2Error("split weight is for (C_in=%d, C_out=%d, ks=%d) on %s, call has (%d, %d, %d)" % (
+            wt.C_in, wt.C_out, wt.ks, wt.wq.device, C_in, C_out, ks))
+    if L_out is None:
+        L_out = L_in
+    if out is None:
+        out = torch.empty((B, C_out, L_out), device=xs.data.device, dtype=torch.float32)
+    _chk(out, "out", 3)
+    assert out.shape == (B, C_out, L_out), (out.shape, (B, C_out, L_out))
+    d = ConvDesc()
+    d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil, d.pad_left = B, C_in, C_out, L_in, L_out, ks, dil, pad_left
+    d.xs, d.xs_cg, d.xs_lp, d.xs_halo = xs.data.data_ptr(), xs.cg, xs.Lp, xs.halo
+    d.wq, d.wq_co_pad, d.wq_cin_pad = wt.wq.data_ptr(), wt.co_pad, wt.cin_pad
+    d.x_scale, d.out_scale = F16S_X_SCALE, 1.0 / (F16S_X_SCALE * wt.w_scale)
+    _chk(bias, "bias", 1)
+    d.bias = _ptr(bias)
+    d.y, d.y_bs, d.y_cs = out.data_ptr(), out.stride(0), out.stride(1)
+    _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope)
+    part = None
+    if want_stats:
+        nt = (L_out + 127) // 128
+        part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
+        d.part, d.part_nt = part.data_ptr(), nt
+    _launch_conv(lib.st2_conv1d_xs, "st2_conv1d_xs", d)
+    if want_stats:
+        return out, stats_finalize(part, L_out)
+    return out
+
+
+def _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope):
+    if res is not None:
+        _chk(res, "res", 3)
+        assert res.shape[0] == B and res.shape[1] == C_out and res.shape[2] == (L_out + (1 << res_shift) - 1 >> res_shift)
+        d.res, d.res_bs, d.res_cs, d.res_shift = res.data_ptr(), res.stride(0), res.stride(1), res_shift
+    if res2 is not None:
+        _chk(res2, "res2", 3)
+        assert res2.shape == (B, C_out, L_out)
+        d.res2, d.res2_bs, d.res2_cs = res2.data_ptr(), res2.stride(0), res2.stride(1)
+    d.div = div
+    d.act, d.act_split, d.act_slope = act, act_split, act_slope
+
+
+def _launch_conv(fn, fname, d):
+    if _conv_timer is not None and _conv_timer.matches(d):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(fn(C.byref(d), _stream()), fname)
+        e1.record()
+        _conv_timer.pairs.append((e0, e1))
+    else:
+        _lib.check(fn(C.byref(d), _stream()), fname)
+
+
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
-    """Fused Conv1d, see `st2_conv1d` / `st2_conv1d_f16s` in include/st2.h.  wt is either the packed K-major fp32
-    weight [C_in*ks, w_ld] of weights.pack_conv() (exact-fp32 MFMA kernel) or a weights.SplitConvWeight from
-    weights.pack_conv_f16s() (split-f16 MFMA kernel, fp32-class accuracy at 5.3x the rate ceiling)."""
+           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False):
+    """Fused Conv1d, see `st2_conv1d` / `st2_conv1d_f16s` / `st2_conv1d_xs` in include/st2.h.  wt is either the
+    packed K-major fp32 weight [C_in*ks, w_ld] of weights.pack_conv() (exact-fp32 MFMA kernel) or a
+    weights.SplitConvWeight from weights.pack_conv_f16s() (split-f16 MFMA kernels, fp32-class accuracy at 5.3x the
+    rate ceiling).  With a SplitConvWeight, a prologue and conv_path() == "xs" the call is issued as
+    st2_act_split + st2_conv1d_xs.  want_stats=True returns (out, InstanceNorm statistics of out [B, C_out, 2])."""
     lib = _lib.load()
     _chk(x, "x", 3)
     B, C_in, L_in = x.shape
     split = isinstance(wt, SplitConvWeight)
+    if split and pro != PRO_NONE and pad_left <= XS_HALO and L_in >= XS_MIN_L and conv_path() == "xs":
+        xs = activate(x, pro=pro, slope=slope, stats=stats, gamma=gamma, beta=beta,
+                                    gamma_plus_one=gamma_plus_one, alpha=alpha)
+        return conv1d_xs(xs, wt, C_out, ks, dil=dil, pad_left=pad_left, L_out=L_out, bias=bias, out=out, res=res,
+                         res_shift=res_shift, res2=res2, div=div, act=act, act_split=act_split, act_slope=act_slope,
+                         want_stats=want_stats)
     if split:
         if (wt.C_in, wt.C_out, wt.ks) != (C_in, C_out, ks) or not wt.wq.is_cuda or not wt.wq.is_contiguous():
             raise _lib.St2Error("split weight is for (C_in=%d, C_out=%d, ks=%d) on %s, call has (%d, %d, %d)" % (
@@ -119,24 +266,10 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         _chk(alpha, "alpha", 1)
         assert alpha.numel() == C_in and alpha.is_contiguous()
         d.alpha = alpha.data_ptr()
-    if res is not None:
-        _chk(res, "res", 3)
-        assert res.shape[0] == B and res.shape[1] == C_out and res.shape[2] == (L_out + (1 << res_shift) - 1 >> res_shift)
-        d.res, d.res_bs, d.res_cs, d.res_shift = res.data_ptr(), res.stride(0), res.stride(1), res_shift
-    if res2 is not None:
-        _chk(res2, "res2", 3)
-        assert res2.shape == (B, C_out, L_out)
-        d.res2, d.res2_bs, d.res2_cs = res2.data_ptr(), res2.stride(0), res2.stride(1)
-    d.div = div
-    d.act, d.act_split, d.act_slope = act, act_split, act_slope
-    if _conv_timer is not None and _conv_timer.matches(d):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(fn(C.byref(d), _stream()), fname)
-        e1.record()
-        _conv_timer.pairs.append((e0, e1))
-        return out
-    _lib.check(fn(C.byref(d), _stream()), fname)
+    _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope)
+    _launch_conv(fn, fname, d)
+    if want_stats:
+        return out, instnorm_stats(out)
     return out
 
 

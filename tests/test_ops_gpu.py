@@ -88,13 +88,15 @@ F16S_EXTRA_CASES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["f32", "f16s"])
+@pytest.mark.parametrize("kernel", ["f32", "f16s", "xs"])
 @pytest.mark.parametrize("case", CONV_CASES + F16S_EXTRA_CASES, ids=lambda c: "ci%d_co%d_L%d_k%d_d%d_p%d" % (
     c["C_in"], c["C_out"], c["L"], c["ks"], c["dil"], c["pro"]))
-def test_conv1d_matches_contract(case, kernel):
-    """Both conv kernels against the same contract: `f32` = exact-fp32 MFMA (st2_conv1d), `f16s` = split-f16 MFMA
-    (st2_conv1d_f16s).  The f16s contract carries the operand split (hi + lo of v * scale), so the bar is the same
-    fp32 round-off class for both."""
+def test_conv1d_matches_contract(case, kernel, monkeypatch):
+    """All conv kernels against the same contract: `f32` = exact-fp32 MFMA (st2_conv1d), `f16s` = split-f16 MFMA with
+    the prologue fused (st2_conv1d_f16s), `xs` = activation pass + pure split-f16 MFMA conv (st2_act_split +
+    st2_conv1d_xs).  The split contract carries the operand split (hi + lo of v * scale), so the bar is the same
+    fp32 round-off class for all three."""
+    monkeypatch.setenv("ST2_CONV_PATH", "xs" if kernel == "xs" else "fused")
     x, w, kw = make_conv_case(seed=1234, **case)
     wt = weights.pack_conv(w) if kernel == "f32" else weights.pack_conv_f16s(w)
     C_out, ks = w.shape[0], w.shape[2]
@@ -102,7 +104,12 @@ def test_conv1d_matches_contract(case, kernel):
     exact = R.conv1d(x.double(), weights.pack_conv(w).double(), C_out, ks,
                      **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
     kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
-    out = ops.conv1d(g(x), g(wt) if kernel == "f32" else wt.to(DEV), C_out, ks, **kwg)
+    if kernel == "xs":  # the pair called directly (ops.conv1d keeps PRO_NONE and short rows on the fused kernel)
+        PRO_KEYS = ("pro", "slope", "stats", "gamma", "beta", "alpha")
+        xs = ops.activate(g(x), **{k: v for k, v in kwg.items() if k in PRO_KEYS})
+        out = ops.conv1d_xs(xs, wt.to(DEV), C_out, ks, **{k: v for k, v in kwg.items() if k not in PRO_KEYS})
+    else:
+        out = ops.conv1d(g(x), g(wt) if kernel == "f32" else wt.to(DEV), C_out, ks, **kwg)
     torch.cuda.synchronize()
     assert out.shape == ref.shape
     e = rel_err(out, ref)
@@ -110,6 +117,55 @@ def test_conv1d_matches_contract(case, kernel):
     # and against an fp64 evaluation of the un-split operands: fp32-class for both kernels
     e64 = rel_err(out, exact)
     assert e64 < 2e-5, "rel err vs fp64 %g" % e64
+
+
+@pytest.mark.parametrize("occ", [2, 3])
+@pytest.mark.parametrize("B,C_in,C_out,L,ks,dil,res", [(2, 128, 128, 2500, 11, 5, True), (1, 256, 256, 515, 3, 1, False),
+                                                       (2, 64, 64, 777, 7, 3, True), (1, 32, 22, 1300, 7, 1, False),
+                                                       (2, 128, 128, 48001, 11, 1, True)])
+def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, occ, monkeypatch):
+    """want_stats: InstanceNorm statistics of the conv OUTPUT from the epilogue's per-tile partial sums
+    (st2_conv1d_xs part + st2_stats_finalize) against the fp64 reduction of the stored tensor; both register
+    budgets of the 128-row variant (st2_conv1d_xs_set_occupancy)."""
+    from styletts2_amd import _lib
+    monkeypatch.setenv("ST2_CONV_PATH", "xs")
+    x, w, kw = make_conv_case(seed=99, B=B, C_in=C_in, C_out=C_out, L=L, ks=ks, dil=dil, pro=R.PRO_ADAIN_SNAKE, res=res)
+    wt = weights.pack_conv_f16s(w)
+    kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    _lib.check(_lib.load().st2_conv1d_xs_set_occupancy(occ), "set_occupancy")
+    try:
+        out, st = ops.conv1d(g(x), wt.to(DEV), C_out, ks, want_stats=True, **kwg)
+        torch.cuda.synchronize()
+    finally:
+        _lib.load().st2_conv1d_xs_set_occupancy(3)
+    ref = R.conv1d(x, wt, C_out, ks, **kw)
+    assert rel_err(out, ref) < 2e-5
+    st_ref = R.instnorm_stats(out.cpu())
+    assert st.shape == st_ref.shape == (B, C_out, 2)
+    assert (st.cpu()[..., 0] - st_ref[..., 0]).abs().max().item() < 2e-6 * max(1.0, st_ref[..., 0].abs().max().item())
+    assert ((st.cpu()[..., 1] - st_ref[..., 1]).abs() / st_ref[..., 1]).max().item() < 5e-6
+
+
+@pytest.mark.parametrize("pro", [R.PRO_NONE, R.PRO_LEAKY, R.PRO_ADAIN_LEAKY, R.PRO_ADAIN_SNAKE, R.PRO_SNAKE,
+                                 R.PRO_COLNORM])
+def test_activate_planes_match_contract(pro):
+    """st2_act_split: hi + lo planes reconstruct 8 * pro(x); halo, tail and channel padding are exact zeros; every
+    stored half is finite and |lo| <= half an ulp of hi."""
+    B, C, L = 2, 70, 333
+    x, w, kw = make_conv_case(seed=5, B=B, C_in=C, C_out=8, L=L, ks=1, dil=1, pro=pro)
+    akw = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()
+           if k in ("pro", "slope", "stats", "gamma", "beta", "alpha")}
+    xs = ops.activate(g(x), **akw)
+    torch.cuda.synchronize()
+    d = xs.data.cpu().float()                                   # [B, 2, cg, Lp, 8]
+    assert xs.C == C and xs.L == L and d.shape[2] * 8 >= C and d.shape[3] >= L + xs.halo
+    val = (d[:, 0] + d[:, 1]).permute(0, 1, 3, 2).reshape(B, -1, d.shape[3]) / 8.0   # [B, cg*8, Lp]
+    ref = R.activate(x, **{k: v for k, v in kw.items() if k in ("pro", "slope", "stats", "gamma", "beta", "alpha")})
+    got = val[:, :C, xs.halo:xs.halo + L]
+    assert (got - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    assert val[:, :, :xs.halo].abs().max().item() == 0.0 and val[:, :, xs.halo + L:].abs().max().item() == 0.0
+    assert val[:, C:].abs().max().item() == 0.0
+    assert bool(torch.isfinite(d).all())
 
 
 def test_conv1d_writes_into_channel_slice():

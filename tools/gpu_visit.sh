@@ -26,5 +26,5 @@ if ! has pmc; then
     python tools/pmc_summary.py /tmp/pmc_${TAG}_$i > $OUT/pmc_$i.txt 2>&1; grep -v "at::\|elementwise" $OUT/pmc_$i.txt | cut -c1-60,100-200 | head -40
     grep probe_dom $OUT/pmc_$i.log
   done
-  python tools/pmc_summary.py --json $OUT/pmc_dominant.json --kernel "conv1d_f16s_kernel<11" /tmp/pmc_${TAG}_1 /tmp/pmc_${TAG}_2 | tail -1
+  python tools/pmc_summary.py --json $OUT/pmc_dominant.json --kernel "conv1d_xs_kernel" /tmp/pmc_${TAG}_1 /tmp/pmc_${TAG}_2 | tail -1
 fi

@@ -1,4 +1,6 @@
-"""GPU probe: times st2_conv1d on the vocoder's dominant shapes (HIP events on the launch stream)."""
+"""GPU probe: times the conv kernels on the vocoder's dominant shapes (HIP events on the launch stream).
+fused = st2_conv1d_f16s (prologue inside the MFMA kernel); xs = st2_act_split + st2_conv1d_xs (both register
+budgets, with and without the epilogue statistics)."""
 import json
 import math
 import sys
@@ -7,52 +9,64 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from styletts2_amd import ops, weights
+from styletts2_amd import _lib, ops, weights
 
 dev = "cuda"
 B = int(os.environ.get("PROBE_B", "8"))
 cases = [  # C, L, ks, dil
     (128, 48001, 3, 1), (128, 48001, 7, 3), (128, 48001, 11, 5), (128, 48001, 11, 1),
     (256, 8000, 3, 1), (256, 8000, 7, 1), (256, 8000, 11, 5),
-    (64, 120000, 7, 3), (32, 240000, 11, 1),
+    (64, 120000, 7, 3), (32, 240000, 11, 1), (1024, 400, 3, 1),
 ]
-KERNELS = os.environ.get("PROBE_KERNELS", "f32,f16s").split(",")
+lib = _lib.load()
+
+
+def timed(fn, n=5):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
 rows = []
 for (Cc, L, ks, dil) in cases:
     x = torch.randn(B, Cc, L, device=dev)
     w = torch.randn(Cc, Cc, ks, device=dev) / math.sqrt(Cc * ks)
-    wts = {"f32": weights.pack_conv(w), "f16s": weights.pack_conv_f16s(w).to(dev)}
+    wt = weights.pack_conv_f16s(w).to(dev)
     bias = torch.randn(Cc, device=dev)
     st = ops.instnorm_stats(x)
     h = torch.randn(B, 2 * Cc, device=dev) * 0.3
     alpha = torch.rand(Cc, device=dev) + 0.5
     out = torch.empty_like(x)
-    for kern, pro in [(k, p) for k in KERNELS for p in (ops.PRO_NONE, ops.PRO_ADAIN_SNAKE)]:
-        wt = wts[kern]
-        kw = dict(dil=dil, pad_left=(ks - 1) * dil // 2, bias=bias, out=out, pro=pro)
-        if pro == ops.PRO_ADAIN_SNAKE:
-            kw.update(stats=st, gamma=h[:, :Cc], beta=h[:, Cc:], alpha=alpha, res=x)
-        for _ in range(2):
-            ops.conv1d(x, wt, Cc, ks, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 5
-        e0.record()
-        for _ in range(n):
-            ops.conv1d(x, wt, Cc, ks, **kw)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
-        flop = 2.0 * B * Cc * Cc * ks * L
-        rows.append(dict(kernel=kern, C=Cc, L=L, ks=ks, dil=dil, pro=pro, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 1)))
-        print(rows[-1], flush=True)
-    # stats kernel
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        ops.instnorm_stats(x, out=st)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
-    print(dict(stats_C=Cc, L=L, ms=ms, GBs=B * Cc * L * 4 / ms / 1e6), flush=True)
+    flop = 2.0 * B * Cc * Cc * ks * L
+    pad = (ks - 1) * dil // 2
+    akw = dict(pro=ops.PRO_ADAIN_SNAKE, stats=st, gamma=h[:, :Cc], beta=h[:, Cc:], alpha=alpha)
+    os.environ["ST2_CONV_PATH"] = "fused"
+    r = dict(C=Cc, L=L, ks=ks, dil=dil)
+    r["fused_pro0"] = timed(lambda: ops.conv1d(x, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out))
+    r["fused_pro3"] = timed(lambda: ops.conv1d(x, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x, **akw))
+    r["stats"] = timed(lambda: ops.instnorm_stats(x, out=st))
+    r["act"] = timed(lambda: ops.activate(x, **akw))
+    xs = ops.activate(x, **akw)
+    for occ in (2, 3):
+        lib.st2_conv1d_xs_set_occupancy(occ)
+        r["xs_occ%d" % occ] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x))
+        r["xs_occ%d_stats" % occ] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias,
+                                                                out=out, res=x, want_stats=True))
+    lib.st2_conv1d_xs_set_occupancy(3)
+    r = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+    r["tflops_fused_pro3"] = round(flop / r["fused_pro3"] / 1e9, 1)
+    best = min(r["xs_occ2"], r["xs_occ3"])
+    r["tflops_xs_conv"] = round(flop / best / 1e9, 1)
+    r["act_GBps"] = round(B * Cc * L * 8 / r["act"] / 1e6, 1)
+    r["layer_fused_ms"] = round(r["fused_pro3"] + r["stats"], 4)
+    r["layer_xs_ms"] = round(r["act"] + min(r["xs_occ2_stats"], r["xs_occ3_stats"]), 4)
+    rows.append(r)
+    print(r, flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(rows, open("gpurun_out/probe_conv.json", "w"), indent=1)
