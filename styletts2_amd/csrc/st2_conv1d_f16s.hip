@@ -226,14 +226,15 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
 #pragma unroll
       for (int t = 0; t < KS; ++t) {
         const int cur = (s * KS + t) & 1, nxt = cur ^ 1;
-        ap += a_step;
-        if (more || s + 1 < S16 || t + 1 < KS) {  // prefetch the next k-step's weights
-          a_hi[nxt] = ap[0];
-          a_lo[nxt] = ap[1];
-        }
+        // All VMEM below is issued unconditionally (the very last prefetch re-reads the last fragment, the last
+        // chunk's activation loads clamp to the last channel): a branch around a load makes hipcc's in-order vmcnt
+        // bookkeeping conservative, and the next weight wait then drains the activation loads at HBM latency.
+        if (more || s + 1 < S16 || t + 1 < KS) ap += a_step;
+        a_hi[nxt] = ap[0];  // prefetch the next k-step's weights
+        a_lo[nxt] = ap[1];
         // next chunk's activations: issued AFTER the weight prefetch so that the in-order vmcnt wait of the next
         // k-step does not have to drain these (possibly HBM-latency) loads
-        if (s == 0 && t == 0 && more) load_chunk((c + 1) * CI_T);
+        if (s == 0 && t == 0) load_chunk((c + 1) * CI_T);
         __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch stays a full k-step ahead
         const h8 ah = a_hi[cur], al = a_lo[cur];
         const h8* xp = xbuf + (2 * s) * XW + t * d.dil;

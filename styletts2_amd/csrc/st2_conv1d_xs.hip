@@ -78,7 +78,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   static_assert(WM * WN == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  h8* lds = reinterpret_cast<h8*>(smem_raw);  // [2 buffers][ROWS][XW] slots of 16 B
+  h8* lds = reinterpret_cast<h8*>(smem_raw);  // [2 buffers][NS*NT >= ROWS*XW] slots of 16 B, image = [ROWS][XW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,26 +97,27 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   const int64_t gplane = (int64_t)d.xs_cg * Lp;  // slots per plane of one batch item
   // slot (row, col) of the chunk image <- xs[b][plane = row / CG][c*CG + row % CG][n0 - pad_left + halo + col]
   const h8* xsb = reinterpret_cast<const h8*>(d.xs) + (int64_t)b * 2 * gplane + (n0 - d.pad_left + d.xs_halo);
+  // Loads and LDS stores are UNCONDITIONAL (slots past the image re-read slot 0 and land in the buffer's slack):
+  // with predicated loads hipcc cannot count the in-order VMEM queue and drains it at the next weight wait.
   int soff[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int slot = tid + i * NT;
     const int row = slot / XW;
     const int col = slot - row * XW;
-    soff[i] = slot < S ? (int)((row / CG) * gplane + (int64_t)(row % CG) * Lp + col) : -1;
+    soff[i] = slot < S ? (int)((row / CG) * gplane + (int64_t)(row % CG) * Lp + col) : 0;
   }
+  constexpr int LBUF = NS * NT;  // LDS slots per buffer (>= S)
   h8 xr[NS];
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
     const h8* src = xsb + (int64_t)c * CG * Lp;
 #pragma unroll
-    for (int i = 0; i < NS; ++i)
-      if (soff[i] >= 0) xr[i] = src[soff[i]];
+    for (int i = 0; i < NS; ++i) xr[i] = src[soff[i]];
   };
   auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-    h8* dst = lds + (size_t)buf * S;
+    h8* dst = lds + (size_t)buf * LBUF;
 #pragma unroll
-    for (int i = 0; i < NS; ++i)
-      if (soff[i] >= 0) dst[tid + i * NT] = xr[i];
+    for (int i = 0; i < NS; ++i) dst[tid + i * NT] = xr[i];
   };
 
   f32x16 acc[TN];
@@ -133,33 +134,42 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
 
   load_chunk(0);
   constexpr int SPC = S16 * KS;  // k-steps per chunk
-  h8 a_hi[2], a_lo[2];           // two NAMED register sets indexed by the compile-time parity of the k-step
+  // Weight fragments run TWO k-steps ahead in three NAMED register sets (set = k-step index within the chunk mod 3,
+  // a compile-time constant after unrolling).  VMEM returns in order, so the first weight wait that also has to
+  // drain the activation loads of the next chunk (issued at k-step 0, after that step's prefetch) is the one of
+  // k-step 3: three k-steps (>= 1100 MFMA cycles per wave) of slack for their HBM latency.
+  h8 a_hi[3], a_lo[3];
   a_hi[0] = ap[0];
   a_lo[0] = ap[1];
+  const int nsteps = nchunk * SPC;
+  if (nsteps > 1) ap += a_step;
+  a_hi[1] = ap[0];
+  a_lo[1] = ap[1];
   store_chunk(0);
   __syncthreads();
 
   const int plane = CG * XW;  // LDS slots per plane of a chunk image
+  // Every load and LDS store below is issued unconditionally (the last chunk re-stages itself into the idle buffer
+  // and re-reads its last weight fragment): a branch around VMEM makes hipcc's in-order vmcnt bookkeeping
+  // conservative and the next weight wait then drains the activation loads at HBM latency.
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunk;
-    const h8* xbuf = lds + (size_t)buf * S + kg * XW + wn * (32 * TN) + l31;
+    const h8* xbuf = lds + (size_t)buf * LBUF + kg * XW + wn * (32 * TN) + l31;
 #pragma unroll
     for (int s = 0; s < S16; ++s) {
 #pragma unroll
       for (int t = 0; t < KS; ++t) {
-        const int cur = (s * KS + t) & 1, nxt = cur ^ 1;
-        ap += a_step;
-        if (more || s + 1 < S16 || t + 1 < KS) {  // prefetch the next k-step's weights
-          a_hi[nxt] = ap[0];
-          a_lo[nxt] = ap[1];
-        }
-        // next chunk's activations: issued AFTER the weight prefetch so that the in-order vmcnt wait of the next
-        // k-step does not have to drain these (possibly HBM-latency) loads
-        if (s == 0 && t == 0 && more) load_chunk(c + 1);
+        const int i = s * KS + t;           // k-step within the chunk (compile-time after unrolling)
+        const int cur = i % 3, pre = (i + 2) % 3;
+        if (more || i + 2 < SPC) ap += a_step;  // scalar select, no branch around the loads
+        a_hi[pre] = ap[0];                      // prefetch the weights of k-step i + 2
+        a_lo[pre] = ap[1];
+        // next chunk's activations: issued AFTER this step's weight prefetch (see above)
+        if (i == 0) load_chunk(more ? c + 1 : c);
         // ... and parked in the other LDS buffer at the chunk's last k-step (free since the previous barrier)
-        if (s == S16 - 1 && t == KS - 1 && more) store_chunk(buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch stays a full k-step ahead
+        if (i == SPC - 1) store_chunk(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch distance is kept
         const h8 ah = a_hi[cur], al = a_lo[cur];
         const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
         h8 bh[TN], bl[TN];
@@ -176,9 +186,19 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
         for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
       }
     }
-    if (SPC & 1) {  // odd step count: next chunk's step 0 reads set 0
-      a_hi[0] = a_hi[1];
-      a_lo[0] = a_lo[1];
+    // the next chunk indexes its steps from 0 again: rotate the two live sets (steps SPC, SPC+1) to sets 0, 1
+    if (SPC % 3 == 1) {
+      const h8 th = a_hi[1], tl = a_lo[1];  // sets (1, 2) -> (0, 1)
+      a_hi[1] = a_hi[2];
+      a_lo[1] = a_lo[2];
+      a_hi[0] = th;
+      a_lo[0] = tl;
+    } else if (SPC % 3 == 2) {
+      const h8 th = a_hi[0], tl = a_lo[0];  // sets (2, 0) -> (0, 1)
+      a_hi[0] = a_hi[2];
+      a_lo[0] = a_lo[2];
+      a_hi[1] = th;
+      a_lo[1] = tl;
     }
     __syncthreads();
   }
@@ -269,7 +289,8 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   constexpr int BN = 32 * TN * WN;
   const int XW = BN + (KS - 1) * d.dil;
   const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
-  const size_t smem = (size_t)2 * (2 * CI_T / 8) * XW * 16;
+  constexpr int NS = ((2 * CI_T / 8) * (BN + (KS - 1) * 8) + NT - 1) / NT;
+  const size_t smem = (size_t)2 * NS * NT * 16;
   ST2_REQUIRE(smem <= 160 * 1024, "st2_conv1d_xs: tile needs %zu B of LDS (ks=%d dil=%d)", smem, KS, d.dil);
   ST2_REQUIRE(d.wq_cin_pad == C_pad, "st2_conv1d_xs: packed weight has %d input channels, kernel needs %d",
               d.wq_cin_pad, C_pad);
