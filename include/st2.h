@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 4
+#define ST2_ABI_VERSION 5
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -240,6 +240,18 @@ int st2_attention(const float* q, const float* k, const float* v, int64_t bs, in
  * :450,523-528,545-566 (duration LSTM / DurationEncoder), :453,498 (shared F0/N LSTM). */
 int st2_lstm_bidir(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
                    int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* stream);
+
+/* Cooperative form of the same recurrence: W_hh stays in registers, split over 8 workgroups (CUs) per group of up to
+ * 8 utterances of one direction, which exchange the new hidden state once per step through `scratch` (agent-scope
+ * release/acquire on a monotonic counter).  ~5x lower latency per step than st2_lstm_bidir, same results up to fp32
+ * summation order.  `scratch` (256-byte aligned, >= st2_lstm_coop_scratch_bytes(B) bytes, contents irrelevant) is
+ * zeroed and used by the call; scratch[0..3] holds an int32 status afterwards (0 = ok, 1 = a bounded spin timed out
+ * and the outputs are invalid).  st2_lstm_coop_scratch_bytes returns 0 when B is too large for one co-resident
+ * launch (B > 48): use st2_lstm_bidir. */
+int64_t st2_lstm_coop_scratch_bytes(int32_t B);
+int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
+                        int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,
+                        void* scratch, int64_t scratch_bytes, void* stream);
 
 /* generic fused elementwise helpers used by the sampler / denoiser glue */
 /* y[b][c][n] = x[b][c][n] + v[b][c]  (x = x + mapping, modules.py:152,394) */

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(HERE, "libst2_hip.so")
 
-SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_xs.hip", "st2_actsplit.hip", "st2_norm.hip", "st2_misc.hip", "st2_source.hip", "st2_attention.hip", "st2_lstm.hip"]
+SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_xs.hip", "st2_actsplit.hip", "st2_norm.hip", "st2_misc.hip", "st2_source.hip", "st2_attention.hip", "st2_lstm.hip", "st2_lstm_coop.hip"]
 # -ffp-contract=off: the SineGen phase path must reproduce ATen-CPU rounding (no implicit FMA);
 # fused multiply-adds are written explicitly (fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",

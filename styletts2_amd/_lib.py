@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -90,6 +90,9 @@ _SIGNATURES = {
                                 C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "st2_lstm_bidir": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, f32p,
                                  C.c_int64, C.c_int32, C.c_void_p]),
+    "st2_lstm_coop_scratch_bytes": (C.c_int64, [C.c_int32]),
+    "st2_lstm_bidir_coop": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "st2_add_chanvec": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, f32p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "st2_mean_tokens": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -1,0 +1,234 @@
+// Bidirectional LSTM recurrence (H = 256), cooperative multi-CU form.
+//
+// The single-CU kernel (st2_lstm.hip) streams the whole W_hh (1 MB per direction) from L2 on EVERY time step: the
+// step is bound by one CU's L2 port (~15 us), 400 steps take 6.5 ms.  Here W_hh is REGISTER RESIDENT: a group of 8
+// workgroups (one per CU) serves U utterances of one direction; workgroup `sl` owns hidden units [32 sl, 32 sl + 32),
+// i.e. 128 of the 1024 gate rows, and keeps its 128 x 256 fp32 slice in VGPRs (128 per thread) for the whole
+// sequence.  Per step a workgroup
+//   1. multiplies its slice with the previous hidden state of its U utterances (LDS broadcast reads of h, 128 FMAs
+//      per utterance per thread; thread = (unit, 32-wide k slice) holds all four gates of its unit),
+//   2. reduces the 8 k-slice partials through LDS, applies the gate non-linearities and updates c / h for its
+//      32 units x U utterances (one thread each),
+//   3. publishes its 32 x U new h values to a double-buffered exchange array in global memory and
+//   4. meets the other 7 workgroups of the group at a monotonic counter (agent-scope release / acquire, the
+//      placement-independent hand-off of cdna_hip_programming.md section 6), then reloads the full h into LDS.
+// The step costs the FMA time of the slice (~1 us for U = 8) plus one L2/fabric round trip instead of a 1 MB
+// stream.  Every spin is bounded: on a time-out the group raises status[0] and every workgroup leaves.
+//
+// Packed-sequence semantics are those of st2_lstm_bidir (outputs past `length` are zero, the reverse direction
+// starts at t = length - 1); arithmetic per gate row is a fixed-order fp32 sum (k ascending inside a 32-slice, the
+// 8 slices ascending), bitwise reproducible.
+#include "st2_common.h"
+
+namespace {
+
+constexpr int H = 256;
+constexpr int NSL = 8;         // workgroups (hidden-unit slices) per group
+constexpr int UNITS = H / NSL;  // 32 hidden units per workgroup
+constexpr int SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int U>
+__global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict__ G, int64_t g_bs, int g_cs,
+                                                        const float* __restrict__ whh_t,  // [2][H][4H]
+                                                        const int* __restrict__ lengths, int B, int N,
+                                                        float* __restrict__ Y, int64_t y_bs, int y_cs,
+                                                        int* __restrict__ status,   // [0] error flag
+                                                        int* __restrict__ counters,  // [groups]
+                                                        float* __restrict__ hx) {   // [groups][2][U][H]
+  __shared__ __attribute__((aligned(16))) float hs[U][H];
+  __shared__ float part[U][4][NSL][UNITS];
+  __shared__ int s_fail;
+
+  const int tid = threadIdx.x;
+  const int sl = blockIdx.x;                       // slice of hidden units
+  const int blk = blockIdx.y;                      // utterance block
+  const int dir = blockIdx.z;
+  const int group = dir * gridDim.y + blk;
+  const int unit = tid & 31;                       // hidden unit inside the slice (matvec role and update role)
+  const int kq = tid >> 5;                         // matvec role: k slice [32 kq, 32 kq + 32)
+  const int uu = tid >> 5;                         // update role: utterance inside the block (valid if < U)
+  const int hu = sl * UNITS + unit;                // global hidden unit
+
+  // ---- weight slice into registers: w[g][kk] = W_hh[g*H + hu][32 kq + kk] ------------------------------
+  float w[4][32];
+  {
+    const float* Wd = whh_t + (int64_t)dir * H * 4 * H;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w[g][kk] = Wd[(int64_t)(kq * 32 + kk) * 4 * H + g * H + hu];
+  }
+
+  // ---- update-role state ------------------------------------------------------------------------------
+  const int b = blk * U + uu;
+  const bool live = uu < U && b < B;
+  const int len = live ? (lengths ? min(lengths[b], N) : N) : 0;
+  int maxlen = 0;  // steps this group runs = longest sequence in the block (same value in all 8 workgroups)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int bb = blk * U + u;
+    if (bb < B) maxlen = max(maxlen, lengths ? min(lengths[bb], N) : N);
+  }
+  const float* Gb = G + (int64_t)(live ? b : 0) * g_bs + (int64_t)(dir * 4 * H + hu) * g_cs;
+  float* Yb = Y + (int64_t)(live ? b : 0) * y_bs + (int64_t)(dir * H + hu) * y_cs;
+  if (live)
+    for (int t = len; t < N; ++t) Yb[t] = 0.f;  // pad_packed_sequence tail
+
+  for (int e = tid; e < U * H; e += 256) (&hs[0][0])[e] = 0.f;
+  if (tid == 0) s_fail = 0;
+  float c = 0.f, h = 0.f;
+  const int dt = dir == 0 ? 1 : -1;
+  int t = dir == 0 ? 0 : len - 1;
+  float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+  if (live && len > 0) {
+    gi = Gb[(int64_t)(0 * H) * g_cs + t];
+    gf = Gb[(int64_t)(1 * H) * g_cs + t];
+    gg = Gb[(int64_t)(2 * H) * g_cs + t];
+    go = Gb[(int64_t)(3 * H) * g_cs + t];
+  }
+  int* cnt = counters + group;
+  float* hxg = hx + (int64_t)group * 2 * U * H;
+  __syncthreads();
+
+  for (int s = 0; s < maxlen; ++s) {
+    // prefetch the next step's projected inputs (update role)
+    const bool act = live && s < len;
+    const int tn = t + dt;
+    float ni = 0.f, nf = 0.f, ng = 0.f, no = 0.f;
+    if (live && s + 1 < len) {
+      ni = Gb[(int64_t)(0 * H) * g_cs + tn];
+      nf = Gb[(int64_t)(1 * H) * g_cs + tn];
+      ng = Gb[(int64_t)(2 * H) * g_cs + tn];
+      no = Gb[(int64_t)(3 * H) * g_cs + tn];
+    }
+    // 1. partial gate sums of this thread's (unit, k slice) for every utterance of the block
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float4* hp = reinterpret_cast<const float4*>(&hs[u][kq * 32]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 hv = hp[q];  // the same address in all 32 lanes of a half-wave: LDS broadcast
+        a0 = fmaf(w[0][4 * q + 0], hv.x, a0); a1 = fmaf(w[1][4 * q + 0], hv.x, a1);
+        a2 = fmaf(w[2][4 * q + 0], hv.x, a2); a3 = fmaf(w[3][4 * q + 0], hv.x, a3);
+        a0 = fmaf(w[0][4 * q + 1], hv.y, a0); a1 = fmaf(w[1][4 * q + 1], hv.y, a1);
+        a2 = fmaf(w[2][4 * q + 1], hv.y, a2); a3 = fmaf(w[3][4 * q + 1], hv.y, a3);
+        a0 = fmaf(w[0][4 * q + 2], hv.z, a0); a1 = fmaf(w[1][4 * q + 2], hv.z, a1);
+        a2 = fmaf(w[2][4 * q + 2], hv.z, a2); a3 = fmaf(w[3][4 * q + 2], hv.z, a3);
+        a0 = fmaf(w[0][4 * q + 3], hv.w, a0); a1 = fmaf(w[1][4 * q + 3], hv.w, a1);
+        a2 = fmaf(w[2][4 * q + 3], hv.w, a2); a3 = fmaf(w[3][4 * q + 3], hv.w, a3);
+      }
+      part[u][0][kq][unit] = a0;
+      part[u][1][kq][unit] = a1;
+      part[u][2][kq][unit] = a2;
+      part[u][3][kq][unit] = a3;
+    }
+    __syncthreads();
+    // 2. gate non-linearities and state update: thread = (unit, utterance uu)
+    if (uu < U) {
+      if (act) {
+        float ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f;
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) {
+          ai += part[uu][0][q][unit];
+          af += part[uu][1][q][unit];
+          ag += part[uu][2][q][unit];
+          ao += part[uu][3][q][unit];
+        }
+        const float iv = sigmoidf_(gi + ai);
+        const float fv = sigmoidf_(gf + af);
+        const float gv = tanhf(gg + ag);
+        const float ov = sigmoidf_(go + ao);
+        c = fv * c + iv * gv;
+        h = ov * tanhf(c);
+        Yb[t] = h;
+      }
+      // 3. publish (a finished or absent utterance republishes its last state: nobody consumes it)
+      hxg[((int64_t)(s & 1) * U + uu) * H + hu] = h;
+    }
+    // 4. group hand-off: all stores of this workgroup complete -> release -> count -> wait -> acquire
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int target = NSL * (s + 1);
+      int spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_fail = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_fail) return;
+    // full new hidden state of the block's utterances -> LDS (thread = hidden unit index)
+    const float* src = hxg + (int64_t)(s & 1) * U * H;
+#pragma unroll
+    for (int u = 0; u < U; ++u) hs[u][tid] = src[u * H + tid];
+    gi = ni; gf = nf; gg = ng; go = no;
+    if (act) t = tn;
+    __syncthreads();
+  }
+}
+
+template <int U>
+int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, const int* lengths, int B, int N, float* Y,
+                int64_t y_bs, int y_cs, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  const int nblk = st2_cdiv(B, U);
+  const int groups = 2 * nblk;
+  const size_t head = ((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256;
+  const size_t need = head + (size_t)groups * 2 * U * H * sizeof(float);
+  ST2_REQUIRE(scratch_bytes >= need, "st2_lstm_bidir_coop: scratch of %zu B, need %zu B", scratch_bytes, need);
+  ST2_REQUIRE(groups * NSL <= 192, "st2_lstm_bidir_coop: %d workgroups must be co-resident (<= 192)", groups * NSL);
+  int* status = reinterpret_cast<int*>(scratch);
+  int* counters = status + 1;
+  float* hx = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + head);
+  if (hipMemsetAsync(scratch, 0, head, s) != hipSuccess) {
+    st2_set_error("st2_lstm_bidir_coop: hipMemsetAsync failed");
+    return 1;
+  }
+  hipLaunchKernelGGL((lstm_coop_kernel<U>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths, B, N, Y,
+                     y_bs, y_cs, status, counters, hx);
+  ST2_CHECK_LAUNCH("st2_lstm_bidir_coop");
+  return 0;
+}
+
+int block_size(int B) { return B > 48 ? 0 : (B > 4 ? 8 : (B > 1 ? 4 : 1)); }
+
+}  // namespace
+
+extern "C" int64_t st2_lstm_coop_scratch_bytes(int32_t B) {
+  const int U = block_size(B);
+  if (U == 0) return 0;  // batch too large for one co-resident launch: use st2_lstm_bidir
+  const int groups = 2 * st2_cdiv(B, U);
+  return (int64_t)(((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256 + (size_t)groups * 2 * U * H * sizeof(float));
+}
+
+extern "C" int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t,
+                                   const int32_t* lengths, int32_t B, int32_t Hn, int32_t N, float* Y, int64_t y_bs,
+                                   int32_t y_cs, void* scratch, int64_t scratch_bytes, void* stream) {
+  ST2_REQUIRE(G && whh_t && Y && scratch && B > 0 && N > 0, "st2_lstm_bidir_coop: bad arguments");
+  ST2_REQUIRE(Hn == H, "st2_lstm_bidir_coop: hidden size %d unsupported (built for 256)", Hn);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255) == 0, "st2_lstm_bidir_coop: scratch must be 256-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int* len = reinterpret_cast<const int*>(lengths);
+  switch (block_size(B)) {
+    case 8:
+      return launch_coop<8>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
+    case 4:
+      return launch_coop<4>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
+    case 1:
+      return launch_coop<1>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
+    default:
+      st2_set_error("st2_lstm_bidir_coop: batch %d needs more co-resident workgroups than one launch may hold", B);
+      return 1;
+  }
+}

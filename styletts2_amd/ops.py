@@ -443,8 +443,22 @@ def attention(q, k, v, heads, scale, out=None):
     return out
 
 
+_last_lstm_scratch = None  # scratch of the most recent cooperative launch (tests read its status word)
+
+
+def lstm_mode():
+    """"coop" (default): W_hh register-resident over 8 CUs per group, one hidden-state exchange per step
+    (st2_lstm_bidir_coop); "single": one CU per (utterance, direction) streaming W_hh from L2 (st2_lstm_bidir).
+    Read from ST2_LSTM at call time."""
+    mode = os.environ.get("ST2_LSTM", "coop")
+    if mode not in ("coop", "single"):
+        raise ValueError("ST2_LSTM must be coop or single, got %r" % mode)
+    return mode
+
+
 def lstm_bidir(G, whh_t, lengths=None, out=None):
     """G [B, 8H, N] projected inputs (both directions) -> Y [B, 2H, N]; lengths: int32 [B] on the device or None."""
+    global _last_lstm_scratch
     lib = _lib.load()
     _chk(G, "G", 3)
     _chk(whh_t, "whh_t", 3)
@@ -455,10 +469,25 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
         assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.numel() == B and lengths.is_contiguous()
     if out is None:
         out = torch.empty((B, 2 * H, N), device=G.device, dtype=torch.float32)
-    _lib.check(lib.st2_lstm_bidir(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(),
-                                  0 if lengths is None else lengths.data_ptr(), B, H, N, out.data_ptr(),
-                                  out.stride(0), out.stride(1), _stream()), "st2_lstm_bidir")
+    lp = 0 if lengths is None else lengths.data_ptr()
+    nbytes = lib.st2_lstm_coop_scratch_bytes(B) if lstm_mode() == "coop" else 0
+    if nbytes > 0:
+        scratch = torch.empty((nbytes,), device=G.device, dtype=torch.uint8)
+        _lib.check(lib.st2_lstm_bidir_coop(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
+                                           out.data_ptr(), out.stride(0), out.stride(1), scratch.data_ptr(), nbytes,
+                                           _stream()), "st2_lstm_bidir_coop")
+        _last_lstm_scratch = scratch
+        return out
+    _lib.check(lib.st2_lstm_bidir(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
+                                  out.data_ptr(), out.stride(0), out.stride(1), _stream()), "st2_lstm_bidir")
     return out
+
+
+def lstm_coop_status():
+    """Status word of the most recent cooperative LSTM launch (synchronises): 0 = ok, 1 = a spin timed out."""
+    if _last_lstm_scratch is None:
+        return 0
+    return int(_last_lstm_scratch[:4].view(torch.int32).item())
 
 
 def add_chanvec(x, v, out=None):

@@ -356,24 +356,38 @@ def test_token_glue():
     assert rel_err(ops.axpbypcz(g(x), 0.3, g(y), -1.2), R.axpbypcz(x, 0.3, y, -1.2)) < 1e-6
 
 
-@pytest.mark.parametrize("B,N,ragged", [(2, 17, False), (3, 40, True)])
-def test_lstm_bidir_matches_torch_lstm(B, N, ragged):
-    """Input projection on st2_conv1d + st2_lstm_bidir == nn.LSTM(bidirectional) with pack/pad semantics."""
+@pytest.mark.parametrize("mode", ["coop", "single"])
+@pytest.mark.parametrize("B,N,ragged", [(2, 17, False), (3, 40, True), (1, 33, False), (9, 25, True), (32, 60, False),
+                                        (13, 101, True)])
+def test_lstm_bidir_matches_torch_lstm(B, N, ragged, mode, monkeypatch):
+    """Input projection on st2_conv1d + the recurrence kernel == nn.LSTM(bidirectional) with pack/pad semantics, for
+    both recurrence kernels: `coop` = st2_lstm_bidir_coop (register-resident W_hh over 8 CUs per group; utterance
+    blocks of 1 / 4 / 8, partial blocks, ragged lengths inside a block), `single` = st2_lstm_bidir."""
     from styletts2_amd.text import EngineLSTM
+    monkeypatch.setenv("ST2_LSTM", mode)
     torch.manual_seed(N)
     lstm = EngineLSTM(640, 256)
     ref_lstm = torch.nn.LSTM(640, 256, 1, batch_first=True, bidirectional=True)
     ref_lstm.load_state_dict(lstm.state_dict())
     x = torch.randn(B, N, 640)
-    lengths = torch.tensor([N, N - 7, 5][:B]) if ragged else torch.full((B,), N)
+    if ragged:
+        lengths = torch.randint(1, N + 1, (B,), generator=torch.Generator().manual_seed(B))
+        lengths[0] = N
+        if B > 2:
+            lengths[2] = 5
+    else:
+        lengths = torch.full((B,), N)
     with torch.no_grad():
         packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, batch_first=True, enforce_sorted=False)
         ref, _ = torch.nn.utils.rnn.pad_packed_sequence(ref_lstm(packed)[0], batch_first=True, total_length=N)
     lstm = lstm.to(DEV)
     lens = lengths.to(torch.int32).to(DEV) if ragged else None
     out = lstm.forward_cm(g(x).transpose(1, 2).contiguous(), lens).transpose(1, 2)
+    torch.cuda.synchronize()
+    if mode == "coop":
+        assert ops.lstm_coop_status() == 0, "a cooperative LSTM group timed out"
     assert out.shape == ref.shape
     assert (out.cpu() - ref).abs().max().item() < 2e-5
     if not ragged:
         y, _ = lstm(g(x))
-        assert torch.equal(y, out)
+        assert torch.equal(y, out)  # bitwise reproducible

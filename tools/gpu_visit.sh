@@ -13,6 +13,7 @@ has() { [[ ",$SKIP," == *",$1,"* ]]; }
 if ! has pytest; then echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log; tail -12 $OUT/pytest_gpu.log; fi
 if ! has smoke; then echo "== smoke"; timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -3 $OUT/smoke.log; fi
 if ! has probe; then echo "== probe e2e"; timeout 300 python tools/probe_e2e.py > $OUT/probe_e2e.log 2>&1; tail -6 $OUT/probe_e2e.log
+  echo "== probe lstm"; timeout 300 python tools/probe_lstm.py > $OUT/probe_lstm.log 2>&1; tail -8 $OUT/probe_lstm.log
   echo "== probe conv"; PROBE_KERNELS=f16s timeout 300 python tools/probe_conv.py > $OUT/probe_conv.log 2>&1; tail -40 $OUT/probe_conv.log; fi
 if ! has bench; then echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -4 $OUT/bench.err; fi
 if ! has rocprof; then echo "== rocprof stats"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/bench_prof.json 2> $R/$OUT/bench_prof.err ); echo "rocprof exit $?"

@@ -1,0 +1,31 @@
+"""GPU probe: the two BiLSTM recurrence kernels at the bench shapes (B=32; N=100 text side, T=400 prosody side)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from styletts2_amd import ops
+
+dev = "cuda"
+B, H = int(os.environ.get("PROBE_B", "32")), 256
+whh = (torch.randn(2, H, 4 * H, device=dev) / 16).contiguous()
+for N in (100, 400):
+    G = torch.randn(B, 8 * H, N, device=dev)
+    outs = {}
+    for mode in ("single", "coop"):
+        os.environ["ST2_LSTM"] = mode
+        for _ in range(2):
+            y = ops.lstm_bidir(G, whh)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            y = ops.lstm_bidir(G, whh)
+        e1.record()
+        torch.cuda.synchronize()
+        outs[mode] = y
+        print("lstm %s B=%d N=%d: %.3f ms (%.2f us/step) status=%d" % (mode, B, N, e0.elapsed_time(e1) / 5,
+                                                                      e0.elapsed_time(e1) / 5 / N * 1e3,
+                                                                      ops.lstm_coop_status() if mode == "coop" else 0),
+              flush=True)
+    print("   max |coop - single| = %.3g" % (outs["coop"] - outs["single"]).abs().max().item(), flush=True)
