@@ -66,7 +66,7 @@ __device__ __forceinline__ float halfwave_reduce16(const float (&s)[16], int l31
 // Two builds of the body: an uncapped one (accumulators in AGPRs, every B fragment of a k-step in flight at once,
 // ~196 registers -> 2 workgroups per CU) and one capped at 168 VGPRs (3 workgroups per CU: trades some of that
 // intra-wave pipelining for a third wave per SIMD to hide LDS / L2 latency behind).
-template <int KS, int CI_T, int WM, int WN, int TN, bool PIN>
+template <int KS, int CI_T, int WM, int WN, int TN>
 __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
@@ -75,11 +75,10 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   constexpr int S16 = CI_T / 16;   // MFMA k-steps per tap per chunk
   constexpr int MAXXW = BN + (KS - 1) * 8;
   constexpr int NS = (ROWS * MAXXW + NT - 1) / NT;  // staged 16-byte slots per thread per chunk
-  constexpr bool PIPE = S16 * KS >= 4;              // software-pipelined k loop (3 LDS buffers), see below
   static_assert(WM * WN == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  h8* lds = reinterpret_cast<h8*>(smem_raw);  // [2 or 3 buffers][NS*NT >= ROWS*XW] slots of 16 B, image = [ROWS][XW]
+  h8* lds = reinterpret_cast<h8*>(smem_raw);  // [2 buffers][NS*NT >= ROWS*XW] slots of 16 B, image = [ROWS][XW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -150,101 +149,29 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   __syncthreads();
 
   const int plane = CG * XW;  // LDS slots per plane of a chunk image
-  const h8* xwave = lds + kg * XW + wn * (32 * TN) + l31;  // this lane's fragment column in buffer 0
-
-  // Every load and LDS store below is issued unconditionally (the last chunk re-stages itself into an idle buffer
+  // Every load and LDS store below is issued unconditionally (the last chunk re-stages itself into the idle buffer
   // and re-reads its last weight fragment): a branch around VMEM makes hipcc's in-order vmcnt bookkeeping
   // conservative and the next weight wait then drains the activation loads at HBM latency.
-  if constexpr (PIPE) {
-    // ---- software-pipelined k loop: the B fragments (8 x ds_read_b128) of k-step i+1 are issued BEFORE the 12 MFMAs
-    // of k-step i into the other of two named register sets, so no MFMA ever waits on the LDS.  That needs the next
-    // chunk's image visible one k-step early: it is parked in LDS at k-step SPC-2 (the barrier follows at once) into
-    // the third of THREE rotating buffers -- with two, a wave one barrier ahead could overwrite the image a slower
-    // wave is still reading in its last k-step.
-    h8 bh[2][TN], bl[2][TN];
-    auto read_frags = [&](int bufi, int i, int set) __attribute__((always_inline)) {  // fragments of k-step i
-      const h8* xp = xwave + (size_t)bufi * LBUF + (2 * (i / KS)) * XW + (i % KS) * d.dil;
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunk;
+    const h8* xbuf = lds + (size_t)buf * LBUF + kg * XW + wn * (32 * TN) + l31;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[set][j] = xp[j * 32];
-        bl[set][j] = xp[plane + j * 32];
-      }
-    };
-    read_frags(0, 0, 0);
-    int buf = 0;  // LDS buffer of chunk c (c % 3)
-    auto chunk_body = [&](int c, auto parity_tag) __attribute__((always_inline)) {
-      constexpr int P = decltype(parity_tag)::value;  // register set holding k-step 0 of this chunk
-      const bool more = c + 1 < nchunk;
-      const int nbuf = buf == 2 ? 0 : buf + 1;
+    for (int s = 0; s < S16; ++s) {
 #pragma unroll
-      for (int i = 0; i < SPC; ++i) {
+      for (int t = 0; t < KS; ++t) {
+        const int i = s * KS + t;           // k-step within the chunk (compile-time after unrolling)
         const int cur = i % 3, pre = (i + 2) % 3;
-        const int bs = (P + i) & 1;
         if (more || i + 2 < SPC) ap += a_step;  // scalar select, no branch around the loads
-        a_hi[pre] = ap[0];                      // weights of k-step i + 2
+        a_hi[pre] = ap[0];                      // prefetch the weights of k-step i + 2
         a_lo[pre] = ap[1];
-        if (i == 0) load_chunk(more ? c + 1 : c);  // next chunk's activations, AFTER this step's weight prefetch
-        if (i == SPC - 2) {                        // ... parked in the third buffer; visible from k-step SPC-1 on
-          store_chunk(nbuf);
-          __syncthreads();
-        }
-        if (i + 1 < SPC)
-          read_frags(buf, i + 1, bs ^ 1);
-        else
-          read_frags(nbuf, 0, bs ^ 1);  // k-step 0 of the next chunk (the last chunk re-reads its own copy)
-        // PIN: VMEM, LDS and MFMA all stay on their side of this line, so the fragment reads above really are one
-        // k-step ahead (costs ~56 more live VGPRs: only the 2-workgroups-per-CU build of the 128-row variant can
-        // afford it); otherwise only VMEM and MFMA are held and hipcc places the LDS reads itself.
-        if constexpr (PIN)
-          __builtin_amdgcn_sched_barrier(0x406);
-        else
-          __builtin_amdgcn_sched_barrier(0x786);
-        const h8 ah = a_hi[cur], al = a_lo[cur];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[bs][j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[bs][j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[bs][j], acc[j], 0, 0, 0);
-      }
-      // the next chunk indexes its steps from 0 again: rotate the two live weight sets (steps SPC, SPC+1) to 0, 1
-      if (SPC % 3 == 1) {
-        const h8 th = a_hi[1], tl = a_lo[1];
-        a_hi[1] = a_hi[2];
-        a_lo[1] = a_lo[2];
-        a_hi[0] = th;
-        a_lo[0] = tl;
-      } else if (SPC % 3 == 2) {
-        const h8 th = a_hi[0], tl = a_lo[0];
-        a_hi[0] = a_hi[2];
-        a_lo[0] = a_lo[2];
-        a_hi[1] = th;
-        a_lo[1] = tl;
-      }
-      buf = nbuf;
-    };
-    for (int c = 0; c < nchunk; c += 2) {  // two chunks per trip: the B register-set parity is compile-time
-      chunk_body(c, std::integral_constant<int, 0>{});
-      if (c + 1 < nchunk) chunk_body(c + 1, std::integral_constant<int, SPC & 1>{});
-    }
-  } else {
-    // ---- plain k loop (chunks of fewer than 4 k-steps): fragments read in the k-step that uses them, the next
-    // chunk parked at the last k-step, barrier at the chunk end, two buffers.
-    for (int c = 0; c < nchunk; ++c) {
-      const int buf = c & 1;
-      const bool more = c + 1 < nchunk;
-      const h8* xbuf = xwave + (size_t)buf * LBUF;
-#pragma unroll
-      for (int i = 0; i < SPC; ++i) {
-        const int cur = i % 3, pre = (i + 2) % 3;
-        if (more || i + 2 < SPC) ap += a_step;
-        a_hi[pre] = ap[0];
-        a_lo[pre] = ap[1];
+        // next chunk's activations: issued AFTER this step's weight prefetch (see above)
         if (i == 0) load_chunk(more ? c + 1 : c);
+        // ... and parked in the other LDS buffer at the chunk's last k-step (free since the previous barrier)
         if (i == SPC - 1) store_chunk(buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0x786);
+        __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch distance is kept
         const h8 ah = a_hi[cur], al = a_lo[cur];
-        const h8* xp = xbuf + (2 * (i / KS)) * XW + (i % KS) * d.dil;
+        const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
         h8 bh[TN], bl[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -258,21 +185,22 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
       }
-      if (SPC % 3 == 1) {
-        const h8 th = a_hi[1], tl = a_lo[1];
-        a_hi[1] = a_hi[2];
-        a_lo[1] = a_lo[2];
-        a_hi[0] = th;
-        a_lo[0] = tl;
-      } else if (SPC % 3 == 2) {
-        const h8 th = a_hi[0], tl = a_lo[0];
-        a_hi[0] = a_hi[2];
-        a_lo[0] = a_lo[2];
-        a_hi[1] = th;
-        a_lo[1] = tl;
-      }
-      __syncthreads();
     }
+    // the next chunk indexes its steps from 0 again: rotate the two live sets (steps SPC, SPC+1) to sets 0, 1
+    if (SPC % 3 == 1) {
+      const h8 th = a_hi[1], tl = a_lo[1];  // sets (1, 2) -> (0, 1)
+      a_hi[1] = a_hi[2];
+      a_lo[1] = a_lo[2];
+      a_hi[0] = th;
+      a_lo[0] = tl;
+    } else if (SPC % 3 == 2) {
+      const h8 th = a_hi[0], tl = a_lo[0];  // sets (2, 0) -> (0, 1)
+      a_hi[0] = a_hi[2];
+      a_lo[0] = a_lo[2];
+      a_hi[1] = th;
+      a_lo[1] = tl;
+    }
+    __syncthreads();
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
@@ -281,22 +209,34 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
   const float osc = d.out_scale;
   const bool want_part = d.part != nullptr;
-  auto epilogue_as = [&](auto act_tag) __attribute__((always_inline)) {
+  // Interior tiles (every tile but the last along l / co) take the FULL path: no per-element bounds tests, one 64-bit
+  // address per output row (the four 32-column groups of a lane are immediate offsets from it).  The generic version
+  // of this loop cost ~2900 VALU instructions per wave against 1056 MFMAs in the k loop.
+  const int col0 = n0 + wn * (32 * TN) + l31;
+  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
+  auto epilogue_as = [&](auto act_tag, auto full_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool FULL = decltype(full_tag)::value;
     float ps[16], pq[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ps[r] = pq[r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const bool rok = FULL || row < d.C_out;
+      const int rowc = FULL ? row : min(row, d.C_out - 1);
+      float* yp = yb + (int64_t)rowc * d.y_cs + col0;
+      const float* rp = rb ? rb + (int64_t)rowc * d.res_cs + (col0 >> d.res_shift) : nullptr;
+      const float* r2p = r2b ? r2b + (int64_t)rowc * d.res2_cs + col0 : nullptr;
+      const float bias_r = d.bias ? d.bias[rowc] : 0.f;
+      const int rstep = 32 >> d.res_shift;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (32 * TN) + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (row < d.C_out && col < d.L_out) {
-          float v = acc[j][r] * osc;
-          if (d.bias) v += d.bias[row];
-          if (rb) v += rb[(int64_t)row * d.res_cs + (col >> d.res_shift)];
-          if (r2b) v = r2b[(int64_t)row * d.res2_cs + col] + v;
+      for (int j = 0; j < TN; ++j) {
+        const bool ok = FULL || (rok && col0 + j * 32 < d.L_out);
+        float v = acc[j][r] * osc;
+        if (d.bias) v += bias_r;
+        if (ok) {
+          if (rp) v += rp[j * rstep];
+          if (r2p) v = r2p[j * 32] + v;
           if (d.div != 1.0f) v = v / d.div;
           if constexpr (ACT == ST2_ACT_GELU) {
             v = gelu_erf(v);
@@ -307,11 +247,14 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
           } else if constexpr (ACT == ST2_ACT_LEAKY) {
             v = leaky(v, d.act_slope);
           }
-          yb[(int64_t)row * d.y_cs + col] = v;
-          ps[r] += v;
-          pq[r] += v * v;
+          yp[j * 32] = v;
+          s1 += v;
+          s2 += v * v;
         }
       }
+      ps[r] = s1;
+      pq[r] = s2;
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
     }
     if (want_part) {  // wave-uniform
       const float ts = halfwave_reduce16(ps, l31);
@@ -325,32 +268,38 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       }
     }
   };
+  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
+    if (full_tile)
+      epilogue_as(act_tag, std::true_type{});
+    else
+      epilogue_as(act_tag, std::false_type{});
+  };
   switch (d.act) {
     case ST2_ACT_GELU:
-      epilogue_as(std::integral_constant<int, ST2_ACT_GELU>{});
+      epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
       break;
     case ST2_ACT_EXP_SIN:
-      epilogue_as(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
+      epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
       break;
     case ST2_ACT_TANH:
-      epilogue_as(std::integral_constant<int, ST2_ACT_TANH>{});
+      epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
       break;
     case ST2_ACT_LEAKY:
-      epilogue_as(std::integral_constant<int, ST2_ACT_LEAKY>{});
+      epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
       break;
     default:
-      epilogue_as(std::integral_constant<int, ST2_ACT_NONE>{});
+      epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
       break;
   }
 }
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
 __global__ __launch_bounds__(NT) void conv1d_xs_kernel(const st2_conv_desc d) {  // OCC == 2: no register cap
-  conv1d_xs_body<KS, CI_T, WM, WN, TN, WM == 4>(d);
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
 template <int KS, int CI_T, int WM, int WN, int TN>
 __global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc d) {  // <= 168 VGPRs
-  conv1d_xs_body<KS, CI_T, WM, WN, TN, false>(d);
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
 
 int g_occ3 = 1;  // st2_conv1d_xs_set_occupancy(): use the 3-workgroups-per-CU build of the 128-row variants
@@ -362,8 +311,7 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   const int XW = BN + (KS - 1) * d.dil;
   const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
   constexpr int NS = ((2 * CI_T / 8) * (BN + (KS - 1) * 8) + NT - 1) / NT;
-  constexpr int NBUF = (CI_T / 16) * KS >= 4 ? 3 : 2;
-  const size_t smem = (size_t)NBUF * NS * NT * 16;
+  const size_t smem = (size_t)2 * NS * NT * 16;
   ST2_REQUIRE(smem <= 160 * 1024, "st2_conv1d_xs: tile needs %zu B of LDS (ks=%d dil=%d)", smem, KS, d.dil);
   ST2_REQUIRE(d.wq_cin_pad == C_pad, "st2_conv1d_xs: packed weight has %d input channels, kernel needs %d",
               d.wq_cin_pad, C_pad);

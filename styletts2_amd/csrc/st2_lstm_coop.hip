@@ -29,7 +29,10 @@ constexpr int SPIN_LIMIT = 1 << 22;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int U>
+// SC1 = true: the exchanged hidden state travels as agent-scope (sc1) atomic stores / loads, which bypass the
+// non-coherent cache levels, so the per-step hand-off needs no L2 write-back / invalidate fence -- only the counter.
+// SC1 = false: plain stores / loads bracketed by agent-scope release / acquire fences (whole-L2 maintenance per step).
+template <int U, bool SC1>
 __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict__ G, int64_t g_bs, int g_cs,
                                                         const float* __restrict__ whh_t,  // [2][H][4H]
                                                         const int* __restrict__ lengths, int B, int N,
@@ -146,14 +149,20 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
         Yb[t] = h;
       }
       // 3. publish (a finished or absent utterance republishes its last state: nobody consumes it)
-      hxg[((int64_t)(s & 1) * U + uu) * H + hu] = h;
+      float* dst = &hxg[((int64_t)(s & 1) * U + uu) * H + hu];
+      if constexpr (SC1)
+        __hip_atomic_store(dst, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *dst = h;
     }
     // 4. group hand-off: all stores of this workgroup complete -> release -> count -> wait -> acquire
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int target = NSL * (s + 1);
       int spins = 0;
@@ -165,19 +174,26 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if constexpr (!SC1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (s_fail) return;
     // full new hidden state of the block's utterances -> LDS (thread = hidden unit index)
-    const float* src = hxg + (int64_t)(s & 1) * U * H;
+    float* src = hxg + (int64_t)(s & 1) * U * H;
 #pragma unroll
-    for (int u = 0; u < U; ++u) hs[u][tid] = src[u * H + tid];
+    for (int u = 0; u < U; ++u) {
+      if constexpr (SC1)
+        hs[u][tid] = __hip_atomic_load(&src[u * H + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        hs[u][tid] = src[u * H + tid];
+    }
     gi = ni; gf = nf; gg = ng; go = no;
     if (act) t = tn;
     __syncthreads();
   }
 }
+
+int g_sc1 = 1;  // st2_lstm_coop_set_exchange()
 
 template <int U>
 int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, const int* lengths, int B, int N, float* Y,
@@ -195,8 +211,12 @@ int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, cons
     st2_set_error("st2_lstm_bidir_coop: hipMemsetAsync failed");
     return 1;
   }
-  hipLaunchKernelGGL((lstm_coop_kernel<U>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths, B, N, Y,
-                     y_bs, y_cs, status, counters, hx);
+  if (g_sc1)
+    hipLaunchKernelGGL((lstm_coop_kernel<U, true>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
+                       B, N, Y, y_bs, y_cs, status, counters, hx);
+  else
+    hipLaunchKernelGGL((lstm_coop_kernel<U, false>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
+                       B, N, Y, y_bs, y_cs, status, counters, hx);
   ST2_CHECK_LAUNCH("st2_lstm_bidir_coop");
   return 0;
 }
@@ -204,6 +224,11 @@ int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, cons
 int block_size(int B) { return B > 48 ? 0 : (B > 4 ? 8 : (B > 1 ? 4 : 1)); }
 
 }  // namespace
+
+extern "C" int st2_lstm_coop_set_exchange(int sc1) {
+  g_sc1 = sc1 != 0;
+  return 0;
+}
 
 extern "C" int64_t st2_lstm_coop_scratch_bytes(int32_t B) {
   const int U = block_size(B);

@@ -98,7 +98,7 @@ constexpr int FC_BT = 8;
 __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__ s, int B, int K,
                                                        const float* __restrict__ wt, const float* __restrict__ bias,
                                                        int J, int act, float* __restrict__ h) {
-  extern __shared__ float sl[];  // [FC_BT][K]
+  extern __shared__ __attribute__((aligned(16))) float sl[];  // [FC_BT][K]
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int b0 = blockIdx.y * FC_BT;
   const int nb = min(FC_BT, B - b0);
@@ -111,7 +111,24 @@ __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__
   float acc[FC_BT];
 #pragma unroll
   for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = 0.f;
-  for (int k = 0; k < K; ++k) {
+  // four k per trip: four independent weight loads in flight and one 16-byte LDS broadcast read per batch row
+  // instead of four scalar ones (the loop is LDS-issue bound otherwise); accumulation order is unchanged (k ascending)
+  int k = 0;
+  if ((K & 3) == 0) {
+    for (; k < K; k += 4) {
+      const float w0 = wt[(int64_t)k * J + j], w1 = wt[(int64_t)(k + 1) * J + j];
+      const float w2 = wt[(int64_t)(k + 2) * J + j], w3 = wt[(int64_t)(k + 3) * J + j];
+#pragma unroll
+      for (int bb = 0; bb < FC_BT; ++bb) {
+        const float4 sv = *reinterpret_cast<const float4*>(&sl[bb * K + k]);
+        acc[bb] = fmaf(sv.x, w0, acc[bb]);
+        acc[bb] = fmaf(sv.y, w1, acc[bb]);
+        acc[bb] = fmaf(sv.z, w2, acc[bb]);
+        acc[bb] = fmaf(sv.w, w3, acc[bb]);
+      }
+    }
+  }
+  for (; k < K; ++k) {
     const float w = wt[(int64_t)k * J + j];
 #pragma unroll
     for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sl[bb * K + k], w, acc[bb]);

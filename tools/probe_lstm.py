@@ -5,7 +5,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from styletts2_amd import ops
+from styletts2_amd import _lib, ops
 
 dev = "cuda"
 B, H = int(os.environ.get("PROBE_B", "32")), 256
@@ -13,8 +13,9 @@ whh = (torch.randn(2, H, 4 * H, device=dev) / 16).contiguous()
 for N in (100, 400):
     G = torch.randn(B, 8 * H, N, device=dev)
     outs = {}
-    for mode in ("single", "coop"):
-        os.environ["ST2_LSTM"] = mode
+    for mode in ("single", "coop_fence", "coop"):
+        os.environ["ST2_LSTM"] = "single" if mode == "single" else "coop"
+        _lib.load().st2_lstm_coop_set_exchange(0 if mode == "coop_fence" else 1)
         for _ in range(2):
             y = ops.lstm_bidir(G, whh)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,6 +27,8 @@ for N in (100, 400):
         outs[mode] = y
         print("lstm %s B=%d N=%d: %.3f ms (%.2f us/step) status=%d" % (mode, B, N, e0.elapsed_time(e1) / 5,
                                                                       e0.elapsed_time(e1) / 5 / N * 1e3,
-                                                                      ops.lstm_coop_status() if mode == "coop" else 0),
+                                                                      ops.lstm_coop_status() if mode != "single" else 0),
               flush=True)
-    print("   max |coop - single| = %.3g" % (outs["coop"] - outs["single"]).abs().max().item(), flush=True)
+    print("   max |coop - single| = %.3g, |coop_fence - single| = %.3g" % (
+        (outs["coop"] - outs["single"]).abs().max().item(), (outs["coop_fence"] - outs["single"]).abs().max().item()),
+        flush=True)
