@@ -249,8 +249,8 @@ int st2_lstm_bidir(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_
  * and the outputs are invalid).  st2_lstm_coop_scratch_bytes returns 0 when B is too large for one co-resident
  * launch (B > 48): use st2_lstm_bidir. */
 int64_t st2_lstm_coop_scratch_bytes(int32_t B);
-/* Tuning knob (process-wide): 1 (default) = hidden-state exchange by agent-scope (sc1) atomic stores/loads, no cache
- * maintenance; 0 = plain stores/loads bracketed by agent-scope release/acquire fences. */
+/* Tuning knob (process-wide): 0 (default) = plain stores/loads bracketed by agent-scope release/acquire fences;
+ * 1 = hidden-state exchange by agent-scope (sc1) atomic stores/loads, no cache maintenance (measured slower). */
 int st2_lstm_coop_set_exchange(int sc1);
 int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
                         int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,

@@ -265,19 +265,31 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
   const float osc = d.out_scale;
-  auto epilogue_as = [&](auto act_tag) __attribute__((always_inline)) {
+  // Interior tiles take the FULL path: no per-element bounds tests, one 64-bit address per output row (the four
+  // 32-column groups of a lane are immediate offsets from it); see st2_conv1d_xs.hip.
+  const int col0 = n0 + wn * (32 * TN) + l31;
+  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
+  auto epilogue_as = [&](auto act_tag, auto full_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const bool rok = FULL || row < d.C_out;
+      const int rowc = FULL ? row : min(row, d.C_out - 1);
+      float* yp = yb + (int64_t)rowc * d.y_cs + col0;
+      const float* rp = rb ? rb + (int64_t)rowc * d.res_cs + (col0 >> d.res_shift) : nullptr;
+      const float* r2p = r2b ? r2b + (int64_t)rowc * d.res2_cs + col0 : nullptr;
+      const float bias_r = d.bias ? d.bias[rowc] : 0.f;
+      const int rstep = 32 >> d.res_shift;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (row < d.C_out && col < d.L_out) {
-          float v = acc[j][r] * osc;
-          if (d.bias) v += d.bias[row];
-          if (rb) v += rb[(int64_t)row * d.res_cs + (col >> d.res_shift)];
-          if (r2b) v = r2b[(int64_t)row * d.res2_cs + col] + v;
+      for (int j = 0; j < TN; ++j) {
+        const bool ok = FULL || (rok && col0 + j * 32 < d.L_out);
+        float v = acc[j][r] * osc;
+        if (d.bias) v += bias_r;
+        if (ok) {
+          if (rp) v += rp[j * rstep];
+          if (r2p) v = r2p[j * 32] + v;
           if (d.div != 1.0f) v = v / d.div;
           if constexpr (ACT == ST2_ACT_GELU) {
             v = gelu_erf(v);
@@ -288,26 +300,33 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
           } else if constexpr (ACT == ST2_ACT_LEAKY) {
             v = leaky(v, d.act_slope);
           }
-          yb[(int64_t)row * d.y_cs + col] = v;
+          yp[j * 32] = v;
         }
       }
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
     }
+  };
+  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
+    if (full_tile)
+      epilogue_as(act_tag, std::true_type{});
+    else
+      epilogue_as(act_tag, std::false_type{});
   };
   switch (d.act) {
     case ST2_ACT_GELU:
-      epilogue_as(std::integral_constant<int, ST2_ACT_GELU>{});
+      epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
       break;
     case ST2_ACT_EXP_SIN:
-      epilogue_as(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
+      epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
       break;
     case ST2_ACT_TANH:
-      epilogue_as(std::integral_constant<int, ST2_ACT_TANH>{});
+      epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
       break;
     case ST2_ACT_LEAKY:
-      epilogue_as(std::integral_constant<int, ST2_ACT_LEAKY>{});
+      epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
       break;
     default:
-      epilogue_as(std::integral_constant<int, ST2_ACT_NONE>{});
+      epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
       break;
   }
 }

@@ -92,14 +92,24 @@ __global__ __launch_bounds__(64 * CW) void colnorm_stats_kernel(const float* __r
   }
 }
 
-// h[b][j] = bias[j] + sum_k s[b][k] * wt[k*J + j]; one thread per j, all batch rows in registers
-// chunks of 8 (style vectors staged in LDS).
+// h[b][j] = act(bias[j] + sum_k s[b][k] * wt[k*J + j]).  The layers behind this are tiny GEMMs (B <= 32 rows) with
+// K = 128..1024: with one thread per output and a K-long serial loop the kernel was latency bound (16 workgroups,
+// ~100 us for the denoiser's 1024x1024 mapping layers).  Workgroup = 64 outputs x 4 k-slices: thread (jj, ks) sweeps
+// k in [ks*K/4, (ks+1)*K/4) for 8 batch rows (style vectors in LDS, read as 16-byte broadcasts; four independent
+// coalesced weight loads in flight), the four partials are combined through LDS in slice order (fixed order =>
+// bitwise reproducible).
 constexpr int FC_BT = 8;
+constexpr int FC_J = 64;
+constexpr int FC_KS = 4;
 __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__ s, int B, int K,
                                                        const float* __restrict__ wt, const float* __restrict__ bias,
                                                        int J, int act, float* __restrict__ h) {
-  extern __shared__ __attribute__((aligned(16))) float sl[];  // [FC_BT][K]
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float sl[];  // [FC_BT][K] then [FC_KS][FC_BT][FC_J]
+  float* red = sl + FC_BT * K;
+  const int jj = threadIdx.x & (FC_J - 1);
+  const int ks = threadIdx.x / FC_J;
+  const int j = blockIdx.x * FC_J + jj;
+  const int jc = min(j, J - 1);
   const int b0 = blockIdx.y * FC_BT;
   const int nb = min(FC_BT, B - b0);
   for (int e = threadIdx.x; e < FC_BT * K; e += 256) {
@@ -107,40 +117,55 @@ __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__
     sl[e] = bb < nb ? s[(int64_t)(b0 + bb) * K + k] : 0.f;
   }
   __syncthreads();
-  if (j >= J) return;
   float acc[FC_BT];
 #pragma unroll
   for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = 0.f;
-  // four k per trip: four independent weight loads in flight and one 16-byte LDS broadcast read per batch row
-  // instead of four scalar ones (the loop is LDS-issue bound otherwise); accumulation order is unchanged (k ascending)
-  int k = 0;
-  if ((K & 3) == 0) {
-    for (; k < K; k += 4) {
-      const float w0 = wt[(int64_t)k * J + j], w1 = wt[(int64_t)(k + 1) * J + j];
-      const float w2 = wt[(int64_t)(k + 2) * J + j], w3 = wt[(int64_t)(k + 3) * J + j];
+  const int kq = ((K + 3) / 4 + FC_KS - 1) / FC_KS * 4;  // k per slice, a multiple of 4, FC_KS * kq >= K
+  const int k0 = ks * kq, k1 = min(K, k0 + kq);
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    const float w0 = wt[(int64_t)k * J + jc], w1 = wt[(int64_t)(k + 1) * J + jc];
+    const float w2 = wt[(int64_t)(k + 2) * J + jc], w3 = wt[(int64_t)(k + 3) * J + jc];
 #pragma unroll
-      for (int bb = 0; bb < FC_BT; ++bb) {
-        const float4 sv = *reinterpret_cast<const float4*>(&sl[bb * K + k]);
-        acc[bb] = fmaf(sv.x, w0, acc[bb]);
-        acc[bb] = fmaf(sv.y, w1, acc[bb]);
-        acc[bb] = fmaf(sv.z, w2, acc[bb]);
-        acc[bb] = fmaf(sv.w, w3, acc[bb]);
+    for (int bb = 0; bb < FC_BT; ++bb) {
+      const float* sp = &sl[bb * K + k];
+      float s0, s1, s2, s3;
+      if ((K & 3) == 0) {
+        const float4 sv = *reinterpret_cast<const float4*>(sp);
+        s0 = sv.x; s1 = sv.y; s2 = sv.z; s3 = sv.w;
+      } else {
+        s0 = sp[0]; s1 = sp[1]; s2 = sp[2]; s3 = sp[3];
       }
+      acc[bb] = fmaf(s0, w0, acc[bb]);
+      acc[bb] = fmaf(s1, w1, acc[bb]);
+      acc[bb] = fmaf(s2, w2, acc[bb]);
+      acc[bb] = fmaf(s3, w3, acc[bb]);
     }
   }
-  for (; k < K; ++k) {
-    const float w = wt[(int64_t)k * J + j];
+  for (; k < k1; ++k) {
+    const float w = wt[(int64_t)k * J + jc];
 #pragma unroll
     for (int bb = 0; bb < FC_BT; ++bb) acc[bb] = fmaf(sl[bb * K + k], w, acc[bb]);
   }
-  const float bj = bias ? bias[j] : 0.f;
 #pragma unroll
-  for (int bb = 0; bb < FC_BT; ++bb)
-    if (bb < nb) {
-      float v = acc[bb] + bj;
-      if (act == ST2_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-      h[(int64_t)(b0 + bb) * J + j] = v;
+  for (int bb = 0; bb < FC_BT; ++bb) red[(ks * FC_BT + bb) * FC_J + jj] = acc[bb];
+  __syncthreads();
+  // thread (jj, ks) finishes batch rows ks and ks + 4
+  if (j < J) {
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int half = 0; half < FC_BT / FC_KS; ++half) {
+      const int bb = ks + half * FC_KS;
+      if (bb < nb) {
+        float v = red[(0 * FC_BT + bb) * FC_J + jj];
+#pragma unroll
+        for (int q = 1; q < FC_KS; ++q) v += red[(q * FC_BT + bb) * FC_J + jj];
+        v += bj;
+        if (act == ST2_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        h[(int64_t)(b0 + bb) * J + j] = v;
+      }
     }
+  }
 }
 
 }  // namespace
@@ -174,8 +199,8 @@ extern "C" int st2_style_fc(const float* sv, int32_t B, int32_t K, const float* 
   ST2_REQUIRE(K <= 2048, "st2_style_fc: K=%d too large", K);
   ST2_REQUIRE(act == ST2_ACT_NONE || act == ST2_ACT_GELU, "st2_style_fc: act must be NONE or GELU");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t smem = (size_t)FC_BT * K * sizeof(float);
-  hipLaunchKernelGGL(style_fc_kernel, dim3(st2_cdiv(J, 256), st2_cdiv(B, FC_BT)), dim3(256), smem, s, sv, B, K, wt,
+  const size_t smem = ((size_t)FC_BT * K + (size_t)FC_KS * FC_BT * FC_J) * sizeof(float);
+  hipLaunchKernelGGL(style_fc_kernel, dim3(st2_cdiv(J, FC_J), st2_cdiv(B, FC_BT)), dim3(256), smem, s, sv, B, K, wt,
                      bias, J, act, h);
   ST2_CHECK_LAUNCH("st2_style_fc");
   return 0;

@@ -275,8 +275,14 @@ class _Transformer(nn.Module):
             embedding = torch.where(mask, fixed, embedding)
         C = self.channels
 
+        # Token-merged layout (single-speaker net): storage is [F, B*N] -- channel-major over ALL tokens of the batch --
+        # so every Linear is ONE k=1 conv over B*N contiguous columns (25 full 128-column tiles at B=32, N=100 instead
+        # of 32 x one 78%-full tile), while attention / norm statistics / the mapping add see the same memory as
+        # [B, F, N] through strides.  The multi-speaker net keeps [B, F, N]: its AdaLayerNorm affine is per utterance.
+        s.merged = not self.multispeaker
+
         def base(e):  # channel-major [x | embedding] buffer; rows < C are rewritten on every net call
-            buf = torch.empty((B, self.features, N), device=dev, dtype=torch.float32)
+            buf = self._alloc(s, self.features)
             buf[:, C:].copy_(e.transpose(1, 2))
             return buf
 
@@ -302,16 +308,34 @@ class _Transformer(nn.Module):
         m = ops.style_fc(m, pk.map0, pk.map0_b, ops.ACT_GELU)
         return ops.style_fc(m, pk.map2, pk.map2_b, ops.ACT_GELU)
 
+    @staticmethod
+    def _alloc(s, C):
+        """[B, C, N] activation buffer; in the merged layout a strided view of a [C, B*N] block."""
+        dev = s.pk.device
+        if s.merged:
+            return torch.empty((C, s.B, s.N), device=dev, dtype=torch.float32).permute(1, 0, 2)
+        return torch.empty((s.B, C, s.N), device=dev, dtype=torch.float32)
+
+    @staticmethod
+    def _cv(s, t):
+        """The view of an activation buffer the k=1 convs consume: [1, C, B*N] (merged) or [B, C, N]."""
+        if not s.merged:
+            return t
+        C = t.shape[1]
+        return t.permute(1, 0, 2).reshape(1, C, s.B * s.N)  # a view: the storage is [C, B, N] contiguous
+
     def _run(self, s, base, x, m):
         pk = s.pk
         B, N, Fz, C = s.B, s.N, self.features, self.channels
         mid = self.heads * self.head_features
+        A, V = (lambda c: self._alloc(s, c)), (lambda t: self._cv(s, t))
         base[:, :C].copy_(x.reshape(B, C, 1).expand(B, C, N))
-        X = ops.add_chanvec(base, m)
+        X = ops.add_chanvec(base, m, out=A(Fz))
         nblk = len(pk.blocks)
         for i, b in enumerate(pk.blocks):
             st = ops.colnorm_stats(X)
-            qkv = torch.empty((B, 3 * mid, N), device=X.device, dtype=torch.float32)
+            stv = st.view(1, B * N, 2) if s.merged else st
+            qkv = A(3 * mid)
             if self.multispeaker:
                 o = 4 * Fz * i
                 g1, b1 = s.ada[:, o:o + Fz], s.ada[:, o + Fz:o + 2 * Fz]
@@ -321,14 +345,15 @@ class _Transformer(nn.Module):
             else:
                 kw1 = dict(gamma=b.n_w, beta=b.n_b)
                 kw2 = dict(gamma=b.nc_w, beta=b.nc_b)
-            ops.conv1d(X, b.q, mid, 1, pro=ops.PRO_COLNORM, stats=st, out=qkv[:, :mid], **kw1)
-            ops.conv1d(X, b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=st, out=qkv[:, mid:], **kw2)
+            ops.conv1d(V(X), b.q, mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=V(qkv)[:, :mid], **kw1)
+            ops.conv1d(V(X), b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=V(qkv)[:, mid:], **kw2)
             att = ops.attention(qkv[:, :mid], qkv[:, mid:2 * mid], qkv[:, 2 * mid:], self.heads,
-                                self.head_features ** -0.5)
-            X1 = ops.conv1d(att, b.o, Fz, 1, bias=b.o_b, res=X)
-            hmid = ops.conv1d(X1, b.f1, b.f1_out, 1, bias=b.f1_b, act=ops.ACT_GELU)
-            X2 = ops.conv1d(hmid, b.f2, Fz, 1, bias=b.f2_b, res=X1)
-            X = ops.add_chanvec(X2, m) if i + 1 < nblk else X2
+                                self.head_features ** -0.5, out=A(mid))
+            X1, hmid, X2 = A(Fz), A(b.f1_out), A(Fz)
+            ops.conv1d(V(att), b.o, Fz, 1, bias=b.o_b, res=V(X), out=V(X1))
+            ops.conv1d(V(X1), b.f1, b.f1_out, 1, bias=b.f1_b, act=ops.ACT_GELU, out=V(hmid))
+            ops.conv1d(V(hmid), b.f2, Fz, 1, bias=b.f2_b, res=V(X1), out=V(X2))
+            X = ops.add_chanvec(X2, m, out=A(Fz)) if i + 1 < nblk else X2
         mean = ops.mean_tokens(X)  # unmasked mean over tokens, modules.py:155,397
         return ops.style_fc(mean, pk.out_t, pk.out_b).reshape(B, 1, C)
 
