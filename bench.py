@@ -105,8 +105,8 @@ def roofline(ach, durs, avg_ms, flop, B, L_dom):
     if os.path.exists(PMC_FILE):
         pm = json.load(open(PMC_FILE))
         traffic, note = pm.get("hbm_bytes_per_launch"), pm.get("note")
-    return {"bound": "mfma", "kernel": "conv1d_f16s_kernel<11,16,4,1,4> (C=128, L=48001, B=32, k=11; AdaIN+Snake "
-                                       "prologue, bias/residual epilogue)",
+    return {"bound": "mfma", "kernel": "conv1d_xs_kernel_o3<11,16,4,1,4> (st2_conv1d_xs: C=128, L=48001, B=32, k=11 on "
+                                       "pre-activated split-f16 planes; bias/residual/statistics epilogue)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
             "traffic": traffic, "traffic_note": note,
             "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 products per fp32-class multiply",

@@ -51,7 +51,7 @@ class EngineLSTM(nn.LSTM):
             pk = type("PackedLSTM", (), {})()
             pk.device = device
             w_ih = torch.cat([self.weight_ih_l0.detach(), self.weight_ih_l0_reverse.detach()], dim=0).float()
-            pk.w_ih = W.pack_linear(w_ih).to(device)                                  # [I, 8H]
+            pk.w_ih = W.pack_linear_auto(w_ih).to(device)                             # [I, 8H] (split-f16 by default)
             pk.bias = d(torch.cat([self.bias_ih_l0.detach() + self.bias_hh_l0.detach(),
                                    self.bias_ih_l0_reverse.detach() + self.bias_hh_l0_reverse.detach()]))
             pk.whh_t = d(torch.stack([self.weight_hh_l0.detach().t(), self.weight_hh_l0_reverse.detach().t()]))
