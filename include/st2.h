@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 5
+#define ST2_ABI_VERSION 6
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -58,7 +58,9 @@ enum st2_epilogue_act {
   ST2_ACT_GELU = 1,     /* exact erf GELU                                modules.py:484-490 */
   ST2_ACT_EXP_SIN = 2,  /* rows < act_split: exp, rows >= act_split: sin istftnet.py:378-379 */
   ST2_ACT_TANH = 3,     /*                                               hifigan.py:345     */
-  ST2_ACT_LEAKY = 4     /* leaky(act_slope)                                                  */
+  ST2_ACT_LEAKY = 4,    /* leaky(act_slope)                                                  */
+  ST2_ACT_GELU_TANH = 5 /* 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3))): HF "gelu_new", the ALBERT FFN of PL-BERT
+                           (Utils/PLBERT/util.py:19-20 -> transformers AlbertConfig.hidden_act)               */
 };
 
 typedef struct st2_conv_desc {
@@ -230,6 +232,23 @@ int st2_istft(const float* sp, int64_t sp_bs, int32_t sp_cs, int32_t B, int32_t 
 int st2_attention(const float* q, const float* k, const float* v, int64_t bs, int32_t cs,
                   float* o, int64_t o_bs, int32_t o_cs,
                   int32_t B, int32_t H, int32_t D, int32_t N, float scale, void* stream);
+
+/* Same with key padding: keys m >= key_len[b] are excluded from the softmax of every query of utterance b (the HF
+ * additive -inf attention mask of a right-padded batch, Utils/PLBERT/util.py:8-11 -> AlbertAttention); key_len may be
+ * NULL (= st2_attention).  key_len: int32 [B] on the device, every entry >= 1. */
+int st2_attention_keylen(const float* q, const float* k, const float* v, int64_t bs, int32_t cs,
+                         float* o, int64_t o_bs, int32_t o_cs,
+                         int32_t B, int32_t H, int32_t D, int32_t N, float scale, const int32_t* key_len, void* stream);
+
+/* ---- LayerNorm over channels, applied: y[b,c,l] = act( (x[b,c,l] - mean[b,l]) * rstd[b,l] * G[b,c] + Bt[b,c] ),
+ * G = gamma[b*gb_bs + c] (+1 if gamma_plus_one), stats [B][L][2] from st2_colnorm_stats; act NONE or LEAKY(slope);
+ * positions l >= len[b] are written as 0 when len != NULL (the masked_fill_ after each block of the text encoders).
+ * Replaces nn.LayerNorm / AdaLayerNorm applications whose result is needed as a tensor (residual inputs): ALBERT
+ * post-LN blocks, models.py:270-282,308-312 (TextEncoder), :418-438,547-556 (DurationEncoder). */
+int st2_colnorm_apply(const float* x, int64_t x_bs, int32_t x_cs, const float* stats, const float* gamma,
+                      const float* beta, int64_t gb_bs, int32_t gamma_plus_one, int32_t act, float slope,
+                      const int32_t* len, float* y, int64_t y_bs, int32_t y_cs,
+                      int32_t B, int32_t C, int32_t L, void* stream);
 
 /* ---- bidirectional LSTM recurrence (hidden size H = 256) ------------------------------------- *
  * G [B][2*4H][N]: input projections W_ih x_t + b_ih + b_hh for both directions (rows 0..4H-1 forward,

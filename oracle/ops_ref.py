@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
-ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY = range(5)
+ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY, ACT_GELU_TANH = range(6)
 
 
 def _snake(u, alpha):
@@ -86,6 +86,8 @@ def _conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=N
         y = torch.tanh(y)
     elif act == ACT_LEAKY:
         y = F.leaky_relu(y, act_slope)
+    elif act == ACT_GELU_TANH:
+        y = F.gelu(y, approximate="tanh")
     if out is not None:
         out.copy_(y)
         return out
@@ -203,13 +205,16 @@ def istft(sp, n_fft, hop):
     return y.unsqueeze(-2)
 
 
-def attention(q, k, v, heads, scale, out=None):
+def attention(q, k, v, heads, scale, out=None, key_len=None):
     B, HD, N = q.shape
     D = HD // heads
     qh = q.reshape(B, heads, D, N)
     kh = k.reshape(B, heads, D, N)
     vh = v.reshape(B, heads, D, N)
     sim = torch.einsum("bhdn,bhdm->bhnm", qh, kh) * scale
+    if key_len is not None:
+        pad = torch.arange(N).view(1, 1, 1, N) >= key_len.view(B, 1, 1, 1)
+        sim = sim.masked_fill(pad, float("-inf"))
     attn = sim.softmax(dim=-1)
     o = torch.einsum("bhnm,bhdm->bhdn", attn, vh).reshape(B, HD, N)
     if out is not None:
@@ -241,6 +246,23 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
         out.copy_(Y)
         return out
     return Y
+
+
+def colnorm_apply(x, stats, gamma, beta, *, gamma_plus_one=False, act=ACT_NONE, slope=0.0, lengths=None, out=None):
+    n = (x - stats[:, :, 0].unsqueeze(1)) * stats[:, :, 1].unsqueeze(1)
+    g = gamma.unsqueeze(-1)
+    if gamma_plus_one:
+        g = 1.0 + g
+    y = n * g + beta.unsqueeze(-1)
+    if act == ACT_LEAKY:
+        y = F.leaky_relu(y, slope)
+    if lengths is not None:
+        L = x.shape[2]
+        y = y.masked_fill((torch.arange(L).view(1, 1, L) >= lengths.view(-1, 1, 1)), 0.0)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def add_chanvec(x, v, out=None):

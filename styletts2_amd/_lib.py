@@ -14,12 +14,12 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
-ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY = range(5)
+ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY, ACT_GELU_TANH = range(6)
 
 
 class ConvDesc(C.Structure):
@@ -88,6 +88,11 @@ _SIGNATURES = {
                             C.c_void_p]),
     "st2_attention": (C.c_int, [f32p, f32p, f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "st2_attention_keylen": (C.c_int, [f32p, f32p, f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "st2_colnorm_apply": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_float, C.c_void_p, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p]),
     "st2_lstm_bidir": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, f32p,
                                  C.c_int64, C.c_int32, C.c_void_p]),
     "st2_lstm_coop_scratch_bytes": (C.c_int64, [C.c_int32]),

@@ -44,3 +44,8 @@ static __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
+
+// HF "gelu_new" (tanh approximation), the ALBERT FFN activation
+static __device__ __forceinline__ float gelu_tanh(float v) {
+  return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));
+}

@@ -24,7 +24,7 @@ constexpr int AQB = 128;       // queries per workgroup (4 waves x 32)
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, int64_t bs, int cs,
                                                         float* __restrict__ o, int64_t o_bs, int o_cs, int N,
-                                                        float scale) {
+                                                        float scale, const int* __restrict__ key_len) {
   extern __shared__ __attribute__((aligned(16))) float att_smem[];  // 2 x 64 x 129 floats = 66 KB (dynamic: > 64 KB)
   float* ks = att_smem;
   float* vs = att_smem + AD * ALD;
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int64_t base = (int64_t)b * bs + (int64_t)h * AD * cs;
   const int nq = q0 + l31;
   const bool wave_live = q0 < N;  // a wave whose 32 queries are all out of range still helps staging
+  const int NK = key_len ? max(1, min(key_len[b], N)) : N;  // keys >= NK are padding (excluded from the softmax)
 
   // B operand of the QK product: Q[d = 2i + half][q0 + l31], pre-multiplied by nothing (scale is applied to S)
   float qr[AD / 2];
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
   float mx = -INFINITY, den = 0.f;
 
-  for (int c0 = 0; c0 < N; c0 += AKT) {
-    const int ct = min(AKT, N - c0);
+  for (int c0 = 0; c0 < NK; c0 += AKT) {
+    const int ct = min(AKT, NK - c0);
     __syncthreads();
     for (int e = tid; e < AD * AKT; e += 256) {
       const int d = e / AKT, mm = e % AKT;
@@ -129,6 +130,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 extern "C" int st2_attention(const float* q, const float* k, const float* v, int64_t bs, int32_t cs, float* o,
                              int64_t o_bs, int32_t o_cs, int32_t B, int32_t H, int32_t D, int32_t N, float scale,
                              void* stream) {
+  return st2_attention_keylen(q, k, v, bs, cs, o, o_bs, o_cs, B, H, D, N, scale, nullptr, stream);
+}
+
+extern "C" int st2_attention_keylen(const float* q, const float* k, const float* v, int64_t bs, int32_t cs, float* o,
+                                    int64_t o_bs, int32_t o_cs, int32_t B, int32_t H, int32_t D, int32_t N,
+                                    float scale, const int32_t* key_len, void* stream) {
   ST2_REQUIRE(q && k && v && o && B > 0 && H > 0 && N > 0, "st2_attention: bad arguments");
   ST2_REQUIRE(D == AD, "st2_attention: head_features=%d unsupported (built for %d)", D, AD);
   ST2_REQUIRE(B <= 65535 && H <= 65535, "st2_attention: grid too large");
@@ -141,7 +148,7 @@ extern "C" int st2_attention(const float* q, const float* k, const float* v, int
     attr_done = true;
   }
   hipLaunchKernelGGL(attention_kernel, dim3(st2_cdiv(N, AQB), H, B), dim3(256), smem, s, q, k, v, bs, cs, o, o_bs,
-                     o_cs, N, scale);
+                     o_cs, N, scale, reinterpret_cast<const int*>(key_len));
   ST2_CHECK_LAUNCH("st2_attention");
   return 0;
 }

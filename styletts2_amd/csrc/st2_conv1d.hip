@@ -209,6 +209,9 @@ __global__ __launch_bounds__(NT) void conv1d_mfma_kernel(const st2_conv_desc d) 
             case ST2_ACT_LEAKY:
               v = leaky(v, d.act_slope);
               break;
+            case ST2_ACT_GELU_TANH:
+              v = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));
+              break;
             default:
               break;
           }

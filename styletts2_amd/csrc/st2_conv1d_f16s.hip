@@ -299,6 +299,8 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
             v = tanhf(v);
           } else if constexpr (ACT == ST2_ACT_LEAKY) {
             v = leaky(v, d.act_slope);
+          } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
+            v = gelu_tanh(v);
           }
           yp[j * 32] = v;
         }
@@ -324,6 +326,9 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
       break;
     case ST2_ACT_LEAKY:
       epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
+      break;
+    case ST2_ACT_GELU_TANH:
+      epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
       break;
     default:
       epilogue(std::integral_constant<int, ST2_ACT_NONE>{});

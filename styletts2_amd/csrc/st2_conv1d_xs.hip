@@ -246,6 +246,8 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
             v = tanhf(v);
           } else if constexpr (ACT == ST2_ACT_LEAKY) {
             v = leaky(v, d.act_slope);
+          } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
+            v = gelu_tanh(v);
           }
           yp[j * 32] = v;
           s1 += v;
@@ -286,6 +288,9 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       break;
     case ST2_ACT_LEAKY:
       epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
+      break;
+    case ST2_ACT_GELU_TANH:
+      epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
       break;
     default:
       epilogue(std::integral_constant<int, ST2_ACT_NONE>{});

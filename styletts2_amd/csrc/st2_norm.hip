@@ -168,7 +168,52 @@ __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__
   }
 }
 
+// y = act((x - mean[b,l]) * rstd[b,l] * G[b,c] + Bt[b,c]), zero for l >= len[b].  HBM-bound elementwise pass; lanes run
+// along l (coalesced rows), one thread handles 4 channels so the per-position statistics are loaded once per 4 outputs.
+__global__ __launch_bounds__(256) void colnorm_apply_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int64_t gb_bs, int plus_one,
+                                                            int act, float slope, const int* __restrict__ len,
+                                                            float* __restrict__ y, int64_t y_bs, int y_cs, int C, int L) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * 4;
+  const int b = blockIdx.z;
+  if (l >= L) return;
+  const bool live = !len || l < len[b];
+  const float2 st = reinterpret_cast<const float2*>(stats)[(int64_t)b * L + l];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    if (c >= C) break;
+    float v = 0.f;
+    if (live) {
+      const float g0 = gamma[(int64_t)b * gb_bs + c];
+      const float g = plus_one ? 1.0f + g0 : g0;
+      const float u = (x[(int64_t)b * x_bs + (int64_t)c * x_cs + l] - st.x) * st.y;
+      v = u * g + beta[(int64_t)b * gb_bs + c];
+      if (act == ST2_ACT_LEAKY) v = v >= 0.f ? v : v * slope;
+    }
+    y[(int64_t)b * y_bs + (int64_t)c * y_cs + l] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int st2_colnorm_apply(const float* x, int64_t x_bs, int32_t x_cs, const float* stats, const float* gamma,
+                                 const float* beta, int64_t gb_bs, int32_t gamma_plus_one, int32_t act, float slope,
+                                 const int32_t* len, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
+                                 int32_t L, void* stream) {
+  ST2_REQUIRE(x && stats && gamma && beta && y && B > 0 && C > 0 && L > 0, "st2_colnorm_apply: bad arguments");
+  ST2_REQUIRE(act == ST2_ACT_NONE || act == ST2_ACT_LEAKY, "st2_colnorm_apply: act must be NONE or LEAKY");
+  ST2_REQUIRE(B <= 65535 && (C + 3) / 4 <= 65535, "st2_colnorm_apply: grid too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colnorm_apply_kernel, dim3(st2_cdiv(L, 256), st2_cdiv(C, 4), B), dim3(256), 0, s, x, x_bs, x_cs,
+                     stats, gamma, beta, gb_bs, gamma_plus_one, act, slope, reinterpret_cast<const int*>(len), y, y_bs,
+                     y_cs, C, L);
+  ST2_CHECK_LAUNCH("st2_colnorm_apply");
+  return 0;
+}
 
 extern "C" int st2_instnorm_stats(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
                                   float eps, float* stats, void* stream) {

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from .weights import F16S_X_SCALE, SplitConvWeight
-from ._lib import (ACT_EXP_SIN, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_TANH, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE,  # noqa: F401
+from ._lib import (ACT_EXP_SIN, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY, ACT_NONE, ACT_TANH, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE,  # noqa: F401
                    PRO_COLNORM, PRO_LEAKY, PRO_NONE, PRO_SNAKE, ConvDesc)
 
 
@@ -430,8 +430,9 @@ def istft(sp, n_fft, hop):
     return wave
 
 
-def attention(q, k, v, heads, scale, out=None):
-    """q, k, v: [B, heads*D, N] views with identical strides -> [B, heads*D, N]."""
+def attention(q, k, v, heads, scale, out=None, key_len=None):
+    """q, k, v: [B, heads*D, N] views with identical strides -> [B, heads*D, N].  key_len (int32 [B] on the device):
+    keys m >= key_len[b] are padding and excluded from the softmax (`st2_attention_keylen`)."""
     lib = _lib.load()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n, 3)
@@ -441,8 +442,36 @@ def attention(q, k, v, heads, scale, out=None):
     assert _bs_cs(q) == _bs_cs(k) == _bs_cs(v)
     if out is None:
         out = torch.empty((B, HD, N), device=q.device, dtype=torch.float32)
-    _lib.check(lib.st2_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1), out.data_ptr(),
-                                 out.stride(0), out.stride(1), B, heads, D, N, scale, _stream()), "st2_attention")
+    if key_len is not None:
+        assert key_len.is_cuda and key_len.dtype == torch.int32 and key_len.numel() == B and key_len.is_contiguous()
+    _lib.check(lib.st2_attention_keylen(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(1),
+                                        out.data_ptr(), out.stride(0), out.stride(1), B, heads, D, N, scale,
+                                        0 if key_len is None else key_len.data_ptr(), _stream()), "st2_attention")
+    return out
+
+
+def colnorm_apply(x, stats, gamma, beta, *, gamma_plus_one=False, act=ACT_NONE, slope=0.0, lengths=None, out=None):
+    """LayerNorm over channels applied (`st2_colnorm_apply`): x [B, C, L], stats [B, L, 2] from colnorm_stats,
+    gamma / beta [1 or B, C]; positions l >= lengths[b] (int32 [B] on the device) are written as zero."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(stats, "stats", 3)
+    _chk(gamma, "gamma", 2)
+    _chk(beta, "beta", 2)
+    B, Cc, L = x.shape
+    assert tuple(stats.shape) == (B, L, 2) and stats.is_contiguous()
+    assert gamma.shape[1] == Cc and beta.shape == gamma.shape and gamma.shape[0] in (1, B)
+    gbs = gamma.stride(0) if gamma.shape[0] > 1 else 0
+    assert (beta.stride(0) if beta.shape[0] > 1 else 0) == gbs and gamma.stride(1) == 1 and beta.stride(1) == 1
+    if lengths is not None:
+        assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.numel() == B and lengths.is_contiguous()
+    if out is None:
+        out = torch.empty((B, Cc, L), device=x.device, dtype=torch.float32)
+    _chk(out, "out", 3)
+    _lib.check(lib.st2_colnorm_apply(x.data_ptr(), x.stride(0), x.stride(1), stats.data_ptr(), gamma.data_ptr(),
+                                     beta.data_ptr(), gbs, 1 if gamma_plus_one else 0, act, slope,
+                                     0 if lengths is None else lengths.data_ptr(), out.data_ptr(), out.stride(0),
+                                     out.stride(1), B, Cc, L, _stream()), "st2_colnorm_apply")
     return out
 
 

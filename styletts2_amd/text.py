@@ -129,12 +129,13 @@ class TextEncoder(_PackedCache, nn.Module):
         h = self.embedding(x).transpose(1, 2).contiguous()  # [B, C, N]
         mk = m.to(x.device).unsqueeze(1)
         h.masked_fill_(mk, 0.0)
+        lens = _device_lengths(input_lengths, h.shape[2], h.device)
         for c, pc in zip(self.cnn, pk.convs):
             h = ops.conv1d(h, pc.wt, pc.c_out, pc.ks, pad_left=(pc.ks - 1) // 2, bias=pc.bias)
-            h = F.layer_norm(h.transpose(1, 2), (c[1].channels,), c[1].gamma, c[1].beta, c[1].eps).transpose(1, 2)
-            h = F.leaky_relu(h, 0.2).contiguous()
-            h.masked_fill_(mk, 0.0)
-        y = self.lstm.forward_cm(h, _device_lengths(input_lengths, h.shape[2], h.device))  # [B, C, N]
+            # LayerNorm over channels + LeakyReLU(0.2) + masked_fill in one pass (models.py:270-282,308-312)
+            h = ops.colnorm_apply(h, ops.colnorm_stats(h, eps=c[1].eps), c[1].gamma.reshape(1, -1),
+                                  c[1].beta.reshape(1, -1), act=ops.ACT_LEAKY, slope=0.2, lengths=lens)
+        y = self.lstm.forward_cm(h, lens)  # [B, C, N]
         y.masked_fill_(mk, 0.0)
         return y
 
@@ -167,20 +168,27 @@ class DurationEncoder(nn.Module):
     @torch.no_grad()
     def forward(self, x, style, text_lengths, m):
         """x [B, d_model, N], style [B, sty] -> [B, N, d_model + sty]."""
-        mk = m.to(x.device)
-        N = x.shape[2]
+        mk = m.to(x.device).unsqueeze(1)  # [B, 1, N]
+        B, _, N = x.shape
         lens = _device_lengths(text_lengths, N, x.device)
-        s = style.unsqueeze(1).expand(-1, N, -1)
-        h = torch.cat([x.transpose(1, 2), s], dim=-1)
-        h = h.masked_fill(mk.unsqueeze(-1), 0.0)
+        # channel-major throughout: [x | style] rows, the LSTMs and the AdaLayerNorm all work on [B, C, N]
+        sty = style.float().unsqueeze(-1).expand(-1, -1, N)
+        h = torch.cat([x.float(), sty], dim=1)
+        h.masked_fill_(mk, 0.0)
         for block in self.lstms:
             if isinstance(block, _AdaLayerNorm):
-                h = block(h, style)
-                h = torch.cat([h, s], dim=-1)
-                h = h.masked_fill(mk.unsqueeze(-1), 0.0)
+                gb = F.linear(style, block.fc.weight, block.fc.bias)  # [B, 2C]: gamma | beta (models.py:430-435)
+                C = block.channels
+                nh = torch.empty((B, C + self.sty_dim, N), device=h.device, dtype=torch.float32)
+                ops.colnorm_apply(h, ops.colnorm_stats(h, eps=block.eps), gb[:, :C], gb[:, C:], gamma_plus_one=True,
+                                  lengths=lens, out=nh[:, :C])
+                nh[:, C:].copy_(sty)
+                if lens is not None:
+                    nh[:, C:].masked_fill_(mk, 0.0)
+                h = nh
             else:
-                h = block.forward_cm(h.transpose(1, 2).contiguous(), lens).transpose(1, 2)
-        return h
+                h = block.forward_cm(h.contiguous(), lens)
+        return h.transpose(1, 2)
 
 
 class _LinearNorm(nn.Module):
@@ -243,14 +251,103 @@ class ProsodyPredictor(_PackedCache, nn.Module):
 
 
 def build_plbert(plbert_params):
-    """PL-BERT (Utils/PLBERT/util.py:6-20): an HF AlbertModel subclass whose forward returns
-    `last_hidden_state`, so its state_dict is the reference's key for key.  `transformers` is imported lazily so
-    that the rest of the engine imports without it."""
+    """PL-BERT (Utils/PLBERT/util.py:6-20): an HF AlbertModel subclass -- so `config`, the parameters and the
+    state_dict are the reference's key for key -- whose forward runs on the engine's HIP kernels and returns
+    `last_hidden_state`.  `transformers` is imported lazily so that the rest of the engine imports without it.
+
+    Engine forward (ST2_BERT=hf keeps the HF / hipBLASLt forward for A-B runs): tokens are channel-major and
+    token-merged ([768, B*N] storage), every Linear is one k=1 split-f16 MFMA conv over B*N columns (q|k|v fused into
+    one 768->2304 conv), attention is `st2_attention_keylen` (12 heads x 64, key padding from the attention mask),
+    the post-LN residual blocks are `st2_colnorm_stats` + `st2_colnorm_apply` (eps 1e-12), the FFN activation
+    (gelu_new) sits in the conv epilogue; the embedding LayerNorm is the prologue of the 128->768 mapping conv.
+    The 12 layers share one weight set (ALBERT), packed once per load."""
+    import os
+
     from transformers import AlbertConfig, AlbertModel
 
     class CustomAlbert(AlbertModel):
+        def _apply(self, fn, *a, **k):
+            self._pk = None
+            return super()._apply(fn, *a, **k)
+
+        def load_state_dict(self, state_dict, *a, **k):
+            self._pk = None
+            return super().load_state_dict(state_dict, *a, **k)
+
+        def refresh(self):
+            self._pk = None
+
+        def _packed(self, device):
+            pk = getattr(self, "_pk", None)
+            if pk is not None and pk.device == device:
+                return pk
+            cfg = self.config
+            assert cfg.num_hidden_groups == 1 and cfg.inner_group_num == 1, "PL-BERT shares one ALBERT layer"
+            assert cfg.hidden_act == "gelu_new" and cfg.hidden_size // cfg.num_attention_heads == 64
+            d = lambda t: t.detach().float().contiguous().to(device)
+            row = lambda t: d(t).reshape(1, -1)
+            lay = self.encoder.albert_layer_groups[0].albert_layers[0]
+            att = lay.attention
+            pk = type("PackedAlbert", (), {})()
+            pk.device = device
+            emb = self.embeddings
+            pk.word, pk.pos, pk.tok0 = d(emb.word_embeddings.weight), d(emb.position_embeddings.weight), d(
+                emb.token_type_embeddings.weight[0])
+            pk.eln_w, pk.eln_b = row(emb.LayerNorm.weight), row(emb.LayerNorm.bias)
+            pk.map, pk.map_b = (W.pack_linear_auto(self.encoder.embedding_hidden_mapping_in.weight.detach().float())
+                                .to(device), d(self.encoder.embedding_hidden_mapping_in.bias))
+            wqkv = torch.cat([att.query.weight, att.key.weight, att.value.weight], dim=0).detach().float()
+            pk.qkv, pk.qkv_b = W.pack_linear_auto(wqkv).to(device), d(torch.cat([att.query.bias, att.key.bias,
+                                                                               att.value.bias]))
+            pk.dense, pk.dense_b = W.pack_linear_auto(att.dense.weight.detach().float()).to(device), d(att.dense.bias)
+            pk.aln_w, pk.aln_b = row(att.LayerNorm.weight), row(att.LayerNorm.bias)
+            pk.ffn, pk.ffn_b = W.pack_linear_auto(lay.ffn.weight.detach().float()).to(device), d(lay.ffn.bias)
+            pk.out, pk.out_b = W.pack_linear_auto(lay.ffn_output.weight.detach().float()).to(device), d(
+                lay.ffn_output.bias)
+            pk.fln_w, pk.fln_b = row(lay.full_layer_layer_norm.weight), row(lay.full_layer_layer_norm.bias)
+            self._pk = pk
+            return pk
+
         @torch.no_grad()
-        def forward(self, *args, **kwargs):
-            return super().forward(*args, **kwargs).last_hidden_state
+        def forward(self, input_ids=None, attention_mask=None, **kwargs):
+            if os.environ.get("ST2_BERT", "engine") == "hf" or not input_ids.is_cuda or kwargs:
+                return super().forward(input_ids, attention_mask=attention_mask, **kwargs).last_hidden_state
+            return self.forward_engine(input_ids, attention_mask)
+
+        @torch.no_grad()
+        def forward_engine(self, input_ids, attention_mask=None):
+            cfg = self.config
+            pk = self._packed(input_ids.device)
+            B, N = input_ids.shape
+            Hd, heads, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps
+            dev = input_ids.device
+            key_len = None
+            if attention_mask is not None:  # right-padded batch (length_to_mask): valid keys are a prefix
+                key_len = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32).contiguous()
+
+            def alloc(C):  # [B, C, N] view of a [C, B*N] block (token-merged channel-major)
+                return torch.empty((C, B, N), device=dev, dtype=torch.float32).permute(1, 0, 2)
+
+            cv = lambda t: t.permute(1, 0, 2).reshape(1, t.shape[1], B * N)  # the k=1 convs' view (no copy)
+            E = alloc(cfg.embedding_size)
+            E.copy_((pk.word[input_ids] + pk.tok0 + pk.pos[:N].unsqueeze(0)).permute(0, 2, 1))  # gather glue
+            st = ops.colnorm_stats(E, eps=eps)
+            X = alloc(Hd)
+            ops.conv1d(cv(E), pk.map, Hd, 1, bias=pk.map_b, pro=ops.PRO_COLNORM, stats=st.view(1, B * N, 2),
+                       gamma=pk.eln_w, beta=pk.eln_b, out=cv(X))
+            for _ in range(cfg.num_hidden_layers):
+                qkv = alloc(3 * Hd)
+                ops.conv1d(cv(X), pk.qkv, 3 * Hd, 1, bias=pk.qkv_b, out=cv(qkv))
+                ctx = ops.attention(qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:], heads, 64 ** -0.5, out=alloc(Hd),
+                                    key_len=key_len)
+                Y = alloc(Hd)
+                ops.conv1d(cv(ctx), pk.dense, Hd, 1, bias=pk.dense_b, res=cv(X), out=cv(Y))
+                X1 = ops.colnorm_apply(Y, ops.colnorm_stats(Y, eps=eps), pk.aln_w, pk.aln_b, out=alloc(Hd))
+                Hm = alloc(cfg.intermediate_size)
+                ops.conv1d(cv(X1), pk.ffn, cfg.intermediate_size, 1, bias=pk.ffn_b, act=ops.ACT_GELU_TANH, out=cv(Hm))
+                Z = alloc(Hd)
+                ops.conv1d(cv(Hm), pk.out, Hd, 1, bias=pk.out_b, res=cv(X1), out=cv(Z))
+                X = ops.colnorm_apply(Z, ops.colnorm_stats(Z, eps=eps), pk.fln_w, pk.fln_b, out=alloc(Hd))
+            return X.permute(0, 2, 1)  # [B, N, 768] view
 
     return CustomAlbert(AlbertConfig(**plbert_params))

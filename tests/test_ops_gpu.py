@@ -72,6 +72,7 @@ CONV_CASES = [
     dict(B=2, C_in=64, C_out=60, L=50, ks=2, dil=1, pro=R.PRO_LEAKY, pad_left=1, L_out=51),
     dict(B=1, C_in=512, C_out=512, L=37, ks=5, dil=1, pro=R.PRO_NONE, act=R.ACT_LEAKY),
     dict(B=3, C_in=2, C_out=3, L=5, ks=3, dil=1, pro=R.PRO_NONE),
+    dict(B=1, C_in=768, C_out=2048, L=700, ks=1, dil=1, pro=R.PRO_NONE, act=R.ACT_GELU_TANH),
 ]
 
 
@@ -343,6 +344,61 @@ def test_attention(B, N):
     t = g(qkv)
     out = ops.attention(t[:, :512], t[:, 512:1024], t[:, 1024:], 8, 64 ** -0.5)
     assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(3, 100), (2, 37)])
+def test_attention_key_padding(B, N):
+    """st2_attention_keylen: keys past key_len[b] are excluded from every query's softmax (HF additive -inf mask)."""
+    gen = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(B, 12 * 64, N, generator=gen) for _ in range(3))
+    lens = torch.tensor([N, max(1, N // 3), 1][:B], dtype=torch.int32)
+    ref = R.attention(q, k, v, 12, 0.125, key_len=lens)
+    out = ops.attention(g(q), g(k), g(v), 12, 0.125, key_len=lens.to(DEV))
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("plus_one,act,ragged", [(False, R.ACT_NONE, False), (True, R.ACT_NONE, True),
+                                                 (False, R.ACT_LEAKY, True)])
+def test_colnorm_apply(plus_one, act, ragged):
+    gen = torch.Generator().manual_seed(3)
+    B, C, L = 3, 70, 301
+    x = torch.randn(B, C, L, generator=gen) * 2 + 0.5
+    st = R.colnorm_stats(x, eps=1e-12)
+    gamma = torch.randn(B if plus_one else 1, C, generator=gen)
+    beta = torch.randn(B if plus_one else 1, C, generator=gen)
+    lens = torch.tensor([L, 17, 200], dtype=torch.int32) if ragged else None
+    ref = R.colnorm_apply(x, st, gamma, beta, gamma_plus_one=plus_one, act=act, slope=0.2, lengths=lens)
+    big = torch.full((B, C + 6, L), -7.0, device=DEV)
+    out = ops.colnorm_apply(g(x), ops.colnorm_stats(g(x), eps=1e-12), g(gamma), g(beta), gamma_plus_one=plus_one,
+                            act=act, slope=0.2, lengths=None if lens is None else lens.to(DEV), out=big[:, 3:3 + C])
+    assert rel_err(out, ref) < 1e-5
+    assert (big[:, :3] == -7.0).all() and (big[:, 3 + C:] == -7.0).all()
+    if ragged:
+        assert float(out[1, :, 17:].abs().max()) == 0.0
+
+
+def test_plbert_engine_matches_hf():
+    """PL-BERT on the engine's kernels (GPU) against the HF AlbertModel forward on CPU, padded batch."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _util import manifest
+    from transformers import AlbertModel
+    from styletts2_amd import models, synth
+    bert = models.load_plbert(manifest("ljspeech")["plbert"]).eval()
+    synth.init_synthetic_(bert, 15)
+    B, N = 4, 100
+    gen = torch.Generator().manual_seed(0)
+    ids = torch.randint(1, 178, (B, N), generator=gen)
+    ids[:, 0] = 0
+    lens = torch.tensor([100, 61, 100, 7])
+    mask = (torch.arange(N).unsqueeze(0) < lens.unsqueeze(1)).int()
+    with torch.no_grad():
+        ref = AlbertModel.forward(bert, ids, attention_mask=mask).last_hidden_state
+    bert = bert.to(DEV)
+    out = bert(g(ids), attention_mask=g(mask))
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
 
 
 def test_token_glue():
