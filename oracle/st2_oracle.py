@@ -431,7 +431,8 @@ def plbert(sd, plbert_params, tokens, attention_mask):
 
 
 def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_noise, diffusion_steps=5,
-              embedding_scale=1.0, ref_s=None, alpha=0.3, beta=0.7, durations=None, taps=None):
+              embedding_scale=1.0, ref_s=None, alpha=0.3, beta=0.7, durations=None, taps=None, s_prev=None, t=0.7,
+              lj_tail=None):
     """The notebook `inference` cell (Demo/Inference_LJSpeech.ipynb:268-315; Demo/Inference_LibriTTS.ipynb:258-325),
     batched over equal-length utterances.  `sds` maps module name -> reference-layout state_dict; cfg =
     config['model_params']."""
@@ -444,10 +445,14 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
     s_pred = sample_style(sub(sds["diffusion"], "unet"), noise, bert_dur, diffusion_steps, step_noise,
                           sigma_data=cfg["diffusion"]["dist"]["sigma_data"], features=ref_s,
                           embedding_scale=embedding_scale).squeeze(1)
+    if s_prev is not None:  # LFinference: convex combination of previous and current style
+        s_pred = t * s_prev + (1 - t) * s_pred
     s, ref = s_pred[:, 128:], s_pred[:, :128]
     if multispeaker:
         ref = alpha * ref + (1 - alpha) * ref_s[:, :128]
         s = beta * s + (1 - beta) * ref_s[:, 128:]
+    if taps is not None:
+        taps["s_mixed"] = torch.cat([ref, s], dim=-1)
     psd = sds["predictor"]
     d = duration_encoder(sub(psd, "text_encoder"), d_en, s, lengths, mask)
     if durations is None:
@@ -455,7 +460,7 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
         dur = torch.sigmoid(F.linear(x, psd["duration_proj.linear_layer.weight"],
                                      psd["duration_proj.linear_layer.bias"])).sum(dim=-1)
         durations = torch.round(dur).clamp(min=1).long()
-        if not multispeaker:
+        if (not multispeaker) if lj_tail is None else lj_tail:
             durations[:, -1] += 5
     T = int(durations[0].sum())
     aln = torch.zeros(B, N, T)
@@ -474,3 +479,24 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
         taps.update(s_pred=s_pred, durations=durations, F0=F0_pred, N=N_pred, asr=asr, en=en, t_en=t_en, d=d,
                     bert_dur=bert_dur)
     return decoder(sds["decoder"], cfg["decoder"], asr, F0_pred, N_pred, ref, noise=sine_noise, taps=taps)
+
+
+def long_form(sds, cfg, plbert_params, sentences, noises, step_noises, sine_noises, diffusion_steps=5,
+              embedding_scale=1.0, ref_s=None, alpha=0.3, beta=0.7, t=0.7, trim=None):
+    """The long-form driver loops of the notebooks (Demo/Inference_LibriTTS.ipynb LFinference + "for text in
+    sentences"; Demo/Inference_LJSpeech.ipynb "Long-form generation"): sentence k is synthesised with
+    s_prev = the mixed style LFinference returned for sentence k-1; no +5 tail frames; `trim` samples cut from each
+    sentence's end (100 in the LibriTTS notebook, none in the LJSpeech one)."""
+    if trim is None:
+        trim = 100 if ref_s is not None else 0
+    s_prev, waves = None, []
+    for k, tok in enumerate(sentences):
+        taps = {}
+        tokens = tok.reshape(1, -1)
+        w = inference(sds, cfg, plbert_params, tokens, torch.LongTensor([tokens.shape[1]]), noises[k], step_noises[k],
+                      sine_noises[k], diffusion_steps=diffusion_steps, embedding_scale=embedding_scale, ref_s=ref_s,
+                      alpha=alpha, beta=beta, taps=taps, s_prev=s_prev, t=t, lj_tail=False)
+        s_prev = taps["s_mixed"]
+        w = w.reshape(-1)
+        waves.append(w[:-trim] if trim else w)
+    return waves, s_prev

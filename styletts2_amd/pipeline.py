@@ -36,16 +36,16 @@ def predict_durations(model, d, lj_tail=False):
 
 
 @torch.no_grad()
-def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
-              ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
-              taps=None):
-    """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
+def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
+            ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, lj_tail=None, s_prev=None, t=0.7,
+            taps=None):
+    """Everything in front of the decoder: text encoder, PL-BERT, style diffusion, style mixing, duration and
+    prosody prediction, alignment expansion.  Returns the decoder's inputs {asr, F0, N, ref} plus the mixed style
+    vector `s_pred` [B, 256] (what LFinference hands to the next sentence) and the durations.
 
-    Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
-    (Demo/Inference_LibriTTS.ipynb:285-286).  All utterances of one call must expand to the same number of
-    frames (the decoder's InstanceNorm spans the whole utterance, so padding would change results: section 7.3-6);
-    callers bucket by length or pass `durations`.
-    """
+    `s_prev` / `t`: long-form style carry-over, `s_pred = t * s_prev + (1 - t) * s_pred` applied to the sampler output
+    before the speaker mixing (Demo/Inference_LibriTTS.ipynb LFinference; the LJSpeech notebook calls the same weight
+    `alpha`)."""
     dev = tokens.device
     B, N = tokens.shape
     if input_lengths is None:
@@ -68,6 +68,8 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
     if taps is not None:
         taps["s_pred"] = s_pred
+    if s_prev is not None:
+        s_pred = t * s_prev + (1 - t) * s_pred  # convex combination of previous and current style
     s = s_pred[:, 128:]
     ref = s_pred[:, :128]
     if multispeaker:
@@ -95,4 +97,77 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     F0_pred, N_pred = model.predictor.F0Ntrain(en.contiguous(), s)
     if taps is not None:
         taps.update(F0=F0_pred, N=N_pred, asr=asr, en=en)
-    return model.decoder(asr.contiguous(), F0_pred, N_pred, ref, noise=sine_noise)
+    return dict(asr=asr.contiguous(), F0=F0_pred, N=N_pred, ref=ref, s_pred=torch.cat([ref, s], dim=-1),
+                durations=durations)
+
+
+@torch.no_grad()
+def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
+              ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
+              taps=None):
+    """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
+
+    Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
+    (Demo/Inference_LibriTTS.ipynb:285-286).  All utterances of one call must expand to the same number of
+    frames (the decoder's InstanceNorm spans the whole utterance, so padding would change results: section 7.3-6);
+    callers bucket by length or pass `durations`.
+    """
+    p = prepare(model, sampler, tokens, input_lengths, noise, diffusion_steps, embedding_scale, ref_s, alpha, beta,
+                durations, step_noise, lj_tail, taps=taps)
+    return model.decoder(p["asr"], p["F0"], p["N"], p["ref"], noise=sine_noise)
+
+
+@torch.no_grad()
+def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, t=0.7, diffusion_steps=5,
+                    embedding_scale=1.0, noises=None, step_noises=None, sine_noises=None, durations=None, trim=None,
+                    overlap=True, on_chunk=None):
+    """Long-form synthesis (BASELINE.json configs[4]; Demo/Inference_LibriTTS.ipynb LFinference + its driver loop,
+    Demo/Inference_LJSpeech.ipynb "Long-form generation"): `sentences` is a list of token tensors [N_i] (id 0
+    prepended); each sentence is synthesised with the previous sentence's mixed style carried over
+    (`s_pred = t * s_prev + (1 - t) * s_pred`) and its waveform is handed out as soon as it is ready.
+
+    The passage is sequential in the style vector only, and that vector is final before the sentence's decoder
+    runs.  So the engine streams in two stages on two HIP streams: the front of sentence k+1 (text encoder, PL-BERT,
+    diffusion, duration / prosody prediction; its one host sync is the predicted frame count) is issued on a side
+    stream while the decoder + vocoder of sentence k (>= 2/3 of the sentence's time) still occupies the main stream;
+    an event hands the decoder inputs over.  Returns (list of waveforms [600*T_i - trim], final style [1, 256]);
+    `on_chunk(k, wave)` is called per sentence for streaming consumers.  `trim` samples are dropped from every
+    sentence's end as the notebooks do ("weird pulse at the end of the model": 100 multi-speaker, 0 single-speaker).
+    """
+    dev = sentences[0].device
+    multispeaker = ref_s is not None
+    if trim is None:
+        trim = 100 if multispeaker else 0
+    use_streams = overlap and dev.type == "cuda"
+    main = torch.cuda.current_stream(dev) if use_streams else None
+    side = torch.cuda.Stream(dev) if use_streams else None
+    if use_streams:
+        side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
+    s_prev, waves = None, []
+    for k, tok in enumerate(sentences):
+        tokens = tok.reshape(1, -1)
+        noise = noises[k] if noises is not None else None
+        kw = dict(noise=noise, diffusion_steps=diffusion_steps, embedding_scale=embedding_scale, ref_s=ref_s,
+                  alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
+                  step_noise=step_noises[k] if step_noises is not None else None,
+                  durations=durations[k] if durations is not None else None)
+        if use_streams:
+            with torch.cuda.stream(side):
+                p = prepare(model, sampler, tokens, **kw)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            main.wait_event(ready)
+            for v in (p["asr"], p["F0"], p["N"], p["ref"]):
+                v.record_stream(main)  # allocated on the side stream, consumed on the main stream
+        else:
+            p = prepare(model, sampler, tokens, **kw)
+        s_prev = p["s_pred"]
+        wave = model.decoder(p["asr"], p["F0"], p["N"], p["ref"],
+                             noise=sine_noises[k] if sine_noises is not None else None)
+        wave = wave.reshape(-1)
+        if trim:
+            wave = wave[:-trim]
+        waves.append(wave)
+        if on_chunk is not None:
+            on_chunk(k, wave)
+    return waves, s_prev

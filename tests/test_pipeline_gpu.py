@@ -77,3 +77,46 @@ def test_predicted_durations_path_runs():
     T = int(taps["durations"].sum())
     assert out.shape == (1, 1, 600 * T) and bool(torch.isfinite(out).all())
     assert int(taps["durations"].min()) >= 1
+
+
+@pytest.mark.parametrize("tag", ["libritts", "ljspeech"])
+def test_long_form_streaming_matches_oracle_and_sequential(tag):
+    """BASELINE.json configs[4]: pipeline.synthesize_long (two-stream front / decoder overlap, style carry-over) --
+    (a) the overlapped run is bitwise the sequential run, (b) the style vector handed from sentence to sentence and the
+    per-sentence HiFi-GAN waveforms match the oracle's restatement of the notebooks' long-form loop."""
+    man, model, sds = _model(tag)
+    g = torch.Generator().manual_seed(11)
+    lens, steps = [9, 6, 12, 7], 3
+    sentences = [torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, 178, (n - 1,), generator=g)]) for n in lens]
+    noises = [torch.randn(1, 1, 256, generator=g) for _ in lens]
+    step_noises = [torch.randn(steps - 1, 1, 1, 256, generator=g) for _ in lens]
+    durs = [torch.full((1, n), 2, dtype=torch.long) for n in lens]
+    sine = [torch.randn(1, 600 * 2 * n, 9, generator=g) for n in lens]
+    multi = man["config"]["multispeaker"]
+    ref_s = torch.randn(1, 256, generator=g) if multi else None
+    ref_waves, s_prev = [], None
+    for k in range(len(lens)):
+        taps = {}
+        w = O.inference(sds, man["config"], man["plbert"], sentences[k].reshape(1, -1), torch.LongTensor([lens[k]]),
+                        noises[k], step_noises[k], sine[k], diffusion_steps=steps, ref_s=ref_s, durations=durs[k],
+                        taps=taps, s_prev=s_prev, t=0.7, lj_tail=False)
+        s_prev = taps["s_mixed"]
+        ref_waves.append(w.reshape(-1)[:-100] if multi else w.reshape(-1))
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model)
+    d = lambda xs: [x.to(DEV) for x in xs]
+    kw = dict(ref_s=None if ref_s is None else ref_s.to(DEV), t=0.7, diffusion_steps=steps, noises=d(noises),
+              step_noises=d(step_noises), sine_noises=d(sine), durations=durs)
+    order = []
+    waves, style = pipeline.synthesize_long(model, sampler, d(sentences), overlap=True,
+                                            on_chunk=lambda k, w: order.append(k), **kw)
+    waves_seq, style_seq = pipeline.synthesize_long(model, sampler, d(sentences), overlap=False, **kw)
+    torch.cuda.synchronize()
+    assert order == list(range(len(lens)))
+    assert torch.equal(style, style_seq) and all(torch.equal(a, b) for a, b in zip(waves, waves_seq))
+    assert (style.cpu() - s_prev).abs().max().item() < 5e-5 * max(1.0, s_prev.abs().max().item())
+    for w, r in zip(waves, ref_waves):
+        assert w.shape == r.shape and bool(torch.isfinite(w).all())
+        if man["config"]["decoder"]["type"] == "hifigan":
+            assert rms(w.cpu() - r) < WAVE_RMS_TOL

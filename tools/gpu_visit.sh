@@ -18,6 +18,7 @@ if ! has probe; then echo "== probe e2e"; timeout 300 python tools/probe_e2e.py 
 if ! has bench; then echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -4 $OUT/bench.err; fi
 if ! has rocprof; then echo "== rocprof stats"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/bench_prof.json 2> $R/$OUT/bench_prof.err ); echo "rocprof exit $?"
   for f in $(find /tmp/prof_$TAG -name '*kernel_stats.csv'); do cp $f $OUT/; done
+  for f in $(find /tmp/prof_$TAG -name '*kernel_trace.csv'); do cut -d, -f8-12,16- $f | tail -n 2600 | gzip > $OUT/kernel_trace_tail.csv.gz; head -1 $f > $OUT/kernel_trace_header.txt; done
   head -22 $OUT/*kernel_stats.csv 2>/dev/null | cut -c1-180; fi
 if ! has pmc; then
   i=0
