@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="issue every step on one stream (no front/decoder overlap)")
     a = ap.parse_args()
 
     from _util import manifest
@@ -152,9 +153,16 @@ def main():
     tokens, lengths, noise, durations = synthetic_inputs(B, 1000 + rank)
     tokens, noise = tokens.to(dev), noise.to(dev)
 
+    # Two HIP streams: the front of step k+1 (text encoder, PL-BERT, diffusion sampler, duration / prosody predictors:
+    # latency-bound small kernels) is issued on `front` and overlaps the decoder + vocoder of step k on the main
+    # stream.  Every step is still one complete pass tokens -> waveform over the batch; --single-stream turns it off.
+    front = None if a.single_stream else torch.cuda.Stream(dev)
+    if front is not None:
+        front.wait_stream(torch.cuda.current_stream(dev))
+
     def step():
         return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=DIFFUSION_STEPS,
-                                  embedding_scale=1.0, durations=durations)
+                                  embedding_scale=1.0, durations=durations, front_stream=front)
 
     for i in range(a.warmup):
         out = step()
@@ -194,6 +202,7 @@ def main():
                                    "5 diffusion steps, 1xMI355X per rank (BASELINE.json configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "phonemes": N_PHONEMES,
                        "audio_s_per_utt": AUDIO_S_PER_UTT, "parallelism": "utterance-sharded x%d" % world,
+                       "streams": "1" if front is None else "2 (front of step k+1 overlaps decoder of step k)",
                        "weights": "seeded random init, broadcast %d B from rank 0" % nbytes},
             "roofline": roofline(ach, durs, avg_ms, flop, B, L_dom),
         }

@@ -104,16 +104,34 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 @torch.no_grad()
 def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
               ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
-              taps=None):
+              taps=None, front_stream=None):
     """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
 
     Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
     (Demo/Inference_LibriTTS.ipynb:285-286).  All utterances of one call must expand to the same number of
     frames (the decoder's InstanceNorm spans the whole utterance, so padding would change results: section 7.3-6);
     callers bucket by length or pass `durations`.
+
+    `front_stream` (a torch.cuda.Stream): everything in front of the decoder is issued on that stream and handed to
+    the decoder (on the current stream) through an event.  A caller that synthesises batch after batch thereby
+    overlaps batch k+1's front -- a long chain of small, latency-bound kernels (BiLSTM recurrences on 64 CUs, 100-token
+    transformer layers) -- with batch k's decoder, whose big convolutions fill whatever CUs the front leaves idle.
+    Results are identical to the single-stream call.
     """
-    p = prepare(model, sampler, tokens, input_lengths, noise, diffusion_steps, embedding_scale, ref_s, alpha, beta,
-                durations, step_noise, lj_tail, taps=taps)
+    kw = dict(input_lengths=input_lengths, noise=noise, diffusion_steps=diffusion_steps,
+              embedding_scale=embedding_scale, ref_s=ref_s, alpha=alpha, beta=beta, durations=durations,
+              step_noise=step_noise, lj_tail=lj_tail, taps=taps)
+    if front_stream is None:
+        p = prepare(model, sampler, tokens, **kw)
+    else:
+        main = torch.cuda.current_stream(tokens.device)
+        with torch.cuda.stream(front_stream):
+            p = prepare(model, sampler, tokens, **kw)
+            ready = torch.cuda.Event()
+            ready.record(front_stream)
+        main.wait_event(ready)
+        for v in (p["asr"], p["F0"], p["N"], p["ref"]):
+            v.record_stream(main)  # allocated on the front stream, consumed on the main stream
     return model.decoder(p["asr"], p["F0"], p["N"], p["ref"], noise=sine_noise)
 
 

@@ -120,3 +120,37 @@ def test_long_form_streaming_matches_oracle_and_sequential(tag):
         assert w.shape == r.shape and bool(torch.isfinite(w).all())
         if man["config"]["decoder"]["type"] == "hifigan":
             assert rms(w.cpu() - r) < WAVE_RMS_TOL
+
+
+def test_two_stream_inference_is_bitwise_the_single_stream_result():
+    """pipeline.inference(front_stream=...): front on a side stream, decoder on the main stream, several batches
+    back to back (the bench's overlap mode) == the single-stream results."""
+    man, model, sds = _model("ljspeech")
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model)
+    g = torch.Generator().manual_seed(5)
+    B, N, steps = 3, 21, 3
+    batches = []
+    for _ in range(3):
+        tokens = torch.randint(1, 178, (B, N), generator=g)
+        tokens[:, 0] = 0
+        batches.append(dict(tokens=tokens.to(DEV), noise=torch.randn(B, 1, 256, generator=g).to(DEV),
+                            step_noise=torch.randn(steps - 1, B, 1, 256, generator=g).to(DEV),
+                            sine_noise=torch.randn(B, 600 * 2 * N, 9, generator=g).to(DEV)))
+    dur = torch.full((B, N), 2, dtype=torch.long)
+
+    def run(front):
+        outs = []
+        for b in batches:
+            outs.append(pipeline.inference(model, sampler, b["tokens"], None, b["noise"], diffusion_steps=steps,
+                                           durations=dur, step_noise=b["step_noise"], sine_noise=b["sine_noise"],
+                                           front_stream=front))
+        torch.cuda.synchronize()
+        return outs
+
+    ref = run(None)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out = run(side)
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
