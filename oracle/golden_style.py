@@ -1,0 +1,38 @@
+"""Golden vectors for the reference-audio style encoders, produced by the UNMODIFIED reference
+`StyleEncoder` (models.py:139-164) in the build container:  python -m oracle.golden_style
+
+Weights and inputs are regenerated from seeds on the test side (styletts2_amd/synth.py), only reference OUTPUTS are
+stored.  Two geometries: a small one and the shipped LibriTTS one (dim_in 64, style_dim 128, max_conv_dim 512)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref_harness as RH
+from styletts2_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+CASES = {"small": dict(dim_in=16, style_dim=32, max_conv_dim=64, B=3, T=83, seed=21),
+         "libritts": dict(dim_in=64, style_dim=128, max_conv_dim=512, B=2, T=120, seed=22)}
+
+
+def case_input(c):
+    g = torch.Generator().manual_seed(c["seed"])
+    return torch.randn(c["B"], 1, 80, c["T"], generator=g) * 0.8 - 0.2   # normalised log-mel range
+
+
+def main():
+    ref = RH.load_reference()
+    out = {}
+    for tag, c in CASES.items():
+        enc = ref.models.StyleEncoder(dim_in=c["dim_in"], style_dim=c["style_dim"], max_conv_dim=c["max_conv_dim"]).eval()
+        synth.init_spectral_norm_(enc, c["seed"])
+        with torch.no_grad():
+            out["style_" + tag] = enc(case_input(c)).numpy()
+    path = os.path.join(GOLDEN, "style_vectors.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,8 @@ import torch
 from oracle import ref_harness as RH
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-HOT_MODULES = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]
+HOT_MODULES = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert", "style_encoder",
+               "predictor_encoder"]
 HIFIGAN_OVERRIDE = {"multispeaker": True,
                     "decoder": {"type": "hifigan", "upsample_rates": [10, 5, 3, 2],
                                 "upsample_kernel_sizes": [20, 10, 6, 4]}}

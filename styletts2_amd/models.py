@@ -14,6 +14,7 @@ import torch.nn as nn
 from .decoder import Decoder
 from .diffusion import (ADPM2Sampler, AudioDiffusionConditional, DiffusionSampler, KarrasSchedule,  # noqa: F401
                         StyleTransformer1d, Transformer1d)
+from .style import StyleEncoder
 from .text import ProsodyPredictor, TextEncoder, build_plbert
 from .utils import Munch, recursive_munch  # noqa: F401
 from .weights import strip_module_prefix
@@ -68,8 +69,9 @@ def build_model(args, text_aligner=None, pitch_extractor=None, bert=None):
         predictor=predictor,
         decoder=decoder,
         text_encoder=text_encoder,
-        predictor_encoder=OutOfScope("predictor_encoder (reference-audio prosodic style encoder)"),
-        style_encoder=OutOfScope("style_encoder (reference-audio acoustic style encoder)"),
+        # reference-audio style encoders (models.py:639-640): acoustic / prosodic halves of ref_s, see style.py
+        predictor_encoder=StyleEncoder(dim_in=args.dim_in, style_dim=args.style_dim, max_conv_dim=args.hidden_dim),
+        style_encoder=StyleEncoder(dim_in=args.dim_in, style_dim=args.style_dim, max_conv_dim=args.hidden_dim),
         diffusion=diffusion,
         text_aligner=text_aligner if text_aligner is not None else OutOfScope("text_aligner (training only)"),
         pitch_extractor=pitch_extractor if pitch_extractor is not None else OutOfScope("pitch_extractor (training only)"),

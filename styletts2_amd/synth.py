@@ -87,6 +87,38 @@ def init_synthetic_(module, seed):
     return module
 
 
+def init_spectral_norm_(module, seed):
+    """Synthetic initialisation for modules under old-style spectral norm (`weight_orig` / `weight_u` / `weight_v`:
+    the style encoders, models.py:97-164): seeded `weight_orig` / biases as in `init_synthetic_`, then u, v = the
+    leading singular pair from a fixed number of fp64 power iterations, so that sigma = u.(W v) is the spectral norm
+    and the folded weights are O(1) like a trained checkpoint's (random u, v would give an arbitrary, often tiny
+    sigma)."""
+    sd = module.state_dict()
+    out = {}
+    for name, t in sd.items():
+        if name.endswith("weight_u") or name.endswith("weight_v") or not torch.is_floating_point(t):
+            out[name] = t.clone()
+            continue
+        leaf = "weight" if name.endswith("weight_orig") else name.split(".")[-1]
+        out[name] = torch.from_numpy(synthetic_tensor(name[:-len("weight_orig")] + leaf if name.endswith("weight_orig")
+                                                      else name, t.shape, seed)).reshape(t.shape)
+    for name in sd:
+        if name.endswith("weight_orig"):
+            w = out[name].double().reshape(out[name].shape[0], -1).numpy()
+            r = _rng(seed, name + ".u")
+            u = r.standard_normal(w.shape[0])
+            for _ in range(30):
+                v = w.T @ u
+                v /= np.linalg.norm(v) + 1e-12
+                u = w @ v
+                u /= np.linalg.norm(u) + 1e-12
+            base = name[:-len("weight_orig")]
+            out[base + "weight_u"] = torch.from_numpy(u.astype(np.float32))
+            out[base + "weight_v"] = torch.from_numpy(v.astype(np.float32))
+    module.load_state_dict(out)
+    return module
+
+
 # ---- inputs --------------------------------------------------------------------------------------
 def f0_contour(B, frames, seed):
     """Speech-like F0 (Hz) at the 2T frame rate: voiced arcs in 90-260 Hz with unvoiced (0 Hz) gaps."""

@@ -5,7 +5,7 @@ import pytest
 from _util import manifest
 from styletts2_amd import models
 
-HOT = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]
+HOT = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert", "style_encoder", "predictor_encoder"]
 
 
 @pytest.mark.parametrize("tag", ["ljspeech", "libritts"])

@@ -1,0 +1,73 @@
+"""Reference-audio style path: StyleEncoder against golden vectors produced by the unmodified
+reference module (oracle/golden_style.py), the mel front-end's defining properties (torchaudio is not installed here:
+"parity unpinned", see style.py), compute_style wiring and the token table."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLDEN, manifest
+from styletts2_amd import models, style, synth, text_utils
+
+CASES = {"small": dict(dim_in=16, style_dim=32, max_conv_dim=64, B=3, T=83, seed=21),
+         "libritts": dict(dim_in=64, style_dim=128, max_conv_dim=512, B=2, T=120, seed=22)}
+
+
+@pytest.mark.parametrize("tag", ["small", "libritts"])
+def test_style_encoder_matches_reference_vectors(tag):
+    c = CASES[tag]
+    gold = np.load(os.path.join(GOLDEN, "style_vectors.npz"))["style_" + tag]
+    enc = style.StyleEncoder(dim_in=c["dim_in"], style_dim=c["style_dim"], max_conv_dim=c["max_conv_dim"]).eval()
+    synth.init_spectral_norm_(enc, c["seed"])
+    g = torch.Generator().manual_seed(c["seed"])
+    x = torch.randn(c["B"], 1, 80, c["T"], generator=g) * 0.8 - 0.2
+    out = enc(x).numpy()
+    assert out.shape == gold.shape
+    assert np.abs(out - gold).max() < 2e-6 * max(1.0, np.abs(gold).max())
+
+
+def test_mel_frontend_properties():
+    sr, L = 24000, 24000
+    t = torch.arange(L) / sr
+    wave = 0.5 * torch.sin(2 * math.pi * 1000.0 * t)
+    mel = style.mel_spectrogram(wave)
+    assert mel.shape == (80, L // 300 + 1)
+    raw = torch.exp(mel * style.MEL_STD + style.MEL_MEAN) - 1e-5
+    fb = style.mel_filterbank()
+    assert fb.shape == (1025, 80) and float(fb.min()) >= 0.0
+    # every FFT bin is covered by at most two overlapping triangles that sum to <= 1 (HTK scale, norm=None)
+    assert float(fb.sum(dim=1).max()) <= 1.0 + 1e-5
+    # the reference never passes sample_rate: the bank is laid out for 16 kHz, so a 1 kHz tone at 24 kHz (bin
+    # 1000 / 24000 * 2048 = 85.3) lands in the filter whose 16 kHz-grid centre is 85.3 / 1024 * 8000 = 667 Hz
+    peak = int(raw[:, 10:-10].mean(dim=1).argmax())
+    mel_pts = torch.linspace(0, 2595.0 * math.log10(1 + 8000 / 700.0), 82)
+    centres = (700.0 * (10.0 ** (mel_pts / 2595.0) - 1.0))[1:-1]
+    assert abs(float(centres[peak]) - 667.0) < 40.0
+    # linearity in power: doubling the amplitude adds log(4) / 4 to the normalised log-mel where the tone dominates
+    mel2 = style.mel_spectrogram(2 * wave)
+    assert abs(float((mel2 - mel)[peak, 20:60].mean()) - math.log(4.0) / 4.0) < 1e-3
+
+
+def test_compute_style_and_builder_wiring():
+    man = manifest("libritts")
+    args = models.recursive_munch(man["config"])
+    model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))
+    assert isinstance(model.style_encoder, style.StyleEncoder) and isinstance(model.predictor_encoder, style.StyleEncoder)
+    synth.init_spectral_norm_(model.style_encoder, 3)
+    synth.init_spectral_norm_(model.predictor_encoder, 4)
+    wave = torch.randn(2, 24000 * 2, generator=torch.Generator().manual_seed(0)) * 0.1
+    ref_s = style.compute_style(model, wave)
+    assert ref_s.shape == (2, 256) and bool(torch.isfinite(ref_s).all())
+    one = style.compute_style(model, wave[0])
+    assert torch.allclose(one, ref_s[:1], atol=1e-6)
+
+
+def test_text_cleaner_table():
+    tc = text_utils.TextCleaner()
+    assert len(text_utils.SYMBOLS) == 178 and text_utils.SYMBOL_TO_ID["$"] == 0
+    ids = tc("ðɪs ɪz ɐ tˈɛst!")
+    assert len(ids) == 15 and all(0 < i < 178 for i in ids)
+    assert tc.encode("a") == [0, text_utils.SYMBOL_TO_ID["a"]]
+    assert tc("a#b") == [text_utils.SYMBOL_TO_ID["a"], text_utils.SYMBOL_TO_ID["b"]]  # unknown symbols are dropped
