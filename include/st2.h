@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 6
+#define ST2_ABI_VERSION 7
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -137,8 +137,6 @@ int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t
                   int32_t gamma_plus_one, const float* alpha, float x_scale,
                   void* xs, int32_t xs_cg, int32_t Lp, int32_t halo, void* stream);
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
-/* Tuning knob (process-wide): build of the 128-output-row variants held to 2 or 3 workgroups per CU (default 3). */
-int st2_conv1d_xs_set_occupancy(int wg_per_cu);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *

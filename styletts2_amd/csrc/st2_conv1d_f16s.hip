@@ -41,7 +41,7 @@ struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
 };
 
 template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) {
+__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
@@ -265,54 +265,88 @@ __global__ __launch_bounds__(NT) void conv1d_f16s_kernel(const st2_conv_desc d) 
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
   const float osc = d.out_scale;
-  // Interior tiles take the FULL path: no per-element bounds tests, one 64-bit address per output row (the four
-  // 32-column groups of a lane are immediate offsets from it); see st2_conv1d_xs.hip.
+  // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
+  // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
+  // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
+  // tile but the last along l / co -- of the plain-output convs dispatch ONCE to a build with those terms as
+  // compile-time constants: no bounds tests, one 64-bit address per output row (the four 32-column groups of a lane
+  // are immediate offsets), the row's residual loads issued together ahead of the arithmetic.  Edge tiles and rare
+  // combinations take the generic build (MODE < 0: run-time flags, per-element bounds).
   const int col0 = n0 + wn * (32 * TN) + l31;
   const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
-  auto epilogue_as = [&](auto act_tag, auto full_tag) __attribute__((always_inline)) {
+  const int rstep = 32 >> d.res_shift;
+  auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
-    constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
+    constexpr bool FULL = MODE >= 0;
+    const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
+    const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
+    const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
       const bool rok = FULL || row < d.C_out;
       const int rowc = FULL ? row : min(row, d.C_out - 1);
-      float* yp = yb + (int64_t)rowc * d.y_cs + col0;
-      const float* rp = rb ? rb + (int64_t)rowc * d.res_cs + (col0 >> d.res_shift) : nullptr;
-      const float* r2p = r2b ? r2b + (int64_t)rowc * d.res2_cs + col0 : nullptr;
-      const float bias_r = d.bias ? d.bias[rowc] : 0.f;
-      const int rstep = 32 >> d.res_shift;
+      // 32-bit element offsets from the (scalar) per-batch bases: one VALU mad per row and tensor, and the memory
+      // instructions take the SGPR-base + VGPR-offset form (a batch item is < 2^31 elements, checked at launch)
+      const int yo = rowc * d.y_cs + col0;
+      const int ro = rowc * d.res_cs + (col0 >> d.res_shift);  // used only if use_res
+      const int r2o = rowc * d.res2_cs + col0;                 // used only if use_res2
+      // unconditional load + select (a branch here would split the rows into separate basic blocks); without a bias
+      // the packed weights serve as a valid address
+      const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
+      const float bias_r = d.bias ? braw : 0.f;
+      bool ok[TN];
+      float rv[TN], r2v[TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const bool ok = FULL || (rok && col0 + j * 32 < d.L_out);
-        float v = acc[j][r] * osc;
-        if (d.bias) v += bias_r;
-        if (ok) {
-          if (rp) v += rp[j * rstep];
-          if (r2p) v = r2p[j * 32] + v;
-          if (d.div != 1.0f) v = v / d.div;
-          if constexpr (ACT == ST2_ACT_GELU) {
-            v = gelu_erf(v);
-          } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
-            v = row < d.act_split ? expf(v) : sin_acc(v);
-          } else if constexpr (ACT == ST2_ACT_TANH) {
-            v = tanhf(v);
-          } else if constexpr (ACT == ST2_ACT_LEAKY) {
-            v = leaky(v, d.act_slope);
-          } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
-            v = gelu_tanh(v);
-          }
-          yp[j * 32] = v;
+        ok[j] = FULL || (rok && col0 + j * 32 < d.L_out);
+        rv[j] = (use_res && ok[j]) ? rb[ro + j * rstep] : 0.f;
+        r2v[j] = (use_res2 && ok[j]) ? r2b[r2o + j * 32] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v = acc[j][r] * osc + bias_r;
+        if (use_res) v += rv[j];
+        if (use_res2) v = r2v[j] + v;
+        if (use_div) v = v / d.div;
+        if constexpr (ACT == ST2_ACT_GELU) {
+          v = gelu_erf(v);
+        } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
+          v = row < d.act_split ? expf(v) : sin_acc(v);
+        } else if constexpr (ACT == ST2_ACT_TANH) {
+          v = tanhf(v);
+        } else if constexpr (ACT == ST2_ACT_LEAKY) {
+          v = leaky(v, d.act_slope);
+        } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
+          v = gelu_tanh(v);
+        }
+        if (ok[j]) {
+          yb[yo + j * 32] = v;
         }
       }
       if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
     }
   };
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
-    if (full_tile)
-      epilogue_as(act_tag, std::true_type{});
-    else
-      epilogue_as(act_tag, std::false_type{});
+    constexpr int ACT = decltype(act_tag)::value;
+    const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
+    if (!full_tile) return epilogue_as(act_tag, std::integral_constant<int, -1>{});
+    if constexpr (ACT == ST2_ACT_NONE) {
+      switch (mode) {
+        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
+        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{});
+        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{});
+        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{});
+        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{});
+        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{});
+        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{});
+        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
+      }
+    } else {
+      if (mode == 0) return epilogue_as(act_tag, std::integral_constant<int, 0>{});
+      return epilogue_as(act_tag, std::integral_constant<int, -1>{});
+    }
   };
   switch (d.act) {
     case ST2_ACT_GELU:
@@ -394,6 +428,9 @@ extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(d.res_shift >= 0 && d.res_shift <= 1, "st2_conv1d_f16s: res_shift must be 0 or 1");
   ST2_REQUIRE(d.x_scale > 0.f && d.out_scale > 0.f, "st2_conv1d_f16s: x_scale / out_scale must be set");
   ST2_REQUIRE(d.B <= 65535, "st2_conv1d_f16s: grid too large");
+  ST2_REQUIRE((int64_t)d.C_out * d.y_cs < (1ll << 31) && (!d.res || (int64_t)d.C_out * d.res_cs < (1ll << 31)) &&
+                  (!d.res2 || (int64_t)d.C_out * d.res2_cs < (1ll << 31)),
+              "st2_conv1d_f16s: a batch item of y / res / res2 must span < 2^31 elements");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.ks) {
     case 1:

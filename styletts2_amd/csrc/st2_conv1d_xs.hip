@@ -63,9 +63,9 @@ __device__ __forceinline__ float halfwave_reduce16(const float (&s)[16], int l31
   return a1;
 }
 
-// Two builds of the body: an uncapped one (accumulators in AGPRs, every B fragment of a k-step in flight at once,
-// ~196 registers -> 2 workgroups per CU) and one capped at 168 VGPRs (3 workgroups per CU: trades some of that
-// intra-wave pipelining for a third wave per SIMD to hide LDS / L2 latency behind).
+// Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
+// one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
+// 0.42 ms vs 0.48 ms on the dominant layer at B = 8).
 template <int KS, int CI_T, int WM, int WN, int TN>
 __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   constexpr int BM = 32 * WM;
@@ -209,47 +209,66 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
   const float osc = d.out_scale;
   const bool want_part = d.part != nullptr;
-  // Interior tiles (every tile but the last along l / co) take the FULL path: no per-element bounds tests, one 64-bit
-  // address per output row (the four 32-column groups of a lane are immediate offsets from it).  The generic version
-  // of this loop cost ~2900 VALU instructions per wave against 1056 MFMAs in the k loop.
+  // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
+  // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
+  // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
+  // tile but the last along l / co -- of the plain-output convs dispatch ONCE to a build with those terms as
+  // compile-time constants: no bounds tests, one 64-bit address per output row (the four 32-column groups of a lane
+  // are immediate offsets), the row's residual loads issued together ahead of the arithmetic.  Edge tiles and rare
+  // combinations take the generic build (MODE < 0: run-time flags, per-element bounds).
   const int col0 = n0 + wn * (32 * TN) + l31;
   const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
-  auto epilogue_as = [&](auto act_tag, auto full_tag) __attribute__((always_inline)) {
+  const int rstep = 32 >> d.res_shift;
+  auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
-    constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
+    constexpr bool FULL = MODE >= 0;
+    const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
+    const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
+    const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
     float ps[16], pq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
       const bool rok = FULL || row < d.C_out;
       const int rowc = FULL ? row : min(row, d.C_out - 1);
-      float* yp = yb + (int64_t)rowc * d.y_cs + col0;
-      const float* rp = rb ? rb + (int64_t)rowc * d.res_cs + (col0 >> d.res_shift) : nullptr;
-      const float* r2p = r2b ? r2b + (int64_t)rowc * d.res2_cs + col0 : nullptr;
-      const float bias_r = d.bias ? d.bias[rowc] : 0.f;
-      const int rstep = 32 >> d.res_shift;
+      // 32-bit element offsets from the (scalar) per-batch bases: one VALU mad per row and tensor, and the memory
+      // instructions take the SGPR-base + VGPR-offset form (a batch item is < 2^31 elements, checked at launch)
+      const int yo = rowc * d.y_cs + col0;
+      const int ro = rowc * d.res_cs + (col0 >> d.res_shift);  // used only if use_res
+      const int r2o = rowc * d.res2_cs + col0;                 // used only if use_res2
+      // unconditional load + select (a branch here would split the rows into separate basic blocks); without a bias
+      // the packed weights serve as a valid address
+      const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
+      const float bias_r = d.bias ? braw : 0.f;
+      bool ok[TN];
+      float rv[TN], r2v[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        ok[j] = FULL || (rok && col0 + j * 32 < d.L_out);
+        rv[j] = (use_res && ok[j]) ? rb[ro + j * rstep] : 0.f;
+        r2v[j] = (use_res2 && ok[j]) ? r2b[r2o + j * 32] : 0.f;
+      }
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const bool ok = FULL || (rok && col0 + j * 32 < d.L_out);
-        float v = acc[j][r] * osc;
-        if (d.bias) v += bias_r;
-        if (ok) {
-          if (rp) v += rp[j * rstep];
-          if (r2p) v = r2p[j * 32] + v;
-          if (d.div != 1.0f) v = v / d.div;
-          if constexpr (ACT == ST2_ACT_GELU) {
-            v = gelu_erf(v);
-          } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
-            v = row < d.act_split ? expf(v) : sin_acc(v);
-          } else if constexpr (ACT == ST2_ACT_TANH) {
-            v = tanhf(v);
-          } else if constexpr (ACT == ST2_ACT_LEAKY) {
-            v = leaky(v, d.act_slope);
-          } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
-            v = gelu_tanh(v);
-          }
-          yp[j * 32] = v;
+        float v = acc[j][r] * osc + bias_r;
+        if (use_res) v += rv[j];
+        if (use_res2) v = r2v[j] + v;
+        if (use_div) v = v / d.div;
+        if constexpr (ACT == ST2_ACT_GELU) {
+          v = gelu_erf(v);
+        } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
+          v = row < d.act_split ? expf(v) : sin_acc(v);
+        } else if constexpr (ACT == ST2_ACT_TANH) {
+          v = tanhf(v);
+        } else if constexpr (ACT == ST2_ACT_LEAKY) {
+          v = leaky(v, d.act_slope);
+        } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
+          v = gelu_tanh(v);
+        }
+        if (ok[j]) {
+          yb[yo + j * 32] = v;
           s1 += v;
           s2 += v * v;
         }
@@ -271,10 +290,24 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     }
   };
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
-    if (full_tile)
-      epilogue_as(act_tag, std::true_type{});
-    else
-      epilogue_as(act_tag, std::false_type{});
+    constexpr int ACT = decltype(act_tag)::value;
+    const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
+    if (!full_tile) return epilogue_as(act_tag, std::integral_constant<int, -1>{});
+    if constexpr (ACT == ST2_ACT_NONE) {
+      switch (mode) {
+        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
+        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{});
+        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{});
+        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{});
+        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{});
+        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{});
+        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{});
+        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
+      }
+    } else {
+      if (mode == 0) return epilogue_as(act_tag, std::integral_constant<int, 0>{});
+      return epilogue_as(act_tag, std::integral_constant<int, -1>{});
+    }
   };
   switch (d.act) {
     case ST2_ACT_GELU:
@@ -299,15 +332,13 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
 }
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
-__global__ __launch_bounds__(NT) void conv1d_xs_kernel(const st2_conv_desc d) {  // OCC == 2: no register cap
+__global__ __launch_bounds__(NT, 2) void conv1d_xs_kernel(const st2_conv_desc d) {  // >= 2 workgroups per CU
   conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
 template <int KS, int CI_T, int WM, int WN, int TN>
 __global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc d) {  // <= 168 VGPRs
   conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
-
-int g_occ3 = 1;  // st2_conv1d_xs_set_occupancy(): use the 3-workgroups-per-CU build of the 128-row variants
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
 int launch(const st2_conv_desc& d, hipStream_t s) {
@@ -351,27 +382,17 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
 
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
-  if (d.C_out > 64)  // 128 co x 128 l
-    return g_occ3 ? launch<KS, CI_T, 4, 1, 4, 3>(d, s) : launch<KS, CI_T, 4, 1, 4, 2>(d, s);
-  if (d.C_out > 32) {  // 64 co x 256 l (the capped build spills with 32-channel chunks)
-    if constexpr (CI_T == 16) {
-      if (g_occ3) return launch<KS, CI_T, 2, 2, 4, 3>(d, s);
-    }
-    return launch<KS, CI_T, 2, 2, 4, 2>(d, s);
+  if (d.C_out > 64) return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
+  if (d.C_out > 32) {                                           // 64 co x 256 l
+    if constexpr (CI_T == 16)
+      return launch<KS, CI_T, 2, 2, 4, 3>(d, s);
+    else
+      return launch<KS, CI_T, 2, 2, 4, 2>(d, s);  // the 168-VGPR build spills with 32-channel chunks
   }
   return launch<KS, CI_T, 1, 4, 4, 2>(d, s);  // 32 co x 512 l
 }
 
 }  // namespace
-
-extern "C" int st2_conv1d_xs_set_occupancy(int wg_per_cu) {
-  if (wg_per_cu != 2 && wg_per_cu != 3) {
-    st2_set_error("st2_conv1d_xs_set_occupancy: %d (have 2, 3)", wg_per_cu);
-    return 1;
-  }
-  g_occ3 = wg_per_cu == 3;
-  return 0;
-}
 
 extern "C" int st2_conv1d_xs(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(dp != nullptr, "st2_conv1d_xs: null descriptor");
@@ -387,6 +408,9 @@ extern "C" int st2_conv1d_xs(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(d.res_shift >= 0 && d.res_shift <= 1, "st2_conv1d_xs: res_shift must be 0 or 1");
   ST2_REQUIRE(d.out_scale > 0.f, "st2_conv1d_xs: out_scale must be set");
   ST2_REQUIRE(d.B <= 65535, "st2_conv1d_xs: grid too large");
+  ST2_REQUIRE((int64_t)d.C_out * d.y_cs < (1ll << 31) && (!d.res || (int64_t)d.C_out * d.res_cs < (1ll << 31)) &&
+                  (!d.res2 || (int64_t)d.C_out * d.res2_cs < (1ll << 31)),
+              "st2_conv1d_xs: a batch item of y / res / res2 must span < 2^31 elements");
   if (d.part) ST2_REQUIRE((reinterpret_cast<uintptr_t>(d.part) & 7) == 0, "st2_conv1d_xs: part must be 8-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.ks) {

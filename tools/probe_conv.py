@@ -53,19 +53,16 @@ for (Cc, L, ks, dil) in cases:
     r["stats"] = timed(lambda: ops.instnorm_stats(x, out=st))
     r["act"] = timed(lambda: ops.activate(x, **akw))
     xs = ops.activate(x, **akw)
-    for occ in (2, 3):
-        lib.st2_conv1d_xs_set_occupancy(occ)
-        r["xs_occ%d" % occ] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x))
-        r["xs_occ%d_stats" % occ] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias,
-                                                                out=out, res=x, want_stats=True))
-    lib.st2_conv1d_xs_set_occupancy(3)
+    r["xs_plain"] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out))
+    r["xs_res"] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x))
+    r["xs_res_stats"] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x,
+                                                    want_stats=True))
     r = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
     r["tflops_fused_pro3"] = round(flop / r["fused_pro3"] / 1e9, 1)
-    best = min(r["xs_occ2"], r["xs_occ3"])
-    r["tflops_xs_conv"] = round(flop / best / 1e9, 1)
+    r["tflops_xs_conv"] = round(flop / r["xs_plain"] / 1e9, 1)
     r["act_GBps"] = round(B * Cc * L * 8 / r["act"] / 1e6, 1)
     r["layer_fused_ms"] = round(r["fused_pro3"] + r["stats"], 4)
-    r["layer_xs_ms"] = round(r["act"] + min(r["xs_occ2_stats"], r["xs_occ3_stats"]), 4)
+    r["layer_xs_ms"] = round(r["act"] + r["xs_res_stats"], 4)
     rows.append(r)
     print(r, flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
