@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="issue every step on one stream (no front/decoder overlap)")
+    ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
     a = ap.parse_args()
 
     from _util import manifest
@@ -156,7 +157,9 @@ def main():
     # Two HIP streams: the front of step k+1 (text encoder, PL-BERT, diffusion sampler, duration / prosody predictors:
     # latency-bound small kernels) is issued on `front` and overlaps the decoder + vocoder of step k on the main
     # stream.  Every step is still one complete pass tokens -> waveform over the batch; --single-stream turns it off.
-    front = None if a.single_stream else torch.cuda.Stream(dev)
+    # the front stream gets the higher priority: its small kernels then take CU slots as the decoder's workgroups
+    # retire instead of queueing behind them (--front-priority 0 = equal priorities)
+    front = None if a.single_stream else torch.cuda.Stream(dev, priority=a.front_priority)
     if front is not None:
         front.wait_stream(torch.cuda.current_stream(dev))
 

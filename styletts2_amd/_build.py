@@ -12,7 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(HERE, "libst2_hip.so")
 
-SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_xs.hip", "st2_actsplit.hip", "st2_norm.hip", "st2_misc.hip", "st2_source.hip", "st2_attention.hip", "st2_lstm.hip", "st2_lstm_coop.hip"]
+SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_f16s_k0.hip", "st2_conv1d_f16s_k1.hip",
+           "st2_conv1d_f16s_k2.hip", "st2_conv1d_xs.hip", "st2_conv1d_xs_k0.hip", "st2_conv1d_xs_k1.hip",
+           "st2_conv1d_xs_k2.hip", "st2_actsplit.hip", "st2_norm.hip", "st2_misc.hip", "st2_source.hip", "st2_attention.hip", "st2_lstm.hip", "st2_lstm_coop.hip"]
 # -ffp-contract=off: the SineGen phase path must reproduce ATen-CPU rounding (no implicit FMA);
 # fused multiply-adds are written explicitly (fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
@@ -37,7 +39,8 @@ def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "st2_common.h"), os.path.join(CSRC, "st2_act.h"), os.path.join(INCLUDE, "st2.h")]
+    headers = [os.path.join(CSRC, h) for h in ("st2_common.h", "st2_act.h", "st2_conv1d_xs_impl.h",
+                                                "st2_conv1d_f16s_impl.h")] + [os.path.join(INCLUDE, "st2.h")]
     objs = []
     procs = []
     for s in SOURCES:

@@ -1,411 +1,14 @@
-// Fused Conv1d on the CDNA4 f16 matrix pipe with fp32-class accuracy: "f16 hi/lo split", 3 products.
-//
-//   y[b,co,l] = epi( bias[co] + sum_{ci,t} W[co,ci,t] * pro(x)[b,ci, l + t*dil - pad_left] )
-//
-// Every operand v is carried as two halves  v*s = hi + lo  (hi = f16(v*s), lo = f16(v*s - hi); s a power
-// of two that keeps lo in the normal f16 range) and the product is evaluated as
-//       hi_w*hi_x + hi_w*lo_x + lo_w*hi_x          (lo_w*lo_x ~ 2^-22 relative: dropped)
-// by three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator.  f16 x f16 products are exact in fp32, so the
-// only errors are the 2^-22-relative operand residue and the fp32 accumulation every fp32 conv has anyway:
-// measured through the whole decoder the waveform differs from an fp64 evaluation by 2.6e-7 RMS, the fp32
-// ATen path by 2.4e-7 (tools/probe_split_precision.py).  Rate: 3 MFMAs at 1024 FLOP/clk/SIMD = 5.3x the
-// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, st2_conv1d.hip) for the same algorithmic FLOPs.
-//
-// GEMM view per batch item: M = C_out, N = L_out, K = C_in*ks, k ordered (ci/16, tap, ci%16) so that one
-// MFMA k-step = 16 consecutive input channels at one tap.
-//   * B operand (activations): the workgroup stages the ACTIVATED, split input tile for CI_T channels,
-//     [hi|lo][ci/8][BN + (ks-1)*dil positions][8 halves], in LDS -- one ds_read_b128 per fragment, consecutive
-//     lanes read consecutive 16-byte slots (conflict free), taps are just a shift of the position index.
-//     Double buffered: global loads for chunk c+1 are issued before the MFMAs of chunk c and the prologue
-//     (AdaIN affine, Snake / LeakyReLU, split) runs on them afterwards; one barrier per chunk.
-//   * A operand (weights): pre-split and packed per load as [ci/16][tap][k-half][co][hi8|lo8]; every wave owns
-//     distinct output-channel rows, so its A fragments are read straight from L2 into registers (32 B per
-//     lane, prefetched one k-step ahead) and never touch LDS.  The whole packed weight (<= 0.7 MB for the
-//     vocoder layers) is L2 resident.
-//   * wave tile = 32 (co) x 32*TN (l): TN accumulators of 16 registers.  Waves are arranged WM x WN over
-//     (co, l): 4x1 for C_out >= 96, 2x2 for C_out in (32, 96), 1x4 for C_out <= 32.
-#include "st2_common.h"
-#include "st2_act.h"
-#include <type_traits>
+// C entry points of the f16s conv family; the kernels live in st2_conv1d_f16s_impl.h and are instantiated in
+// st2_conv1d_f16s_k{0,1,2}.hip.
+#include "st2_conv1d_f16s_impl.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+extern template int st2f16s::launch_by_cout<1, 32>(const st2_conv_desc&, hipStream_t);
+extern template int st2f16s::launch_by_cout<2, 32>(const st2_conv_desc&, hipStream_t);
+extern template int st2f16s::launch_by_cout<3, 32>(const st2_conv_desc&, hipStream_t);
+extern template int st2f16s::launch_by_cout<5, 16>(const st2_conv_desc&, hipStream_t);
+extern template int st2f16s::launch_by_cout<7, 16>(const st2_conv_desc&, hipStream_t);
+extern template int st2f16s::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t);
 
-namespace {
-
-constexpr int NT = 256;
-
-struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
-  float mean, rstd, g, beta, alpha, inv_alpha, pad0, pad1;
-};
-
-template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d) {
-  constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * TN * WN;
-  constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
-  constexpr int TPG = NT / CG;    // staging threads per group
-  constexpr int S16 = CI_T / 16;  // MFMA k-steps per tap per chunk
-  constexpr int MAXXW = BN + (KS - 1) * 8;
-  constexpr int R = (MAXXW + TPG - 1) / TPG;  // staging rounds (positions per thread)
-  static_assert(WM * WN == 4, "4 waves");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int kg = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN;
-  const int wn = wave % WN;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
-  const int b = blockIdx.z;
-
-  const int XW = BN + (KS - 1) * d.dil;  // staged positions
-  // LDS: [2 buffers][2 planes hi/lo][CG][XW] slots of 16 B, then the channel parameter table
-  h8* xs = reinterpret_cast<h8*>(smem_raw);
-  const int plane = CG * XW;  // slots per plane
-  ChanPar* par = reinterpret_cast<ChanPar*>(smem_raw + (size_t)4 * plane * 16);
-
-  const int pro = d.pro;
-  const bool has_par = pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE ||
-                       pro == ST2_PRO_COLNORM;
-  const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
-  if (has_par) {
-    for (int ci = tid; ci < C_pad; ci += NT) {
-      ChanPar p = {0.f, 1.f, 1.f, 0.f, 1.f, 1.f, 0.f, 0.f};
-      if (ci < d.C_in) {
-        if (pro == ST2_PRO_COLNORM) {  // per-channel affine of a LayerNorm over channels (statistics are per position)
-          const float g = d.gamma[(int64_t)b * d.gb_bs + ci];
-          p.g = d.gamma_plus_one ? 1.0f + g : g;
-          p.beta = d.beta[(int64_t)b * d.gb_bs + ci];
-        } else if (pro != ST2_PRO_SNAKE) {
-          const float* st = d.stats + ((int64_t)b * d.C_in + ci) * 2;
-          p.mean = st[0];
-          p.rstd = st[1];
-          p.g = 1.0f + d.gamma[(int64_t)b * d.gb_bs + ci];
-          p.beta = d.beta[(int64_t)b * d.gb_bs + ci];
-        }
-        if (pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE) {
-          p.alpha = d.alpha[ci];
-          p.inv_alpha = 1.0f / p.alpha;
-        }
-      }
-      par[ci] = p;
-    }
-  }
-
-  // ---- staging assignment: thread -> (channel group, R positions); identical for every chunk ----------
-  const int sg = tid / TPG;
-  const int sp0 = tid % TPG;
-  const float* xb = d.x + (int64_t)b * d.x_bs;
-  const int lin0 = n0 - d.pad_left;  // input position held by staged column 0
-  float xr[R][8];
-
-  // loads are unconditional on clamped (always valid) addresses; out-of-range values are zeroed in store_chunk
-  auto load_chunk = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int l = min(max(lin0 + sp0 + r * TPG, 0), d.L_in - 1);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ci = min(c0 + sg * 8 + e, d.C_in - 1);
-        xr[r][e] = xb[(int64_t)ci * d.x_cs + l];
-      }
-    }
-  };
-
-  // prologue + hi/lo split of the R x 8 loaded values, written to LDS buffer `buf`; PRO is a compile-time
-  // constant inside so the element loops carry no branches
-  auto store_chunk_as = [&](int c0, int buf, auto pro_tag) __attribute__((always_inline)) {
-    constexpr int PRO = decltype(pro_tag)::value;
-    h8* dst = xs + (size_t)buf * 2 * plane + sg * XW;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int pos = sp0 + r * TPG;
-      if (pos >= XW) continue;
-      const int l = lin0 + pos;
-      const bool lok = l >= 0 && l < d.L_in;
-      float cmean = 0.f, crstd = 1.f;
-      if constexpr (PRO == ST2_PRO_COLNORM) {
-        const float* st = d.stats + ((int64_t)b * d.L_in + min(max(l, 0), d.L_in - 1)) * 2;
-        cmean = st[0];
-        crstd = st[1];
-      }
-      h8 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ci = c0 + sg * 8 + e;
-        float v = xr[r][e];
-        if constexpr (PRO == ST2_PRO_LEAKY) {
-          v = leaky(v, d.slope);
-        } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
-          const ChanPar p = par[ci];
-          float u = (v - p.mean) * p.rstd;
-          u = p.g * u + p.beta;
-          v = leaky(u, d.slope);
-        } else if constexpr (PRO == ST2_PRO_ADAIN_SNAKE) {
-          const ChanPar p = par[ci];
-          float u = (v - p.mean) * p.rstd;
-          u = p.g * u + p.beta;
-          v = snake(u, p.alpha, p.inv_alpha);
-        } else if constexpr (PRO == ST2_PRO_SNAKE) {
-          const ChanPar p = par[ci];
-          v = snake(v, p.alpha, p.inv_alpha);
-        } else if constexpr (PRO == ST2_PRO_COLNORM) {
-          const ChanPar p = par[ci];
-          const float u = (v - cmean) * crstd;
-          v = u * p.g + p.beta;
-        }
-        // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor
-        v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
-        const _Float16 h = (_Float16)v;
-        hi[e] = h;
-        lo[e] = (_Float16)(v - (float)h);
-      }
-      dst[pos] = hi;
-      dst[plane + pos] = lo;
-    }
-  };
-  auto store_chunk = [&](int c0, int buf) __attribute__((always_inline)) {
-    switch (pro) {
-      case ST2_PRO_LEAKY:
-        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_LEAKY>{});
-        break;
-      case ST2_PRO_ADAIN_LEAKY:
-        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_ADAIN_LEAKY>{});
-        break;
-      case ST2_PRO_ADAIN_SNAKE:
-        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_ADAIN_SNAKE>{});
-        break;
-      case ST2_PRO_SNAKE:
-        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_SNAKE>{});
-        break;
-      case ST2_PRO_COLNORM:
-        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_COLNORM>{});
-        break;
-      default:
-        store_chunk_as(c0, buf, std::integral_constant<int, ST2_PRO_NONE>{});
-        break;
-    }
-  };
-
-  f32x16 acc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  // ---- A operand stream: 32 B (hi8|lo8) per lane per k-step, constant stride between steps -----------
-  const int co_a = m0 + wm * 32 + l31;  // < wq_co_pad by construction of the packing
-  const h8* ap = reinterpret_cast<const h8*>(d.wq) + ((int64_t)kg * d.wq_co_pad + co_a) * 2;
-  const int64_t a_step = (int64_t)2 * d.wq_co_pad * 2;  // h8 units per k-step
-  const int nchunk = C_pad / CI_T;
-
-  load_chunk(0);
-  if (has_par) __syncthreads();  // parameter table visible
-  store_chunk(0, 0);
-  // weight fragments are double buffered in two NAMED register sets indexed by the (compile-time) parity of the
-  // k-step inside the chunk; with one set hipcc re-uses the registers and sinks the prefetch to ~4 MFMAs ahead
-  // of its consumer
-  constexpr int SPC = S16 * KS;  // k-steps per chunk
-  h8 a_hi[2], a_lo[2];
-  a_hi[0] = ap[0];
-  a_lo[0] = ap[1];
-  __syncthreads();
-
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    const bool more = c + 1 < nchunk;
-    const h8* xbuf = xs + (size_t)buf * 2 * plane + kg * XW + wn * (32 * TN) + l31;
-#pragma unroll
-    for (int s = 0; s < S16; ++s) {
-#pragma unroll
-      for (int t = 0; t < KS; ++t) {
-        const int cur = (s * KS + t) & 1, nxt = cur ^ 1;
-        // All VMEM below is issued unconditionally (the very last prefetch re-reads the last fragment, the last
-        // chunk's activation loads clamp to the last channel): a branch around a load makes hipcc's in-order vmcnt
-        // bookkeeping conservative, and the next weight wait then drains the activation loads at HBM latency.
-        if (more || s + 1 < S16 || t + 1 < KS) ap += a_step;
-        a_hi[nxt] = ap[0];  // prefetch the next k-step's weights
-        a_lo[nxt] = ap[1];
-        // next chunk's activations: issued AFTER the weight prefetch so that the in-order vmcnt wait of the next
-        // k-step does not have to drain these (possibly HBM-latency) loads
-        if (s == 0 && t == 0) load_chunk((c + 1) * CI_T);
-        __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch stays a full k-step ahead
-        const h8 ah = a_hi[cur], al = a_lo[cur];
-        const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
-        h8 bh[TN], bl[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh[j] = xp[j * 32];
-          bl[j] = xp[plane + j * 32];
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
-      }
-    }
-    if (SPC & 1) {  // odd step count: next chunk's step 0 reads set 0
-      a_hi[0] = a_hi[1];
-      a_lo[0] = a_lo[1];
-    }
-    if (more) store_chunk((c + 1) * CI_T, buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue ---------------------------------------------------------------------------------------
-  float* yb = d.y + (int64_t)b * d.y_bs;
-  const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
-  const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
-  const float osc = d.out_scale;
-  // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
-  // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
-  // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
-  // tile but the last along l / co -- of the plain-output convs dispatch ONCE to a build with those terms as
-  // compile-time constants: no bounds tests, one 64-bit address per output row (the four 32-column groups of a lane
-  // are immediate offsets), the row's residual loads issued together ahead of the arithmetic.  Edge tiles and rare
-  // combinations take the generic build (MODE < 0: run-time flags, per-element bounds).
-  const int col0 = n0 + wn * (32 * TN) + l31;
-  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
-  const int rstep = 32 >> d.res_shift;
-  auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_tag)::value;
-    constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
-    constexpr bool FULL = MODE >= 0;
-    const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
-    const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
-    const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const bool rok = FULL || row < d.C_out;
-      const int rowc = FULL ? row : min(row, d.C_out - 1);
-      // 32-bit element offsets from the (scalar) per-batch bases: one VALU mad per row and tensor, and the memory
-      // instructions take the SGPR-base + VGPR-offset form (a batch item is < 2^31 elements, checked at launch)
-      const int yo = rowc * d.y_cs + col0;
-      const int ro = rowc * d.res_cs + (col0 >> d.res_shift);  // used only if use_res
-      const int r2o = rowc * d.res2_cs + col0;                 // used only if use_res2
-      // unconditional load + select (a branch here would split the rows into separate basic blocks); without a bias
-      // the packed weights serve as a valid address
-      const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
-      const float bias_r = d.bias ? braw : 0.f;
-      bool ok[TN];
-      float rv[TN], r2v[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        ok[j] = FULL || (rok && col0 + j * 32 < d.L_out);
-        rv[j] = (use_res && ok[j]) ? rb[ro + j * rstep] : 0.f;
-        r2v[j] = (use_res2 && ok[j]) ? r2b[r2o + j * 32] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float v = acc[j][r] * osc + bias_r;
-        if (use_res) v += rv[j];
-        if (use_res2) v = r2v[j] + v;
-        if (use_div) v = v / d.div;
-        if constexpr (ACT == ST2_ACT_GELU) {
-          v = gelu_erf(v);
-        } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
-          v = row < d.act_split ? expf(v) : sin_acc(v);
-        } else if constexpr (ACT == ST2_ACT_TANH) {
-          v = tanhf(v);
-        } else if constexpr (ACT == ST2_ACT_LEAKY) {
-          v = leaky(v, d.act_slope);
-        } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
-          v = gelu_tanh(v);
-        }
-        if (ok[j]) {
-          yb[yo + j * 32] = v;
-        }
-      }
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
-    }
-  };
-  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_tag)::value;
-    const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
-    if (!full_tile) return epilogue_as(act_tag, std::integral_constant<int, -1>{});
-    if constexpr (ACT == ST2_ACT_NONE) {
-      switch (mode) {
-        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{});
-        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{});
-        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{});
-        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{});
-        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{});
-        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{});
-        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
-      }
-    } else {
-      if (mode == 0) return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-      return epilogue_as(act_tag, std::integral_constant<int, -1>{});
-    }
-  };
-  switch (d.act) {
-    case ST2_ACT_GELU:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
-      break;
-    case ST2_ACT_EXP_SIN:
-      epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
-      break;
-    case ST2_ACT_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
-      break;
-    case ST2_ACT_LEAKY:
-      epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
-      break;
-    case ST2_ACT_GELU_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
-      break;
-    default:
-      epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
-      break;
-  }
-}
-
-template <int KS, int CI_T, int WM, int WN, int TN>
-int launch(const st2_conv_desc& d, hipStream_t s) {
-  constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * TN * WN;
-  const int XW = BN + (KS - 1) * d.dil;
-  const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
-  const bool has_par = d.pro == ST2_PRO_ADAIN_LEAKY || d.pro == ST2_PRO_ADAIN_SNAKE || d.pro == ST2_PRO_SNAKE ||
-                       d.pro == ST2_PRO_COLNORM;
-  const size_t smem = (size_t)4 * (CI_T / 8) * XW * 16 + (has_par ? (size_t)C_pad * 32 : 0);
-  ST2_REQUIRE(smem <= 160 * 1024, "st2_conv1d_f16s: tile needs %zu B of LDS (ks=%d dil=%d C_in=%d)", smem, KS,
-              d.dil, d.C_in);
-  ST2_REQUIRE(d.wq_cin_pad == C_pad, "st2_conv1d_f16s: packed weight has %d input channels, kernel needs %d",
-              d.wq_cin_pad, C_pad);
-  ST2_REQUIRE(d.wq_co_pad % BM == 0 && d.wq_co_pad >= d.C_out, "st2_conv1d_f16s: wq_co_pad=%d must be a multiple "
-              "of %d covering C_out=%d", d.wq_co_pad, BM, d.C_out);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  // rows beyond C_out inside the last co block are computed on zero weights and not stored
-  dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B);
-  hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
-  ST2_CHECK_LAUNCH("st2_conv1d_f16s");
-  return 0;
-}
-
-template <int KS, int CI_T>
-int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
-  if (d.C_out > 64) return launch<KS, CI_T, 4, 1, 4>(d, s);  // 128 co x 128 l
-  if (d.C_out > 32) return launch<KS, CI_T, 2, 2, 4>(d, s);  // 64 co x 256 l
-  return launch<KS, CI_T, 1, 4, 4>(d, s);                    // 32 co x 512 l
-}
-
-}  // namespace
 
 extern "C" int st2_conv1d_f16s_chunk(int ks) { return ks <= 3 ? 32 : 16; }
 
@@ -434,17 +37,17 @@ extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (d.ks) {
     case 1:
-      return launch_by_cout<1, 32>(d, s);
+      return st2f16s::launch_by_cout<1, 32>(d, s);
     case 2:
-      return launch_by_cout<2, 32>(d, s);
+      return st2f16s::launch_by_cout<2, 32>(d, s);
     case 3:
-      return launch_by_cout<3, 32>(d, s);
+      return st2f16s::launch_by_cout<3, 32>(d, s);
     case 5:
-      return launch_by_cout<5, 16>(d, s);
+      return st2f16s::launch_by_cout<5, 16>(d, s);
     case 7:
-      return launch_by_cout<7, 16>(d, s);
+      return st2f16s::launch_by_cout<7, 16>(d, s);
     case 11:
-      return launch_by_cout<11, 16>(d, s);
+      return st2f16s::launch_by_cout<11, 16>(d, s);
     default:
       st2_set_error("st2_conv1d_f16s: unsupported kernel size %d (have 1,2,3,5,7,11)", d.ks);
       return 1;

@@ -15,11 +15,15 @@ if ! has smoke; then echo "== smoke"; timeout 300 python __graft_entry__.py smok
 if ! has probe; then echo "== probe e2e"; timeout 300 python tools/probe_e2e.py > $OUT/probe_e2e.log 2>&1; tail -6 $OUT/probe_e2e.log
   echo "== probe lstm"; timeout 300 python tools/probe_lstm.py > $OUT/probe_lstm.log 2>&1; tail -8 $OUT/probe_lstm.log
   echo "== probe conv"; PROBE_KERNELS=f16s timeout 300 python tools/probe_conv.py > $OUT/probe_conv.log 2>&1; tail -40 $OUT/probe_conv.log; fi
-if ! has bench; then echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -4 $OUT/bench.err; fi
-if ! has rocprof; then echo "== rocprof stats"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/bench_prof.json 2> $R/$OUT/bench_prof.err ); echo "rocprof exit $?"
+if ! has bench; then echo "== bench (default: two streams, high-priority front)"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cut -c1-400 $OUT/bench.json; tail -4 $OUT/bench.err
+  echo "== bench --front-priority 0"; timeout 600 python bench.py --front-priority 0 --no-cpu-baseline > $OUT/bench_prio0.json 2> $OUT/bench_prio0.err; cut -c1-230 $OUT/bench_prio0.json
+  echo "== bench --single-stream"; timeout 600 python bench.py --single-stream --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err; cut -c1-230 $OUT/bench_single.json
+  echo "== probe e2e libritts (HiFi-GAN, 10 steps)"; PROBE_TAG=libritts PROBE_STEPS=10 timeout 600 python tools/probe_e2e.py > $OUT/probe_e2e_libritts.log 2>&1; tail -3 $OUT/probe_e2e_libritts.log; fi
+if ! has rocprof; then echo "== rocprof stats (default bench command)"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/bench_prof.json 2> $R/$OUT/bench_prof.err ); echo "rocprof exit $?"
   for f in $(find /tmp/prof_$TAG -name '*kernel_stats.csv'); do cp $f $OUT/; done
-  for f in $(find /tmp/prof_$TAG -name '*kernel_trace.csv'); do cut -d, -f8-12,16- $f | tail -n 2600 | gzip > $OUT/kernel_trace_tail.csv.gz; head -1 $f > $OUT/kernel_trace_header.txt; done
-  head -22 $OUT/*kernel_stats.csv 2>/dev/null | cut -c1-180; fi
+  echo "== rocprof stats (--single-stream: un-overlapped per-kernel durations)"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1_$TAG -o bench1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream > $R/$OUT/bench_prof_single.json 2> $R/$OUT/bench_prof_single.err ); echo "rocprof exit $?"
+  for f in $(find /tmp/prof1_$TAG -name '*kernel_stats.csv'); do cp $f $OUT/bench_single_kernel_stats.csv; done
+  head -12 $OUT/bench_single_kernel_stats.csv 2>/dev/null | cut -c1-180; fi
 if ! has pmc; then
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
