@@ -218,6 +218,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
   a_lo[0] = ap[1];
   __syncthreads();
 
+  // Workgroups sharing a CU run out of phase: while this wave is in its k loop, a neighbour's may be in its epilogue
+  // (VALU + global memory).  Raised priority for the k loop keeps the matrix pipe fed first (cdna_hip_programming.md
+  // T5: pays where waves have different roles); dropped again before the epilogue.
+  __builtin_amdgcn_s_setprio(1);
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunk;
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
     __syncthreads();
   }
 
+  __builtin_amdgcn_s_setprio(0);
   // ---- epilogue ---------------------------------------------------------------------------------------
   float* yb = d.y + (int64_t)b * d.y_bs;
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;

@@ -153,6 +153,10 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   // Every load and LDS store below is issued unconditionally (the last chunk re-stages itself into the idle buffer
   // and re-reads its last weight fragment): a branch around VMEM makes hipcc's in-order vmcnt bookkeeping
   // conservative and the next weight wait then drains the activation loads at HBM latency.
+  // Workgroups sharing a CU run out of phase: while this wave is in its k loop, a neighbour's may be in its epilogue
+  // (VALU + global memory).  Raised priority for the k loop keeps the matrix pipe fed first (cdna_hip_programming.md
+  // T5: pays where waves have different roles); dropped again before the epilogue.
+  __builtin_amdgcn_s_setprio(1);
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunk;
@@ -204,6 +208,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     __syncthreads();
   }
 
+  __builtin_amdgcn_s_setprio(0);
   // ---- epilogue ---------------------------------------------------------------------------------------
   float* yb = d.y + (int64_t)b * d.y_bs;
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
