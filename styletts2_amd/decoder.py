@@ -5,10 +5,12 @@ models.py:617-633 does).
     decoder(asr[B,512,T], F0_curve[B,2T], N[B,2T], s[B,128]) -> wave[B,1,600*T]
 
 The module keeps the reference's state_dict layout (layers.py) and, on first use after a load,
-folds weight-norm and packs every conv into the K-major layout of `st2_conv1d`.  forward() is a
-straight-line plan of HIP kernel launches on torch's current stream: no host synchronisation, no
-per-forward weight-norm, one batched style-FC GEMM for all AdaIN layers, InstanceNorm statistics
-from a dedicated reduction kernel and AdaIN/Snake/LeakyReLU applied inside the conv prologue.
+folds weight-norm and packs every conv into the pre-split f16 layout of `st2_conv1d_xs` / `st2_conv1d_f16s`
+(`st2_conv1d`'s K-major fp32 layout under ST2_CONV_PRECISION=f32).  forward() is a straight-line plan of HIP
+kernel launches on torch's current stream: no host synchronisation, no per-forward weight-norm, one batched
+style-FC GEMM for all AdaIN layers; every AdaIN + Snake / LeakyReLU is one HBM-bound `st2_act_split` pass that
+hands the following MFMA conv pre-split operands, and the InstanceNorm statistics it needs come out of the
+producing conv's epilogue (`want_stats`), so no tensor is read just to be reduced.
 """
 import math
 import os
@@ -215,7 +217,7 @@ class Generator(nn.Module):
         result are those of the single-stream order (ST2_MRF_STREAMS=0)."""
         n = self.num_kernels
         blocks = pk.resblocks[i * n:(i + 1) * n]
-        if not x.is_cuda or n < 2 or os.environ.get("ST2_MRF_STREAMS", "1") == "0":
+        if not x.is_cuda or n < 2 or os.environ.get("ST2_MRF_STREAMS", "0") != "1":
             acc = None
             for j in range(n):
                 acc = run_resblock1(blocks[j], bank, h, x, x_stats=st, mrf_acc=acc, mrf_last=(j == n - 1), n_mrf=n)
