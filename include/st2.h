@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 8
+#define ST2_ABI_VERSION 7
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -93,8 +93,7 @@ typedef struct st2_conv_desc {
   /* st2_conv1d_xs only: pre-activated, pre-split input planes written by st2_act_split (x/pro/stats/... unused) */
   const void* xs; int32_t xs_cg; int32_t xs_lp; int32_t xs_halo;
   /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
-     part[((b*C_out + co)*part_nt + l/P)*2 + {0,1}] = (sum, sum of squares) over the P columns of that tile,
-     P = st2_conv1d_xs_part_cols(C_out) */
+     part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) over the 128 columns of that tile */
   float* part; int32_t part_nt;
 } st2_conv_desc;
 
@@ -138,10 +137,6 @@ int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t
                   int32_t gamma_plus_one, const float* alpha, float x_scale,
                   void* xs, int32_t xs_cg, int32_t Lp, int32_t halo, void* stream);
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
-/* Tuning knob (process-wide): wave tile of the 128-output-row variants, 32 (co) x 128 (l) [default] or 64 x 64. */
-int st2_conv1d_xs_set_wave_tile(int rows);
-/* Columns covered by one entry of st2_conv_desc.part (128, or 64 with the 64 x 64 wave tile): part_nt >= L_out / that. */
-int st2_conv1d_xs_part_cols(int C_out);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *

@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 7
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -59,8 +59,6 @@ _SIGNATURES = {
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
     "st2_conv1d_xs": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
-    "st2_conv1d_xs_set_wave_tile": (C.c_int, [C.c_int]),
-    "st2_conv1d_xs_part_cols": (C.c_int, [C.c_int]),
     "st2_act_split": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                 f32p, f32p, f32p, C.c_int64, C.c_int32, f32p, C.c_float, f32p, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),

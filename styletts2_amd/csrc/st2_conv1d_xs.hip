@@ -10,22 +10,6 @@ extern template int st2xs::launch_by_cout<7, 16>(const st2_conv_desc&, hipStream
 extern template int st2xs::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t);
 
 
-namespace st2xs {
-int g_wave_tile_64 = 0;
-}
-
-extern "C" int st2_conv1d_xs_set_wave_tile(int rows) {
-  if (rows != 32 && rows != 64) {
-    st2_set_error("st2_conv1d_xs_set_wave_tile: %d (have 32, 64)", rows);
-    return 1;
-  }
-  st2xs::g_wave_tile_64 = rows == 64;
-  return 0;
-}
-
-/* columns covered by one entry of st2_conv_desc.part for a conv with C_out output channels */
-extern "C" int st2_conv1d_xs_part_cols(int C_out) { return (C_out > 64 && st2xs::g_wave_tile_64) ? 64 : 128; }
-
 extern "C" int st2_conv1d_xs(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(dp != nullptr, "st2_conv1d_xs: null descriptor");
   const st2_conv_desc& d = *dp;

@@ -67,12 +67,9 @@ __device__ __forceinline__ float halfwave_reduce16(const float (&s)[16], int l31
 // Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
 // one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
 // 0.42 ms vs 0.48 ms on the dominant layer at B = 8).
-// Wave tile = (32 TM) x (32 TN): TM = 1, TN = 4 (32 co x 128 l: 2 weight + 8 activation fragments per k-step) or
-// TM = TN = 2 (64 co x 64 l: 4 + 4 fragments -- half the LDS reads and no fragment waited for in mid-step, twice the
-// L2 -> register weight traffic); 12 MFMAs per k-step either way.
-template <int KS, int CI_T, int WM, int WN, int TN, int TM>
+template <int KS, int CI_T, int WM, int WN, int TN>
 __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
-  constexpr int BM = 32 * TM * WM;
+  constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;     // 8-channel groups per chunk
   constexpr int ROWS = 2 * CG;     // staged rows per chunk: (plane, group)
@@ -124,39 +121,31 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     for (int i = 0; i < NS; ++i) dst[tid + i * NT] = xr[i];
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // ---- A operand stream: TM x 32 B (hi8|lo8) per lane per k-step, constant stride between steps -----------
-  const int co_a = m0 + wm * (32 * TM) + l31;  // < wq_co_pad by construction of the packing (row block i: + 32 i)
+  // ---- A operand stream: 32 B (hi8|lo8) per lane per k-step, constant stride between steps -----------
+  const int co_a = m0 + wm * 32 + l31;  // < wq_co_pad by construction of the packing
   const h8* ap = reinterpret_cast<const h8*>(d.wq) + ((int64_t)kg * d.wq_co_pad + co_a) * 2;
   const int64_t a_step = (int64_t)2 * d.wq_co_pad * 2;  // h8 units per k-step
   const int nchunk = d.wq_cin_pad / CI_T;
 
   load_chunk(0);
   constexpr int SPC = S16 * KS;  // k-steps per chunk
-  // Weight fragments run PFD k-steps ahead in PFD + 1 NAMED register sets (set = k-step index within the chunk mod
-  // (PFD + 1), a compile-time constant after unrolling); PFD = 2 for the 32-row wave tile, 1 for the 64-row one (its
-  // fragments are twice as many).  VMEM returns in order, so the first weight wait that also has to drain the
-  // activation loads of the next chunk (issued at k-step 0, after that step's prefetch) is the one of k-step PFD + 1.
-  constexpr int PFD = TM == 1 ? 2 : 1;
-  constexpr int NSET = PFD + 1;
-  h8 a_hi[NSET][TM], a_lo[NSET][TM];
+  // Weight fragments run TWO k-steps ahead in three NAMED register sets (set = k-step index within the chunk mod 3,
+  // a compile-time constant after unrolling).  VMEM returns in order, so the first weight wait that also has to
+  // drain the activation loads of the next chunk (issued at k-step 0, after that step's prefetch) is the one of
+  // k-step 3: three k-steps (>= 1100 MFMA cycles per wave) of slack for their HBM latency.
+  h8 a_hi[3], a_lo[3];
+  a_hi[0] = ap[0];
+  a_lo[0] = ap[1];
   const int nsteps = nchunk * SPC;
-#pragma unroll
-  for (int p = 0; p < PFD; ++p) {
-    if (p > 0 && nsteps > p) ap += a_step;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      a_hi[p][i] = ap[i * 64];
-      a_lo[p][i] = ap[i * 64 + 1];
-    }
-  }
+  if (nsteps > 1) ap += a_step;
+  a_hi[1] = ap[0];
+  a_lo[1] = ap[1];
   store_chunk(0);
   __syncthreads();
 
@@ -177,18 +166,16 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
 #pragma unroll
       for (int t = 0; t < KS; ++t) {
         const int i = s * KS + t;           // k-step within the chunk (compile-time after unrolling)
-        const int cur = i % NSET, pre = (i + PFD) % NSET;
-        if (more || i + PFD < SPC) ap += a_step;  // scalar select, no branch around the loads
-#pragma unroll
-        for (int q = 0; q < TM; ++q) {            // prefetch the weights of k-step i + PFD
-          a_hi[pre][q] = ap[q * 64];
-          a_lo[pre][q] = ap[q * 64 + 1];
-        }
+        const int cur = i % 3, pre = (i + 2) % 3;
+        if (more || i + 2 < SPC) ap += a_step;  // scalar select, no branch around the loads
+        a_hi[pre] = ap[0];                      // prefetch the weights of k-step i + 2
+        a_lo[pre] = ap[1];
         // next chunk's activations: issued AFTER this step's weight prefetch (see above)
         if (i == 0) load_chunk(more ? c + 1 : c);
         // ... and parked in the other LDS buffer at the chunk's last k-step (free since the previous barrier)
         if (i == SPC - 1) store_chunk(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch distance is kept
+        const h8 ah = a_hi[cur], al = a_lo[cur];
         const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
         h8 bh[TN], bl[TN];
 #pragma unroll
@@ -197,39 +184,26 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
           bl[j] = xp[plane + j * 32];
         }
 #pragma unroll
-        for (int q = 0; q < TM; ++q)
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur][q], bh[j], acc[q][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < TM; ++q)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur][q], bl[j], acc[q][j], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < TM; ++q)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[cur][q], bh[j], acc[q][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
       }
     }
-    // the next chunk indexes its steps from 0 again: rotate the live sets (steps SPC .. SPC + PFD - 1) to 0 .. PFD - 1
-    if (SPC % NSET != 0) {
-      h8 th[PFD][TM], tl[PFD][TM];
-#pragma unroll
-      for (int p = 0; p < PFD; ++p)
-#pragma unroll
-        for (int q = 0; q < TM; ++q) {
-          th[p][q] = a_hi[(SPC + p) % NSET][q];
-          tl[p][q] = a_lo[(SPC + p) % NSET][q];
-        }
-#pragma unroll
-      for (int p = 0; p < PFD; ++p)
-#pragma unroll
-        for (int q = 0; q < TM; ++q) {
-          a_hi[p][q] = th[p][q];
-          a_lo[p][q] = tl[p][q];
-        }
+    // the next chunk indexes its steps from 0 again: rotate the two live sets (steps SPC, SPC+1) to sets 0, 1
+    if (SPC % 3 == 1) {
+      const h8 th = a_hi[1], tl = a_lo[1];  // sets (1, 2) -> (0, 1)
+      a_hi[1] = a_hi[2];
+      a_lo[1] = a_lo[2];
+      a_hi[0] = th;
+      a_lo[0] = tl;
+    } else if (SPC % 3 == 2) {
+      const h8 th = a_hi[0], tl = a_lo[0];  // sets (2, 0) -> (0, 1)
+      a_hi[0] = a_hi[2];
+      a_lo[0] = a_lo[2];
+      a_hi[1] = th;
+      a_lo[1] = tl;
     }
     __syncthreads();
   }
@@ -260,10 +234,8 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
     float ps[16], pq[16];
 #pragma unroll
-    for (int q = 0; q < TM; ++q) {
-#pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * (32 * TM) + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
       const bool rok = FULL || row < d.C_out;
       const int rowc = FULL ? row : min(row, d.C_out - 1);
       // 32-bit element offsets from the (scalar) per-batch bases: one VALU mad per row and tensor, and the memory
@@ -286,7 +258,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float v = acc[q][j][r] * osc + bias_r;
+        float v = acc[j][r] * osc + bias_r;
         if (use_res) v += rv[j];
         if (use_res2) v = r2v[j] + v;
         if (use_div) v = v / d.div;
@@ -315,13 +287,12 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       const float ts = halfwave_reduce16(ps, l31);
       const float tq = halfwave_reduce16(pq, l31);
       const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + ((l31 >> 1) & 1);
-      const int row = m0 + wm * (32 * TM) + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const int tile = blockIdx.x * WN + wn;  // index of this wave's 32 TN-column tile
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const int tile = blockIdx.x * WN + wn;  // 128-column tile index
       if ((l31 & 1) == 0 && row < d.C_out && tile < d.part_nt) {
         float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + row) * d.part_nt + tile;
         *pp = make_float2(ts, tq);
       }
-    }
     }
   };
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
@@ -366,18 +337,18 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   }
 }
 
-template <int KS, int CI_T, int WM, int WN, int TN, int TM>
+template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
 __global__ __launch_bounds__(NT, 2) void conv1d_xs_kernel(const st2_conv_desc d) {  // >= 2 workgroups per CU
-  conv1d_xs_body<KS, CI_T, WM, WN, TN, TM>(d);
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
-template <int KS, int CI_T, int WM, int WN, int TN, int TM>
+template <int KS, int CI_T, int WM, int WN, int TN>
 __global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc d) {  // <= 168 VGPRs
-  conv1d_xs_body<KS, CI_T, WM, WN, TN, TM>(d);
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
 
-template <int KS, int CI_T, int WM, int WN, int TN, int TM, int OCC>
+template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
 int launch(const st2_conv_desc& d, hipStream_t s) {
-  constexpr int BM = 32 * TM * WM;
+  constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   const int XW = BN + (KS - 1) * d.dil;
   const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
@@ -394,23 +365,23 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   ST2_REQUIRE((int64_t)(n_tiles - 1) * BN - d.pad_left + d.xs_halo + XW <= d.xs_lp,
               "st2_conv1d_xs: xs rows of %d slots are too short for L_out=%d (tile %d, ks=%d, dil=%d, halo=%d)",
               d.xs_lp, d.L_out, BN, KS, d.dil, d.xs_halo);
-  if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 32 * TN), "st2_conv1d_xs: part_nt=%d < %d tiles of %d "
-                          "columns", d.part_nt, st2_cdiv(d.L_out, 32 * TN), 32 * TN);
+  if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_xs: part_nt=%d < %d tiles", d.part_nt,
+                          st2_cdiv(d.L_out, 128));
   static bool attr_done = false;
   if (!attr_done) {
     if constexpr (OCC == 3)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN, TM>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     else
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel<KS, CI_T, WM, WN, TN, TM>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
   if constexpr (OCC == 3)
-    hipLaunchKernelGGL((conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN, TM>), grid, dim3(NT), smem, s, d);
+    hipLaunchKernelGGL((conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
   else
-    hipLaunchKernelGGL((conv1d_xs_kernel<KS, CI_T, WM, WN, TN, TM>), grid, dim3(NT), smem, s, d);
+    hipLaunchKernelGGL((conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>), grid, dim3(NT), smem, s, d);
   ST2_CHECK_LAUNCH("st2_conv1d_xs");
   return 0;
 }
@@ -419,21 +390,16 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
 
 namespace st2xs {
 
-extern int g_wave_tile_64;  // st2_conv1d_xs_set_wave_tile(): 64 x 64 wave tiles for the 128-output-row variants
-
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
-  if (d.C_out > 64) {  // 128 co x 128 l per workgroup, 3 workgroups / CU
-    if (g_wave_tile_64) return launch<KS, CI_T, 2, 2, 2, 2, 3>(d, s);  // waves 2 x 2 of 64 co x 64 l
-    return launch<KS, CI_T, 4, 1, 4, 1, 3>(d, s);                       // waves 4 x 1 of 32 co x 128 l
-  }
-  if (d.C_out > 32) {  // 64 co x 256 l
+  if (d.C_out > 64) return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
+  if (d.C_out > 32) {                                           // 64 co x 256 l
     if constexpr (CI_T == 16)
-      return launch<KS, CI_T, 2, 2, 4, 1, 3>(d, s);
+      return launch<KS, CI_T, 2, 2, 4, 3>(d, s);
     else
-      return launch<KS, CI_T, 2, 2, 4, 1, 2>(d, s);  // the 168-VGPR build spills with 32-channel chunks
+      return launch<KS, CI_T, 2, 2, 4, 2>(d, s);  // the 168-VGPR build spills with 32-channel chunks
   }
-  return launch<KS, CI_T, 1, 4, 4, 1, 2>(d, s);  // 32 co x 512 l
+  return launch<KS, CI_T, 1, 4, 4, 2>(d, s);  // 32 co x 512 l
 }
 
 }  // namespace st2xs

@@ -172,8 +172,7 @@ def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, ou
     _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope)
     part = None
     if want_stats:
-        pc = lib.st2_conv1d_xs_part_cols(C_out)
-        nt = (L_out + pc - 1) // pc
+        nt = (L_out + 127) // 128
         part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
         d.part, d.part_nt = part.data_ptr(), nt
     _launch_conv(lib.st2_conv1d_xs, "st2_conv1d_xs", d)

@@ -89,17 +89,7 @@ F16S_EXTRA_CASES = [
 ]
 
 
-@pytest.fixture
-def wave_tile(request):
-    """Sets the xs conv's wave-tile knob (st2_conv1d_xs_set_wave_tile) for one test and restores the default."""
-    from styletts2_amd import _lib
-    lib = _lib.load()
-    _lib.check(lib.st2_conv1d_xs_set_wave_tile(request.param), "set_wave_tile")
-    yield request.param
-    lib.st2_conv1d_xs_set_wave_tile(32)
-
-
-@pytest.mark.parametrize("kernel", ["f32", "f16s", "xs", "xs64"])
+@pytest.mark.parametrize("kernel", ["f32", "f16s", "xs"])
 @pytest.mark.parametrize("case", CONV_CASES + F16S_EXTRA_CASES, ids=lambda c: "ci%d_co%d_L%d_k%d_d%d_p%d" % (
     c["C_in"], c["C_out"], c["L"], c["ks"], c["dil"], c["pro"]))
 def test_conv1d_matches_contract(case, kernel, monkeypatch):
@@ -107,9 +97,7 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
     the prologue fused (st2_conv1d_f16s), `xs` = activation pass + pure split-f16 MFMA conv (st2_act_split +
     st2_conv1d_xs).  The split contract carries the operand split (hi + lo of v * scale), so the bar is the same
     fp32 round-off class for all three."""
-    from styletts2_amd import _lib
-    monkeypatch.setenv("ST2_CONV_PATH", "xs" if kernel.startswith("xs") else "fused")
-    _lib.load().st2_conv1d_xs_set_wave_tile(64 if kernel == "xs64" else 32)  # 64 x 64 wave tiles for C_out > 64
+    monkeypatch.setenv("ST2_CONV_PATH", "xs" if kernel == "xs" else "fused")
     x, w, kw = make_conv_case(seed=1234, **case)
     wt = weights.pack_conv(w) if kernel == "f32" else weights.pack_conv_f16s(w)
     C_out, ks = w.shape[0], w.shape[2]
@@ -117,14 +105,13 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
     exact = R.conv1d(x.double(), weights.pack_conv(w).double(), C_out, ks,
                      **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
     kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
-    if kernel.startswith("xs"):  # the pair called directly (ops.conv1d keeps PRO_NONE and short rows on the fused kernel)
+    if kernel == "xs":  # the pair called directly (ops.conv1d keeps PRO_NONE and short rows on the fused kernel)
         PRO_KEYS = ("pro", "slope", "stats", "gamma", "beta", "alpha")
         xs = ops.activate(g(x), **{k: v for k, v in kwg.items() if k in PRO_KEYS})
         out = ops.conv1d_xs(xs, wt.to(DEV), C_out, ks, **{k: v for k, v in kwg.items() if k not in PRO_KEYS})
     else:
         out = ops.conv1d(g(x), g(wt) if kernel == "f32" else wt.to(DEV), C_out, ks, **kwg)
     torch.cuda.synchronize()
-    _lib.load().st2_conv1d_xs_set_wave_tile(32)
     assert out.shape == ref.shape
     e = rel_err(out, ref)
     assert e < 2e-5, "rel err vs contract %g" % e
@@ -136,8 +123,7 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
 @pytest.mark.parametrize("B,C_in,C_out,L,ks,dil,res", [(2, 128, 128, 2500, 11, 5, True), (1, 256, 256, 515, 3, 1, False),
                                                        (2, 64, 64, 777, 7, 3, True), (1, 32, 22, 1300, 7, 1, False),
                                                        (2, 128, 128, 48001, 11, 1, True)])
-@pytest.mark.parametrize("wave_tile", [32, 64], indirect=True)
-def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, wave_tile, monkeypatch):
+def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
     """want_stats: InstanceNorm statistics of the conv OUTPUT from the epilogue's per-tile partial sums
     (st2_conv1d_xs part + st2_stats_finalize) against the fp64 reduction of the stored tensor."""
     monkeypatch.setenv("ST2_CONV_PATH", "xs")

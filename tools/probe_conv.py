@@ -15,7 +15,8 @@ dev = "cuda"
 B = int(os.environ.get("PROBE_B", "8"))
 cases = [  # C, L, ks, dil
     (128, 48001, 3, 1), (128, 48001, 7, 3), (128, 48001, 11, 5), (128, 48001, 11, 1),
-    (256, 8000, 3, 1), (256, 8000, 7, 1), (256, 8000, 11, 5), (1024, 400, 3, 1),
+    (256, 8000, 3, 1), (256, 8000, 7, 1), (256, 8000, 11, 5),
+    (64, 120000, 7, 3), (32, 240000, 11, 1), (1024, 400, 3, 1),
 ]
 lib = _lib.load()
 
@@ -52,14 +53,10 @@ for (Cc, L, ks, dil) in cases:
     r["stats"] = timed(lambda: ops.instnorm_stats(x, out=st))
     r["act"] = timed(lambda: ops.activate(x, **akw))
     xs = ops.activate(x, **akw)
-    for wt_rows in (32, 64):
-        lib.st2_conv1d_xs_set_wave_tile(wt_rows)
-        sfx = "" if wt_rows == 32 else "_wt64"
-        r["xs_plain" + sfx] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out))
-        r["xs_res" + sfx] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x))
-        r["xs_res_stats" + sfx] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out,
-                                                              res=x, want_stats=True))
-    lib.st2_conv1d_xs_set_wave_tile(32)
+    r["xs_plain"] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out))
+    r["xs_res"] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x))
+    r["xs_res_stats"] = timed(lambda: ops.conv1d_xs(xs, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x,
+                                                    want_stats=True))
     r = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
     r["tflops_fused_pro3"] = round(flop / r["fused_pro3"] / 1e9, 1)
     r["tflops_xs_conv"] = round(flop / r["xs_plain"] / 1e9, 1)
