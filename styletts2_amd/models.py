@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .decoder import Decoder
-from .diffusion import (ADPM2Sampler, AudioDiffusionConditional, DiffusionSampler, KarrasSchedule,  # noqa: F401
+from .diffusion import (GraphedSampler, ADPM2Sampler, AudioDiffusionConditional, DiffusionSampler, KarrasSchedule,  # noqa: F401
                         StyleTransformer1d, Transformer1d)
 from .style import StyleEncoder
 from .text import ProsodyPredictor, TextEncoder, build_plbert
@@ -96,7 +96,9 @@ def load_checkpoint(model, optimizer, path, load_only_params=True, ignore_module
     return model, optimizer, 0, 0
 
 
-def make_sampler(model, clamp=False):
-    """The sampler every notebook builds (Demo/Inference_LJSpeech.ipynb:234-239)."""
-    return DiffusionSampler(model.diffusion.diffusion, sampler=ADPM2Sampler(),
-                            sigma_schedule=KarrasSchedule(sigma_min=0.0001, sigma_max=3.0, rho=9.0), clamp=clamp)
+def make_sampler(model, clamp=False, graph=False):
+    """The sampler every notebook builds (Demo/Inference_LJSpeech.ipynb:234-239); graph=True wraps it in
+    `GraphedSampler` (one hipGraph replay per run instead of ~300 kernel launches)."""
+    sampler = DiffusionSampler(model.diffusion.diffusion, sampler=ADPM2Sampler(),
+                               sigma_schedule=KarrasSchedule(sigma_min=0.0001, sigma_max=3.0, rho=9.0), clamp=clamp)
+    return GraphedSampler(sampler) if graph else sampler

@@ -71,3 +71,36 @@ def test_denoiser_forward_signature_and_schedule():
     assert abs(up - 0.548182) < 1e-5 and abs(down - 0.103756) < 1e-5 and abs(mid - 1.55188) < 1e-4
     with pytest.raises(AssertionError):
         diff.unet(x.to(DEV), t.to(DEV))  # embedding is mandatory
+
+
+@pytest.mark.parametrize("tag,B,N,steps,scale", [("ljspeech", 2, 41, 5, 1.0), ("libritts", 3, 100, 4, 1.5)])
+def test_graphed_sampler_replays_match_eager(tag, B, N, steps, scale):
+    """GraphedSampler (hipGraph capture of a whole sampler run, BASELINE.json configs[4]): replays with NEW inputs of a
+    captured signature are bitwise the eager results; a second signature gets its own graph; without explicit step
+    noise two replays draw different noise."""
+    man, diff = _diffusion(tag)
+    diff = diff.to(DEV)
+    eager = models.DiffusionSampler(diff.diffusion, sampler=models.ADPM2Sampler(),
+                                    sigma_schedule=models.KarrasSchedule(1e-4, 3.0, 9.0), clamp=False)
+    graphed = models.GraphedSampler(eager)
+    multi = man["config"]["multispeaker"]
+    g = torch.Generator().manual_seed(7)
+
+    def case(n):
+        kw = dict(embedding=torch.randn(B, n, 768, generator=g).to(DEV), embedding_scale=scale, num_steps=steps,
+                  step_noise=torch.randn(steps - 1, B, 1, 256, generator=g).to(DEV))
+        if multi:
+            kw["features"] = torch.randn(B, 256, generator=g).to(DEV)
+        return torch.randn(B, 1, 256, generator=g).to(DEV), kw
+
+    for n in (N, N, N + 3, N):  # capture, replay, second signature, replay of the first again
+        noise, kw = case(n)
+        ref = eager(noise, **kw)
+        out = graphed(noise, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    assert len(graphed._graphs) == 2
+    noise, kw = case(N)
+    kw.pop("step_noise")
+    a, b = graphed(noise, **kw), graphed(noise, **kw)
+    assert bool(torch.isfinite(a).all()) and not torch.equal(a, b)
