@@ -22,7 +22,7 @@ KEYS = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "be
 for i, k in enumerate(KEYS):
     synth.init_synthetic_(model[k], 10 + i)
     model[k].eval().to(dev)
-sampler = models.make_sampler(model)
+sampler = models.make_sampler(model, graph=os.environ.get("PROBE_GRAPH", "0") == "1")
 g = torch.Generator().manual_seed(0)
 tokens = torch.randint(1, 178, (B, N), generator=g).to(dev)
 lengths = torch.full((B,), N, dtype=torch.long)
