@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 7
+#define ST2_ABI_VERSION 8
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -191,6 +191,15 @@ int st2_convt_interleave(const float* phases, int64_t p_bs, int32_t p_cs, int32_
                          float* out, int64_t o_bs, int32_t o_cs,
                          int32_t B, int32_t C, int32_t stride, int32_t pad, int32_t L_raw,
                          int32_t reflect_left, void* stream);
+
+/* Same, additionally emitting per-tile InstanceNorm partial sums of the stored output (tiles of 1024 positions):
+ * part[((b*C + co)*part_nt + l/1024)*2 + {0,1}] = (sum, sum of squares); part may be NULL.  Feed to
+ * st2_stats_finalize: the AdaIN that follows the up-sampling needs no pass over the tensor. */
+int st2_convt_interleave_stats(const float* phases, int64_t p_bs, int32_t p_cs, int32_t Lq,
+                               const float* bias, const float* add, int64_t a_bs, int32_t a_cs,
+                               float* out, int64_t o_bs, int32_t o_cs,
+                               int32_t B, int32_t C, int32_t stride, int32_t pad, int32_t L_raw,
+                               int32_t reflect_left, float* part, int32_t part_nt, void* stream);
 
 /* ---- AdaIN + LeakyReLU + depthwise ConvTranspose1d(k3,s2,p1,op1) ("pool") ------------ *
  * Replaces Modules/istftnet.py:441-444 with upsample=True (weights w[c][3], bias[c]). */

@@ -145,7 +145,13 @@ def style_fc(s, wt, bias, act=ACT_NONE, out=None):
     return h
 
 
-def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None):
+def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None,
+                     want_stats=False):
+    y = _convt_interleave(phases, C_out, stride, pad, L_raw, bias=bias, add=add, reflect_left=reflect_left, out=out)
+    return (y, instnorm_stats(y)) if want_stats else y
+
+
+def _convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None):
     B, RC, Lq = phases.shape
     ph = phases.reshape(B, stride, C_out, Lq)
     full = ph.permute(0, 2, 3, 1).reshape(B, C_out, Lq * stride)  # index q*stride + r

@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -76,6 +76,9 @@ _SIGNATURES = {
     "st2_convt_interleave": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, f32p, f32p, C.c_int64, C.c_int32,
                                        f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p]),
+    "st2_convt_interleave_stats": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, f32p, f32p, C.c_int64, C.c_int32,
+                                             f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, f32p, C.c_int32, C.c_void_p]),
     "st2_adain_leaky_pool": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_float, f32p,
                                        f32p, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p]),

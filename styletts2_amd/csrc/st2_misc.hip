@@ -48,26 +48,72 @@ __global__ __launch_bounds__(256) void phase_split_kernel(const float* __restric
   xp[(int64_t)b * p_bs + (int64_t)(ci * stride + r) * p_cs + u] = v;
 }
 
+// Tile of CVT_TILE outputs per workgroup: the `stride` phase rows it needs are read coalesced (each a contiguous run of
+// ~CVT_TILE/stride floats) into LDS and de-interleaved from there, instead of a 6-way gather of 44-byte runs per
+// wave; the per-tile (sum, sum of squares) of the stored row segment is emitted for the InstanceNorm that follows
+// (fixed-order wave + LDS reduction), so the output is not read again just to be reduced.
+constexpr int CVT_TILE = 1024;
 __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __restrict__ ph, int64_t p_bs, int p_cs,
                                                                int Lq, const float* __restrict__ bias,
                                                                const float* __restrict__ add, int64_t a_bs, int a_cs,
                                                                float* __restrict__ out, int64_t o_bs, int o_cs, int C,
-                                                               int stride, int pad, int L_raw, int reflect_left) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
+                                                               int stride, int pad, int L_raw, int reflect_left,
+                                                               float* __restrict__ part, int part_nt) {
+  extern __shared__ float cvt_tile[];  // [stride][nqp]
+  __shared__ float red[2][4];
   const int co = blockIdx.y;
   const int b = blockIdx.z;
   const int L_out = L_raw + reflect_left;
-  if (o >= L_out) return;
-  int l = o;
-  if (reflect_left) l = (o == 0) ? 1 : o - 1;
-  const int lp = l + pad;
-  const int r = lp % stride;
-  const int q = lp / stride;
-  float v = 0.f;
-  if (q < Lq) v = ph[(int64_t)b * p_bs + (int64_t)(r * C + co) * p_cs + q];
-  if (bias) v += bias[co];
-  if (add) v += add[(int64_t)b * a_bs + (int64_t)co * a_cs + o];
-  out[(int64_t)b * o_bs + (int64_t)co * o_cs + o] = v;
+  const int o0 = blockIdx.x * CVT_TILE;
+  const int nqp = (CVT_TILE / stride + 3) | 1;  // odd row pitch: the de-interleaving reads spread over the banks
+  // raw positions this tile touches: l in [l_lo, l_lo + CVT_TILE] (one extra on the left for the reflected sample)
+  const int l_lo = max(o0 - reflect_left, 0);
+  const int q_lo = (l_lo + pad) / stride;
+  const int nq = CVT_TILE / stride + 3;
+  for (int r = 0; r < stride; ++r) {
+    const float* row = ph + (int64_t)b * p_bs + (int64_t)(r * C + co) * p_cs;
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const int q = q_lo + i;
+      cvt_tile[r * nqp + i] = q < Lq ? row[q] : 0.f;
+    }
+  }
+  __syncthreads();
+  const float bj = bias ? bias[co] : 0.f;
+  const float* ab = add ? add + (int64_t)b * a_bs + (int64_t)co * a_cs : nullptr;
+  float* ob = out + (int64_t)b * o_bs + (int64_t)co * o_cs;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CVT_TILE / 256; ++k) {
+    const int o = o0 + k * 256 + threadIdx.x;
+    if (o < L_out) {
+      int l = o;
+      if (reflect_left) l = (o == 0) ? 1 : o - 1;
+      const int lp = l + pad;
+      const int q = lp / stride;
+      const int r = lp - q * stride;
+      float v = cvt_tile[r * nqp + (q - q_lo)];
+      v += bj;
+      if (ab) v += ab[o];
+      ob[o] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  if (part) {
+    s1 = st2_wave_sum(s1);
+    s2 = st2_wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      red[0][wave] = s1;
+      red[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float t1 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+      const float t2 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+      reinterpret_cast<float2*>(part)[((int64_t)b * C + co) * part_nt + blockIdx.x] = make_float2(t1, t2);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void adain_leaky_pool_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
@@ -172,13 +218,29 @@ extern "C" int st2_convt_interleave(const float* phases, int64_t p_bs, int32_t p
                                     const float* add, int64_t a_bs, int32_t a_cs, float* out, int64_t o_bs,
                                     int32_t o_cs, int32_t B, int32_t C, int32_t stride, int32_t pad, int32_t L_raw,
                                     int32_t reflect_left, void* stream) {
+  return st2_convt_interleave_stats(phases, p_bs, p_cs, Lq, bias, add, a_bs, a_cs, out, o_bs, o_cs, B, C, stride, pad,
+                                    L_raw, reflect_left, nullptr, 0, stream);
+}
+
+extern "C" int st2_convt_interleave_stats(const float* phases, int64_t p_bs, int32_t p_cs, int32_t Lq,
+                                          const float* bias, const float* add, int64_t a_bs, int32_t a_cs, float* out,
+                                          int64_t o_bs, int32_t o_cs, int32_t B, int32_t C, int32_t stride, int32_t pad,
+                                          int32_t L_raw, int32_t reflect_left, float* part, int32_t part_nt,
+                                          void* stream) {
   ST2_REQUIRE(phases && out && B > 0 && C > 0 && stride > 0 && L_raw > 0 && Lq > 0,
               "st2_convt_interleave: bad arguments");
   ST2_REQUIRE(reflect_left == 0 || (reflect_left == 1 && L_raw >= 2), "st2_convt_interleave: bad reflect_left");
+  ST2_REQUIRE(stride <= 64, "st2_convt_interleave: stride %d too large", stride);
+  const int L_out = L_raw + reflect_left;
+  const int nt = st2_cdiv(L_out, CVT_TILE);
+  if (part) ST2_REQUIRE(part_nt >= nt && (reinterpret_cast<uintptr_t>(part) & 7) == 0,
+                        "st2_convt_interleave: part_nt=%d < %d tiles (or part not 8-byte aligned)", part_nt, nt);
+  ST2_REQUIRE(B <= 65535 && C <= 65535, "st2_convt_interleave: grid too large");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(convt_interleave_kernel, dim3(st2_cdiv(L_raw + reflect_left, 256), C, B), dim3(256), 0, s,
-                     phases, p_bs, p_cs, Lq, bias, add, a_bs, a_cs, out, o_bs, o_cs, C, stride, pad, L_raw,
-                     reflect_left);
+  const int nq = CVT_TILE / stride + 3;
+  const size_t smem = (size_t)stride * (nq | 1) * sizeof(float);
+  hipLaunchKernelGGL(convt_interleave_kernel, dim3(nt, C, B), dim3(256), smem, s, phases, p_bs, p_cs, Lq, bias, add,
+                     a_bs, a_cs, out, o_bs, o_cs, C, stride, pad, L_raw, reflect_left, part, part_nt);
   ST2_CHECK_LAUNCH("st2_convt_interleave");
   return 0;
 }

@@ -287,9 +287,9 @@ class Generator(nn.Module):
                 pad, L_raw = u // 2 + u % 2, (L_in - 1) * u - 2 * (u // 2 + u % 2) + k + u % 2
                 pro = dict(pro=ops.PRO_SNAKE, alpha=pk.alphas[i])
             Y = ops.conv1d(x, pk.ups_wt[i], u * C, 2, pad_left=1, L_out=L_in + 1, **pro)
-            x = ops.convt_interleave(Y, C, u, pad, L_raw, bias=pk.ups_b[i], add=xs, reflect_left=(ist and last))
+            x, st = ops.convt_interleave(Y, C, u, pad, L_raw, bias=pk.ups_b[i], add=xs, reflect_left=(ist and last),
+                                         want_stats=True)  # statistics for the MRF's first AdaINs ride along
             # multi-receptive-field fusion (istftnet.py:369-375)
-            st = ops.instnorm_stats(x)
             x = self._mrf(pk, bank, h, x, st, i)
             if taps is not None:
                 taps["stage%d" % i] = x

@@ -347,7 +347,13 @@ def style_fc(s, wt, bias, act=ACT_NONE, out=None):
     return out
 
 
-def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None):
+CVT_TILE = 1024  # positions per st2_convt_interleave tile (= per entry of its partial-sum output)
+
+
+def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, reflect_left=False, out=None,
+                     want_stats=False):
+    """`st2_convt_interleave[_stats]`; with want_stats returns (out, InstanceNorm statistics of out [B, C_out, 2]) from
+    the kernel's per-tile partial sums + `st2_stats_finalize`."""
     lib = _lib.load()
     _chk(phases, "phases", 3)
     _chk(bias, "bias", 1)
@@ -360,10 +366,16 @@ def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, ref
     if add is not None:
         assert add.shape == (B, C_out, L_out), (add.shape, (B, C_out, L_out))
     a_bs, a_cs = (add.stride(0), add.stride(1)) if add is not None else (0, 0)
-    _lib.check(lib.st2_convt_interleave(phases.data_ptr(), phases.stride(0), phases.stride(1), Lq, _ptr(bias),
-                                        _ptr(add), a_bs, a_cs, out.data_ptr(), out.stride(0), out.stride(1), B,
-                                        C_out, stride, pad, L_raw, 1 if reflect_left else 0, _stream()),
-               "st2_convt_interleave")
+    part, nt = None, 0
+    if want_stats:
+        nt = (L_out + CVT_TILE - 1) // CVT_TILE
+        part = torch.empty((B, C_out, nt, 2), device=phases.device, dtype=torch.float32)
+    _lib.check(lib.st2_convt_interleave_stats(phases.data_ptr(), phases.stride(0), phases.stride(1), Lq, _ptr(bias),
+                                              _ptr(add), a_bs, a_cs, out.data_ptr(), out.stride(0), out.stride(1), B,
+                                              C_out, stride, pad, L_raw, 1 if reflect_left else 0, _ptr(part), nt,
+                                              _stream()), "st2_convt_interleave")
+    if want_stats:
+        return out, stats_finalize(part, L_out)
     return out
 
 

@@ -220,7 +220,8 @@ def test_style_fc(B, K, J, act):
 
 @pytest.mark.parametrize("C_in,C_out,s,p,op,L,reflect", [(16, 8, 10, 5, 0, 33, False), (12, 6, 6, 3, 0, 50, True),
                                                         (8, 8, 5, 3, 1, 21, False), (8, 4, 3, 2, 1, 19, False),
-                                                        (6, 4, 2, 1, 0, 40, False)])
+                                                        (6, 4, 2, 1, 0, 40, False), (8, 6, 6, 3, 0, 517, True),
+                                                        (4, 5, 10, 5, 0, 311, False), (4, 3, 2, 1, 0, 1700, False)])
 def test_conv_transpose_polyphase(C_in, C_out, s, p, op, L, reflect):
     """ups[i] of both vocoders: polyphase GEMM + interleave == ConvTranspose1d (+ ReflectionPad1d((1,0)))."""
     gen = torch.Generator().manual_seed(s)
@@ -239,6 +240,12 @@ def test_conv_transpose_polyphase(C_in, C_out, s, p, op, L, reflect):
     out = ops.convt_interleave(Y, C_out, s, p, L_raw, bias=g(b), add=g(add), reflect_left=reflect)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 2e-5
+    # the same with the InstanceNorm statistics of the output from the kernel's per-tile partial sums
+    out2, st = ops.convt_interleave(Y, C_out, s, p, L_raw, bias=g(b), add=g(add), reflect_left=reflect, want_stats=True)
+    assert torch.equal(out2, out)
+    st_ref = R.instnorm_stats(out.cpu())
+    assert (st.cpu()[..., 0] - st_ref[..., 0]).abs().max().item() < 2e-6 * max(1.0, st_ref[..., 0].abs().max().item())
+    assert ((st.cpu()[..., 1] - st_ref[..., 1]).abs() / st_ref[..., 1]).max().item() < 5e-6
 
 
 def test_conv1d_direct():
