@@ -310,9 +310,9 @@ def build_plbert(plbert_params):
 
         @torch.no_grad()
         def forward(self, input_ids=None, attention_mask=None, **kwargs):
-            if os.environ.get("ST2_BERT", "engine") == "hf" or not input_ids.is_cuda or kwargs:
+            if os.environ.get("ST2_BERT", "engine") == "hf" or kwargs:  # explicit A-B switch / unsupported HF options
                 return super().forward(input_ids, attention_mask=attention_mask, **kwargs).last_hidden_state
-            return self.forward_engine(input_ids, attention_mask)
+            return self.forward_engine(input_ids, attention_mask)  # no CPU fallback: non-HIP tensors raise in ops
 
         @torch.no_grad()
         def forward_engine(self, input_ids, attention_mask=None):

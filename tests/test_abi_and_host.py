@@ -75,3 +75,15 @@ def test_utils():
     assert m.tolist() == [[False, False, False], [False, True, True]]
     cfg = recursive_munch({"a": {"b": [1, {"c": 2}]}})
     assert cfg.a.b[1].c == 2
+
+
+def test_plbert_has_no_cpu_fallback():
+    """The engine PL-BERT must not silently run the HF forward on CPU tensors (ST2_BERT=hf is the explicit switch)."""
+    import torch
+    from _util import manifest
+    from styletts2_amd import models
+    from styletts2_amd._lib import St2Error
+    bert = models.load_plbert(manifest("ljspeech")["plbert"]).eval()
+    ids = torch.zeros(1, 5, dtype=torch.long)
+    with pytest.raises(St2Error):
+        bert(ids, attention_mask=torch.ones(1, 5, dtype=torch.int32))
