@@ -3,7 +3,7 @@ inputs and noise tensors, tap-pointed as section 8c prescribes."""
 import pytest
 import torch
 
-from _util import WAVE_RMS_TOL, decoder_kwargs, manifest, phase_err_weighted, rms
+from _util import MEL_L1_TOL, WAVE_RMS_TOL, decoder_kwargs, manifest, mel_l1, phase_err_weighted, rms
 from oracle import st2_oracle as O
 from styletts2_amd import synth
 from styletts2_amd.decoder import Decoder
@@ -39,6 +39,8 @@ def test_decoder_matches_oracle_with_injected_har(tag, B, T):
     err = rms(out.cpu() - ref)
     assert err < WAVE_RMS_TOL, "waveform RMS error %g (signal RMS %g)" % (err, rms(ref))
     assert (out.cpu() - ref).abs().max().item() < 20 * WAVE_RMS_TOL
+    ml1 = mel_l1(out, ref)  # north_star's other bar: 1e-3 L1 in the reference's normalised log-mel space
+    assert ml1 < MEL_L1_TOL, "mel L1 %g" % ml1
 
 
 @pytest.mark.parametrize("tag", ["ljspeech", "libritts"])
