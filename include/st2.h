@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns
- *     all memory; nothing is allocated or freed inside the library;
+ *     all memory; nothing is allocated or freed inside the library (one exception: the 64-byte
+ *     host-mapped status word of st2_status(), allocated once per process);
  *   - tensors are row-major "NCL": element (b, c, l) of tensor t lives at
  *     t + b * t_bs + c * t_cs + l   (strides in ELEMENTS; bs = batch, cs = channel);
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
@@ -27,13 +28,28 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 8
+#define ST2_ABI_VERSION 9
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
 const char* st2_last_error(void);
 /* Fills name (<= cap bytes) with the gcnArchName of device `dev`, returns CU count or <0. */
 int st2_device_info(int dev, char* name, int cap);
+
+/* ---- sticky device-side status --------------------------------------------------------------------------------- *
+ * Conditions a kernel can only detect on the device are OR-ed into ONE process-wide status word that lives in
+ * host-mapped (pinned) memory -- the single allocation this library makes, 64 bytes, on the first call that needs
+ * it -- so the host reads it without a device synchronisation; a bit is visible once the kernel that raised it has
+ * completed.  Bits:
+ *   ST2_STATUS_F16_RANGE     an operand of a split-f16 conv exceeded the f16 range after scaling (|x * x_scale| >
+ *                            65504) and was clamped to +-65504 (st2_act_split, st2_conv1d_f16s): the result is finite
+ *                            but not the fp32 conv's; re-run that layer with a smaller x_scale or on st2_conv1d;
+ *   ST2_STATUS_LSTM_TIMEOUT  a bounded spin of st2_lstm_bidir_coop expired (a group's workgroups were not
+ *                            co-resident in time): the outputs of that call are invalid.
+ * st2_status(clear != 0) returns the word and atomically clears it.  Returns < 0 if no HIP device is usable. */
+#define ST2_STATUS_F16_RANGE 1
+#define ST2_STATUS_LSTM_TIMEOUT 2
+int st2_status(int clear);
 
 /* ---- fused Conv1d (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32) ------------ *
  * y[b,co,l] = epi( bias[co] + sum_{ci,t} W[co,ci,t] * pro(x)[b,ci, l + t*dil - pad_left] )
@@ -89,7 +105,10 @@ typedef struct st2_conv_desc {
   /* st2_conv1d_f16s only: split-f16 packed weights (see below); ignored by st2_conv1d */
   const void* wq; int32_t wq_co_pad; int32_t wq_cin_pad;
   float x_scale;                     /* power of two applied to pro(x) before the hi/lo split (8 by default) */
-  float out_scale;                   /* 1 / (x_scale * weight scale), applied to the accumulator first */
+  float out_scale;                   /* applied to the accumulator first: 1 / (x_scale * weight scale), or 1 / x_scale
+                                        when w_row_scale carries the per-row weight scales */
+  const float* w_row_scale;          /* [wq_co_pad] or NULL: 1 / (per-output-row weight scale); the accumulator of row co
+                                        is multiplied by out_scale * w_row_scale[co] (both powers of two: exact) */
   /* st2_conv1d_xs only: pre-activated, pre-split input planes written by st2_act_split (x/pro/stats/... unused) */
   const void* xs; int32_t xs_cg; int32_t xs_lp; int32_t xs_halo;
   /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
@@ -107,9 +126,11 @@ int st2_conv1d(const st2_conv_desc* d, void* stream);
  * 2.6e-7 RMS, the fp32 ATen path by 2.4e-7; the rate ceiling is 5.3x that of the exact-fp32 MFMA.
  * Weights are pre-split once per load (the d.wt field is unused):
  *   wq[((ci/16 * ks + t) * 2 + (ci%16)/8) * wq_co_pad + co][16 halves] = hi[0..7] | lo[0..7]
- *   over the 8 channels ci..ci+7 of W[co, ., t] * w_scale, zero padded to wq_cin_pad input channels
+ *   over the 8 channels ci..ci+7 of W[co, ., t] * w_scale[co], zero padded to wq_cin_pad input channels
  *   (a multiple of st2_conv1d_f16s_chunk(ks)) and wq_co_pad rows (a multiple of
- *   st2_conv1d_f16s_co_block(C_out)); w_scale is the power of two that puts max|W| in [2^13, 2^14).
+ *   st2_conv1d_f16s_co_block(C_out)); w_scale[co] is the power of two that puts max_{ci,t}|W[co]| in [2^13, 2^14)
+ *   (per OUTPUT ROW, so a checkpoint whose rows differ by many octaves keeps every row's lo halves in the normal
+ *   f16 range; d.w_row_scale = 1 / w_scale[co]).  Operands are clamped to the f16 range (ST2_STATUS_F16_RANGE).
  * Replaces the same reference call sites as st2_conv1d (decoder / vocoder convolutions, denoiser Linears). */
 int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
 int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
@@ -275,8 +296,12 @@ int st2_lstm_bidir(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_
  * and the outputs are invalid).  st2_lstm_coop_scratch_bytes returns 0 when B is too large for one co-resident
  * launch (B > 48): use st2_lstm_bidir. */
 int64_t st2_lstm_coop_scratch_bytes(int32_t B);
-/* Tuning knob (process-wide): 0 (default) = plain stores/loads bracketed by agent-scope release/acquire fences;
- * 1 = hidden-state exchange by agent-scope (sc1) atomic stores/loads, no cache maintenance (measured slower). */
+/* Hand-off variant (process-wide): 2 (default) = the data is the flag: every new hidden value travels as ONE 8-byte
+ * agent-scope store {step tag, value} and the consumers re-read their granules until every tag matches -- one fabric
+ * round trip per step, no counter, no cache maintenance; 0 = plain stores/loads bracketed by agent-scope release /
+ * acquire fences around a monotonic counter (three round trips); 1 = sc1 atomic stores/loads + the counter.
+ * A time-out also raises ST2_STATUS_LSTM_TIMEOUT in st2_status().  st2_lstm_bidir_coop refuses (returns non-zero)
+ * when the device cannot hold the launch's workgroups co-resident (occupancy query): use st2_lstm_bidir then. */
 int st2_lstm_coop_set_exchange(int sc1);
 int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
                         int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,
@@ -289,6 +314,11 @@ int st2_add_chanvec(const float* x, int64_t x_bs, int32_t x_cs, const float* v, 
 /* m[b][c] = mean_n x[b][c][n]  (modules.py:155,397) */
 int st2_mean_tokens(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_t m_bs,
                     int32_t B, int32_t C, int32_t N, void* stream);
+/* Same over the first len[b] tokens only (int32 [B] on the device, NULL = all N): a right-padded batch then gives
+ * every utterance the result of its own un-padded run (the reference runs one utterance at a time,
+ * Demo/Inference_LJSpeech.ipynb:268-290). */
+int st2_mean_tokens_len(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_t m_bs,
+                        int32_t B, int32_t C, int32_t N, const int32_t* len, void* stream);
 /* out[i] = a*x[i] + b*y[i] + c*z[i] (z may be NULL): sampler updates, sampler.py:184-208,497-510 */
 int st2_axpbypcz(const float* x, float a, const float* y, float b, const float* z, float c,
                  float* out, int64_t n, void* stream);

@@ -58,7 +58,7 @@ def _conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=N
                  alpha=alpha)
     if hasattr(wt, "wq"):  # split-f16 packing (st2_conv1d_f16s): operands are hi + lo of v * scale; lo*lo dropped
         w = wt.dense()
-        xs = 8.0
+        xs = 8.0 if pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_COLNORM) else 1.0  # ops.x_scale_for(pro)
         hi = (u * xs).half().float()
         u = (hi + ((u * xs) - hi).half().float()) / xs
     else:
@@ -279,8 +279,11 @@ def add_chanvec(x, v, out=None):
     return y
 
 
-def mean_tokens(x, out=None):
-    m = x.mean(dim=2)
+def mean_tokens(x, out=None, lengths=None):
+    if lengths is None:
+        m = x.mean(dim=2)
+    else:
+        m = torch.stack([x[b, :, :int(lengths[b])].mean(dim=1) for b in range(x.shape[0])])
     if out is not None:
         out.copy_(m)
         return out

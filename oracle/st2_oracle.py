@@ -442,9 +442,15 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
     t_en = text_encoder(sds["text_encoder"], tokens, lengths, mask)
     bert_dur = plbert(sds["bert"], plbert_params, tokens, (~mask).int())
     d_en = F.linear(bert_dur, sds["bert_encoder"]["weight"], sds["bert_encoder"]["bias"]).transpose(-1, -2)
-    s_pred = sample_style(sub(sds["diffusion"], "unet"), noise, bert_dur, diffusion_steps, step_noise,
-                          sigma_data=cfg["diffusion"]["dist"]["sigma_data"], features=ref_s,
-                          embedding_scale=embedding_scale).squeeze(1)
+    skw = dict(sigma_data=cfg["diffusion"]["dist"]["sigma_data"], embedding_scale=embedding_scale)
+    if bool((lengths == N).all()):
+        s_pred = sample_style(sub(sds["diffusion"], "unet"), noise, bert_dur, diffusion_steps, step_noise,
+                              features=ref_s, **skw).squeeze(1)
+    else:  # a right-padded batch: the notebooks synthesise ONE utterance per call, so the denoiser never sees padding
+        s_pred = torch.cat([sample_style(sub(sds["diffusion"], "unet"), noise[b:b + 1],
+                                         bert_dur[b:b + 1, :int(lengths[b])], diffusion_steps, step_noise[:, b:b + 1],
+                                         features=None if ref_s is None else ref_s[b:b + 1], **skw).squeeze(1)
+                            for b in range(B)])
     if s_prev is not None:  # LFinference: convex combination of previous and current style
         s_pred = t * s_prev + (1 - t) * s_pred
     s, ref = s_pred[:, 128:], s_pred[:, :128]
@@ -456,12 +462,12 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
     psd = sds["predictor"]
     d = duration_encoder(sub(psd, "text_encoder"), d_en, s, lengths, mask)
     if durations is None:
-        x = _lstm(psd, "lstm", d)
+        x = _lstm(psd, "lstm", d, lengths)  # per-utterance semantics for a padded batch (pack/pad = un-padded run)
         dur = torch.sigmoid(F.linear(x, psd["duration_proj.linear_layer.weight"],
                                      psd["duration_proj.linear_layer.bias"])).sum(dim=-1)
-        durations = torch.round(dur).clamp(min=1).long()
+        durations = torch.round(dur).clamp(min=1).long().masked_fill(mask, 0)
         if (not multispeaker) if lj_tail is None else lj_tail:
-            durations[:, -1] += 5
+            durations[torch.arange(B), lengths - 1] += 5  # ipynb:301 `pred_dur[-1] += 5` of each utterance
     T = int(durations[0].sum())
     aln = torch.zeros(B, N, T)
     for b in range(B):  # the notebook's one-hot alignment loop, ipynb:303-307

@@ -14,11 +14,12 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
+STATUS_F16_RANGE, STATUS_LSTM_TIMEOUT = 1, 2
 ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY, ACT_GELU_TANH = range(6)
 
 
@@ -43,6 +44,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("act_split", C.c_int32), ("act_slope", C.c_float),
         ("wq", f32p), ("wq_co_pad", C.c_int32), ("wq_cin_pad", C.c_int32),
         ("x_scale", C.c_float), ("out_scale", C.c_float),
+        ("w_row_scale", f32p),
         ("xs", f32p), ("xs_cg", C.c_int32), ("xs_lp", C.c_int32), ("xs_halo", C.c_int32),
         ("part", f32p), ("part_nt", C.c_int32),
     ]
@@ -54,6 +56,7 @@ _SIGNATURES = {
     "st2_last_error": (C.c_char_p, []),
     "st2_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "st2_sizeof_conv_desc": (C.c_int, []),
+    "st2_status": (C.c_int, [C.c_int]),
     "st2_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
@@ -105,6 +108,8 @@ _SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "st2_mean_tokens": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p]),
+    "st2_mean_tokens_len": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p]),
     "st2_axpbypcz": (C.c_int, [f32p, C.c_float, f32p, C.c_float, f32p, C.c_float, f32p, C.c_int64, C.c_void_p]),
 }
 

@@ -7,6 +7,11 @@ typedef _Float16 st2_h8 __attribute__((ext_vector_type(8)));
 
 static __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
+// Largest finite f16 magnitude; operands of the split-f16 convs are clamped to it before the hi cast (NaN passes).
+static __device__ __forceinline__ float st2_clamp_f16(float u) {
+  return u > 65504.f ? 65504.f : (u < -65504.f ? -65504.f : u);
+}
+
 // sin(x)^2 to ~2.4e-7 absolute: n = rint(x/pi), r = x - n*pi (two-term, fma-exact), odd minimax
 // polynomial of degree 9 on [-pi/2, pi/2] (max abs error 1.2e-7, fitted in tools/fit_sin.py).
 static __device__ __forceinline__ float sin_sq(float x) {

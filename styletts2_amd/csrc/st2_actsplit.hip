@@ -23,6 +23,7 @@ struct ActArgs {
   const float* alpha;
   float x_scale;
   st2_h8* xs; int xs_cg, Lp, halo;
+  int* status;  // sticky status word (st2_status), may be null
 };
 
 template <int PRO>
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
     crstd = st[1];
   }
   st2_h8 hi, lo;
+  bool sat = false;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ci = cg * 8 + e;
@@ -78,10 +80,15 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
       u = w * g + bt;
     }
     u = (lok && ci < a.C) ? u * a.x_scale : 0.f;
-    const _Float16 h = (_Float16)u;
+    // saturate to the f16 range instead of overflowing to inf (hi) / NaN (lo = u - inf): the conv then stays finite
+    // and the condition is reported through the sticky status word (NaN inputs propagate as NaN, like fp32)
+    const float uc = st2_clamp_f16(u);
+    sat |= uc != u;
+    const _Float16 h = (_Float16)uc;
     hi[e] = h;
-    lo[e] = (_Float16)(u - (float)h);
+    lo[e] = (_Float16)(uc - (float)h);
   }
+  if (__any(sat) && (threadIdx.x & 63) == 0) st2_raise_status(a.status, ST2_STATUS_F16_RANGE);
   const int64_t plane = (int64_t)a.xs_cg * a.Lp;
   st2_h8* dst = a.xs + ((int64_t)b * 2 * a.xs_cg + cg) * a.Lp + pos;
   dst[0] = hi;
@@ -138,6 +145,7 @@ extern "C" int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.gb_bs = gb_bs; a.gamma_plus_one = gamma_plus_one;
   a.alpha = alpha; a.x_scale = x_scale;
   a.xs = reinterpret_cast<st2_h8*>(xs); a.xs_cg = xs_cg; a.Lp = Lp; a.halo = halo;
+  a.status = st2_status_device_ptr();
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (pro) {
     case ST2_PRO_LEAKY: launch_act<ST2_PRO_LEAKY>(a, B, s); break;

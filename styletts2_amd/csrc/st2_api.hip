@@ -30,3 +30,41 @@ extern "C" int st2_device_info(int dev, char* name, int cap) {
   }
   return p.multiProcessorCount;
 }
+
+// ---- sticky status word (host-mapped, see st2.h) --------------------------------------------------------------------
+static int* g_status_host = nullptr;  // host view
+static int* g_status_dev = nullptr;   // device view of the same 64 bytes
+static bool g_status_tried = false;
+
+// Device pointer the kernels OR their status bits into; nullptr when no device is usable (the kernels then skip the
+// report).  First call allocates -- never inside a stream capture: every launcher that reports calls this before it
+// launches, and graph users run one eager pass first (GraphedSampler / the engine's capture path do).
+int* st2_status_device_ptr() {
+  if (!g_status_tried) {
+    g_status_tried = true;
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+      memset(h, 0, 64);
+      void* dptr = nullptr;
+      if (hipHostGetDevicePointer(&dptr, h, 0) == hipSuccess && dptr) {
+        g_status_host = reinterpret_cast<int*>(h);
+        g_status_dev = reinterpret_cast<int*>(dptr);
+      } else {
+        (void)hipHostFree(h);
+      }
+    }
+    (void)hipGetLastError();
+  }
+  return g_status_dev;
+}
+
+extern "C" int st2_status(int clear) {
+  if (!st2_status_device_ptr()) {
+    st2_set_error("st2_status: no HIP device / host-mapped allocation failed");
+    return -1;
+  }
+  int v = 0;
+  for (int i = 0; i < 2; ++i)
+    v |= clear ? __atomic_exchange_n(g_status_host + i, 0, __ATOMIC_SEQ_CST) : __atomic_load_n(g_status_host + i, __ATOMIC_SEQ_CST);
+  return v;
+}

@@ -42,7 +42,7 @@ struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
 };
 
 template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d) {
+__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d, int* status) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
         crstd = st[1];
       }
       h8 hi, lo;
+      bool sat = false;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int ci = c0 + sg * 8 + e;
@@ -163,10 +164,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
         }
         // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor
         v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
-        const _Float16 h = (_Float16)v;
+        const float vc = st2_clamp_f16(v);  // saturate instead of inf / NaN, reported via st2_status()
+        sat |= vc != v;
+        const _Float16 h = (_Float16)vc;
         hi[e] = h;
-        lo[e] = (_Float16)(v - (float)h);
+        lo[e] = (_Float16)(vc - (float)h);
       }
+      if (sat) st2_raise_status(status, ST2_STATUS_F16_RANGE);
       dst[pos] = hi;
       dst[plane + pos] = lo;
     }
@@ -271,6 +275,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
   const float osc = d.out_scale;
+  // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
+  const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
   // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
   // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
   // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
@@ -302,6 +308,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
       // the packed weights serve as a valid address
       const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
       const float bias_r = d.bias ? braw : 0.f;
+      const float sraw = rsc[row];  // row < wq_co_pad by construction of the packing
+      const float osc_r = d.w_row_scale ? osc * sraw : osc;
       bool ok[TN];
       float rv[TN], r2v[TN];
 #pragma unroll
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float v = acc[j][r] * osc + bias_r;
+        float v = acc[j][r] * osc_r + bias_r;
         if (use_res) v += rv[j];
         if (use_res2) v = r2v[j] + v;
         if (use_div) v = v / d.div;
@@ -399,7 +407,7 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   }
   // rows beyond C_out inside the last co block are computed on zero weights and not stored
   dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B);
-  hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
+  hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, st2_status_device_ptr());
   ST2_CHECK_LAUNCH("st2_conv1d_f16s");
   return 0;
 }

@@ -30,36 +30,26 @@ namespace {
 
 constexpr int NT = 256;
 
-// Sum 16 per-lane values over the 32 lanes that share (lane >> 5).  Reduce-scatter: after the 5 exchange rounds lane
-// l holds the total of element  8*bit4(l) + 4*bit3(l) + 2*bit2(l) + bit1(l)  (both lanes of a pair hold it).
-// 16 cross-lane moves instead of 80; summation order is fixed (bitwise reproducible).
-__device__ __forceinline__ float halfwave_reduce16(const float (&s)[16], int l31) {
-  float a8[8], a4[4], a2[2];
+// Sum 4 per-lane values over the 32 lanes that share (lane >> 5).  Reduce-scatter: after the exchange rounds lane l
+// holds the total of element 2*bit4(l) + bit3(l) (all 8 lanes of that group hold it).  6 cross-lane moves instead of
+// 20; summation order is fixed (bitwise reproducible).  Done once per group of 4 output rows so that only 2 x 4
+// partial sums are live next to the 64 accumulators (the 2 x 16 of a whole-tile reduction made the 168-VGPR build
+// spill in its epilogue).
+__device__ __forceinline__ float halfwave_reduce4(const float (&s)[4], int l31) {
+  float a2[2];
   bool up = (l31 & 16) != 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float mine = up ? s[8 + i] : s[i];
-    const float theirs = up ? s[i] : s[8 + i];
-    a8[i] = mine + __shfl_xor(theirs, 16, 64);
+  for (int i = 0; i < 2; ++i) {
+    const float mine = up ? s[2 + i] : s[i];
+    const float theirs = up ? s[i] : s[2 + i];
+    a2[i] = mine + __shfl_xor(theirs, 16, 64);
   }
   up = (l31 & 8) != 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float mine = up ? a8[4 + i] : a8[i];
-    const float theirs = up ? a8[i] : a8[4 + i];
-    a4[i] = mine + __shfl_xor(theirs, 8, 64);
-  }
-  up = (l31 & 4) != 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float mine = up ? a4[2 + i] : a4[i];
-    const float theirs = up ? a4[i] : a4[2 + i];
-    a2[i] = mine + __shfl_xor(theirs, 4, 64);
-  }
-  up = (l31 & 2) != 0;
   const float mine = up ? a2[1] : a2[0];
   const float theirs = up ? a2[0] : a2[1];
-  float a1 = mine + __shfl_xor(theirs, 2, 64);
+  float a1 = mine + __shfl_xor(theirs, 8, 64);
+  a1 += __shfl_xor(a1, 4, 64);
+  a1 += __shfl_xor(a1, 2, 64);
   a1 += __shfl_xor(a1, 1, 64);
   return a1;
 }
@@ -214,7 +204,10 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
   const float osc = d.out_scale;
+  // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
+  const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
   const bool want_part = d.part != nullptr;
+  const int ptile = blockIdx.x * WN + wn;  // 128-column tile index of this wave's partial sums
   // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
   // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
   // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
@@ -232,7 +225,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
     const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
     const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
-    float ps[16], pq[16];
+    float ps[4], pq[4];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -247,6 +240,8 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       // the packed weights serve as a valid address
       const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
       const float bias_r = d.bias ? braw : 0.f;
+      const float sraw = rsc[row];  // row < wq_co_pad by construction of the packing
+      const float osc_r = d.w_row_scale ? osc * sraw : osc;
       bool ok[TN];
       float rv[TN], r2v[TN];
 #pragma unroll
@@ -258,7 +253,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float v = acc[j][r] * osc + bias_r;
+        float v = acc[j][r] * osc_r + bias_r;
         if (use_res) v += rv[j];
         if (use_res2) v = r2v[j] + v;
         if (use_div) v = v / d.div;
@@ -279,19 +274,20 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
           s2 += v * v;
         }
       }
-      ps[r] = s1;
-      pq[r] = s2;
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
-    }
-    if (want_part) {  // wave-uniform
-      const float ts = halfwave_reduce16(ps, l31);
-      const float tq = halfwave_reduce16(pq, l31);
-      const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + ((l31 >> 1) & 1);
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const int tile = blockIdx.x * WN + wn;  // 128-column tile index
-      if ((l31 & 1) == 0 && row < d.C_out && tile < d.part_nt) {
-        float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + row) * d.part_nt + tile;
-        *pp = make_float2(ts, tq);
+      ps[r & 3] = s1;
+      pq[r & 3] = s2;
+      if ((r & 3) == 3) {
+        if (want_part) {  // wave-uniform: the (sum, sumsq) of these 4 rows over the wave's 128 columns
+          const float ts = halfwave_reduce4(ps, l31);
+          const float tq = halfwave_reduce4(pq, l31);
+          const int rr = (r & ~3) + ((l31 >> 4) & 1) * 2 + ((l31 >> 3) & 1);
+          const int prow = m0 + wm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kg;
+          if ((l31 & 7) == 0 && prow < d.C_out && ptile < d.part_nt) {
+            float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + prow) * d.part_nt + ptile;
+            *pp = make_float2(ts, tq);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
       }
     }
   };

@@ -10,10 +10,14 @@
 //   2. reduces the 8 k-slice partials through LDS, applies the gate non-linearities and updates c / h for its
 //      32 units x U utterances (one thread each),
 //   3. publishes its 32 x U new h values to a double-buffered exchange array in global memory and
-//   4. meets the other 7 workgroups of the group at a monotonic counter (agent-scope release / acquire, the
-//      placement-independent hand-off of cdna_hip_programming.md section 6), then reloads the full h into LDS.
-// The step costs the FMA time of the slice (~1 us for U = 8) plus one L2/fabric round trip instead of a 1 MB
-// stream.  Every spin is bounded: on a time-out the group raises status[0] and every workgroup leaves.
+//   4. hands them to the other 7 workgroups of the group, then reloads the full h into LDS.  Three hand-off forms
+//      (XCH): 2 (default) "the data is the flag" -- every value is ONE 8-byte agent-scope store {step tag, value}
+//      and each consumer thread re-reads its U granules until every tag equals the step (cdna_hip_programming.md
+//      guideline 16, recipe R2): one fabric round trip per step, no counter, no cache maintenance; 0 = plain stores /
+//      loads bracketed by agent-scope release / acquire fences around a monotonic counter (store-ack, counter,
+//      reload: three round trips, 8.1 us / step measured); 1 = sc1 atomic stores / loads + the counter (9.2 us).
+// The step costs the FMA time of the slice (~1 us for U = 8) plus the hand-off instead of a 1 MB stream.  Every
+// spin is bounded: on a time-out the group raises status[0] (and ST2_STATUS_LSTM_TIMEOUT) and every workgroup leaves.
 //
 // Packed-sequence semantics are those of st2_lstm_bidir (outputs past `length` are zero, the reverse direction
 // starts at t = length - 1); arithmetic per gate row is a fixed-order fp32 sum (k ascending inside a 32-slice, the
@@ -32,14 +36,19 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // SC1 = true: the exchanged hidden state travels as agent-scope (sc1) atomic stores / loads, which bypass the
 // non-coherent cache levels, so the per-step hand-off needs no L2 write-back / invalidate fence -- only the counter.
 // SC1 = false: plain stores / loads bracketed by agent-scope release / acquire fences (whole-L2 maintenance per step).
-template <int U, bool SC1>
+typedef unsigned long long gran_t;  // {tag << 32 | float bits}
+
+template <int U, int XCH>
 __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict__ G, int64_t g_bs, int g_cs,
                                                         const float* __restrict__ whh_t,  // [2][H][4H]
                                                         const int* __restrict__ lengths, int B, int N,
                                                         float* __restrict__ Y, int64_t y_bs, int y_cs,
                                                         int* __restrict__ status,   // [0] error flag
                                                         int* __restrict__ counters,  // [groups]
-                                                        float* __restrict__ hx) {   // [groups][2][U][H]
+                                                        float* __restrict__ hx,     // [groups][2][U][H] (granules: x2)
+                                                        int* gstatus) {              // sticky status word (may be null)
+  constexpr bool SC1 = XCH == 1;
+  constexpr bool GRAN = XCH == 2;
   __shared__ __attribute__((aligned(16))) float hs[U][H];
   __shared__ float part[U][4][NSL][UNITS];
   __shared__ int s_fail;
@@ -92,7 +101,8 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
     go = Gb[(int64_t)(3 * H) * g_cs + t];
   }
   int* cnt = counters + group;
-  float* hxg = hx + (int64_t)group * 2 * U * H;
+  float* hxg = hx + (int64_t)group * 2 * U * H * (GRAN ? 2 : 1);
+  gran_t* gxg = reinterpret_cast<gran_t*>(hxg);
   __syncthreads();
 
   for (int s = 0; s < maxlen; ++s) {
@@ -149,12 +159,53 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
         Yb[t] = h;
       }
       // 3. publish (a finished or absent utterance republishes its last state: nobody consumes it)
-      float* dst = &hxg[((int64_t)(s & 1) * U + uu) * H + hu];
-      if constexpr (SC1)
-        __hip_atomic_store(dst, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        *dst = h;
+      if constexpr (GRAN) {
+        const gran_t g = ((gran_t)(unsigned)(s + 1) << 32) | (gran_t)__float_as_uint(h);
+        __hip_atomic_store(&gxg[((int64_t)(s & 1) * U + uu) * H + hu], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        float* dst = &hxg[((int64_t)(s & 1) * U + uu) * H + hu];
+        if constexpr (SC1)
+          __hip_atomic_store(dst, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          *dst = h;
+      }
     }
+    if constexpr (GRAN) {
+      // 4. the data is the flag: thread = hidden unit index re-reads its U granules of this step's buffer until every
+      //    tag carries the step (tags of the buffer's previous use are s - 1; the memset before the launch left 0).
+      //    `part` is free to be rewritten only after every thread has read it: the sync below also covers that.
+      const gran_t* src = gxg + (int64_t)(s & 1) * U * H + tid;
+      float hv[U];
+      int spins = 0;
+      bool fail = false;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const gran_t g = __hip_atomic_load(src + u * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hv[u] = __uint_as_float((unsigned)g);
+          ok &= (unsigned)(g >> 32) == (unsigned)(s + 1);
+        }
+        if (__all(ok)) break;
+        if (++spins > SPIN_LIMIT) {  // wave-uniform
+          fail = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (fail) {
+        if ((tid & 63) == 0) {
+          __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          st2_raise_status(gstatus, ST2_STATUS_LSTM_TIMEOUT);
+          s_fail = 1;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) hs[u][tid] = hv[u];
+      }
+      __syncthreads();
+      if (s_fail) return;
+    } else {
     // 4. group hand-off: all stores of this workgroup complete -> release -> count -> wait -> acquire
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -169,6 +220,7 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (++spins > SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          st2_raise_status(gstatus, ST2_STATUS_LSTM_TIMEOUT);
           s_fail = 1;
           break;
         }
@@ -187,54 +239,88 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
       else
         hs[u][tid] = src[u * H + tid];
     }
+    }
     gi = ni; gf = nf; gg = ng; go = no;
     if (act) t = tn;
     __syncthreads();
   }
 }
 
-int g_sc1 = 0;  // st2_lstm_coop_set_exchange(): measured 8.1 us/step with fences, 9.2 us with sc1 accesses
+int g_xch = 2;  // st2_lstm_coop_set_exchange(): 0 fences + counter (8.1 us/step), 1 sc1 + counter (9.2 us), 2 granules
+
+size_t scratch_head(int groups) { return ((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256; }
+// sized for the granule form (8 bytes per exchanged value) whatever form runs
+size_t scratch_need(int groups, int U) { return scratch_head(groups) + (size_t)groups * 2 * U * H * sizeof(gran_t); }
+
+template <int U, int XCH>
+int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, const int* lengths, int B, int N,
+                   float* Y, int64_t y_bs, int y_cs, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  const int nblk = st2_cdiv(B, U);
+  const int groups = 2 * nblk;
+  const size_t head = scratch_head(groups);
+  const size_t need = scratch_need(groups, U);
+  ST2_REQUIRE(scratch_bytes >= need, "st2_lstm_bidir_coop: scratch of %zu B, need %zu B", scratch_bytes, need);
+  // Every workgroup of the launch must be resident at once (the groups spin on each other): ask the runtime how many
+  // the device holds instead of assuming a CU count.  One query per (U, XCH) per process.
+  static int capacity = -1;
+  if (capacity < 0) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_coop_kernel<U, XCH>, 256, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      st2_set_error("st2_lstm_bidir_coop: occupancy query failed");
+      return 1;
+    }
+    capacity = per_cu * prop.multiProcessorCount;
+  }
+  ST2_REQUIRE(groups * NSL <= capacity, "st2_lstm_bidir_coop: %d workgroups cannot be co-resident on this device "
+              "(capacity %d): use st2_lstm_bidir", groups * NSL, capacity);
+  int* status = reinterpret_cast<int*>(scratch);
+  int* counters = status + 1;
+  float* hx = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + head);
+  // status, counters and -- granule form -- every tag start at zero on EVERY call (a tag left by an earlier call
+  // would otherwise match); a memset node under graph capture, replayed first
+  if (hipMemsetAsync(scratch, 0, XCH == 2 ? need : head, s) != hipSuccess) {
+    st2_set_error("st2_lstm_bidir_coop: hipMemsetAsync failed");
+    return 1;
+  }
+  hipLaunchKernelGGL((lstm_coop_kernel<U, XCH>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
+                     B, N, Y, y_bs, y_cs, status, counters, hx, st2_status_device_ptr());
+  ST2_CHECK_LAUNCH("st2_lstm_bidir_coop");
+  return 0;
+}
 
 template <int U>
 int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, const int* lengths, int B, int N, float* Y,
                 int64_t y_bs, int y_cs, void* scratch, size_t scratch_bytes, hipStream_t s) {
-  const int nblk = st2_cdiv(B, U);
-  const int groups = 2 * nblk;
-  const size_t head = ((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256;
-  const size_t need = head + (size_t)groups * 2 * U * H * sizeof(float);
-  ST2_REQUIRE(scratch_bytes >= need, "st2_lstm_bidir_coop: scratch of %zu B, need %zu B", scratch_bytes, need);
-  ST2_REQUIRE(groups * NSL <= 192, "st2_lstm_bidir_coop: %d workgroups must be co-resident (<= 192)", groups * NSL);
-  int* status = reinterpret_cast<int*>(scratch);
-  int* counters = status + 1;
-  float* hx = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + head);
-  if (hipMemsetAsync(scratch, 0, head, s) != hipSuccess) {
-    st2_set_error("st2_lstm_bidir_coop: hipMemsetAsync failed");
-    return 1;
+  switch (g_xch) {
+    case 0:
+      return launch_coop_as<U, 0>(G, g_bs, g_cs, whh_t, lengths, B, N, Y, y_bs, y_cs, scratch, scratch_bytes, s);
+    case 1:
+      return launch_coop_as<U, 1>(G, g_bs, g_cs, whh_t, lengths, B, N, Y, y_bs, y_cs, scratch, scratch_bytes, s);
+    default:
+      return launch_coop_as<U, 2>(G, g_bs, g_cs, whh_t, lengths, B, N, Y, y_bs, y_cs, scratch, scratch_bytes, s);
   }
-  if (g_sc1)
-    hipLaunchKernelGGL((lstm_coop_kernel<U, true>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
-                       B, N, Y, y_bs, y_cs, status, counters, hx);
-  else
-    hipLaunchKernelGGL((lstm_coop_kernel<U, false>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
-                       B, N, Y, y_bs, y_cs, status, counters, hx);
-  ST2_CHECK_LAUNCH("st2_lstm_bidir_coop");
-  return 0;
 }
 
 int block_size(int B) { return B > 48 ? 0 : (B > 4 ? 8 : (B > 1 ? 4 : 1)); }
 
 }  // namespace
 
-extern "C" int st2_lstm_coop_set_exchange(int sc1) {
-  g_sc1 = sc1 != 0;
+extern "C" int st2_lstm_coop_set_exchange(int mode) {
+  if (mode < 0 || mode > 2) {
+    st2_set_error("st2_lstm_coop_set_exchange: mode %d (0 fences, 1 sc1, 2 granules)", mode);
+    return 1;
+  }
+  g_xch = mode;
   return 0;
 }
 
 extern "C" int64_t st2_lstm_coop_scratch_bytes(int32_t B) {
   const int U = block_size(B);
   if (U == 0) return 0;  // batch too large for one co-resident launch: use st2_lstm_bidir
-  const int groups = 2 * st2_cdiv(B, U);
-  return (int64_t)(((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256 + (size_t)groups * 2 * U * H * sizeof(float));
+  return (int64_t)scratch_need(2 * st2_cdiv(B, U), U);
 }
 
 extern "C" int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t,

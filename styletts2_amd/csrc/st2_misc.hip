@@ -163,14 +163,16 @@ __global__ __launch_bounds__(256) void add_chanvec_kernel(const float* __restric
 
 // one wave per (b, c) row
 __global__ __launch_bounds__(64) void mean_tokens_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
-                                                         float* __restrict__ m, int64_t m_bs, int C, int N) {
+                                                         float* __restrict__ m, int64_t m_bs, int C, int N,
+                                                         const int* __restrict__ len) {
   const int c = blockIdx.x;
   const int b = blockIdx.y;
   const float* xr = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+  const int n_b = len ? min(max(len[b], 1), N) : N;  // right-padded batch: tokens >= len[b] do not exist
   double s = 0.0;
-  for (int n = threadIdx.x; n < N; n += 64) s += (double)xr[n];
+  for (int n = threadIdx.x; n < n_b; n += 64) s += (double)xr[n];
   s = st2_wave_sum(s);
-  if (threadIdx.x == 0) m[(int64_t)b * m_bs + c] = (float)(s / (double)N);
+  if (threadIdx.x == 0) m[(int64_t)b * m_bs + c] = (float)(s / (double)n_b);
 }
 
 __global__ __launch_bounds__(256) void axpbypcz_kernel(const float* __restrict__ x, float a,
@@ -272,8 +274,19 @@ extern "C" int st2_mean_tokens(const float* x, int64_t x_bs, int32_t x_cs, float
                                int32_t C, int32_t N, void* stream) {
   ST2_REQUIRE(x && m && B > 0 && C > 0 && N > 0, "st2_mean_tokens: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(mean_tokens_kernel, dim3(C, B), dim3(64), 0, s, x, x_bs, x_cs, m, m_bs, C, N);
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(C, B), dim3(64), 0, s, x, x_bs, x_cs, m, m_bs, C, N,
+                     static_cast<const int*>(nullptr));
   ST2_CHECK_LAUNCH("st2_mean_tokens");
+  return 0;
+}
+
+extern "C" int st2_mean_tokens_len(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_t m_bs, int32_t B,
+                                   int32_t C, int32_t N, const int32_t* len, void* stream) {
+  ST2_REQUIRE(x && m && B > 0 && C > 0 && N > 0, "st2_mean_tokens_len: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(C, B), dim3(64), 0, s, x, x_bs, x_cs, m, m_bs, C, N,
+                     reinterpret_cast<const int*>(len));
+  ST2_CHECK_LAUNCH("st2_mean_tokens_len");
   return 0;
 }
 

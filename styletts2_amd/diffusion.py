@@ -326,7 +326,11 @@ class _Transformer(nn.Module):
         return pk
 
     # -- sessions: everything constant across the 2*(steps-1) net calls of one sampler run -------------
-    def open_session(self, x, embedding=None, features=None, embedding_scale=1.0, embedding_mask_proba=0.0):
+    def open_session(self, x, embedding=None, features=None, embedding_scale=1.0, embedding_mask_proba=0.0,
+                     lengths=None):
+        """`lengths` (host or device int tensor [B], optional): token count of every utterance of a right-padded batch.
+        Attention then excludes the pad keys and the output mean runs over each utterance's own tokens, so every row
+        equals that utterance's un-padded run (the reference runs one utterance at a time: no padding exists there)."""
         assert embedding is not None, "the denoiser is conditional: `embedding` is required (modules.py:410)"
         dev = x.device
         pk = self._pk if (self._pk is not None and self._pk.device == dev) else self._prepare(dev)
@@ -335,6 +339,10 @@ class _Transformer(nn.Module):
         assert E == self.emb_features
         s = type("DenoiserSession", (), {})()
         s.pk, s.B, s.N, s.scale = pk, B, N, float(embedding_scale)
+        s.key_len = None
+        if lengths is not None:
+            assert lengths.numel() == B and int(lengths.min()) >= 1 and int(lengths.max()) <= N
+            s.key_len = lengths.to(torch.int32).to(dev).contiguous()
         embedding = embedding.float()
         fixed = pk.fixed[:N].unsqueeze(0).expand(B, -1, -1)
         if embedding_mask_proba > 0.0:  # modules.py:412-416 (classifier-free-guidance dropout; off at inference)
@@ -415,13 +423,13 @@ class _Transformer(nn.Module):
             ops.conv1d(V(X), b.q, mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=V(qkv)[:, :mid], **kw1)
             ops.conv1d(V(X), b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=V(qkv)[:, mid:], **kw2)
             att = ops.attention(qkv[:, :mid], qkv[:, mid:2 * mid], qkv[:, 2 * mid:], self.heads,
-                                self.head_features ** -0.5, out=A(mid))
+                                self.head_features ** -0.5, out=A(mid), key_len=s.key_len)
             X1, hmid, X2 = A(Fz), A(b.f1_out), A(Fz)
             ops.conv1d(V(att), b.o, Fz, 1, bias=b.o_b, res=V(X), out=V(X1))
             ops.conv1d(V(X1), b.f1, b.f1_out, 1, bias=b.f1_b, act=ops.ACT_GELU, out=V(hmid))
             ops.conv1d(V(hmid), b.f2, Fz, 1, bias=b.f2_b, res=V(X1), out=V(X2))
             X = ops.add_chanvec(X2, m, out=A(Fz)) if i + 1 < nblk else X2
-        mean = ops.mean_tokens(X)  # unmasked mean over tokens, modules.py:155,397
+        mean = ops.mean_tokens(X, lengths=s.key_len)  # mean over the utterance's tokens, modules.py:155,397
         return ops.style_fc(mean, pk.out_t, pk.out_b).reshape(B, 1, C)
 
     def run_session(self, s, x, c_noise):
@@ -433,14 +441,15 @@ class _Transformer(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward(self, x, time, embedding_mask_proba=0.0, embedding=None, features=None, embedding_scale=1.0):
+    def forward(self, x, time, embedding_mask_proba=0.0, embedding=None, features=None, embedding_scale=1.0,
+                lengths=None):
         """Reference call signature (modules.py:402-407).  `time` must be batch-uniform (it is c_noise of a
         scalar sigma at inference)."""
         tv = time.reshape(-1)
         if tv.numel() > 1 and not bool((tv == tv[0]).all()):
             raise NotImplementedError("per-item time embeddings are a training-time feature")
         s = self.open_session(x, embedding=embedding, features=features, embedding_scale=embedding_scale,
-                              embedding_mask_proba=embedding_mask_proba)
+                              embedding_mask_proba=embedding_mask_proba, lengths=lengths)
         return self.run_session(s, x.float().contiguous(), float(tv[0]))
 
 

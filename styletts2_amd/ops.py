@@ -65,6 +65,38 @@ def _bs_cs(t):
     return t.stride(0), t.stride(1)
 
 
+def x_scale_for(pro):
+    """Power of two applied to the activated conv input before its f16 hi/lo split.  Normalised inputs (AdaIN /
+    LayerNorm prologues: O(1) values) take 8, which keeps the lo halves of typical activations in the normal f16
+    range; un-normalised inputs (plain / LeakyReLU / Snake prologues: the decoder's `cat` buffer carries the F0 curve
+    in Hz, generator stage outputs, FFN intermediates) take 1, i.e. the full +-65504 of f16 (the lo half is then exact
+    to 2^-25 absolute through f16 subnormals).  Beyond the range the kernels clamp and raise STATUS_F16_RANGE."""
+    return F16S_X_SCALE if pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_COLNORM) else 1.0
+
+
+def status(clear=False):
+    """The library's sticky device-side status word (include/st2.h `st2_status`): no synchronisation; a bit is visible
+    once the kernel that raised it has completed."""
+    return _lib.load().st2_status(1 if clear else 0)
+
+
+def check_status():
+    """Raises St2Error if a kernel reported a device-side condition since the last check (and clears it).  Called by
+    the pipeline at its existing host synchronisation points and at the start of every call for the previous one's
+    kernels, so a failure is never silent and costs no extra synchronisation."""
+    st = status(clear=True)
+    if st <= 0:
+        return
+    msgs = []
+    if st & _lib.STATUS_F16_RANGE:
+        msgs.append("a split-f16 conv operand exceeded the f16 range (|x * x_scale| > 65504) and was clamped: the "
+                    "result is finite but wrong; run with ST2_CONV_PRECISION=f32 or rescale the offending layer")
+    if st & _lib.STATUS_LSTM_TIMEOUT:
+        msgs.append("a cooperative BiLSTM group timed out (its workgroups were not co-resident in time): outputs of "
+                    "that call are invalid; set ST2_LSTM=single")
+    raise _lib.St2Error("device-side status 0x%x: %s" % (st, "; ".join(msgs)))
+
+
 XS_HALO = 32  # zero columns in front of every xs row (>= the largest pad_left on the path: 25)
 XS_MIN_L = 256  # shorter rows stay on the fused kernel: an xs row is >= 640 slots
 XS_MIN_C_PLAIN = 64  # prologue-free convs take the xs pair too from this many input channels on (the split pass is
@@ -85,8 +117,8 @@ class XsTensor:
     """Pre-activated, pre-split conv operand written by `activate`: `data` is float16 [B, 2, cg, Lp, 8]
     (plane 0 = hi, 1 = lo; 16-byte slots of 8 channels), logical shape [B, C, L], `halo` zero columns in front."""
 
-    def __init__(self, data, C, L, halo):
-        self.data, self.C, self.L, self.halo = data, C, L, halo
+    def __init__(self, data, C, L, halo, x_scale=F16S_X_SCALE):
+        self.data, self.C, self.L, self.halo, self.x_scale = data, C, L, halo, x_scale
 
     @property
     def cg(self):
@@ -105,7 +137,8 @@ def xs_row_slots(L):
 
 def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
               c_pad=32):
-    """`st2_act_split`: x [B, C, L] fp32 -> XsTensor holding split_f16(8 * pro(x)) with the conv's zero padding."""
+    """`st2_act_split`: x [B, C, L] fp32 -> XsTensor holding split_f16(x_scale * pro(x)) with the conv's zero padding
+    (x_scale = x_scale_for(pro))."""
     lib = _lib.load()
     _chk(x, "x", 3)
     B, Cc, L = x.shape
@@ -127,9 +160,9 @@ def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, g
         _chk(alpha, "alpha", 1)
         assert alpha.numel() == Cc and alpha.is_contiguous()
     _lib.check(lib.st2_act_split(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, pro, slope, _ptr(stats),
-                                 _ptr(gamma), _ptr(beta), gbs, 1 if gamma_plus_one else 0, _ptr(alpha), F16S_X_SCALE,
-                                 data.data_ptr(), cg, Lp, XS_HALO, _stream()), "st2_act_split")
-    return XsTensor(data, Cc, L, XS_HALO)
+                                 _ptr(gamma), _ptr(beta), gbs, 1 if gamma_plus_one else 0, _ptr(alpha),
+                                 x_scale_for(pro), data.data_ptr(), cg, Lp, XS_HALO, _stream()), "st2_act_split")
+    return XsTensor(data, Cc, L, XS_HALO, x_scale_for(pro))
 
 
 def stats_finalize(part, L, eps=1e-5, out=None):
@@ -165,7 +198,7 @@ def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, ou
     d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil, d.pad_left = B, C_in, C_out, L_in, L_out, ks, dil, pad_left
     d.xs, d.xs_cg, d.xs_lp, d.xs_halo = xs.data.data_ptr(), xs.cg, xs.Lp, xs.halo
     d.wq, d.wq_co_pad, d.wq_cin_pad = wt.wq.data_ptr(), wt.co_pad, wt.cin_pad
-    d.x_scale, d.out_scale = F16S_X_SCALE, 1.0 / (F16S_X_SCALE * wt.w_scale)
+    d.x_scale, d.out_scale, d.w_row_scale = xs.x_scale, 1.0 / xs.x_scale, wt.row_scale.data_ptr()
     _chk(bias, "bias", 1)
     d.bias = _ptr(bias)
     d.y, d.y_bs, d.y_cs = out.data_ptr(), out.stride(0), out.stride(1)
@@ -244,7 +277,8 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     d.x, d.x_bs, d.x_cs = x.data_ptr(), x.stride(0), x.stride(1)
     if split:
         d.wq, d.wq_co_pad, d.wq_cin_pad = wt.wq.data_ptr(), wt.co_pad, wt.cin_pad
-        d.x_scale, d.out_scale = F16S_X_SCALE, 1.0 / (F16S_X_SCALE * wt.w_scale)
+        d.x_scale = x_scale_for(pro)
+        d.out_scale, d.w_row_scale = 1.0 / d.x_scale, wt.row_scale.data_ptr()
         fn, fname = lib.st2_conv1d_f16s, "st2_conv1d_f16s"
     else:
         d.wt, d.w_ld = wt.data_ptr(), wt.shape[1]
@@ -488,6 +522,7 @@ def colnorm_apply(x, stats, gamma, beta, *, gamma_plus_one=False, act=ACT_NONE, 
 
 
 _last_lstm_scratch = None  # scratch of the most recent cooperative launch (tests read its status word)
+_coop_refused = False      # the device could not hold a cooperative launch co-resident: stay on the single-CU kernel
 
 
 def lstm_mode():
@@ -501,8 +536,11 @@ def lstm_mode():
 
 
 def lstm_bidir(G, whh_t, lengths=None, out=None):
-    """G [B, 8H, N] projected inputs (both directions) -> Y [B, 2H, N]; lengths: int32 [B] on the device or None."""
-    global _last_lstm_scratch
+    """G [B, 8H, N] projected inputs (both directions) -> Y [B, 2H, N]; lengths: int32 [B] on the device or None.
+    The cooperative kernel is used when the library accepts the launch (its workgroups must all be co-resident: the
+    library checks the device's occupancy and refuses otherwise -- then, and for B > 48, the single-CU kernel runs).
+    A cooperative group that times out raises STATUS_LSTM_TIMEOUT, surfaced by `check_status()`."""
+    global _last_lstm_scratch, _coop_refused
     lib = _lib.load()
     _chk(G, "G", 3)
     _chk(whh_t, "whh_t", 3)
@@ -514,14 +552,19 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
     if out is None:
         out = torch.empty((B, 2 * H, N), device=G.device, dtype=torch.float32)
     lp = 0 if lengths is None else lengths.data_ptr()
-    nbytes = lib.st2_lstm_coop_scratch_bytes(B) if lstm_mode() == "coop" else 0
+    nbytes = lib.st2_lstm_coop_scratch_bytes(B) if (lstm_mode() == "coop" and not _coop_refused) else 0
     if nbytes > 0:
         scratch = torch.empty((nbytes,), device=G.device, dtype=torch.uint8)
-        _lib.check(lib.st2_lstm_bidir_coop(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
-                                           out.data_ptr(), out.stride(0), out.stride(1), scratch.data_ptr(), nbytes,
-                                           _stream()), "st2_lstm_bidir_coop")
-        _last_lstm_scratch = scratch
-        return out
+        rc = lib.st2_lstm_bidir_coop(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
+                                     out.data_ptr(), out.stride(0), out.stride(1), scratch.data_ptr(), nbytes,
+                                     _stream())
+        if rc == 0:
+            _last_lstm_scratch = scratch
+            return out
+        msg = (lib.st2_last_error() or b"").decode()
+        if "co-resident" not in msg:
+            raise _lib.St2Error("st2_lstm_bidir_coop failed: %s" % msg)
+        _coop_refused = True  # nothing was launched: fall through to the single-CU kernel, now and from here on
     _lib.check(lib.st2_lstm_bidir(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
                                   out.data_ptr(), out.stride(0), out.stride(1), _stream()), "st2_lstm_bidir")
     return out
@@ -547,14 +590,17 @@ def add_chanvec(x, v, out=None):
     return out
 
 
-def mean_tokens(x, out=None):
+def mean_tokens(x, out=None, lengths=None):
+    """m[b, c] = mean over the first lengths[b] tokens (all N when lengths is None; int32 [B] on the device)."""
     lib = _lib.load()
     _chk(x, "x", 3)
     B, Cc, N = x.shape
     if out is None:
         out = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.st2_mean_tokens(x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0), B, Cc, N,
-                                   _stream()), "st2_mean_tokens")
+    if lengths is not None:
+        assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.numel() == B and lengths.is_contiguous()
+    _lib.check(lib.st2_mean_tokens_len(x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0), B, Cc,
+                                       N, 0 if lengths is None else lengths.data_ptr(), _stream()), "st2_mean_tokens")
     return out
 
 

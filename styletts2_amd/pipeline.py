@@ -12,45 +12,71 @@ Differences from the notebooks, all host-side:
 """
 import torch
 
+from . import ops
 from .utils import length_to_mask
 
 
 def expand_by_durations(x, dur, T):
     """x [B, C, N], dur [B, N] (int64, every row sums to T) -> [B, C, T] with frame t taking phoneme idx[t]
-    (== x @ one_hot alignment, Demo/Inference_LJSpeech.ipynb:303-312)."""
+    (== x @ one_hot alignment, Demo/Inference_LJSpeech.ipynb:303-312).  idx[b, t] = #{n : cumsum(dur)[b, n] <= t}:
+    one batched binary search on the device instead of the notebook's Python loop."""
     B, C, N = x.shape
-    ar = torch.arange(N, device=x.device)
-    idx = torch.stack([torch.repeat_interleave(ar, dur[b], output_size=T) for b in range(B)])  # [B, T]
+    cum = torch.cumsum(dur, dim=1)
+    t = torch.arange(T, device=x.device, dtype=cum.dtype).unsqueeze(0).expand(B, T).contiguous()
+    idx = torch.searchsorted(cum, t, right=True).clamp_(max=N - 1)  # [B, T]
     return torch.gather(x, 2, idx.unsqueeze(1).expand(B, C, T))
 
 
-def predict_durations(model, d, lj_tail=False):
-    """ipynb:296-301: duration LSTM -> projection -> sum of sigmoids -> round, clamp(min=1)."""
-    x, _ = model.predictor.lstm(d)
+def predict_durations(model, d, lj_tail=False, input_lengths=None):
+    """ipynb:296-301: duration LSTM -> projection -> sum of sigmoids -> round, clamp(min=1).
+
+    `input_lengths` (host int64 [B]) for a right-padded batch: the BiLSTM runs with packed-sequence semantics (its
+    reverse direction starts at each utterance's own last token), pad positions get duration 0 and the LJSpeech
+    +5-frame tail lands on each utterance's own last token -- every row is then what the notebook computes for that
+    utterance alone."""
+    B, N = d.shape[0], d.shape[1]
+    lstm = model.predictor.lstm
+    ragged = input_lengths is not None and not bool((input_lengths == N).all())
+    if hasattr(lstm, "forward_cm"):
+        lens = input_lengths.to(torch.int32).to(d.device) if ragged else None
+        x = lstm.forward_cm(d.transpose(1, 2).contiguous().float(), lens).transpose(1, 2)
+    else:
+        x, _ = lstm(d)
     duration = model.predictor.duration_proj(x)
     duration = torch.sigmoid(duration).sum(dim=-1)
     pred_dur = torch.round(duration).clamp(min=1).long()
-    if lj_tail:
-        pred_dur[:, -1] += 5  # LJSpeech notebook only (ipynb:301)
+    if ragged:
+        pad = length_to_mask(input_lengths).to(d.device)
+        pred_dur = pred_dur.masked_fill(pad, 0)
+    if lj_tail:  # LJSpeech notebook only (ipynb:301): pred_dur[-1] += 5
+        last = (input_lengths.to(d.device) - 1) if ragged else torch.full((B,), N - 1, device=d.device)
+        pred_dur[torch.arange(B, device=d.device), last] += 5
     return pred_dur
 
 
 @torch.no_grad()
 def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
             ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, lj_tail=None, s_prev=None, t=0.7,
-            taps=None):
+            taps=None, allow_ragged=False):
     """Everything in front of the decoder: text encoder, PL-BERT, style diffusion, style mixing, duration and
     prosody prediction, alignment expansion.  Returns the decoder's inputs {asr, F0, N, ref} plus the mixed style
     vector `s_pred` [B, 256] (what LFinference hands to the next sentence) and the durations.
 
     `s_prev` / `t`: long-form style carry-over, `s_pred = t * s_prev + (1 - t) * s_pred` applied to the sampler output
     before the speaker mixing (Demo/Inference_LibriTTS.ipynb LFinference; the LJSpeech notebook calls the same weight
-    `alpha`)."""
+    `alpha`).
+
+    Utterances of different total duration cannot share a decoder call (its InstanceNorm spans the utterance).  With
+    `allow_ragged` the result then carries `groups`: a list of (utterance indices, {asr, F0, N, ref}) per distinct
+    frame count; without it such a batch raises."""
     dev = tokens.device
     B, N = tokens.shape
+    ops.check_status() if dev.type == "cuda" else None  # device-side conditions raised by the previous call's kernels
     if input_lengths is None:
         input_lengths = torch.full((B,), N, dtype=torch.long)
+    input_lengths = input_lengths.detach().cpu().long()
     text_mask = length_to_mask(input_lengths).to(dev)
+    ragged_n = not bool((input_lengths == N).all())
     multispeaker = ref_s is not None
     hifigan = model.decoder.kind == "hifigan"
     if lj_tail is None:
@@ -65,6 +91,8 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     kw = dict(embedding=bert_dur, embedding_scale=embedding_scale, num_steps=diffusion_steps, step_noise=step_noise)
     if multispeaker:
         kw["features"] = ref_s
+    if ragged_n:  # the denoiser attends over / averages each utterance's own tokens only (the notebooks run B = 1)
+        kw["lengths"] = input_lengths
     s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
     if taps is not None:
         taps["s_pred"] = s_pred
@@ -79,26 +107,46 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 
     d = model.predictor.text_encoder(d_en, s, input_lengths, text_mask)              # [B, N, 640]
     if durations is None:
-        durations = predict_durations(model, d, lj_tail=lj_tail)
-        tot = durations.sum(dim=1)
-        if not bool((tot == tot[0]).all()):
-            raise ValueError("utterances of one call must have equal total duration; bucket them or pass "
-                             "`durations` (frames per utterance: %s)" % tot.tolist())
-    T = int(durations[0].sum())  # host value when `durations` was given on the host: no device sync
+        durations = predict_durations(model, d, lj_tail=lj_tail, input_lengths=input_lengths)
+        tot = durations.sum(dim=1).tolist()  # the path's one data-dependent host sync: the frame counts
+        ops.check_status() if dev.type == "cuda" else None  # everything up to here has completed: free to look
+    else:
+        durations = durations.long()
+        tot = durations.sum(dim=1).tolist()  # host tensor in throughput runs: no device sync (forced durations are the
+        #                                      caller's: frames given to pad tokens are expanded like any other)
     durations = durations.to(dev)
     if taps is not None:
         taps["durations"] = durations
+    out = dict(ref=ref, s_pred=torch.cat([ref, s], dim=-1), durations=durations)
+    d_cm = d.transpose(-1, -2).contiguous()
 
-    en = expand_by_durations(d.transpose(-1, -2).contiguous(), durations, T)          # [B, 640, T]
-    asr = expand_by_durations(t_en, durations, T)                                      # [B, 512, T]
-    if hifigan:  # one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
-        en = torch.cat([en[:, :, :1], en[:, :, :-1]], dim=2)
-        asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
-    F0_pred, N_pred = model.predictor.F0Ntrain(en.contiguous(), s)
-    if taps is not None:
-        taps.update(F0=F0_pred, N=N_pred, asr=asr, en=en)
-    return dict(asr=asr.contiguous(), F0=F0_pred, N=N_pred, ref=ref, s_pred=torch.cat([ref, s], dim=-1),
-                durations=durations)
+    def expand(idx):
+        """Alignment expansion + prosody for the utterances `idx` (all of one frame count T)."""
+        T = int(tot[idx[0]])
+        sel = (lambda v: v) if len(idx) == B else (lambda v: v[torch.as_tensor(idx, device=dev)])
+        dur = sel(durations)
+        en = expand_by_durations(sel(d_cm), dur, T)                                   # [b, 640, T]
+        asr = expand_by_durations(sel(t_en), dur, T)                                  # [b, 512, T]
+        if hifigan:  # one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
+            en = torch.cat([en[:, :, :1], en[:, :, :-1]], dim=2)
+            asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
+        F0_pred, N_pred = model.predictor.F0Ntrain(en.contiguous(), sel(s))
+        return dict(asr=asr.contiguous(), F0=F0_pred, N=N_pred, ref=sel(ref), en=en)
+
+    if len(set(tot)) == 1:
+        g = expand(list(range(B)))
+        if taps is not None:
+            taps.update(F0=g["F0"], N=g["N"], asr=g["asr"], en=g["en"])
+        out.update(asr=g["asr"], F0=g["F0"], N=g["N"])
+        return out
+    if not allow_ragged:
+        raise ValueError("utterances of one call must have equal total duration; bucket them, pass `durations`, or "
+                         "use inference() which decodes per frame count (frames per utterance: %s)" % tot)
+    groups = {}
+    for b, T in enumerate(tot):
+        groups.setdefault(int(T), []).append(b)
+    out["groups"] = [(idx, expand(idx)) for _, idx in sorted(groups.items())]
+    return out
 
 
 @torch.no_grad()
@@ -108,9 +156,11 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
 
     Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
-    (Demo/Inference_LibriTTS.ipynb:285-286).  All utterances of one call must expand to the same number of
-    frames (the decoder's InstanceNorm spans the whole utterance, so padding would change results: section 7.3-6);
-    callers bucket by length or pass `durations`.
+    (Demo/Inference_LibriTTS.ipynb:285-286).  The decoder's InstanceNorm spans the whole utterance, so padding frames
+    would change results (section 7.3-6): utterances whose (predicted) durations sum to different frame counts are
+    decoded in one decoder call per distinct frame count and the result is then a LIST of B waveforms [1, 600*T_b] in
+    utterance order; a batch of equal frame counts (forced `durations`, throughput runs) returns one tensor.  A
+    right-padded batch (`input_lengths`) gives every utterance the result of its own un-padded run.
 
     `front_stream` (a torch.cuda.Stream): everything in front of the decoder is issued on that stream and handed to
     the decoder (on the current stream) through an event.  A caller that synthesises batch after batch thereby
@@ -120,19 +170,31 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     """
     kw = dict(input_lengths=input_lengths, noise=noise, diffusion_steps=diffusion_steps,
               embedding_scale=embedding_scale, ref_s=ref_s, alpha=alpha, beta=beta, durations=durations,
-              step_noise=step_noise, lj_tail=lj_tail, taps=taps)
+              step_noise=step_noise, lj_tail=lj_tail, taps=taps, allow_ragged=True)
     if front_stream is None:
         p = prepare(model, sampler, tokens, **kw)
     else:
         main = torch.cuda.current_stream(tokens.device)
+        front_stream.wait_stream(main)  # inputs the caller produced on its stream (per-call randn, H2D copies) are ready
         with torch.cuda.stream(front_stream):
             p = prepare(model, sampler, tokens, **kw)
             ready = torch.cuda.Event()
             ready.record(front_stream)
         main.wait_event(ready)
-        for v in (p["asr"], p["F0"], p["N"], p["ref"]):
-            v.record_stream(main)  # allocated on the front stream, consumed on the main stream
-    return model.decoder(p["asr"], p["F0"], p["N"], p["ref"], noise=sine_noise)
+        for g in ([p] if "groups" not in p else [g for _, g in p["groups"]]):
+            for v in (g["asr"], g["F0"], g["N"], g["ref"]):
+                v.record_stream(main)  # allocated on the front stream, consumed on the main stream
+    if "groups" not in p:
+        return model.decoder(p["asr"], p["F0"], p["N"], p["ref"], noise=sine_noise)
+    waves = [None] * tokens.shape[0]
+    for idx, g in p["groups"]:
+        sn = None if sine_noise is None else [sine_noise[b] for b in idx]
+        if sn is not None:
+            sn = torch.stack([n[:g["F0"].shape[1] * 300] for n in sn])
+        w = model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=sn)
+        for j, b in enumerate(idx):
+            waves[b] = w[j]
+    return waves
 
 
 @torch.no_grad()

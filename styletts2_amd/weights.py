@@ -39,13 +39,14 @@ def f16s_co_block(C_out):
 
 
 class SplitConvWeight:
-    """Conv weight pre-split for `st2_conv1d_f16s` (include/st2.h): wq is a float16 tensor
-    [C_in_pad/16, ks, 2, co_pad, 16] holding hi[0..7] | lo[0..7] of W * w_scale for 8 consecutive input
-    channels; w_scale is the power of two that puts max|W| in [2^13, 2^14) so that the lo halves stay in the
-    normal f16 range."""
+    """Conv weight pre-split for `st2_conv1d_f16s` / `st2_conv1d_xs` (include/st2.h): wq is a float16 tensor
+    [C_in_pad/16, ks, 2, co_pad, 16] holding hi[0..7] | lo[0..7] of W[co] * w_scale[co] for 8 consecutive input
+    channels; w_scale[co] is the power of two that puts max|W[co]| in [2^13, 2^14) -- per OUTPUT ROW, so rows whose
+    magnitudes differ by many octaves (weight-norm gains of a trained checkpoint) all keep their lo halves in the
+    normal f16 range.  `row_scale` = 1 / w_scale, float32 [co_pad] (the kernels' d.w_row_scale)."""
 
-    def __init__(self, wq, w_scale, C_in, C_out, ks):
-        self.wq, self.w_scale, self.C_in, self.C_out, self.ks = wq, float(w_scale), C_in, C_out, ks
+    def __init__(self, wq, row_scale, C_in, C_out, ks):
+        self.wq, self.row_scale, self.C_in, self.C_out, self.ks = wq, row_scale, C_in, C_out, ks
 
     @property
     def cin_pad(self):
@@ -56,28 +57,30 @@ class SplitConvWeight:
         return self.wq.shape[3]
 
     def to(self, device):
-        return SplitConvWeight(self.wq.to(device), self.w_scale, self.C_in, self.C_out, self.ks)
+        return SplitConvWeight(self.wq.to(device), self.row_scale.to(device), self.C_in, self.C_out, self.ks)
 
     def dense(self):
-        """fp32 [C_out, C_in, ks] value the packed halves represent (hi + lo) / w_scale."""
+        """fp32 [C_out, C_in, ks] value the packed halves represent: (hi + lo) / w_scale[co]."""
         n16, ks, _, co_pad, _ = self.wq.shape
         q = self.wq.float()
-        w = (q[..., :8] + q[..., 8:]) / self.w_scale           # [n16, ks, 2, co_pad, 8]
+        w = q[..., :8] + q[..., 8:]                                 # [n16, ks, 2, co_pad, 8]
         w = w.permute(3, 0, 2, 4, 1).reshape(co_pad, n16 * 16, ks)  # [co, (n16, kg, e), t]
+        w = w * self.row_scale.float().view(-1, 1, 1)
         return w[:self.C_out, :self.C_in].contiguous()
 
 
 def pack_conv_f16s(w):
     """[C_out, C_in, ks] fp32 -> SplitConvWeight."""
-    import math
     w = w.detach().float().cpu()
     C_out, C_in, ks = w.shape
     cin_pad = -(-C_in // f16s_chunk(ks)) * f16s_chunk(ks)
     co_pad = -(-C_out // f16s_co_block(C_out)) * f16s_co_block(C_out)
-    amax = float(w.abs().max())
-    w_scale = 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    amax = w.abs().reshape(C_out, -1).amax(dim=1)
+    # exponent e of amax = m * 2^e, m in [0.5, 1)  ->  scale 2^(14 - e) puts amax in [2^13, 2^14); all-zero rows: 1
+    _, e = torch.frexp(amax)
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), 14 - e), torch.ones_like(amax))
     ws = torch.zeros((co_pad, cin_pad, ks), dtype=torch.float32)
-    ws[:C_out, :C_in] = w * w_scale
+    ws[:C_out, :C_in] = w * scale.view(-1, 1, 1)
     hi = ws.half()
     lo = (ws - hi.float()).half()
     n16 = cin_pad // 16
@@ -86,7 +89,9 @@ def pack_conv_f16s(w):
         return h.reshape(co_pad, n16, 2, 8, ks).permute(1, 4, 2, 0, 3)
 
     wq = torch.cat([arrange(hi), arrange(lo)], dim=-1).contiguous()
-    return SplitConvWeight(wq, w_scale, C_in, C_out, ks)
+    row_scale = torch.ones(co_pad, dtype=torch.float32)
+    row_scale[:C_out] = 1.0 / scale
+    return SplitConvWeight(wq, row_scale, C_in, C_out, ks)
 
 
 def conv_precision():
