@@ -1,21 +1,28 @@
 #!/usr/bin/env python
 """End-to-end throughput bench: audio-seconds per wall-second (RTF^-1) of the text->waveform hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): LJSpeech single-speaker model, iSTFTNet decoder, 5 diffusion steps, a batch of
-32 synthetic 100-phoneme sequences per GPU with durations forced to 4 frames / phoneme (=> exactly 10.0 s of 24 kHz
-audio per utterance), seeded random weights of the reference architecture (no checkpoints offline).  One "step" is
-one full pass token ids -> waveform over the per-GPU batch; inputs are resident in HBM, outputs stay in HBM, the
-random draws the reference makes inside forward (SineGen noise, ADPM2 step noise) are made inside the timed region.
-Multi-GPU is weak scaling: every rank synthesises its own 32 utterances, no collective in steady state; the only
-collective is the start-up weight broadcast over RCCL.
+`--gpus N` without a torch.distributed.run environment makes the script spawn its own N ranks (one process per GPU).
+
+Workloads (`--config`, BASELINE.json `configs`; default = the one the metric is quoted on, configs[1]):
+  ljspeech           configs[1]  LJSpeech single-speaker, iSTFTNet, 5 diffusion steps, 32 x 10 s per GPU
+  libritts_hifigan   configs[2]  LibriTTS multispeaker (ref-audio style vector), HiFi-GAN, 10 steps, 32 x 10 s per GPU
+  libritts_istftnet  configs[3]  LibriTTS zero-shot with the iSTFTNet decoder, 5 steps, 32 x 10 s per GPU (256 over 8 GPUs)
+  longform           configs[4]  one >= 60 s passage as 8 sentence units with style carry-over, hipGraph-captured sampler
+Synthetic 100-phoneme sequences with durations forced to 4 frames / phoneme (=> exactly 10.0 s of 24 kHz audio per
+utterance), seeded random weights of the reference architecture (no checkpoints offline).  One "step" is one full pass
+token ids -> waveform over the per-GPU batch (longform: over the passage); inputs are resident in HBM, outputs stay in
+HBM, the random draws the reference makes inside forward (SineGen noise, ADPM2 step noise) are made inside the timed
+region.  Multi-GPU is weak scaling: every rank synthesises its own utterances, no collective in steady state; the
+only collective is the start-up weight broadcast over RCCL.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -28,7 +35,6 @@ import torch  # noqa: E402
 PER_GPU_BATCH = 32
 N_PHONEMES = 100
 FRAMES_PER_PHONEME = 4
-DIFFUSION_STEPS = 5
 AUDIO_S_PER_UTT = N_PHONEMES * FRAMES_PER_PHONEME * 600 / 24000.0  # 10.0
 # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak ~2.5 PFLOP/s (v_mfma_f32_32x32x16_f16, 1024 FLOP/clk/SIMD).  The
 # dominant kernel evaluates every fp32-class multiply as THREE f16 MFMA products (hi*hi + hi*lo + lo*hi, fp32
@@ -37,13 +43,31 @@ F16_MFMA_PEAK_TFLOPS = 2500.0
 F16S_PRODUCTS = 3
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_dominant.json")  # written by tools/pmc_summary.py --json (rocprofv3 --pmc passes)
 KEYS = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]
+LONGFORM_SENTENCES = [87, 100, 64, 93, 71, 100, 58, 96]  # phonemes per sentence unit: 669 x 4 frames = 66.9 s
+
+CONFIGS = {
+    "ljspeech": dict(manifest="ljspeech", steps=5, multispeaker=False, baseline_config=1,
+                     workload="LJSpeech single-speaker, batch=32x10 s synthetic phoneme seqs per GPU, iSTFTNet, 5 "
+                              "diffusion steps, 1xMI355X per rank (BASELINE.json configs[1])"),
+    "libritts_hifigan": dict(manifest="libritts", steps=10, multispeaker=True, baseline_config=2,
+                             workload="LibriTTS multispeaker (reference-style vector ref_s), batch=32x10 s per GPU, "
+                                      "10 diffusion steps, HiFi-GAN decoder (BASELINE.json configs[2])"),
+    "libritts_istftnet": dict(manifest="libritts_istftnet", steps=5, multispeaker=True, baseline_config=3,
+                              workload="LibriTTS zero-shot (multispeaker, ref_s) with the iSTFTNet decoder, 32x10 s "
+                                       "per GPU = 256 utterances over 8 GPUs, 5 diffusion steps (BASELINE.json "
+                                       "configs[3])"),
+    "longform": dict(manifest="libritts", steps=5, multispeaker=True, baseline_config=4, longform=True,
+                     workload="long-form streaming synthesis: one 66.9 s passage as 8 sentence units (58-100 phonemes) "
+                              "with style carry-over (LFinference, t=0.7), hipGraph-captured diffusion sampler with "
+                              "16-token length buckets, front of sentence k+1 overlapped with the decoder of sentence "
+                              "k, HiFi-GAN decoder (BASELINE.json configs[4])"),
+}
 
 
-def build(man, seed_base=10):
-    from styletts2_amd import models, synth
+def build(man):
+    from styletts2_amd import models
     args = models.recursive_munch(man["config"])
-    model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))
-    return model
+    return models.build_model(args, None, None, models.load_plbert(man["plbert"]))
 
 
 def synthetic_inputs(B, seed):
@@ -53,7 +77,8 @@ def synthetic_inputs(B, seed):
     noise = torch.randn(B, 1, 256, generator=g)
     durations = torch.full((B, N_PHONEMES), FRAMES_PER_PHONEME, dtype=torch.long)
     lengths = torch.full((B,), N_PHONEMES, dtype=torch.long)
-    return tokens, lengths, noise, durations
+    ref_s = torch.randn(B, 256, generator=g)  # style vector of the reference audio (style encoders run once per speaker)
+    return tokens, lengths, noise, durations, ref_s
 
 
 T0 = time.time()
@@ -64,56 +89,172 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
 
 
-def cpu_baseline(man, sds):
-    """The oracle (a CPU restatement of the reference path, kind="port") timed on the host cores on a bounded
-    sample of the same workload: ONE 10 s utterance (BASELINE.json configs[0]), 1 warm-up + best of 3."""
-    from oracle import st2_oracle as O
-    threads = min(os.cpu_count() or 1, int(os.environ.get("ST2_CPU_THREADS", "64")))
-    torch.set_num_threads(threads)  # oneDNN/MKL stop scaling (and start thrashing) far below 256 threads
-    tokens, lengths, noise, durations = synthetic_inputs(1, 0)
-    g = torch.Generator().manual_seed(1)
-    step_noise = torch.randn(DIFFUSION_STEPS - 1, 1, 1, 256, generator=g)
-    sine_noise = torch.randn(1, int(AUDIO_S_PER_UTT * 24000), 9, generator=g)
+def _time_best(fn, threads, budget_s=30.0):
+    """1 warm-up + best of up to 3 runs of fn() at `threads` host threads; a cold run over the budget is reported as is."""
+    torch.set_num_threads(threads)
     best = None
     for it in range(4):
         t0 = time.time()
         with torch.no_grad():
-            O.inference(sds, man["config"], man["plbert"], tokens, lengths, noise, step_noise, sine_noise,
-                        diffusion_steps=DIFFUSION_STEPS, durations=durations)
+            fn()
         dt = time.time() - t0
         log("cpu_baseline run %d: %.2f s on %d threads" % (it, dt, threads))
-        if it > 0 or dt > 30.0:
+        if it > 0 or dt > budget_s:
             best = dt if best is None else min(best, dt)
-        if dt > 30.0:  # keep the bench bounded on a slow host: a single (cold) run is reported as such
+        if dt > budget_s:  # keep the bench bounded on a slow host: a single (cold) run is reported as such
             break
-    return {"value": AUDIO_S_PER_UTT / best, "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 utterance x 10 s (100 phonemes, 5 diffusion steps, iSTFTNet), best of 3 after 1 warm-up, "
-                      "%.2f s wall" % best}
+    return best
 
 
-def roofline(ach, durs, avg_ms, flop, B, L_dom):
-    """Dominant kernel class = the k=11, C=128, L=48001 resblock convs of the last generator stage (12 launches per
-    decoder call).  `achieved` = algorithmic conv FLOPs (2*B*C_in*C_out*ks*L) / mean launch time measured with HIP
-    events on the launch stream inside the timed region; `peak` = dense f16 MFMA peak / 3 products (see above), so
-    `frac` is also (f16 MFMA FLOPs executed / s) / 2.5 PFLOP/s.  `traffic` = HBM bytes per launch from rocprofv3 PMC
-    passes (FETCH_SIZE x2 per the gfx950 correction in MI355X_MICROARCH.md + WRITE_SIZE), read from the committed
-    profiles/pmc_dominant.json; the HBM-side view (algorithmic bytes / s vs 8 TB/s) is reported beside it."""
+def cpu_baseline(man, sds, cfg):
+    """The reference path on the host cores, on a bounded sample of the same workload: ONE 10 s utterance (100 phonemes,
+    the config's diffusion steps and decoder), 1 warm-up + best of 3, at 8 / 16 / 32 / 64 threads (oneDNN / MKL stop
+    scaling far below the GPU box's core count), best reported with its thread count.  kind = "reference": the
+    UNMODIFIED reference modules (oracle/ref_harness.py; only where /root/reference exists, i.e. the build container);
+    kind = "port": the oracle, a CPU restatement of the same path (oracle/st2_oracle.py)."""
+    from oracle import st2_oracle as O
+    steps = cfg["steps"]
+    tokens, lengths, noise, durations, ref_s = synthetic_inputs(1, 0)
+    g = torch.Generator().manual_seed(1)
+    step_noise = torch.randn(steps - 1, 1, 1, 256, generator=g)
+    sine_noise = torch.randn(1, int(AUDIO_S_PER_UTT * 24000), 9, generator=g)
+    rs = ref_s if cfg["multispeaker"] else None
+
+    def run_port():
+        O.inference(sds, man["config"], man["plbert"], tokens, lengths, noise, step_noise, sine_noise,
+                    diffusion_steps=steps, ref_s=rs, durations=durations)
+
+    kind, fn = "port", run_port
+    try:
+        from oracle import ref_harness as RH
+        if RH.reference_available():
+            fn = _reference_runner(RH, man, sds, cfg, tokens, lengths, noise, rs, durations)
+            kind = "reference"
+    except Exception as e:  # the reference needs its import stubs; fall back to the port and say so
+        log("reference harness unavailable (%s): timing the oracle port" % e)
+    ncpu = os.cpu_count() or 1
+    env = os.environ.get("ST2_CPU_THREADS")
+    sweep = [int(env)] if env else sorted({min(t, ncpu) for t in (8, 16, 32, 64)})
+    results = {}
+    t_start = time.time()
+    for th in sweep:
+        results[th] = _time_best(fn, th)
+        if time.time() - t_start > 60.0:  # keep the whole leg bounded
+            break
+    best_th = min(results, key=results.get)
+    best = results[best_th]
+    return {"value": AUDIO_S_PER_UTT / best, "unit": "audio-s/s", "cores": best_th, "kind": kind,
+            "host_cores": ncpu, "threads_tried": {str(k): round(v, 3) for k, v in results.items()},
+            "sample": "1 utterance x 10 s (100 phonemes, %d diffusion steps, %s decoder%s), best of 3 after 1 warm-up "
+                      "at the best of %s threads, %.2f s wall" % (steps, man["config"]["decoder"]["type"],
+                                                                   ", ref_s features" if rs is not None else "",
+                                                                   sorted(results), best)}
+
+
+def _reference_runner(RH, man, sds, cfg, tokens, lengths, noise, ref_s, durations):
+    """One utterance through the UNMODIFIED reference modules, following the notebooks' inference cell with forced
+    durations (same synthetic inputs and weights as the GPU run)."""
+    from oracle.make_golden import istftnet_decoder_override
+    ov = {"ljspeech": ("config.yml", None), "libritts": ("config_libritts.yml", None),
+          "libritts_istftnet": ("config_libritts.yml", istftnet_decoder_override())}[cfg["manifest"]]
+    model, args, rcfg = RH.build_reference_model(ov[0], overrides=ov[1], replace_keys=("decoder",) if ov[1] else ())
+    ref = RH.load_reference()
+    for k in KEYS:
+        model[k].load_state_dict(sds[k])
+    sampler = ref.sampler.DiffusionSampler(model.diffusion.diffusion, sampler=ref.sampler.ADPM2Sampler(),
+                                           sigma_schedule=ref.sampler.KarrasSchedule(sigma_min=0.0001, sigma_max=3.0,
+                                                                                     rho=9.0), clamp=False)
+    N = tokens.shape[1]
+    hifigan = man["config"]["decoder"]["type"] == "hifigan"
+
+    def run():
+        mask = torch.gt(torch.arange(N).unsqueeze(0) + 1, lengths.unsqueeze(1))
+        t_en = model.text_encoder(tokens, lengths, mask)
+        bert_dur = model.bert(tokens, attention_mask=(~mask).int())
+        d_en = model.bert_encoder(bert_dur).transpose(-1, -2)
+        kw = dict(embedding=bert_dur, embedding_scale=1, num_steps=cfg["steps"])
+        if ref_s is not None:
+            kw["features"] = ref_s
+        s_pred = sampler(noise, **kw).squeeze(1)
+        s, rf = s_pred[:, 128:], s_pred[:, :128]
+        if ref_s is not None:
+            rf = 0.3 * rf + 0.7 * ref_s[:, :128]
+            s = 0.7 * s + 0.3 * ref_s[:, 128:]
+        d = model.predictor.text_encoder(d_en, s, lengths, mask)
+        T = int(durations[0].sum())
+        aln = torch.zeros(N, T)
+        c = 0
+        for i in range(N):
+            aln[i, c:c + int(durations[0, i])] = 1
+            c += int(durations[0, i])
+        en = d.transpose(-1, -2) @ aln.unsqueeze(0)
+        asr = t_en @ aln.unsqueeze(0)
+        if hifigan:
+            en = torch.cat([en[:, :, :1], en[:, :, :-1]], dim=2)
+            asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
+        F0, Nn = model.predictor.F0Ntrain(en, s)
+        return model.decoder(asr, F0, Nn, rf.squeeze().unsqueeze(0))
+    return run
+
+
+def roofline(by_class):
+    """Per shape class of the split-f16 convs (HIP events around every launch on its launch stream inside the timed
+    region): `achieved` = algorithmic conv FLOPs (2*B*C_in*C_out*ks*L) / mean launch time; `peak` = dense f16 MFMA
+    peak / 3 products (see above), so `frac` is also (f16 MFMA FLOPs executed / s) / 2.5 PFLOP/s.  The headline object
+    describes the DOMINANT class (largest total time); `classes` lists every class above 2 % of the conv time.
+    `traffic` = HBM bytes per launch of the dominant class from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+    correction in MI355X_MICROARCH.md + WRITE_SIZE), read from the committed profiles/pmc_dominant.json; the HBM-side
+    view (algorithmic bytes / s vs 8 TB/s) is reported beside it."""
     peak = F16_MFMA_PEAK_TFLOPS / F16S_PRODUCTS
+    rows = []
+    total = sum(sum(v) for v in by_class.values()) or 1.0
+    for (ks, ci, co, L, b), durs in by_class.items():
+        flop = 2.0 * b * ci * co * ks * L
+        avg = sum(durs) / len(durs)
+        rows.append(dict(ks=ks, C_in=ci, C_out=co, L=L, B=b, launches=len(durs), avg_launch_ms=avg,
+                         total_ms=sum(durs), share=sum(durs) / total, algorithmic_flop_per_launch=flop,
+                         achieved=flop / (avg * 1e-3) / 1e12, frac=flop / (avg * 1e-3) / 1e12 / peak))
+    rows.sort(key=lambda r: -r["total_ms"])
+    if not rows:
+        return {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
+    dom = rows[0]
     # every launch reads x and writes y (fp32); every second one (convs2) also reads the residual; weights are L2 resident
-    alg_bytes = 2.5 * B * 128 * L_dom * 4
+    alg_bytes = 2.5 * dom["B"] * dom["C_out"] * dom["L"] * 4
     traffic, note = None, "no PMC summary committed"
     if os.path.exists(PMC_FILE):
         pm = json.load(open(PMC_FILE))
-        traffic, note = pm.get("hbm_bytes_per_launch"), pm.get("note")
-    return {"bound": "mfma", "kernel": "conv1d_xs_kernel_o3<11,16,4,1,4> (st2_conv1d_xs: C=128, L=48001, B=32, k=11 on "
-                                       "pre-activated split-f16 planes; bias/residual/statistics epilogue)",
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
+        if (pm.get("shape") or [11, 128, 128, 48001]) == [dom["ks"], dom["C_in"], dom["C_out"], dom["L"]]:
+            traffic, note = pm.get("hbm_bytes_per_launch"), pm.get("note")
+        else:
+            note = "the committed PMC summary is for another shape class"
+    return {"bound": "mfma",
+            "kernel": "st2_conv1d_xs ks=%d C=%d->%d L=%d B=%d (split-f16 MFMA conv on pre-activated planes; bias / "
+                      "residual / statistics epilogue)" % (dom["ks"], dom["C_in"], dom["C_out"], dom["L"], dom["B"]),
+            "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": traffic, "traffic_note": note,
             "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 products per fp32-class multiply",
-            "mfma_tflops_executed": (ach * F16S_PRODUCTS) if ach else None,
-            "launches_timed": len(durs), "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop,
+            "mfma_tflops_executed": dom["achieved"] * F16S_PRODUCTS,
+            "launches_timed": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+            "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
             "algorithmic_bytes_per_launch": alg_bytes,
-            "hbm_view": {"achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if durs else None, "peak_GBps": 8000.0}}
+            "hbm_view": {"achieved_GBps": alg_bytes / (dom["avg_launch_ms"] * 1e-3) / 1e9, "peak_GBps": 8000.0},
+            "classes": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+                        for r in rows if r["share"] >= 0.02]}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned_rank(rank, world, port, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.argv = argv
+    main()
 
 
 def main():
@@ -121,24 +262,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="issue every step on one stream (no front/decoder overlap)")
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
+                                                           "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
 
-    from _util import manifest
-    from styletts2_amd import _lib, models, ops, parallel, pipeline, synth
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one process per GPU, spawned here (the driver's torch.distributed.run
+        # launch sets WORLD_SIZE and takes the other branch)
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned_rank, args=(a.gpus, _free_port(), list(sys.argv)), nprocs=a.gpus, join=True)
+        return
+
+    from styletts2_amd import parallel
 
     rank, local_rank, world = parallel.init_distributed()
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    assert world == a.gpus, "world size %d != --gpus %d" % (world, a.gpus)
+    if a.dry_run:
+        parallel.barrier()
+        dt = parallel.max_over_ranks(0.001 * (rank + 1), torch.device("cpu"))
+        parallel.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": dt}), flush=True)
+        return
+
+    from _util import manifest
+    from styletts2_amd import _lib, models, ops, pipeline, synth
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.load()
+    cfg = CONFIGS[a.config]
+    longform = bool(cfg.get("longform"))
 
-    log("rank %d/%d on %s (%d host cores)" % (rank, world, torch.cuda.get_device_name(local_rank), os.cpu_count()))
-    man = manifest("ljspeech")
+    log("rank %d/%d on %s (%d host cores), config %s" % (rank, world, torch.cuda.get_device_name(local_rank),
+                                                          os.cpu_count(), a.config))
+    man = manifest(cfg["manifest"])
     model = build(man)
     if rank == 0:  # seeded random weights of the reference architecture, generated once ...
         for i, k in enumerate(KEYS):
@@ -147,33 +311,55 @@ def main():
     for k in KEYS:
         model[k].eval().to(dev)
     nbytes = parallel.broadcast_model(model, KEYS, src=0)  # ... and broadcast over RCCL/xGMI (no-op for N=1)
-    sampler = models.make_sampler(model)
+    sampler = models.make_sampler(model, graph=longform)
     log("weights ready (%d B broadcast)" % nbytes)
 
-    B = PER_GPU_BATCH
-    tokens, lengths, noise, durations = synthetic_inputs(B, 1000 + rank)
+    steps_d = cfg["steps"]
+    B = 1 if longform else PER_GPU_BATCH
+    tokens, lengths, noise, durations, ref_s = synthetic_inputs(PER_GPU_BATCH, 1000 + rank)
     tokens, noise = tokens.to(dev), noise.to(dev)
+    ref_s = ref_s.to(dev) if cfg["multispeaker"] else None
 
     # Two HIP streams: the front of step k+1 (text encoder, PL-BERT, diffusion sampler, duration / prosody predictors:
     # latency-bound small kernels) is issued on `front` and overlaps the decoder + vocoder of step k on the main
     # stream.  Every step is still one complete pass tokens -> waveform over the batch; --single-stream turns it off.
     # the front stream gets the higher priority: its small kernels then take CU slots as the decoder's workgroups
     # retire instead of queueing behind them (--front-priority 0 = equal priorities)
-    front = None if a.single_stream else torch.cuda.Stream(dev, priority=a.front_priority)
+    front = None if (a.single_stream or longform) else torch.cuda.Stream(dev, priority=a.front_priority)
     if front is not None:
         front.wait_stream(torch.cuda.current_stream(dev))
 
-    def step():
-        return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=DIFFUSION_STEPS,
-                                  embedding_scale=1.0, durations=durations, front_stream=front)
+    first_chunk_ms = []
+    if longform:
+        sents = [tokens[i % PER_GPU_BATCH, :n].clone() for i, n in enumerate(LONGFORM_SENTENCES)]
+        durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
+        audio_s = sum(LONGFORM_SENTENCES) * FRAMES_PER_PHONEME * 600 / 24000.0
+
+        def step():
+            t_start = time.perf_counter()
+
+            def on_chunk(k, w):
+                if k == 0:
+                    w[-1].item()  # the first sentence's waveform has left the GPU queue: a streaming consumer has it
+                    first_chunk_ms.append((time.perf_counter() - t_start) * 1e3)
+            waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
+                                                durations=durs, overlap=not a.single_stream, bucket=16,
+                                                on_chunk=on_chunk)
+            return waves
+    else:
+        audio_s = B * AUDIO_S_PER_UTT
+
+        def step():
+            return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
+                                      embedding_scale=1.0, ref_s=ref_s, durations=durations, front_stream=front)
 
     for i in range(a.warmup):
         out = step()
         torch.cuda.synchronize()
         log("warm-up step %d done" % i)
-    # roofline leg: per-launch HIP events around the dominant kernel class (C=128, L=48001, k=11 resblock convs)
-    L_dom = N_PHONEMES * FRAMES_PER_PHONEME * 2 * 60 + 1
-    timer = ops.ConvTimer(ks=11, C_in=128, C_out=128, L_out=L_dom)
+    first_chunk_ms.clear()
+    # roofline leg: per-launch HIP events around every split-f16 conv launch, by shape class
+    timer = ops.ConvTimer()
     ops.set_conv_timer(timer)
     torch.cuda.synchronize()
     parallel.barrier()
@@ -186,32 +372,42 @@ def main():
     ops.set_conv_timer(None)
     dt = parallel.max_over_ranks(dt, dev)
     log("timed %d steps: %.1f ms/step" % (a.steps, dt / a.steps * 1e3))
-    assert out.shape == (B, 1, int(AUDIO_S_PER_UTT * 24000)) and bool(torch.isfinite(out).all())
+    if longform:
+        assert len(out) == len(LONGFORM_SENTENCES) and all(bool(torch.isfinite(w).all()) for w in out)
+        assert sum(w.numel() + 100 for w in out) == int(round(audio_s * 24000))  # 100 samples trimmed per sentence
+    else:
+        assert out.shape == (B, 1, int(AUDIO_S_PER_UTT * 24000)) and bool(torch.isfinite(out).all())
     ops.check_status()  # raises if a cooperative BiLSTM group timed out or a split-f16 operand left the f16 range
 
     if rank == 0:
-        durs = timer.durations_ms()
-        flop = 2.0 * B * 128 * 128 * 11 * L_dom
-        avg_ms = sum(durs) / max(len(durs), 1)
-        ach = flop / (avg_ms * 1e-3) / 1e12 if durs else None
+        by_class = timer.by_class()
+        roof = roofline(by_class)
+        roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
+        streams = "1" if (a.single_stream or (front is None and not longform)) else \
+            "2 (front of step k+1 overlaps decoder of step k)"
         res = {
             "metric": "audio-seconds/sec (RTF^-1) end-to-end, 10 s utterance batch",
-            "value": world * B * AUDIO_S_PER_UTT * a.steps / dt,
+            "value": world * audio_s * a.steps / dt,
             "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (convs/linears: f16 hi/lo split, 3 MFMA products, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "LJSpeech single-speaker, batch=32x10 s synthetic phoneme seqs per GPU, iSTFTNet, "
-                                   "5 diffusion steps, 1xMI355X per rank (BASELINE.json configs[1])",
+            "config": {"workload": cfg["workload"], "name": a.config, "baseline_config_index": cfg["baseline_config"],
                        "global_batch": world * B, "per_gpu_batch": B, "phonemes": N_PHONEMES,
-                       "audio_s_per_utt": AUDIO_S_PER_UTT, "parallelism": "utterance-sharded x%d" % world,
-                       "streams": "1" if front is None else "2 (front of step k+1 overlaps decoder of step k)",
-                       "weights": "seeded random init, broadcast %d B from rank 0" % nbytes},
-            "roofline": roofline(ach, durs, avg_ms, flop, B, L_dom),
+                       "diffusion_steps": steps_d, "decoder": man["config"]["decoder"]["type"],
+                       "audio_s_per_step_per_gpu": audio_s, "parallelism": "utterance-sharded x%d" % world,
+                       "streams": streams, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes},
+            "roofline": roof,
         }
+        if longform:
+            res["metric"] = "audio-seconds/sec (RTF^-1) end-to-end, long-form streaming passage"
+            res["config"]["sentences"] = LONGFORM_SENTENCES
+            res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
+                                                       "min": min(first_chunk_ms) if first_chunk_ms else None}
+            res["scaling"] = "weak"  # replicas only: a passage is sequential in its style vector
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(man, sds)
+            res["cpu_baseline"] = cpu_baseline(man, sds, cfg)
         print(json.dumps(res), flush=True)
 
 

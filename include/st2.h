@@ -302,7 +302,10 @@ int64_t st2_lstm_coop_scratch_bytes(int32_t B);
  * acquire fences around a monotonic counter (three round trips); 1 = sc1 atomic stores/loads + the counter.
  * A time-out also raises ST2_STATUS_LSTM_TIMEOUT in st2_status().  st2_lstm_bidir_coop refuses (returns non-zero)
  * when the device cannot hold the launch's workgroups co-resident (occupancy query): use st2_lstm_bidir then. */
-int st2_lstm_coop_set_exchange(int sc1);
+int st2_lstm_coop_set_exchange(int mode);
+/* Polls a waiting workgroup makes before it gives up (process-wide; <= 0 restores the default of 2^22, seconds).
+ * Tests set 1 to provoke ST2_STATUS_LSTM_TIMEOUT. */
+int st2_lstm_coop_set_spin_limit(int polls);
 int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
                         int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,
                         void* scratch, int64_t scratch_bytes, void* stream);

@@ -123,6 +123,71 @@ def frontend_vectors():
             "fe_dur": pred_dur.numpy(), "fe_F0": F0.numpy(), "fe_N": Nn.numpy()}
 
 
+def frontend_vectors_multispeaker_istftnet():
+    """BASELINE.json configs[3] (LibriTTS multispeaker + iSTFTNet decoder) through the reference modules, following
+    the `inference` cell of Demo/Inference_LibriTTS.ipynb: style mixing with the reference style, no +5 tail, and --
+    because decoder.type != "hifigan" -- no one-frame shift of en / asr."""
+    from oracle.make_golden import istftnet_decoder_override
+    model, args, cfg = RH.build_reference_model("config_libritts.yml", overrides=istftnet_decoder_override(),
+                                                replace_keys=("decoder",))
+    assert cfg["model_params"]["multispeaker"] and cfg["model_params"]["decoder"]["type"] == "istftnet"
+    ref = RH.load_reference()
+    for i, k in enumerate(KEYS):
+        synth.init_synthetic_(model[k], 10 + i)
+    N, steps, alpha, beta = 7, 3, 0.3, 0.7
+    g = torch.Generator().manual_seed(21)
+    tokens = torch.randint(1, 178, (1, N), generator=g)
+    tokens[:, 0] = 0
+    lengths = torch.LongTensor([N])
+    noise = torch.randn(1, 1, 256, generator=g)
+    step_noise = torch.randn(steps - 1, 1, 1, 256, generator=g)
+    ref_s = torch.randn(1, 256, generator=g)
+    sampler = ref.sampler.DiffusionSampler(model.diffusion.diffusion, sampler=ref.sampler.ADPM2Sampler(),
+                                           sigma_schedule=ref.sampler.KarrasSchedule(sigma_min=0.0001, sigma_max=3.0,
+                                                                                     rho=9.0), clamp=False)
+    with torch.no_grad():
+        mask = torch.gt(torch.arange(N).unsqueeze(0) + 1, lengths.unsqueeze(1))
+        t_en = model.text_encoder(tokens, lengths, mask)
+        bert_dur = model.bert(tokens, attention_mask=(~mask).int())
+        d_en = model.bert_encoder(bert_dur).transpose(-1, -2)
+        with replay_randn_like({(1, 1, 256): list(step_noise)}):
+            s_pred = sampler(noise, embedding=bert_dur, embedding_scale=1, features=ref_s, num_steps=steps).squeeze(1)
+        s = beta * s_pred[:, 128:] + (1 - beta) * ref_s[:, 128:]
+        rf = alpha * s_pred[:, :128] + (1 - alpha) * ref_s[:, :128]
+        d = model.predictor.text_encoder(d_en, s, lengths, mask)
+        x, _ = model.predictor.lstm(d)
+        duration = torch.sigmoid(model.predictor.duration_proj(x)).sum(axis=-1)
+        pred_dur = torch.round(duration.squeeze()).clamp(min=1)
+        T = int(pred_dur.sum())
+        aln = torch.zeros(N, T)
+        c = 0
+        for i in range(N):
+            aln[i, c:c + int(pred_dur[i])] = 1
+            c += int(pred_dur[i])
+        en = d.transpose(-1, -2) @ aln.unsqueeze(0)
+        F0, Nn = model.predictor.F0Ntrain(en, s)
+        asr = t_en @ aln.unsqueeze(0)
+        sine = torch.randn(1, 600 * T, 9, generator=g)
+        taps = {}
+        dec = model.decoder
+        orig = dec.generator.stft.transform
+
+        def tr(x):
+            a, b = orig(x)
+            taps["har"] = torch.cat([a, b], 1)
+            return a, b
+        dec.generator.stft.transform = tr
+        with replay_randn_like({sine.shape: [sine]}):
+            wave = dec(asr, F0, Nn, rf.squeeze().unsqueeze(0))
+    # the 600*T-sample waveform is stored as per-frame RMS (T values) plus its first / last 2400 samples: enough to pin
+    # the decoder call (same architecture as the LJSpeech decoder, pinned in full by dec_ljspeech_*) at fixture size
+    w = wave.reshape(-1)
+    return {"ms_s_pred": s_pred.numpy(), "ms_ref": rf.numpy(), "ms_dur": pred_dur.numpy(), "ms_F0": F0.numpy(),
+            "ms_N": Nn.numpy(), "ms_asr_sum": asr.sum(dim=1).numpy(), "ms_wave_head": w[:2400].numpy(),
+            "ms_wave_tail": w[-2400:].numpy(), "ms_wave_frame_rms": w.reshape(T, 600).pow(2).mean(dim=1).sqrt().numpy(),
+            "ms_har_mag_mean": taps["har"][:, :11].mean(dim=2).numpy()}
+
+
 def main():
     vec = {}
     vec.update(decoder_vectors("ljspeech", "config.yml"))
@@ -130,6 +195,7 @@ def main():
     vec.update(sampler_vectors("ljspeech", "config.yml"))
     vec.update(sampler_vectors("libritts", "config_libritts.yml"))
     vec.update(frontend_vectors())
+    vec.update(frontend_vectors_multispeaker_istftnet())
     path = os.path.join(GOLDEN, "reference_vectors.npz")
     np.savez_compressed(path, **{k: np.asarray(v, dtype=np.float32) for k, v in vec.items()})
     print(path, os.path.getsize(path), sorted((k, v.shape) for k, v in vec.items()))

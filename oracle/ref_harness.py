@@ -127,8 +127,10 @@ def recursive_munch(d):
     return d
 
 
-def build_reference_model(config_name="config.yml", overrides=None, seed=0):
-    """build_model(...) from the reference (models.py:614-694) with a random-init PL-BERT."""
+def build_reference_model(config_name="config.yml", overrides=None, seed=0, replace_keys=()):
+    """build_model(...) from the reference (models.py:614-694) with a random-init PL-BERT.  `overrides` is merged into
+    model_params key by key; keys named in `replace_keys` are REPLACED wholesale instead (a decoder block of another
+    type must not inherit the old type's list lengths)."""
     import torch
     from transformers import AlbertConfig
     ref = load_reference()
@@ -141,7 +143,9 @@ def build_reference_model(config_name="config.yml", overrides=None, seed=0):
                     merge(d[k], v)
                 else:
                     d[k] = v
-        merge(mp, overrides)
+        for k in replace_keys:
+            mp[k] = overrides[k]
+        merge(mp, {k: v for k, v in overrides.items() if k not in replace_keys})
     args = recursive_munch(mp)
     torch.manual_seed(seed)
     bert = ref.CustomAlbert(AlbertConfig(**plbert_config()))

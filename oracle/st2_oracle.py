@@ -430,12 +430,11 @@ def plbert(sd, plbert_params, tokens, attention_mask):
         return m(tokens, attention_mask=attention_mask).last_hidden_state
 
 
-def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_noise, diffusion_steps=5,
-              embedding_scale=1.0, ref_s=None, alpha=0.3, beta=0.7, durations=None, taps=None, s_prev=None, t=0.7,
-              lj_tail=None):
-    """The notebook `inference` cell (Demo/Inference_LJSpeech.ipynb:268-315; Demo/Inference_LibriTTS.ipynb:258-325),
-    batched over equal-length utterances.  `sds` maps module name -> reference-layout state_dict; cfg =
-    config['model_params']."""
+def front(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, diffusion_steps=5, embedding_scale=1.0,
+          ref_s=None, alpha=0.3, beta=0.7, durations=None, taps=None, s_prev=None, t=0.7, lj_tail=None):
+    """Everything the notebook `inference` cell does in front of the decoder call
+    (Demo/Inference_LJSpeech.ipynb:268-311; Demo/Inference_LibriTTS.ipynb:258-322): returns the decoder's inputs
+    (asr, F0, N, ref) and fills `taps`.  Batched over utterances of equal frame count."""
     B, N = tokens.shape
     mask = torch.gt(torch.arange(N).unsqueeze(0).expand(B, -1) + 1, lengths.unsqueeze(1))  # utils.py:42-46
     multispeaker = ref_s is not None
@@ -468,7 +467,9 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
         durations = torch.round(dur).clamp(min=1).long().masked_fill(mask, 0)
         if (not multispeaker) if lj_tail is None else lj_tail:
             durations[torch.arange(B), lengths - 1] += 5  # ipynb:301 `pred_dur[-1] += 5` of each utterance
-    T = int(durations[0].sum())
+    tot = durations.sum(dim=1)
+    assert bool((tot == tot[0]).all()), "oracle.front batches utterances of equal frame count only: %s" % tot.tolist()
+    T = int(tot[0])
     aln = torch.zeros(B, N, T)
     for b in range(B):  # the notebook's one-hot alignment loop, ipynb:303-307
         c = 0
@@ -482,8 +483,21 @@ def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_
         asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
     F0_pred, N_pred = f0n_train(psd, en, s)
     if taps is not None:
-        taps.update(s_pred=s_pred, durations=durations, F0=F0_pred, N=N_pred, asr=asr, en=en, t_en=t_en, d=d,
-                    bert_dur=bert_dur)
+        taps.update(s_pred=s_pred, durations=durations, F0=F0_pred, N=N_pred, asr=asr,
+                    en=en, t_en=t_en, d=d, bert_dur=bert_dur)
+    return asr, F0_pred, N_pred, ref
+
+
+def inference(sds, cfg, plbert_params, tokens, lengths, noise, step_noise, sine_noise, diffusion_steps=5,
+              embedding_scale=1.0, ref_s=None, alpha=0.3, beta=0.7, durations=None, taps=None, s_prev=None, t=0.7,
+              lj_tail=None):
+    """The notebook `inference` cell (Demo/Inference_LJSpeech.ipynb:268-315; Demo/Inference_LibriTTS.ipynb:258-325),
+    batched over equal-length utterances.  `sds` maps module name -> reference-layout state_dict; cfg =
+    config['model_params']."""
+    asr, F0_pred, N_pred, ref = front(sds, cfg, plbert_params, tokens, lengths, noise, step_noise,
+                                      diffusion_steps=diffusion_steps, embedding_scale=embedding_scale, ref_s=ref_s,
+                                      alpha=alpha, beta=beta, durations=durations, taps=taps, s_prev=s_prev, t=t,
+                                      lj_tail=lj_tail)
     return decoder(sds["decoder"], cfg["decoder"], asr, F0_pred, N_pred, ref, noise=sine_noise, taps=taps)
 
 

@@ -29,7 +29,7 @@ namespace {
 constexpr int H = 256;
 constexpr int NSL = 8;         // workgroups (hidden-unit slices) per group
 constexpr int UNITS = H / NSL;  // 32 hidden units per workgroup
-constexpr int SPIN_LIMIT = 1 << 22;
+constexpr int SPIN_LIMIT_DEFAULT = 1 << 22;  // polls before a group gives up (~seconds); st2_lstm_coop_set_spin_limit
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
                                                         int* __restrict__ status,   // [0] error flag
                                                         int* __restrict__ counters,  // [groups]
                                                         float* __restrict__ hx,     // [groups][2][U][H] (granules: x2)
-                                                        int* gstatus) {              // sticky status word (may be null)
+                                                        int* gstatus,                // sticky status word (may be null)
+                                                        int spin_limit) {
   constexpr bool SC1 = XCH == 1;
   constexpr bool GRAN = XCH == 2;
   __shared__ __attribute__((aligned(16))) float hs[U][H];
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
           ok &= (unsigned)(g >> 32) == (unsigned)(s + 1);
         }
         if (__all(ok)) break;
-        if (++spins > SPIN_LIMIT) {  // wave-uniform
+        if (++spins > spin_limit) {  // wave-uniform
           fail = true;
           break;
         }
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
       const int target = NSL * (s + 1);
       int spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (++spins > spin_limit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           st2_raise_status(gstatus, ST2_STATUS_LSTM_TIMEOUT);
           s_fail = 1;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
   }
 }
 
+int g_spin_limit = SPIN_LIMIT_DEFAULT;
 int g_xch = 2;  // st2_lstm_coop_set_exchange(): 0 fences + counter (8.1 us/step), 1 sc1 + counter (9.2 us), 2 granules
 
 size_t scratch_head(int groups) { return ((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256; }
@@ -286,7 +288,7 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
     return 1;
   }
   hipLaunchKernelGGL((lstm_coop_kernel<U, XCH>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
-                     B, N, Y, y_bs, y_cs, status, counters, hx, st2_status_device_ptr());
+                     B, N, Y, y_bs, y_cs, status, counters, hx, st2_status_device_ptr(), g_spin_limit);
   ST2_CHECK_LAUNCH("st2_lstm_bidir_coop");
   return 0;
 }
@@ -314,6 +316,11 @@ extern "C" int st2_lstm_coop_set_exchange(int mode) {
     return 1;
   }
   g_xch = mode;
+  return 0;
+}
+
+extern "C" int st2_lstm_coop_set_spin_limit(int polls) {
+  g_spin_limit = polls > 0 ? polls : SPIN_LIMIT_DEFAULT;
   return 0;
 }
 

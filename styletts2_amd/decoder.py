@@ -337,6 +337,10 @@ class Decoder(nn.Module):
         self._pk = None
         return super().load_state_dict(W.strip_module_prefix(state_dict), *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):  # also reached when a PARENT module's load_state_dict() recurses here
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
     def refresh(self):
         """Call after mutating parameters in place."""
         self._pk = None

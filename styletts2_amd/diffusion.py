@@ -157,21 +157,32 @@ class GraphedSampler(nn.Module):
 
     @torch.no_grad()
     def forward(self, noise, num_steps=None, step_noise=None, embedding=None, features=None, embedding_scale=1.0,
-                taps=None, **kwargs):
+                taps=None, lengths=None, **kwargs):
         num_steps = num_steps if num_steps is not None else self.sampler.num_steps
         if (not noise.is_cuda) or taps is not None or kwargs or embedding is None:
+            if lengths is not None:
+                kwargs["lengths"] = lengths
             return self.sampler(noise, num_steps=num_steps, step_noise=step_noise, embedding=embedding,
                                 features=features, embedding_scale=embedding_scale, taps=taps, **kwargs)
         B, N = embedding.shape[0], embedding.shape[1]
         if step_noise is None:
             step_noise = torch.randn((num_steps - 1,) + tuple(noise.shape), device=noise.device, dtype=torch.float32)
-        key = (noise.device.index, B, N, int(num_steps), float(embedding_scale), features is not None)
+        key = (noise.device.index, B, N, int(num_steps), float(embedding_scale), features is not None,
+               lengths is not None)
         g = self._graphs.get(key)
+        net = self.sampler.diffusion.net
+        if g is not None and g["pk"] is not getattr(net, "_pk", None):
+            # the denoiser's packed weights were rebuilt (load_state_dict / .to()): every recorded graph still points
+            # at the old, freed pack
+            self._graphs.clear()
+            g = None
         if g is None:
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
-            g = self._capture(noise, num_steps, step_noise, embedding, features, embedding_scale)
+            g = self._capture(noise, num_steps, step_noise, embedding, features, embedding_scale, lengths)
             self._graphs[key] = g
+        if lengths is not None:
+            g["lengths"].copy_(lengths)
         g["noise"].copy_(noise)
         g["step_noise"].copy_(step_noise)
         g["embedding"].copy_(embedding)
@@ -180,16 +191,19 @@ class GraphedSampler(nn.Module):
         g["graph"].replay()
         return g["out"].clone()
 
-    def _capture(self, noise, num_steps, step_noise, embedding, features, embedding_scale):
+    def _capture(self, noise, num_steps, step_noise, embedding, features, embedding_scale, lengths=None):
         st = dict(noise=noise.detach().float().clone(), step_noise=step_noise.detach().float().clone(),
                   embedding=embedding.detach().float().clone(),
-                  features=None if features is None else features.detach().float().clone())
+                  features=None if features is None else features.detach().float().clone(),
+                  lengths=None if lengths is None else lengths.detach().to(torch.int32).to(noise.device).clone())
 
         def run():
             kw = dict(num_steps=num_steps, step_noise=st["step_noise"], embedding=st["embedding"],
                       embedding_scale=embedding_scale)
             if st["features"] is not None:
                 kw["features"] = st["features"]
+            if st["lengths"] is not None:
+                kw["lengths"] = st["lengths"]  # int32 on the device: read by the kernels, never by the host
             return self.sampler(st["noise"], **kw)
 
         cur = torch.cuda.current_stream(noise.device)
@@ -203,6 +217,7 @@ class GraphedSampler(nn.Module):
         with torch.cuda.graph(graph):
             st["out"] = run()
         st["graph"] = graph
+        st["pk"] = self.sampler.diffusion.net._pk  # identity of the packed weights the graph's kernels read
         return st
 
 
@@ -287,6 +302,10 @@ class _Transformer(nn.Module):
         self._pk = None
         return super().load_state_dict(W.strip_module_prefix(state_dict), *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):  # also reached when a PARENT module's load_state_dict() recurses here
+        self._pk = None                        # (models.load_checkpoint loads `diffusion` at the shell level)
+        return super()._load_from_state_dict(*a, **k)
+
     def refresh(self):
         self._pk = None
 
@@ -341,8 +360,12 @@ class _Transformer(nn.Module):
         s.pk, s.B, s.N, s.scale = pk, B, N, float(embedding_scale)
         s.key_len = None
         if lengths is not None:
-            assert lengths.numel() == B and int(lengths.min()) >= 1 and int(lengths.max()) <= N
-            s.key_len = lengths.to(torch.int32).to(dev).contiguous()
+            assert lengths.numel() == B
+            if lengths.dtype == torch.int32 and lengths.device == dev:
+                s.key_len = lengths.contiguous()  # used as is: no host read (legal under hipGraph capture)
+            else:
+                assert int(lengths.min()) >= 1 and int(lengths.max()) <= N
+                s.key_len = lengths.to(torch.int32).to(dev).contiguous()
         embedding = embedding.float()
         fixed = pk.fixed[:N].unsqueeze(0).expand(B, -1, -1)
         if embedding_mask_proba > 0.0:  # modules.py:412-416 (classifier-free-guidance dropout; off at inference)

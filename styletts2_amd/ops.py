@@ -21,18 +21,26 @@ def _stream():
 
 
 class ConvTimer:
-    """Optional per-launch HIP-event timing of one st2_conv1d shape class (bench.py's roofline leg).  Events are
-    recorded on the launch stream around matching launches only and resolved after the caller synchronises."""
+    """Optional per-launch HIP-event timing of the split-f16 conv launches (bench.py's roofline leg).  Events are
+    recorded on the launch stream around every st2_conv1d_xs / st2_conv1d_f16s launch (or only those of one shape
+    class when `key` = (ks, C_in, C_out, L_out) is given) and resolved after the caller synchronises."""
 
-    def __init__(self, ks, C_in, C_out, L_out):
-        self.key = (ks, C_in, C_out, L_out)
-        self.pairs = []
+    def __init__(self, ks=None, C_in=None, C_out=None, L_out=None):
+        self.key = None if ks is None else (ks, C_in, C_out, L_out)
+        self.pairs = []   # (class, start event, end event); class = (ks, C_in, C_out, L_out, B)
 
     def matches(self, d):
-        return (d.ks, d.C_in, d.C_out, d.L_out) == self.key
+        return self.key is None or (d.ks, d.C_in, d.C_out, d.L_out) == self.key
 
     def durations_ms(self):
-        return [a.elapsed_time(b) for a, b in self.pairs]
+        return [a.elapsed_time(b) for _, a, b in self.pairs]
+
+    def by_class(self):
+        """{(ks, C_in, C_out, L_out, B): [launch durations in ms]}"""
+        out = {}
+        for cls, a, b in self.pairs:
+            out.setdefault(cls, []).append(a.elapsed_time(b))
+        return out
 
 
 _conv_timer = None
@@ -233,7 +241,7 @@ def _launch_conv(fn, fname, d):
         e0.record()
         _lib.check(fn(C.byref(d), _stream()), fname)
         e1.record()
-        _conv_timer.pairs.append((e0, e1))
+        _conv_timer.pairs.append(((d.ks, d.C_in, d.C_out, d.L_out, d.B), e0, e1))
     else:
         _lib.check(fn(C.byref(d), _stream()), fname)
 

@@ -13,7 +13,12 @@ Differences from the notebooks, all host-side:
 import torch
 
 from . import ops
-from .utils import length_to_mask
+
+
+def _pad_mask(lengths, N):
+    """utils.length_to_mask (reference utils.py:42-46: True where position >= length) at a fixed width N: a bucketed
+    batch may be wider than its longest utterance."""
+    return torch.arange(N).unsqueeze(0) >= lengths.reshape(-1, 1)
 
 
 def expand_by_durations(x, dur, T):
@@ -46,7 +51,7 @@ def predict_durations(model, d, lj_tail=False, input_lengths=None):
     duration = torch.sigmoid(duration).sum(dim=-1)
     pred_dur = torch.round(duration).clamp(min=1).long()
     if ragged:
-        pad = length_to_mask(input_lengths).to(d.device)
+        pad = _pad_mask(input_lengths, N).to(d.device)
         pred_dur = pred_dur.masked_fill(pad, 0)
     if lj_tail:  # LJSpeech notebook only (ipynb:301): pred_dur[-1] += 5
         last = (input_lengths.to(d.device) - 1) if ragged else torch.full((B,), N - 1, device=d.device)
@@ -75,7 +80,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     if input_lengths is None:
         input_lengths = torch.full((B,), N, dtype=torch.long)
     input_lengths = input_lengths.detach().cpu().long()
-    text_mask = length_to_mask(input_lengths).to(dev)
+    text_mask = _pad_mask(input_lengths, N).to(dev)
     ragged_n = not bool((input_lengths == N).all())
     multispeaker = ref_s is not None
     hifigan = model.decoder.kind == "hifigan"
@@ -92,7 +97,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     if multispeaker:
         kw["features"] = ref_s
     if ragged_n:  # the denoiser attends over / averages each utterance's own tokens only (the notebooks run B = 1)
-        kw["lengths"] = input_lengths
+        kw["lengths"] = input_lengths.to(torch.int32).to(dev)
     s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
     if taps is not None:
         taps["s_pred"] = s_pred
@@ -200,7 +205,7 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
 @torch.no_grad()
 def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, t=0.7, diffusion_steps=5,
                     embedding_scale=1.0, noises=None, step_noises=None, sine_noises=None, durations=None, trim=None,
-                    overlap=True, on_chunk=None):
+                    overlap=True, on_chunk=None, bucket=0):
     """Long-form synthesis (BASELINE.json configs[4]; Demo/Inference_LibriTTS.ipynb LFinference + its driver loop,
     Demo/Inference_LJSpeech.ipynb "Long-form generation"): `sentences` is a list of token tensors [N_i] (id 0
     prepended); each sentence is synthesised with the previous sentence's mixed style carried over
@@ -213,6 +218,11 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     an event hands the decoder inputs over.  Returns (list of waveforms [600*T_i - trim], final style [1, 256]);
     `on_chunk(k, wave)` is called per sentence for streaming consumers.  `trim` samples are dropped from every
     sentence's end as the notebooks do ("weird pulse at the end of the model": 100 multi-speaker, 0 single-speaker).
+
+    `bucket` > 0: every sentence's token row is right-padded to a multiple of `bucket` (the pad tokens are masked
+    everywhere: packed-sequence BiLSTMs, key-padded attention, length-aware mean -- results are those of the un-padded
+    sentence), so that a `GraphedSampler` (models.make_sampler(graph=True)) replays ONE captured hipGraph per bucket
+    instead of capturing one per sentence length.
     """
     dev = sentences[0].device
     multispeaker = ref_s is not None
@@ -225,12 +235,20 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
     s_prev, waves = None, []
     for k, tok in enumerate(sentences):
+        n = tok.numel()
         tokens = tok.reshape(1, -1)
+        dur_k = durations[k] if durations is not None else None
+        lengths = None
+        if bucket and n % bucket:
+            npad = (n + bucket - 1) // bucket * bucket
+            tokens = torch.nn.functional.pad(tokens, (0, npad - n))  # token id 0 = pad (text_utils / ipynb:277)
+            lengths = torch.LongTensor([n])
+            if dur_k is not None:
+                dur_k = torch.nn.functional.pad(dur_k.reshape(1, -1), (0, npad - n))  # pad tokens get no frames
         noise = noises[k] if noises is not None else None
-        kw = dict(noise=noise, diffusion_steps=diffusion_steps, embedding_scale=embedding_scale, ref_s=ref_s,
-                  alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
-                  step_noise=step_noises[k] if step_noises is not None else None,
-                  durations=durations[k] if durations is not None else None)
+        kw = dict(input_lengths=lengths, noise=noise, diffusion_steps=diffusion_steps, embedding_scale=embedding_scale,
+                  ref_s=ref_s, alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
+                  step_noise=step_noises[k] if step_noises is not None else None, durations=dur_k)
         if use_streams:
             with torch.cuda.stream(side):
                 p = prepare(model, sampler, tokens, **kw)

@@ -45,6 +45,10 @@ class EngineLSTM(nn.LSTM):
         self._pk = None
         return super().load_state_dict(state_dict, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):  # also reached when a PARENT module's load_state_dict() recurses here
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
     def _packed(self, device):
         if self._pk is None or self._pk.device != device:
             d = lambda t: t.detach().float().contiguous().to(device)
@@ -93,6 +97,10 @@ class _PackedCache:
     def load_state_dict(self, state_dict, *a, **k):
         self._pk = None
         return super().load_state_dict(W.strip_module_prefix(state_dict), *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):  # also reached when a PARENT module's load_state_dict() recurses here
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
 
     def refresh(self):
         self._pk = None
@@ -273,6 +281,10 @@ def build_plbert(plbert_params):
         def load_state_dict(self, state_dict, *a, **k):
             self._pk = None
             return super().load_state_dict(state_dict, *a, **k)
+
+        def _load_from_state_dict(self, *a, **k):
+            self._pk = None
+            return super()._load_from_state_dict(*a, **k)
 
         def refresh(self):
             self._pk = None

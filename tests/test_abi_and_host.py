@@ -87,3 +87,43 @@ def test_plbert_has_no_cpu_fallback():
     ids = torch.zeros(1, 5, dtype=torch.long)
     with pytest.raises(St2Error):
         bert(ids, attention_mask=torch.ones(1, 5, dtype=torch.int32))
+
+
+def test_xs_conv_hot_builds_do_not_spill(tmp_path):
+    """The 3-workgroups-per-CU builds of the dominant conv family (conv1d_xs_kernel_o3, <= 168 VGPRs) must hold
+    their epilogues in registers: the gfx950 code objects' metadata reports 0 spilled VGPRs and no private (scratch)
+    segment for every one of them, and the disassembly contains no scratch_ instruction."""
+    import shutil
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(tools, "llvm-objdump"), os.path.join(tools, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM binutils not installed")
+    objs = [os.path.join(ROOT, "styletts2_amd", "csrc", "build", "st2_conv1d_xs_k%d.o" % i) for i in range(3)]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("objects not built (run __graft_entry__.build())")
+    seen = 0
+    for o in objs:
+        local = shutil.copy(o, tmp_path)
+        subprocess.check_call([objdump, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in os.listdir(tmp_path) if f.startswith(os.path.basename(o)) and "gfx950" in f]
+        assert co, "no gfx950 code object in %s" % o
+        co = os.path.join(tmp_path, co[0])
+        notes = subprocess.check_output([readelf, "--notes", co], text=True)
+        kernels = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)(?:.|\n)*?\.vgpr_count:\s+(\d+)"
+                             r"\n\s+\.vgpr_spill_count:\s+(\d+)", notes)
+        for name, priv, vgpr, spill in kernels:
+            if "conv1d_xs_kernel_o3" not in name:
+                continue
+            seen += 1
+            assert int(spill) == 0 and int(priv) == 0, "%s spills %s VGPRs (%s B scratch)" % (name, spill, priv)
+            assert int(vgpr) <= 168, "%s uses %s VGPRs: 2 workgroups per CU, not 3" % (name, vgpr)
+        dis = subprocess.check_output([objdump, "-d", co], text=True)
+        in_o3 = False
+        for line in dis.splitlines():
+            if line.endswith(">:"):
+                in_o3 = "conv1d_xs_kernel_o3" in line
+            elif in_o3:
+                assert "scratch_" not in line, line
+        os.remove(co)
+    assert seen >= 9, "expected the o3 builds of every kernel size, saw %d" % seen

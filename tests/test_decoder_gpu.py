@@ -59,22 +59,34 @@ def test_harmonic_source_taps(tag):
 
 
 def test_end_to_end_raw_and_flip_masked_istftnet():
-    """End-to-end without injection.  Reported both raw and with phase-flip frames masked: the reference itself
-    moves by ~3e-3 waveform RMS between batched and single execution because of those flips,
-    so the raw figure is bounded loosely and the masked one at the 1e-4 bar."""
+    """End-to-end without injection.  The generator takes torch.angle of the harmonic STFT as a
+    network INPUT; that value is ill-conditioned wherever it sits at +-pi (a 1e-8 change flips it by 2 pi) or the bin
+    is empty (|X| ~ 0: any angle), and the reference itself moves by ~3e-3 waveform RMS between batched and single
+    execution because of it.  So: raw RMS bounded loosely, and the FLIP-MASKED run -- the engine's
+    own harmonic features everywhere except the ill-conditioned entries (phase differing by > 1e-3 rad from the
+    oracle's), which take the oracle's value -- held to the 1e-4 bar."""
     dc, dec, sd, (asr, F0, N, s, noise) = _setup("ljspeech", 2, 20)
     to, te = {}, {}
     ref = O.decoder(sd, dc, asr, F0, N, s, noise=noise, taps=to)
     dec = dec.to(DEV)
-    out = dec(asr.to(DEV), F0.to(DEV), N.to(DEV), s.to(DEV), noise=noise.to(DEV), taps=te).cpu()
+    args = (asr.to(DEV), F0.to(DEV), N.to(DEV), s.to(DEV))
+    out = dec(*args, noise=noise.to(DEV), taps=te).cpu()
     nb = dc["gen_istft_n_fft"] // 2 + 1
-    flips = ((te["har"].cpu()[:, nb:] - to["har"][:, nb:]).abs() > 1.0).any(dim=1)  # [B, M]
+    har_e, har_o = te["har"].cpu(), to["har"]
+    assert (har_e[:, :nb] - har_o[:, :nb]).abs().max().item() < 2e-6     # magnitudes agree everywhere
+    ill = torch.zeros_like(har_o, dtype=torch.bool)
+    ill[:, nb:] = (har_e[:, nb:] - har_o[:, nb:]).abs() > 1e-3
+    flips = ((har_e[:, nb:] - har_o[:, nb:]).abs() > 1.0).any(dim=1)  # [B, M]
     raw = rms(out - ref)
-    print("e2e raw RMS %g, flip frames %d of %d" % (raw, int(flips.sum()), flips.numel()))
+    print("e2e raw RMS %g, flip frames %d of %d, ill-conditioned phase entries %d of %d" % (
+        raw, int(flips.sum()), flips.numel(), int(ill.sum()), ill[:, nb:].numel()))
     assert flips.float().mean().item() < 0.01, "harmonic-STFT phase flips should be rare"
+    assert ill[:, nb:].float().mean().item() < 0.01, "ill-conditioned phase entries should be rare"
     assert raw < 2e-2
-    if not flips.any():
-        assert raw < WAVE_RMS_TOL
+    masked = dec(*args, noise=noise.to(DEV), har=torch.where(ill, har_o, har_e).to(DEV)).cpu()
+    m = rms(masked - ref)
+    assert m < WAVE_RMS_TOL, "flip-masked end-to-end RMS %g" % m
+    assert mel_l1(masked, ref) < MEL_L1_TOL
 
 
 def test_decoder_is_deterministic_and_rejects_training_mode():

@@ -62,3 +62,35 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _bench_dry_run(cmd):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line, got %r" % out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_spawns_n_ranks():
+    """`python bench.py --gpus N` (how the driver may call it) must run N ranks, not one: with no torch.distributed.run
+    environment the script spawns one process per GPU itself; --dry-run exercises launch, rendezvous (gloo here), barrier
+    and the max-over-ranks reduction without compute."""
+    import sys
+    res = _bench_dry_run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"])
+    assert res["n_gpus"] == 2 and abs(res["max_over_ranks"] - 0.002) < 1e-9  # rank 1's value won the MAX reduction
+
+
+def test_bench_under_torch_distributed_run():
+    import sys
+    res = _bench_dry_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
+                          "--dry-run"])
+    assert res["n_gpus"] == 2

@@ -23,7 +23,8 @@ def _model(tag):
     return man, model, sds
 
 
-@pytest.mark.parametrize("tag,ragged", [("ljspeech", False), ("libritts", False), ("ljspeech", True)])
+@pytest.mark.parametrize("tag,ragged", [("ljspeech", False), ("libritts", False), ("ljspeech", True),
+                                        ("libritts_istftnet", False), ("libritts_istftnet", True)])
 def test_text_to_waveform_taps(tag, ragged):
     man, model, sds = _model(tag)
     g = torch.Generator().manual_seed(0)
@@ -62,6 +63,130 @@ def test_text_to_waveform_taps(tag, ragged):
     assert rms(wave.cpu() - ref) < WAVE_RMS_TOL
     if man["config"]["decoder"]["type"] == "hifigan":  # no ill-conditioned STFT-phase input: true end-to-end bar
         assert rms(out.cpu() - ref) < WAVE_RMS_TOL
+
+
+@pytest.mark.parametrize("tag", ["ljspeech", "libritts", "libritts_istftnet"])
+def test_predicted_durations_are_bit_exact(tag):
+    """The path's integer output (row a14): duration LSTM -> Linear 512->50 -> sum of sigmoids -> round -> clamp(min=1)
+    (Demo/Inference_LJSpeech.ipynb:296-301; +5 tail frames on the last phoneme in the LJSpeech flow only), B = 4
+    utterances of N = 100 phonemes on the engine vs the oracle run one utterance at a time as the notebooks do:
+    torch.equal, no tolerance.  The frame counts differ between utterances, so this also exercises the per-frame-count
+    grouping of `prepare`."""
+    man, model, sds = _model(tag)
+    multi = man["config"]["multispeaker"]
+    g = torch.Generator().manual_seed(101)
+    B, N, steps = 4, 100, 5
+    tokens = torch.randint(1, 178, (B, N), generator=g)
+    tokens[:, 0] = 0
+    lengths = torch.full((B,), N, dtype=torch.long)
+    noise = torch.randn(B, 1, 256, generator=g)
+    step_noise = torch.randn(steps - 1, B, 1, 256, generator=g)
+    ref_s = torch.randn(B, 256, generator=g) if multi else None
+    want = []
+    for b in range(B):
+        to = {}
+        with torch.no_grad():
+            O.front(sds, man["config"], man["plbert"], tokens[b:b + 1], lengths[b:b + 1], noise[b:b + 1],
+                    step_noise[:, b:b + 1], diffusion_steps=steps, ref_s=None if ref_s is None else ref_s[b:b + 1],
+                    durations=None, taps=to)
+        want.append(to["durations"][0])
+    want = torch.stack(want)
+    assert int(want.min()) >= 1
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model)
+    te = {}
+    p = pipeline.prepare(model, sampler, tokens.to(DEV), lengths, noise.to(DEV), diffusion_steps=steps,
+                         ref_s=None if ref_s is None else ref_s.to(DEV), step_noise=step_noise.to(DEV), taps=te,
+                         allow_ragged=True)
+    torch.cuda.synchronize()
+    got = te["durations"].cpu()
+    assert got.dtype == torch.int64 and torch.equal(got, want), (got - want).nonzero().tolist()
+    frames = want.sum(dim=1).tolist()
+    if len(set(frames)) > 1:
+        assert sorted(b for idx, _ in p["groups"] for b in idx) == list(range(B))
+        for idx, grp in p["groups"]:
+            assert grp["asr"].shape == (len(idx), 512, frames[idx[0]]) and grp["F0"].shape[1] == 2 * frames[idx[0]]
+
+
+def test_padded_batch_with_predicted_durations_equals_per_utterance_runs():
+    """A right-padded batch through the predicted-duration path: the duration BiLSTM runs with each
+    utterance's own length (its reverse pass must not start inside the padding), pad tokens get no frames, the +5
+    tail lands on each utterance's own last phoneme, the style denoiser attends / averages over real tokens only, and
+    every utterance is decoded at its own frame count.  Reference semantics = the notebooks' one-utterance-per-call:
+    every row must equal the same utterance run alone, un-padded."""
+    man, model, sds = _model("ljspeech")
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model)
+    g = torch.Generator().manual_seed(33)
+    N, steps = 19, 3
+    lens = [19, 15, 10]
+    B = len(lens)
+    tokens = torch.randint(1, 178, (B, N), generator=g)
+    tokens[:, 0] = 0
+    for b, n in enumerate(lens):
+        tokens[b, n:] = 0
+    noise = torch.randn(B, 1, 256, generator=g)
+    step_noise = torch.randn(steps - 1, B, 1, 256, generator=g)
+    te = {}
+    waves = pipeline.inference(model, sampler, tokens.to(DEV), torch.LongTensor(lens), noise.to(DEV),
+                               diffusion_steps=steps, step_noise=step_noise.to(DEV), taps=te)
+    torch.cuda.synchronize()
+    assert isinstance(waves, list) and len(waves) == B
+    for b, n in enumerate(lens):
+        t1 = {}
+        solo = pipeline.inference(model, sampler, tokens[b:b + 1, :n].to(DEV), torch.LongTensor([n]),
+                                  noise[b:b + 1].to(DEV), diffusion_steps=steps,
+                                  step_noise=step_noise[:, b:b + 1].to(DEV), taps=t1)
+        d_b = te["durations"][b].cpu()
+        assert torch.equal(d_b[:n], t1["durations"][0].cpu()) and int(d_b[n:].sum()) == 0
+        assert int(d_b[n - 1]) > 5, "the LJSpeech tail belongs to the utterance's own last phoneme"
+        assert (te["s_pred"][b] - t1["s_pred"][0]).abs().max().item() < 2e-5
+        assert waves[b].shape[-1] == 600 * int(d_b.sum()) == solo.shape[-1]
+        # un-injected iSTFTNet output: compare magnitudes loosely, the frame count and the front exactly
+        assert bool(torch.isfinite(waves[b]).all())
+    # the same batch against the oracle, one utterance at a time
+    for b, n in enumerate(lens):
+        to = {}
+        with torch.no_grad():
+            O.front(sds, man["config"], man["plbert"], tokens[b:b + 1, :n], torch.LongTensor([n]), noise[b:b + 1],
+                    step_noise[:, b:b + 1], diffusion_steps=steps, durations=None, taps=to)
+        assert torch.equal(te["durations"][b, :n].cpu(), to["durations"][0])
+        assert (te["s_pred"][b].cpu() - to["s_pred"][0]).abs().max().item() < 5e-5
+
+
+def test_golden_multispeaker_istftnet_front():
+    """BASELINE.json configs[3] against vectors the REFERENCE modules produced (tests/golden/reference_vectors.npz
+    `ms_*`, oracle/golden_vectors.py `frontend_vectors_multispeaker_istftnet`): multispeaker denoiser with `features`,
+    style mixing, predicted durations without tail, un-shifted expansion, F0 / N."""
+    import numpy as np
+    from _util import GOLDEN
+    import os
+    gv = np.load(os.path.join(GOLDEN, "reference_vectors.npz"))
+    man, model, sds = _model("libritts_istftnet")
+    assert model.decoder.kind == "istftnet" and man["config"]["multispeaker"]
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model)
+    N, steps = 7, 3
+    g = torch.Generator().manual_seed(21)
+    tokens = torch.randint(1, 178, (1, N), generator=g)
+    tokens[:, 0] = 0
+    noise = torch.randn(1, 1, 256, generator=g)
+    step_noise = torch.randn(steps - 1, 1, 1, 256, generator=g)
+    ref_s = torch.randn(1, 256, generator=g)
+    te = {}
+    p = pipeline.prepare(model, sampler, tokens.to(DEV), torch.LongTensor([N]), noise.to(DEV), diffusion_steps=steps,
+                         ref_s=ref_s.to(DEV), alpha=0.3, beta=0.7, step_noise=step_noise.to(DEV), taps=te)
+    torch.cuda.synchronize()
+    t = lambda k: torch.from_numpy(gv[k])
+    assert torch.equal(te["durations"][0].cpu(), t("ms_dur").long())
+    assert (te["s_pred"].cpu() - t("ms_s_pred")).abs().max().item() < 2e-5
+    assert (p["ref"].cpu() - t("ms_ref")).abs().max().item() < 2e-5
+    assert (te["F0"].cpu() - t("ms_F0")).abs().max().item() < 1e-4 * t("ms_F0").abs().max().item()
+    assert (te["N"].cpu() - t("ms_N")).abs().max().item() < 1e-4 * t("ms_N").abs().max().item()
+    assert (te["asr"].sum(dim=1).cpu() - t("ms_asr_sum")).abs().max().item() < 1e-3
 
 
 def test_predicted_durations_path_runs():

@@ -13,9 +13,9 @@ whh = (torch.randn(2, H, 4 * H, device=dev) / 16).contiguous()
 for N in (100, 400):
     G = torch.randn(B, 8 * H, N, device=dev)
     outs = {}
-    for mode in ("single", "coop_fence", "coop"):
+    for mode in ("single", "coop_fence", "coop_sc1", "coop"):  # coop = tagged 8-byte granules (the default hand-off)
         os.environ["ST2_LSTM"] = "single" if mode == "single" else "coop"
-        _lib.load().st2_lstm_coop_set_exchange(0 if mode == "coop_fence" else 1)
+        _lib.load().st2_lstm_coop_set_exchange({"coop_fence": 0, "coop_sc1": 1}.get(mode, 2))
         for _ in range(2):
             y = ops.lstm_bidir(G, whh)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +29,7 @@ for N in (100, 400):
                                                                       e0.elapsed_time(e1) / 5 / N * 1e3,
                                                                       ops.lstm_coop_status() if mode != "single" else 0),
               flush=True)
+    _lib.load().st2_lstm_coop_set_exchange(2)
     print("   max |coop - single| = %.3g, |coop_fence - single| = %.3g" % (
         (outs["coop"] - outs["single"]).abs().max().item(), (outs["coop_fence"] - outs["single"]).abs().max().item()),
         flush=True)
