@@ -322,6 +322,35 @@ int st2_mean_tokens(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_
  * Demo/Inference_LJSpeech.ipynb:268-290). */
 int st2_mean_tokens_len(const float* x, int64_t x_bs, int32_t x_cs, float* m, int64_t m_bs,
                         int32_t B, int32_t C, int32_t N, const int32_t* len, void* stream);
+/* four[b] = [t, sin(t w_j 2 pi) (j < H2), cos(t w_j 2 pi) (j < H2)], out [B][1 + 2*H2]: LearnedPositionalEmbedding of the
+ * denoiser's time input t = c_noise (Modules/diffusion/modules.py:657-671; op order ((t*w)*2)*pi in fp32). */
+int st2_time_features(float t, const float* w, int32_t H2, int32_t B, float* out, void* stream);
+/* y[b][e][n] = emb[b][n][e]  (b*e_bs + n*E + e): token-major embedding -> channel-major rows of a [B][.][N] tensor
+ * (y points at the first destination row); e_bs = 0 broadcasts one [N][E] table (the fixed embedding of the
+ * classifier-free-guidance branch, modules.py:412-423) over the batch.  Replaces rearrange / cat, modules.py:388-393. */
+int st2_tokens_to_channels(const float* e, int64_t e_bs, int32_t B, int32_t N, int32_t E, float* y, int64_t y_bs,
+                           int32_t y_cs, void* stream);
+/* y[b][c][n] = x[b*x_bs + c] for n < N  (the noisy style vector repeated over the tokens, modules.py:388-390) */
+int st2_broadcast_cols(const float* x, int64_t x_bs, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
+                       int32_t N, void* stream);
+/* strided NCL copy y[b][c][l] = x[b][c][l] (channel slices of concatenation buffers, tap points) */
+int st2_copy_ncl(const float* x, int64_t x_bs, int32_t x_cs, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
+                 int32_t L, void* stream);
+
+/* ---- duration head and alignment expansion (the notebooks' glue between predictor and decoder) ----------------- *
+ * st2_duration_head: x [B][K][N] channel-major output of the duration BiLSTM, w [J][K] / bias [J] = duration_proj
+ * (models.py:450-451); dur[b][n] (int64) = max(1, round(sum_j sigmoid(w_j . x[b,:,n] + bias_j))), 0 for n >= len[b]
+ * (len NULL = no padding), + `tail` frames on token len[b]-1 (5 in the LJSpeech notebook, 0 in the LibriTTS one);
+ * dsum (optional, [B][N]) receives the un-rounded sums.  Replaces Demo/Inference_LJSpeech.ipynb:296-301.
+ * st2_expand_by_durations: y[b][c][t] = x[b][c][idx(b,t)], idx = the phoneme whose frames cover t (every row of dur
+ * sums to T; N <= 512); shift = 1 applies the HiFi-GAN one-frame right shift of Demo/Inference_LibriTTS.ipynb:306-319.
+ * Replaces the one-hot alignment matrix + matmul, Demo/Inference_LJSpeech.ipynb:303-312. */
+int st2_duration_head(const float* x, int64_t x_bs, int32_t x_cs, const float* w, const float* bias, int32_t B,
+                      int32_t K, int32_t J, int32_t N, const int32_t* len, int32_t tail, int64_t* dur, float* dsum,
+                      void* stream);
+int st2_expand_by_durations(const float* x, int64_t x_bs, int32_t x_cs, const int64_t* dur, int32_t B, int32_t C,
+                            int32_t N, int32_t T, int32_t shift, float* y, int64_t y_bs, int32_t y_cs, void* stream);
+
 /* out[i] = a*x[i] + b*y[i] + c*z[i] (z may be NULL): sampler updates, sampler.py:184-208,497-510 */
 int st2_axpbypcz(const float* x, float a, const float* y, float b, const float* z, float c,
                  float* out, int64_t n, void* stream);

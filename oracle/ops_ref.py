@@ -300,3 +300,51 @@ def axpbypcz(x, a, y=None, b=0.0, z=None, c=0.0, out=None):
         out.copy_(r)
         return out
     return r
+
+
+def time_features(t, w, B, out=None):
+    tt = torch.full((B, 1), float(t), dtype=torch.float32)
+    freqs = tt * w.view(1, -1) * 2 * math.pi
+    r = torch.cat([tt, freqs.sin(), freqs.cos()], dim=-1)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def tokens_to_channels(e, out, B=None):
+    out.copy_(e.transpose(-1, -2) if e.dim() == 3 else e.t().unsqueeze(0).expand(out.shape[0], -1, -1))
+    return out
+
+
+def broadcast_cols(x, out):
+    out.copy_(x.unsqueeze(-1).expand_as(out))
+    return out
+
+
+def copy_ncl(x, out):
+    out.copy_(x)
+    return out
+
+
+def duration_head(x, w, bias, lengths=None, tail=0, want_sums=False):
+    B, K, N = x.shape
+    sums = torch.sigmoid(F.linear(x.transpose(1, 2), w, bias)).sum(dim=-1)
+    dur = torch.round(sums).clamp(min=1).long()
+    if lengths is not None:
+        dur = dur.masked_fill(torch.arange(N).view(1, N) >= lengths.view(-1, 1), 0)
+    last = (lengths.long() - 1) if lengths is not None else torch.full((B,), N - 1)
+    dur[torch.arange(B), last] += tail
+    return (dur, sums) if want_sums else dur
+
+
+def expand_by_durations(x, dur, T, shift=False, out=None):
+    B, C, N = x.shape
+    idx = torch.stack([torch.repeat_interleave(torch.arange(N), dur[b], output_size=T) for b in range(B)])
+    y = torch.gather(x, 2, idx.unsqueeze(1).expand(B, C, T))
+    if shift:
+        y = torch.cat([y[:, :, :1], y[:, :, :-1]], dim=2)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y

@@ -111,6 +111,17 @@ _SIGNATURES = {
                                   C.c_void_p]),
     "st2_mean_tokens_len": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p]),
+    "st2_time_features": (C.c_int, [C.c_float, f32p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
+    "st2_tokens_to_channels": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, f32p, C.c_int64, C.c_int32,
+                                         C.c_void_p]),
+    "st2_broadcast_cols": (C.c_int, [f32p, C.c_int64, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p]),
+    "st2_copy_ncl": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_void_p]),
+    "st2_duration_head": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_int32, C.c_void_p, f32p, C.c_void_p]),
+    "st2_expand_by_durations": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_void_p]),
     "st2_axpbypcz": (C.c_int, [f32p, C.c_float, f32p, C.c_float, f32p, C.c_float, f32p, C.c_int64, C.c_void_p]),
 }
 

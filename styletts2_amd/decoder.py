@@ -384,10 +384,10 @@ class Decoder(nn.Module):
         # [x(1024) | asr_res(64) | F0 | N] lives in one buffer; producers write their channel slices in place
         cat = torch.empty((B, 1024 + 64 + 2, T), device=dev, dtype=torch.float32)
         cat0 = torch.empty((B, Cin + 2, T), device=dev, dtype=torch.float32)
-        cat0[:, :Cin].copy_(asr)
+        ops.copy_ncl(asr, cat0[:, :Cin])
         ops.conv1d_direct(F0_curve.unsqueeze(1), pk.f0_w, pk.f0_b, 2, 1, out=cat0[:, Cin:Cin + 1])
         ops.conv1d_direct(N.unsqueeze(1), pk.n_w, pk.n_b, 2, 1, out=cat0[:, Cin + 1:Cin + 2])
-        cat[:, 1088:1090].copy_(cat0[:, Cin:Cin + 2])
+        ops.copy_ncl(cat0[:, Cin:Cin + 2], cat[:, 1088:1090])
         ops.conv1d(asr, pk.asr_res.wt, 64, 1, bias=pk.asr_res.bias, out=cat[:, 1024:1088])
         run_adain_resblk(pk.encode, bank, h, cat0, out=cat[:, :1024])
         if taps is not None:

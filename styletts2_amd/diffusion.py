@@ -381,12 +381,12 @@ class _Transformer(nn.Module):
 
         def base(e):  # channel-major [x | embedding] buffer; rows < C are rewritten on every net call
             buf = self._alloc(s, self.features)
-            buf[:, C:].copy_(e.transpose(1, 2))
+            ops.tokens_to_channels(e, buf[:, C:], B=B)
             return buf
 
-        s.bases = [base(embedding)]
+        s.bases = [base(embedding.contiguous())]
         if s.scale != 1.0:
-            s.bases.append(base(fixed))
+            s.bases.append(base(pk.fixed[:N]) if embedding_mask_proba <= 0.0 else base(fixed.contiguous()))
         s.feat_map, s.ada = None, None
         if self.multispeaker:
             assert features is not None, "context_features exists but no features provided"
@@ -397,12 +397,10 @@ class _Transformer(nn.Module):
 
     def _mapping(self, s, c_noise):
         pk = s.pk
-        t = torch.full((s.B, 1), c_noise, device=pk.device, dtype=torch.float32)
-        freqs = t * pk.time_w.view(1, -1) * 2 * math.pi  # modules.py:666-671
-        four = torch.cat([t, freqs.sin(), freqs.cos()], dim=-1).contiguous()
+        four = ops.time_features(c_noise, pk.time_w, s.B)  # [t, sin(t w 2 pi), cos(t w 2 pi)], modules.py:666-671
         m = ops.style_fc(four, pk.time_lin, pk.time_b, ops.ACT_GELU)
         if s.feat_map is not None:
-            m = m + s.feat_map  # reduce(stack(items), 'sum'), modules.py:140
+            m = ops.axpbypcz(m, 1.0, s.feat_map, 1.0)  # reduce(stack(items), 'sum'), modules.py:140
         m = ops.style_fc(m, pk.map0, pk.map0_b, ops.ACT_GELU)
         return ops.style_fc(m, pk.map2, pk.map2_b, ops.ACT_GELU)
 
@@ -427,7 +425,7 @@ class _Transformer(nn.Module):
         B, N, Fz, C = s.B, s.N, self.features, self.channels
         mid = self.heads * self.head_features
         A, V = (lambda c: self._alloc(s, c)), (lambda t: self._cv(s, t))
-        base[:, :C].copy_(x.reshape(B, C, 1).expand(B, C, N))
+        ops.broadcast_cols(x.reshape(B, C), base[:, :C])
         X = ops.add_chanvec(base, m, out=A(Fz))
         nblk = len(pk.blocks)
         for i, b in enumerate(pk.blocks):

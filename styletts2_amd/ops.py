@@ -626,3 +626,92 @@ def axpbypcz(x, a, y=None, b=0.0, z=None, c=0.0, out=None):
     _lib.check(lib.st2_axpbypcz(x.data_ptr(), a, _ptr(y), b, _ptr(z), c, out.data_ptr(), x.numel(), _stream()),
                "st2_axpbypcz")
     return out
+
+
+def time_features(t, w, B, out=None):
+    """`st2_time_features`: [B, 1 + 2*len(w)] = [t, sin(t w 2 pi), cos(t w 2 pi)] (denoiser time embedding input)."""
+    lib = _lib.load()
+    _chk(w, "w", 1)
+    H2 = w.numel()
+    if out is None:
+        out = torch.empty((B, 1 + 2 * H2), device=w.device, dtype=torch.float32)
+    _lib.check(lib.st2_time_features(float(t), w.data_ptr(), H2, B, out.data_ptr(), _stream()), "st2_time_features")
+    return out
+
+
+def tokens_to_channels(e, out, B=None):
+    """`st2_tokens_to_channels`: e [B, N, E] (or [N, E] broadcast over `B`) -> out[b, :E, :N] = e[b].T, `out` an NCL view."""
+    lib = _lib.load()
+    _chk(e, "e")
+    _chk(out, "out", 3)
+    assert e.is_contiguous()
+    if e.dim() == 2:
+        N, E = e.shape
+        e_bs = 0
+        B = out.shape[0] if B is None else B
+    else:
+        B, N, E = e.shape
+        e_bs = N * E
+    assert out.shape[0] == B and out.shape[1] == E and out.shape[2] == N, (out.shape, (B, E, N))
+    _lib.check(lib.st2_tokens_to_channels(e.data_ptr(), e_bs, B, N, E, out.data_ptr(), out.stride(0), out.stride(1),
+                                          _stream()), "st2_tokens_to_channels")
+    return out
+
+
+def broadcast_cols(x, out):
+    """`st2_broadcast_cols`: out[b, c, n] = x[b, c] for every n; x [B, C] (unit stride along C), out an NCL view."""
+    lib = _lib.load()
+    _chk(x, "x", 2)
+    _chk(out, "out", 3)
+    B, Cc = x.shape
+    assert out.shape[0] == B and out.shape[1] == Cc
+    _lib.check(lib.st2_broadcast_cols(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), out.stride(1), B, Cc,
+                                      out.shape[2], _stream()), "st2_broadcast_cols")
+    return out
+
+
+def copy_ncl(x, out):
+    """`st2_copy_ncl`: strided copy between NCL views of equal shape."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(out, "out", 3)
+    assert x.shape == out.shape
+    B, Cc, L = x.shape
+    _lib.check(lib.st2_copy_ncl(x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0), out.stride(1), B,
+                                Cc, L, _stream()), "st2_copy_ncl")
+    return out
+
+
+def duration_head(x, w, bias, lengths=None, tail=0, want_sums=False):
+    """`st2_duration_head`: x [B, K, N] channel-major, w [J, K], bias [J] -> int64 durations [B, N] (and the un-rounded
+    sigmoid sums when want_sums)."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    _chk(w, "w", 2)
+    _chk(bias, "bias", 1)
+    B, K, N = x.shape
+    J = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous() and bias.numel() == J
+    if lengths is not None:
+        assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.numel() == B and lengths.is_contiguous()
+    dur = torch.empty((B, N), device=x.device, dtype=torch.int64)
+    sums = torch.empty((B, N), device=x.device, dtype=torch.float32) if want_sums else None
+    _lib.check(lib.st2_duration_head(x.data_ptr(), x.stride(0), x.stride(1), w.data_ptr(), bias.data_ptr(), B, K, J, N,
+                                     0 if lengths is None else lengths.data_ptr(), int(tail), dur.data_ptr(),
+                                     _ptr(sums), _stream()), "st2_duration_head")
+    return (dur, sums) if want_sums else dur
+
+
+def expand_by_durations(x, dur, T, shift=False, out=None):
+    """`st2_expand_by_durations`: x [B, C, N], dur int64 [B, N] (rows sum to T) -> [B, C, T]."""
+    lib = _lib.load()
+    _chk(x, "x", 3)
+    B, Cc, N = x.shape
+    assert dur.is_cuda and dur.dtype == torch.int64 and dur.shape == (B, N) and dur.is_contiguous()
+    if out is None:
+        out = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    _chk(out, "out", 3)
+    _lib.check(lib.st2_expand_by_durations(x.data_ptr(), x.stride(0), x.stride(1), dur.data_ptr(), B, Cc, N, T,
+                                           1 if shift else 0, out.data_ptr(), out.stride(0), out.stride(1), _stream()),
+               "st2_expand_by_durations")
+    return out

@@ -21,42 +21,30 @@ def _pad_mask(lengths, N):
     return torch.arange(N).unsqueeze(0) >= lengths.reshape(-1, 1)
 
 
-def expand_by_durations(x, dur, T):
-    """x [B, C, N], dur [B, N] (int64, every row sums to T) -> [B, C, T] with frame t taking phoneme idx[t]
-    (== x @ one_hot alignment, Demo/Inference_LJSpeech.ipynb:303-312).  idx[b, t] = #{n : cumsum(dur)[b, n] <= t}:
-    one batched binary search on the device instead of the notebook's Python loop."""
-    B, C, N = x.shape
-    cum = torch.cumsum(dur, dim=1)
-    t = torch.arange(T, device=x.device, dtype=cum.dtype).unsqueeze(0).expand(B, T).contiguous()
-    idx = torch.searchsorted(cum, t, right=True).clamp_(max=N - 1)  # [B, T]
-    return torch.gather(x, 2, idx.unsqueeze(1).expand(B, C, T))
+def expand_by_durations(x, dur, T, shift=False):
+    """x [B, C, N], dur [B, N] (int64, every row sums to T) -> [B, C, T] with frame t taking the phoneme whose frames
+    cover it (== x @ one_hot alignment, Demo/Inference_LJSpeech.ipynb:303-312): one `st2_expand_by_durations` launch
+    (prefix sum + binary search + gather on the device) instead of the notebook's Python loop and dense matmul.
+    `shift`: the HiFi-GAN flow's one-frame right shift (Demo/Inference_LibriTTS.ipynb:306-319)."""
+    return ops.expand_by_durations(x, dur.contiguous(), T, shift=shift)
 
 
 def predict_durations(model, d, lj_tail=False, input_lengths=None):
-    """ipynb:296-301: duration LSTM -> projection -> sum of sigmoids -> round, clamp(min=1).
+    """ipynb:296-301: duration LSTM -> projection -> sum of sigmoids -> round, clamp(min=1), as two launches: the
+    BiLSTM (k=1 conv input projection + recurrence) and `st2_duration_head` (Linear 512->50, sigmoid sum, round,
+    clamp, pad masking and the LJSpeech +5 tail in one kernel).
 
     `input_lengths` (host int64 [B]) for a right-padded batch: the BiLSTM runs with packed-sequence semantics (its
     reverse direction starts at each utterance's own last token), pad positions get duration 0 and the LJSpeech
     +5-frame tail lands on each utterance's own last token -- every row is then what the notebook computes for that
     utterance alone."""
     B, N = d.shape[0], d.shape[1]
-    lstm = model.predictor.lstm
     ragged = input_lengths is not None and not bool((input_lengths == N).all())
-    if hasattr(lstm, "forward_cm"):
-        lens = input_lengths.to(torch.int32).to(d.device) if ragged else None
-        x = lstm.forward_cm(d.transpose(1, 2).contiguous().float(), lens).transpose(1, 2)
-    else:
-        x, _ = lstm(d)
-    duration = model.predictor.duration_proj(x)
-    duration = torch.sigmoid(duration).sum(dim=-1)
-    pred_dur = torch.round(duration).clamp(min=1).long()
-    if ragged:
-        pad = _pad_mask(input_lengths, N).to(d.device)
-        pred_dur = pred_dur.masked_fill(pad, 0)
-    if lj_tail:  # LJSpeech notebook only (ipynb:301): pred_dur[-1] += 5
-        last = (input_lengths.to(d.device) - 1) if ragged else torch.full((B,), N - 1, device=d.device)
-        pred_dur[torch.arange(B, device=d.device), last] += 5
-    return pred_dur
+    lens = input_lengths.to(torch.int32).to(d.device) if ragged else None
+    x = model.predictor.lstm.forward_cm(d.transpose(1, 2).contiguous().float(), lens)   # [B, 512, N]
+    lin = model.predictor.duration_proj.linear_layer
+    return ops.duration_head(x, lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous(),
+                             lengths=lens, tail=5 if lj_tail else 0)  # LJSpeech notebook only: pred_dur[-1] += 5
 
 
 @torch.no_grad()
@@ -130,13 +118,11 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
         T = int(tot[idx[0]])
         sel = (lambda v: v) if len(idx) == B else (lambda v: v[torch.as_tensor(idx, device=dev)])
         dur = sel(durations)
-        en = expand_by_durations(sel(d_cm), dur, T)                                   # [b, 640, T]
-        asr = expand_by_durations(sel(t_en), dur, T)                                  # [b, 512, T]
-        if hifigan:  # one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
-            en = torch.cat([en[:, :, :1], en[:, :, :-1]], dim=2)
-            asr = torch.cat([asr[:, :, :1], asr[:, :, :-1]], dim=2)
-        F0_pred, N_pred = model.predictor.F0Ntrain(en.contiguous(), sel(s))
-        return dict(asr=asr.contiguous(), F0=F0_pred, N=N_pred, ref=sel(ref), en=en)
+        # hifigan: one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
+        en = expand_by_durations(sel(d_cm), dur, T, shift=hifigan)                    # [b, 640, T]
+        asr = expand_by_durations(sel(t_en), dur, T, shift=hifigan)                   # [b, 512, T]
+        F0_pred, N_pred = model.predictor.F0Ntrain(en, sel(s))
+        return dict(asr=asr, F0=F0_pred, N=N_pred, ref=sel(ref), en=en)
 
     if len(set(tot)) == 1:
         g = expand(list(range(B)))

@@ -9,7 +9,8 @@ from styletts2_amd import ops
 
 _NAMES = ["conv1d", "conv1d_direct", "phase_split", "instnorm_stats", "colnorm_stats", "style_fc", "convt_interleave",
           "adain_leaky_pool", "har_source", "stft_mag_phase", "istft", "attention", "colnorm_apply", "lstm_bidir", "add_chanvec", "mean_tokens",
-          "axpbypcz"]
+          "axpbypcz", "time_features", "tokens_to_channels", "broadcast_cols", "copy_ncl", "duration_head",
+          "expand_by_durations"]
 
 
 @contextlib.contextmanager

@@ -495,6 +495,68 @@ def test_split_f16_conv_per_row_weight_spread(path, monkeypatch):
     assert ops.status() == 0
 
 
+def test_glue_kernels():
+    gen = torch.Generator().manual_seed(19)
+    w = torch.randn(128, generator=gen)
+    assert rel_err(ops.time_features(-1.37, g(w), 5), R.time_features(-1.37, w, 5)) < 1e-6
+    e = torch.randn(3, 37, 70, generator=gen)
+    buf = torch.zeros(3, 90, 37, device=DEV)
+    ops.tokens_to_channels(g(e), buf[:, 20:])
+    assert torch.equal(buf[:, 20:].cpu(), e.transpose(1, 2)) and float(buf[:, :20].abs().max()) == 0.0
+    merged = torch.zeros(70, 3, 37, device=DEV).permute(1, 0, 2)  # the denoiser's token-merged layout
+    ops.tokens_to_channels(g(e[0].contiguous()), merged, B=3)     # [N, E] table broadcast over the batch
+    assert all(torch.equal(merged[b].cpu(), e[0].t()) for b in range(3))
+    x = torch.randn(4, 33, generator=gen)
+    out = torch.zeros(4, 40, 21, device=DEV)
+    ops.broadcast_cols(g(x), out[:, :33])
+    assert torch.equal(out[:, :33].cpu(), x.unsqueeze(-1).expand(4, 33, 21)) and float(out[:, 33:].abs().max()) == 0.0
+    y = torch.randn(2, 9, 300, generator=gen)
+    dst = torch.zeros(2, 12, 300, device=DEV)
+    ops.copy_ncl(g(y)[:, 2:7], dst[:, 5:10])
+    assert torch.equal(dst[:, 5:10].cpu(), y[:, 2:7])
+
+
+@pytest.mark.parametrize("shift", [False, True])
+def test_expand_by_durations_is_the_one_hot_matmul(shift):
+    gen = torch.Generator().manual_seed(20)
+    B, C, N = 3, 130, 57
+    x = torch.randn(B, C, N, generator=gen)
+    dur = torch.randint(0, 9, (B, N), generator=gen)
+    dur[:, 0] = 1
+    T = int(dur.sum(dim=1).max())
+    for b in range(B):  # equal row sums: top every row up on its last token
+        dur[b, -1] += T - int(dur[b].sum())
+    out = ops.expand_by_durations(g(x), g(dur), T, shift=shift)
+    assert torch.equal(out.cpu(), R.expand_by_durations(x, dur, T, shift=shift))  # a gather: bit-exact
+    aln = torch.zeros(B, N, T)
+    for b in range(B):
+        c = 0
+        for i in range(N):
+            aln[b, i, c:c + int(dur[b, i])] = 1
+            c += int(dur[b, i])
+    assert torch.equal(R.expand_by_durations(x, dur, T), x @ aln)
+
+
+def test_duration_head_matches_contract():
+    """Linear 512 -> 50 + sigmoid sum + round + clamp + pad masking + tail in one kernel vs the torch ops of the
+    notebook (ipynb:296-301): the un-rounded sums to fp32 round-off, the integer durations exactly wherever the sum is
+    not within 1e-4 of a rounding tie."""
+    gen = torch.Generator().manual_seed(21)
+    B, K, J, N = 4, 512, 50, 83
+    x = torch.randn(B, K, N, generator=gen) * 0.5
+    w = torch.randn(J, K, generator=gen) / math.sqrt(K)
+    bias = torch.randn(J, generator=gen) * 0.1
+    lens = torch.tensor([83, 40, 1, 82], dtype=torch.int32)
+    for lengths, tail in ((None, 0), (lens, 5)):
+        dur, sums = ops.duration_head(g(x), g(w), g(bias), lengths=g(lengths), tail=tail, want_sums=True)
+        rd, rs = R.duration_head(x, w, bias, lengths=lengths, tail=tail, want_sums=True)
+        assert (sums.cpu() - rs).abs().max().item() < 2e-5
+        safe = ((rs - rs.floor() - 0.5).abs() > 1e-4)
+        assert torch.equal(dur.cpu()[safe], rd[safe]) and dur.dtype == torch.int64
+        if lengths is not None:
+            assert int(dur.cpu()[1, 40:].sum()) == 0 and int(dur[2, 0]) >= 6
+
+
 def test_mean_tokens_with_lengths():
     gen = torch.Generator().manual_seed(18)
     x = torch.randn(4, 40, 57, generator=gen)
