@@ -355,6 +355,107 @@ int st2_expand_by_durations(const float* x, int64_t x_bs, int32_t x_cs, const in
 int st2_axpbypcz(const float* x, float a, const float* y, float b, const float* z, float c,
                  float* out, int64_t n, void* stream);
 
+/* ================================================================================================================ *
+ * Module-level entry points: one call per reference nn.Module.forward.                          *
+ *                                                                                                                      *
+ * An engine handle holds one model's packed weights on one device.  The launch plans behind                            *
+ *   st2_decoder_forward  ==  Decoder.forward            Modules/istftnet.py:499-528 / Modules/hifigan.py:446-475        *
+ *   st2_sampler_run      ==  DiffusionSampler.forward   Modules/diffusion/sampler.py:573-586 (ADPM2 :497-519, KDiffusion *
+ *                            :184-208, Transformer1d / StyleTransformer1d Modules/diffusion/modules.py:283-427, 40-185)  *
+ * live in C++ (styletts2_amd/csrc/st2_engine.hip): a host in any language synthesises with these calls and nothing    *
+ * else.  Memory: the engine owns ONE device allocation for its packed weights (st2_finalize_weights); every forward    *
+ * call works inside a caller-owned workspace (size from the *_workspace_bytes query for the same shape), allocates     *
+ * nothing, never synchronises and is legal under hipStreamBeginCapture after one eager call of the same shape.         *
+ * ================================================================================================================ */
+typedef struct st2_engine st2_engine;
+
+typedef struct st2_model_config {
+  /* decoder: models.py:617-633, Configs/config.yml:49-57 (istftnet) / Configs/config_libritts.yml:49-55 (hifigan) */
+  int32_t decoder_kind;            /* 0 = istftnet, 1 = hifigan */
+  int32_t dim_in;                  /* hidden_dim: asr channels (512) */
+  int32_t style_dim;               /* acoustic style width (128) */
+  int32_t upsample_initial_channel;
+  int32_t n_upsamples;  int32_t upsample_rates[4];  int32_t upsample_kernel_sizes[4];
+  int32_t n_resblock_kernels;  int32_t resblock_kernel_sizes[4];  int32_t resblock_dilations[4][3];
+  int32_t gen_istft_n_fft, gen_istft_hop;   /* istftnet only */
+  /* style denoiser: models.py:643-669, Configs/config.yml:66-83 */
+  int32_t multispeaker;            /* 0 = Transformer1d (LayerNorm), 1 = StyleTransformer1d (AdaLayerNorm on `features`) */
+  int32_t dn_layers, dn_heads, dn_head_features, dn_multiplier;
+  int32_t dn_channels;             /* style vector width = 2 * style_dim (256) */
+  int32_t dn_embedding;            /* PL-BERT hidden size (768) */
+  int32_t dn_context_features;     /* width of `features` (256), multispeaker only */
+  int32_t dn_max_length;           /* fixed-embedding table length (512) */
+} st2_model_config;
+
+int st2_create(const st2_model_config* cfg, st2_engine** out);
+int st2_destroy(st2_engine* e);
+/* Hands one parameter to the engine (copied): `name` = the reference state_dict key below the module, prefixed by
+ * "decoder." / "denoiser." (the Transformer's keys, i.e. `diffusion.unet.*` without that prefix), with weight-norm
+ * pairs FOLDED by the caller: `X.weight` = weight_g * weight_v / ||weight_v|| (norm over all dims but 0; dim 0 of a
+ * ConvTranspose1d is C_in), replacing X.weight_g / X.weight_v.  `data` is a HOST pointer to fp32, C-contiguous. */
+int st2_load_weights(st2_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* Packs everything loaded so far (split-f16 conv layouts, polyphase ConvTranspose / strided-conv forms, concatenated
+ * AdaIN fc matrix) and uploads it in one device allocation.  which: 1 = decoder, 2 = denoiser, 3 = both.
+ * Synchronous; call once after the last st2_load_weights (again after loading new weights). */
+int st2_finalize_weights(st2_engine* e, int32_t which);
+
+/* Optional tap points (NULL = not wanted): device buffers the forward copies intermediates into, for parity work. */
+typedef struct st2_decoder_taps {
+  float* encode;       /* [B][1024][T]                                       istftnet.py:510 */
+  float* front;        /* [B][512][2T]   decoder front = generator input      istftnet.py:513-524 */
+  float* har_source;   /* [B][600T]      tanh(l_linear(sine waves))           istftnet.py:352-354 */
+  float* har;          /* istftnet [B][n_fft+2][120T+1] |STFT| ++ angle; hifigan: unused (== har_source) */
+  float* stage[4];     /* generator stage outputs [B][C_i][L_i]               istftnet.py:359-375 */
+  float* spec_phase;   /* istftnet [B][n_fft+2][120T+1] after exp / sin        istftnet.py:378-379 */
+} st2_decoder_taps;
+
+int64_t st2_decoder_workspace_bytes(st2_engine* e, int32_t B, int32_t T);
+/* wave[B][600*T] = Decoder(asr[B][dim_in][T], F0[B][2T], N[B][2T], s[B][style_dim]).  `sine_noise` [B][600T][9] are
+ * the standard-normal draws of SineGen (istftnet.py:242; the reference draws them inside forward); `har_inject`
+ * (optional) replaces the harmonic-source features with the caller's (tap-point protocol): istftnet
+ * [B][n_fft+2][120T+1], hifigan [B][600T].  All pointers are device pointers, tensors contiguous. */
+int st2_decoder_forward(st2_engine* e, const float* asr, const float* f0, const float* n, const float* s,
+                        const float* sine_noise, const float* har_inject, int32_t B, int32_t T, float* wave,
+                        void* workspace, int64_t workspace_bytes, const st2_decoder_taps* taps, void* stream);
+
+/* Per-step scalars of the ADPM2 loop, all input independent (sampler.py:184-191, 490-495): for step i (sigma_i ->
+ * sigma_{i+1}) row i of `table` holds 11 doubles
+ *   [0..3]  c_skip, c_out, c_in, c_noise at sigma_i        [4..7]  the same at sigma_mid
+ *   [8]     (sigma_mid - sigma_i) / sigma_i                [9]     (sigma_down - sigma_i) / sigma_mid      [10] sigma_up
+ * A Python host fills it with the reference's own torch / python-float arithmetic (bit-faithful to the reference);
+ * st2_sampler_table does the same with libm for other hosts (KarrasSchedule sigma_min / sigma_max / rho, sampler.py:
+ * 328-337; ADPM2 rho = 1).  sigma0 = sigmas[0] (x_0 = sigma0 * noise). */
+#define ST2_SAMPLER_TABLE_COLS 11
+int st2_sampler_table(int32_t steps, double sigma_min, double sigma_max, double rho, double sigma_data, double* table,
+                      double* sigma0);
+int64_t st2_sampler_workspace_bytes(st2_engine* e, int32_t B, int32_t N, int32_t steps, double embedding_scale);
+/* out[B][C] = DiffusionSampler(noise[B][C], embedding[B][N][E], features[B][Fc] or NULL, num_steps = steps,
+ * embedding_scale).  step_noise [steps-1][B][C] are the per-step randn_like draws (sampler.py:509); `lengths` (int32
+ * [B] on the device, or NULL) = token counts of a right-padded batch; step_taps (optional) [steps-1][B][C] receives x
+ * after every step. */
+int st2_sampler_run(st2_engine* e, const float* noise, const float* embedding, const float* features,
+                    const float* step_noise, const int32_t* lengths, int32_t B, int32_t N, int32_t steps,
+                    double embedding_scale, const double* table, double sigma0, float* out, void* workspace,
+                    int64_t workspace_bytes, float* step_taps, void* stream);
+
+/* ---- testing hook ---------------------------------------------------------------------------------------------- *
+ * Replaces the kernel / memory entry points the launch plans call by the caller's (an array of ST2_BACKEND_ENTRIES
+ * function pointers in the order of `enum st2_backend_slot`; NULL restores the HIP kernels).  tests/ uses it to run the
+ * C++ plans on HOST memory against per-kernel CPU contracts, i.e. to validate plan wiring, packing and workspace
+ * aliasing without a GPU.  Never used by the product path. */
+enum st2_backend_slot {
+  ST2_BE_CONV1D_F16S = 0, ST2_BE_CONV1D_XS, ST2_BE_ACT_SPLIT, ST2_BE_STATS_FINALIZE, ST2_BE_CONV1D_DIRECT,
+  ST2_BE_PHASE_SPLIT, ST2_BE_INSTNORM_STATS, ST2_BE_COLNORM_STATS, ST2_BE_STYLE_FC, ST2_BE_CONVT_INTERLEAVE_STATS,
+  ST2_BE_ADAIN_LEAKY_POOL, ST2_BE_HAR_SOURCE, ST2_BE_STFT_MAG_PHASE, ST2_BE_ISTFT, ST2_BE_ATTENTION_KEYLEN,
+  ST2_BE_ADD_CHANVEC, ST2_BE_MEAN_TOKENS_LEN, ST2_BE_AXPBYPCZ, ST2_BE_TIME_FEATURES, ST2_BE_TOKENS_TO_CHANNELS,
+  ST2_BE_BROADCAST_COLS, ST2_BE_COPY_NCL,
+  ST2_BE_DEV_ALLOC,   /* void* (*)(int64_t bytes) */
+  ST2_BE_DEV_FREE,    /* void (*)(void*) */
+  ST2_BE_UPLOAD,      /* int (*)(void* dst, const void* src, int64_t bytes): synchronous host -> device copy */
+  ST2_BACKEND_ENTRIES
+};
+int st2_debug_set_backend(void* const* table, int32_t entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,35 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ModelConfig(C.Structure):
+    """Mirror of `st2_model_config` (include/st2.h)."""
+    _fields_ = [
+        ("decoder_kind", C.c_int32), ("dim_in", C.c_int32), ("style_dim", C.c_int32),
+        ("upsample_initial_channel", C.c_int32),
+        ("n_upsamples", C.c_int32), ("upsample_rates", C.c_int32 * 4), ("upsample_kernel_sizes", C.c_int32 * 4),
+        ("n_resblock_kernels", C.c_int32), ("resblock_kernel_sizes", C.c_int32 * 4),
+        ("resblock_dilations", (C.c_int32 * 3) * 4),
+        ("gen_istft_n_fft", C.c_int32), ("gen_istft_hop", C.c_int32),
+        ("multispeaker", C.c_int32),
+        ("dn_layers", C.c_int32), ("dn_heads", C.c_int32), ("dn_head_features", C.c_int32),
+        ("dn_multiplier", C.c_int32), ("dn_channels", C.c_int32), ("dn_embedding", C.c_int32),
+        ("dn_context_features", C.c_int32), ("dn_max_length", C.c_int32),
+    ]
+
+
+class DecoderTaps(C.Structure):
+    """Mirror of `st2_decoder_taps`."""
+    _fields_ = [("encode", f32p), ("front", f32p), ("har_source", f32p), ("har", f32p), ("stage", f32p * 4),
+                ("spec_phase", f32p)]
+
+
+SAMPLER_TABLE_COLS = 11
+BACKEND_SLOTS = ["conv1d_f16s", "conv1d_xs", "act_split", "stats_finalize", "conv1d_direct", "phase_split",
+                 "instnorm_stats", "colnorm_stats", "style_fc", "convt_interleave_stats", "adain_leaky_pool",
+                 "har_source", "stft_mag_phase", "istft", "attention_keylen", "add_chanvec", "mean_tokens_len",
+                 "axpbypcz", "time_features", "tokens_to_channels", "broadcast_cols", "copy_ncl", "dev_alloc",
+                 "dev_free", "upload"]  # enum st2_backend_slot
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "st2_abi_version": (C.c_int, []),
@@ -122,6 +151,20 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_int32, C.c_void_p, f32p, C.c_void_p]),
     "st2_expand_by_durations": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_void_p]),
+    "st2_create": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]),
+    "st2_destroy": (C.c_int, [C.c_void_p]),
+    "st2_load_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "st2_finalize_weights": (C.c_int, [C.c_void_p, C.c_int32]),
+    "st2_decoder_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "st2_decoder_forward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_int32, f32p,
+                                      C.c_void_p, C.c_int64, C.POINTER(DecoderTaps), C.c_void_p]),
+    "st2_sampler_table": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
+    "st2_sampler_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    "st2_sampler_run": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_double, C.POINTER(C.c_double), C.c_double, f32p, C.c_void_p, C.c_int64, f32p,
+                                  C.c_void_p]),
+    "st2_debug_set_backend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
     "st2_axpbypcz": (C.c_int, [f32p, C.c_float, f32p, C.c_float, f32p, C.c_float, f32p, C.c_int64, C.c_void_p]),
 }
 

@@ -1,0 +1,1301 @@
+// Module-level entry points: the launch plans of Decoder.forward and DiffusionSampler.forward in C++.
+//
+// One st2_engine holds one model's packed weights on one device (the single device allocation this file makes) and
+// issues, per forward call, a straight-line sequence of the kernel entry points declared in st2.h on the caller's
+// stream, inside a caller-owned workspace.  No allocation, no synchronisation, no host read of device data in the
+// forward calls: they are legal under hipStreamBeginCapture.  The same plans exist in Python (styletts2_amd/decoder.py,
+// diffusion.py: the per-kernel path kept for tap-point work and A-B runs); both issue the same kernels with the same
+// arguments, so their results are bitwise equal (tests/test_engine_gpu.py).
+//
+// Every kernel / memory call goes through a function table (st2_debug_set_backend): tests substitute CPU contracts
+// for the HIP kernels and run these plans on host memory, which validates wiring, packing and workspace aliasing
+// without a GPU.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "st2_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// backend table
+// ------------------------------------------------------------------------------------------------------------------
+struct Backend {
+  decltype(&st2_conv1d_f16s) conv1d_f16s;
+  decltype(&st2_conv1d_xs) conv1d_xs;
+  decltype(&st2_act_split) act_split;
+  decltype(&st2_stats_finalize) stats_finalize;
+  decltype(&st2_conv1d_direct) conv1d_direct;
+  decltype(&st2_phase_split) phase_split;
+  decltype(&st2_instnorm_stats) instnorm_stats;
+  decltype(&st2_colnorm_stats) colnorm_stats;
+  decltype(&st2_style_fc) style_fc;
+  decltype(&st2_convt_interleave_stats) convt_interleave_stats;
+  decltype(&st2_adain_leaky_pool) adain_leaky_pool;
+  decltype(&st2_har_source) har_source;
+  decltype(&st2_stft_mag_phase) stft_mag_phase;
+  decltype(&st2_istft) istft;
+  decltype(&st2_attention_keylen) attention_keylen;
+  decltype(&st2_add_chanvec) add_chanvec;
+  decltype(&st2_mean_tokens_len) mean_tokens_len;
+  decltype(&st2_axpbypcz) axpbypcz;
+  decltype(&st2_time_features) time_features;
+  decltype(&st2_tokens_to_channels) tokens_to_channels;
+  decltype(&st2_broadcast_cols) broadcast_cols;
+  decltype(&st2_copy_ncl) copy_ncl;
+  void* (*dev_alloc)(int64_t);
+  void (*dev_free)(void*);
+  int (*upload)(void*, const void*, int64_t);
+};
+
+void* hip_alloc(int64_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)n) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void hip_free(void* p) { (void)hipFree(p); }
+int hip_upload(void* d, const void* s, int64_t n) {
+  return hipMemcpy(d, s, (size_t)n, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+}
+
+const Backend kHipBackend = {st2_conv1d_f16s, st2_conv1d_xs, st2_act_split, st2_stats_finalize, st2_conv1d_direct,
+                             st2_phase_split, st2_instnorm_stats, st2_colnorm_stats, st2_style_fc,
+                             st2_convt_interleave_stats, st2_adain_leaky_pool, st2_har_source, st2_stft_mag_phase,
+                             st2_istft, st2_attention_keylen, st2_add_chanvec, st2_mean_tokens_len, st2_axpbypcz,
+                             st2_time_features, st2_tokens_to_channels, st2_broadcast_cols, st2_copy_ncl,
+                             hip_alloc, hip_free, hip_upload};
+Backend g_be = kHipBackend;
+
+// ------------------------------------------------------------------------------------------------------------------
+// workspace arena, views
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int XS_HALO = 32;        // == styletts2_amd.ops.XS_HALO
+constexpr int XS_MIN_L = 256;      // shorter rows stay on the fused kernel
+constexpr int XS_MIN_C_PLAIN = 64;  // prologue-free convs take the xs pair from this many input channels on
+constexpr int CVT_TILE = 1024;     // positions per st2_convt_interleave_stats partial sum
+
+struct Arena {
+  char* base = nullptr;
+  int64_t off = 0, cap = 0, peak = 0;
+  bool dry = false;  // size query: hand out fake addresses, count the peak
+  bool overflow = false;
+  void* alloc(int64_t bytes) {
+    off = (off + 255) & ~(int64_t)255;
+    void* p = dry ? reinterpret_cast<void*>((uintptr_t)0x10000 + (uintptr_t)off) : static_cast<void*>(base + off);
+    off += bytes;
+    peak = std::max(peak, off);
+    if (!dry && off > cap) overflow = true;
+    return p;
+  }
+  float* f32(int64_t n) { return static_cast<float*>(alloc(n * 4)); }
+};
+
+struct View {  // NCL view, strides in elements
+  float* p = nullptr;
+  int64_t bs = 0;
+  int cs = 0;
+  int B = 0, C = 0, L = 0;
+  View rows(int c0, int c1) const {
+    View v = *this;
+    v.p = p + (int64_t)c0 * cs;
+    v.C = c1 - c0;
+    return v;
+  }
+  bool ok() const { return p != nullptr; }
+};
+
+int pitch_of(int L) { return (L + 31) / 32 * 32; }  // rows of the big activations start 128-byte aligned
+
+struct Ctx {
+  Arena a;
+  void* stream = nullptr;
+  int rc = 0;
+  bool dry = false;
+};
+
+View new_ncl(Ctx& c, int B, int C, int L, bool padded = true) {
+  View v;
+  v.B = B; v.C = C; v.L = L;
+  v.cs = padded ? pitch_of(L) : L;
+  v.bs = (int64_t)C * v.cs;
+  v.p = c.a.f32((int64_t)B * v.bs);
+  return v;
+}
+
+View wrap(const float* p, int B, int C, int L) {
+  View v;
+  v.p = const_cast<float*>(p);
+  v.B = B; v.C = C; v.L = L; v.cs = L; v.bs = (int64_t)C * L;
+  return v;
+}
+
+#define RUN(c, expr)                                   \
+  do {                                                 \
+    if (!(c).dry && (c).rc == 0 && !(c).a.overflow) {  \
+      (c).rc = (expr);                                 \
+    }                                                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// packed weights (host side: offsets into one blob; device side: base + offset)
+// ------------------------------------------------------------------------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t numel() const { return (int64_t)data.size(); }
+};
+
+struct Blob {
+  std::vector<char> host;
+  int64_t add(const void* src, int64_t bytes) {
+    int64_t off = ((int64_t)host.size() + 255) & ~(int64_t)255;
+    host.resize((size_t)(off + bytes));
+    if (src) memcpy(host.data() + off, src, (size_t)bytes);
+    return off;
+  }
+  int64_t add_f32(const std::vector<float>& v) { return add(v.data(), (int64_t)v.size() * 4); }
+};
+
+struct SplitW {  // st2.h: split-f16 packed conv weight
+  int64_t wq = -1, row_scale = -1;
+  int C_in = 0, C_out = 0, ks = 0, co_pad = 0, cin_pad = 0;
+};
+
+struct PConv {
+  SplitW w;
+  int64_t bias = -1;
+  int c_out = 0, ks = 0;
+};
+
+struct PResBlock1 {  // AdaINResBlock1 (Modules/istftnet.py:27-81)
+  int channels = 0, ks = 0;
+  int dil[3] = {1, 3, 5};
+  PConv c1[3], c2[3];
+  int64_t a1[3] = {-1, -1, -1}, a2[3] = {-1, -1, -1};  // alpha
+  int ad1[3] = {0, 0, 0}, ad2[3] = {0, 0, 0};          // style-bank offsets of adain1 / adain2
+};
+
+struct PAdainResBlk {  // AdainResBlk1d (Modules/istftnet.py:410-454)
+  int dim_in = 0, dim_out = 0;
+  bool upsample = false, learned_sc = false;
+  PConv conv1, conv2, sc;
+  int64_t pool_w = -1, pool_b = -1;
+  int n1 = 0, n2 = 0;  // style-bank offsets of norm1 / norm2
+};
+
+int f16s_chunk(int ks) { return ks <= 3 ? 32 : 16; }
+int f16s_co_block(int C_out) { return C_out > 64 ? 128 : (C_out > 32 ? 64 : 32); }
+
+// weights.pack_conv_f16s, bit for bit: per-row power-of-two scale, hi = f16(w*s), lo = f16(w*s - hi),
+// layout [ci/16][tap][k-half][co][hi8 | lo8]
+SplitW pack_split(Blob& blob, const float* w, int C_out, int C_in, int ks) {
+  SplitW r;
+  r.C_in = C_in; r.C_out = C_out; r.ks = ks;
+  const int cb = f16s_chunk(ks), rb = f16s_co_block(C_out);
+  r.cin_pad = (C_in + cb - 1) / cb * cb;
+  r.co_pad = (C_out + rb - 1) / rb * rb;
+  const int n16 = r.cin_pad / 16;
+  std::vector<_Float16> q((size_t)n16 * ks * 2 * r.co_pad * 16, (_Float16)0.0f);
+  std::vector<float> rs((size_t)r.co_pad, 1.0f);
+  for (int co = 0; co < C_out; ++co) {
+    const float* wr = w + (int64_t)co * C_in * ks;
+    float amax = 0.f;
+    for (int i = 0; i < C_in * ks; ++i) amax = std::max(amax, fabsf(wr[i]));
+    float scale = 1.0f;
+    if (amax > 0.f) {
+      int e = 0;
+      (void)frexpf(amax, &e);
+      scale = ldexpf(1.0f, 14 - e);
+    }
+    rs[co] = 1.0f / scale;
+    for (int ci = 0; ci < C_in; ++ci)
+      for (int t = 0; t < ks; ++t) {
+        const float v = wr[(int64_t)ci * ks + t] * scale;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int i16 = ci / 16, kg = (ci % 16) / 8, e8 = ci % 8;
+        const size_t base = ((((size_t)i16 * ks + t) * 2 + kg) * r.co_pad + co) * 16;
+        q[base + e8] = hi;
+        q[base + 8 + e8] = lo;
+      }
+  }
+  r.wq = blob.add(q.data(), (int64_t)q.size() * 2);
+  r.row_scale = blob.add_f32(rs);
+  return r;
+}
+
+// weights.polyphase_convt: ConvTranspose1d weight [C_in][C_out][K = 2*stride] -> Conv1d weight [stride*C_out][C_in][2]
+std::vector<float> polyphase_convt(const float* w, int C_in, int C_out, int stride) {
+  const int K = 2 * stride;
+  std::vector<float> wp((size_t)stride * C_out * C_in * 2);
+  for (int r = 0; r < stride; ++r)
+    for (int co = 0; co < C_out; ++co)
+      for (int ci = 0; ci < C_in; ++ci) {
+        const size_t o = (((size_t)r * C_out + co) * C_in + ci) * 2;
+        wp[o + 0] = w[((int64_t)ci * C_out + co) * K + r + stride];
+        wp[o + 1] = w[((int64_t)ci * C_out + co) * K + r];
+      }
+  return wp;
+}
+
+// weights.polyphase_strided_conv: [C_out][C_in][K = 2*stride] -> [C_out][C_in*stride][2]
+std::vector<float> polyphase_strided(const float* w, int C_out, int C_in, int stride) {
+  const int K = 2 * stride;
+  std::vector<float> wp((size_t)C_out * C_in * stride * 2);
+  for (int co = 0; co < C_out; ++co)
+    for (int ci = 0; ci < C_in; ++ci)
+      for (int r = 0; r < stride; ++r)
+        for (int j = 0; j < 2; ++j)
+          wp[(((size_t)co * C_in * stride) + (size_t)ci * stride + r) * 2 + j] = w[((int64_t)co * C_in + ci) * K + j * stride + r];
+  return wp;
+}
+
+struct PGenerator {
+  int64_t lin_w = -1, lin_b = -1;
+  std::vector<SplitW> noise_wt;
+  std::vector<int> noise_stride;
+  std::vector<int64_t> noise_b;
+  std::vector<PResBlock1> noise_res, resblocks;
+  std::vector<SplitW> ups_wt;
+  std::vector<int64_t> ups_b;
+  PConv post;
+  std::vector<int64_t> alphas;  // hifigan
+  std::vector<int> channels;
+};
+
+struct PDecoder {
+  bool ready = false;
+  int J = 0;                    // style bank width
+  int64_t bank_wt = -1, bank_b = -1;
+  PAdainResBlk encode, decode[4];
+  int64_t f0_w = -1, f0_b = -1, n_w = -1, n_b = -1;
+  PConv asr_res;
+  PGenerator gen;
+};
+
+struct PBlock {
+  int64_t n_w = -1, n_b = -1, nc_w = -1, nc_b = -1;  // LayerNorm affine (single speaker)
+  SplitW q, kv, o, f1, f2;
+  int64_t o_b = -1, f1_b = -1, f2_b = -1;
+  int f1_out = 0;
+};
+
+struct PDenoiser {
+  bool ready = false;
+  int features = 0;  // channels + embedding
+  int64_t time_w = -1, time_lin = -1, time_b = -1, map0 = -1, map0_b = -1, map2 = -1, map2_b = -1;
+  int64_t feat = -1, feat_b = -1, ada_wt = -1, ada_b = -1;
+  int64_t out_t = -1, out_b = -1, fixed = -1;
+  std::vector<PBlock> blocks;
+};
+
+}  // namespace
+
+struct st2_engine {
+  st2_model_config cfg;
+  std::unordered_map<std::string, HostTensor> host;
+  char* wbase = nullptr;  // device blob
+  int64_t wbytes = 0;
+  PDecoder dec;
+  PDenoiser dn;
+  template <class T>
+  T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
+  const float* F(int64_t off) const { return P<const float>(off); }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------------------------------
+struct Packer {
+  st2_engine& e;
+  Blob& blob;
+  bool ok = true;
+  std::string missing;
+  const HostTensor* get(const std::string& name) {
+    auto it = e.host.find(name);
+    if (it == e.host.end()) {
+      if (ok) missing = name;
+      ok = false;
+      return nullptr;
+    }
+    return &it->second;
+  }
+  bool has(const std::string& name) const { return e.host.find(name) != e.host.end(); }
+  int64_t vec(const std::string& name) {  // flat fp32 copy
+    const HostTensor* t = get(name);
+    return t ? blob.add_f32(t->data) : -1;
+  }
+  // nn.Linear weight [out][in] -> [in][out] (the st2_style_fc layout)
+  int64_t lin_t(const std::string& name) {
+    const HostTensor* t = get(name);
+    if (!t || t->shape.size() != 2) { ok = false; if (missing.empty()) missing = name + " (2-D expected)"; return -1; }
+    const int64_t O = t->shape[0], I = t->shape[1];
+    std::vector<float> v((size_t)(O * I));
+    for (int64_t o = 0; o < O; ++o)
+      for (int64_t i = 0; i < I; ++i) v[(size_t)(i * O + o)] = t->data[(size_t)(o * I + i)];
+    return blob.add_f32(v);
+  }
+  SplitW conv_w(const std::string& name) {  // [C_out][C_in][ks] (or nn.Linear [out][in] as ks = 1)
+    const HostTensor* t = get(name);
+    if (!t) return SplitW();
+    const int C_out = (int)t->shape[0], C_in = (int)t->shape[1], ks = t->shape.size() > 2 ? (int)t->shape[2] : 1;
+    return pack_split(blob, t->data.data(), C_out, C_in, ks);
+  }
+  PConv conv(const std::string& prefix, bool bias = true) {
+    PConv c;
+    c.w = conv_w(prefix + ".weight");
+    c.c_out = c.w.C_out;
+    c.ks = c.w.ks;
+    if (bias && has(prefix + ".bias")) c.bias = vec(prefix + ".bias");
+    return c;
+  }
+};
+
+struct Bank {  // decoder.StyleBank: every AdaIN fc of the module in one [style][J] matrix
+  std::vector<const HostTensor*> ws, bs;
+  std::vector<int> chans;
+  int J = 0;
+  int add(Packer& pk, const std::string& prefix, int channels) {
+    ws.push_back(pk.get(prefix + ".fc.weight"));
+    bs.push_back(pk.get(prefix + ".fc.bias"));
+    chans.push_back(channels);
+    const int off = J;
+    J += 2 * channels;
+    return off;
+  }
+  void pack(Packer& pk, int style_dim, int64_t* wt_off, int64_t* b_off) {
+    std::vector<float> wt((size_t)style_dim * J), b((size_t)J);
+    int off = 0;
+    for (size_t m = 0; m < ws.size(); ++m) {
+      const int n = 2 * chans[m];
+      if (!ws[m] || !bs[m]) return;
+      for (int j = 0; j < n; ++j) {
+        for (int k = 0; k < style_dim; ++k) wt[(size_t)k * J + off + j] = ws[m]->data[(size_t)j * style_dim + k];
+        b[(size_t)off + j] = bs[m]->data[(size_t)j];
+      }
+      off += n;
+    }
+    *wt_off = pk.blob.add_f32(wt);
+    *b_off = pk.blob.add_f32(b);
+  }
+};
+
+PResBlock1 pack_resblock1(Packer& pk, const std::string& prefix, int channels, int ks, const int* dil) {
+  PResBlock1 r;
+  r.channels = channels;
+  r.ks = ks;
+  for (int i = 0; i < 3; ++i) {
+    const std::string si = std::to_string(i);
+    r.dil[i] = dil[i];
+    r.c1[i] = pk.conv(prefix + ".convs1." + si);
+    r.c2[i] = pk.conv(prefix + ".convs2." + si);
+    r.a1[i] = pk.vec(prefix + ".alpha1." + si);
+    r.a2[i] = pk.vec(prefix + ".alpha2." + si);
+  }
+  return r;
+}
+
+PAdainResBlk pack_adain_resblk(Packer& pk, const std::string& prefix, int dim_in, int dim_out, bool upsample) {
+  PAdainResBlk r;
+  r.dim_in = dim_in; r.dim_out = dim_out; r.upsample = upsample; r.learned_sc = dim_in != dim_out;
+  r.conv1 = pk.conv(prefix + ".conv1");
+  r.conv2 = pk.conv(prefix + ".conv2");
+  if (r.learned_sc) r.sc = pk.conv(prefix + ".conv1x1", false);
+  if (upsample) {
+    r.pool_w = pk.vec(prefix + ".pool.weight");  // [C][1][3] folded
+    r.pool_b = pk.vec(prefix + ".pool.bias");
+  }
+  return r;
+}
+
+int prod_from(const int32_t* v, int lo, int hi) {
+  int p = 1;
+  for (int i = lo; i < hi; ++i) p *= v[i];
+  return p;
+}
+
+int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
+  const st2_model_config& cfg = e.cfg;
+  Packer pk{e, blob};
+  PDecoder d;
+  Bank bank;
+  const std::string D = "decoder.";
+  const int sty = cfg.style_dim, Cin = cfg.dim_in;
+  // registration order of decoder.Decoder._prepare: encode, decode[0..3], then the generator's noise_res + resblocks
+  d.encode = pack_adain_resblk(pk, D + "encode", Cin + 2, 1024, false);
+  d.encode.n1 = bank.add(pk, D + "encode.norm1", Cin + 2);
+  d.encode.n2 = bank.add(pk, D + "encode.norm2", 1024);
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = D + "decode." + std::to_string(i);
+    const bool up = i == 3;
+    d.decode[i] = pack_adain_resblk(pk, p, 1024 + 2 + 64, up ? 512 : 1024, up);
+    d.decode[i].n1 = bank.add(pk, p + ".norm1", 1024 + 2 + 64);
+    d.decode[i].n2 = bank.add(pk, p + ".norm2", up ? 512 : 1024);
+  }
+  d.f0_w = pk.vec(D + "F0_conv.weight"); d.f0_b = pk.vec(D + "F0_conv.bias");
+  d.n_w = pk.vec(D + "N_conv.weight");   d.n_b = pk.vec(D + "N_conv.bias");
+  d.asr_res = pk.conv(D + "asr_res.0");
+
+  PGenerator& g = d.gen;
+  const std::string G = D + "generator.";
+  const int nu = cfg.n_upsamples, nk = cfg.n_resblock_kernels;
+  const bool ist = cfg.decoder_kind == 0;
+  const int c0 = cfg.upsample_initial_channel;
+  g.lin_w = pk.vec(G + "m_source.l_linear.weight");
+  g.lin_b = pk.vec(G + "m_source.l_linear.bias");
+  static const int dil135[3] = {1, 3, 5};
+  for (int i = 0; i < nu; ++i) g.channels.push_back(c0 >> (i + 1));
+  // noise_res first, then resblocks (Generator.register)
+  for (int i = 0; i < nu; ++i) {
+    const bool last = i + 1 == nu;
+    PResBlock1 r = pack_resblock1(pk, G + "noise_res." + std::to_string(i), g.channels[i], last ? 11 : 7, dil135);
+    g.noise_res.push_back(r);
+  }
+  for (int i = 0; i < nu; ++i)
+    for (int k = 0; k < nk; ++k) {
+      PResBlock1 r = pack_resblock1(pk, G + "resblocks." + std::to_string(i * nk + k), g.channels[i],
+                                    cfg.resblock_kernel_sizes[k], cfg.resblock_dilations[k]);
+      g.resblocks.push_back(r);
+    }
+  for (auto* list : {&g.noise_res, &g.resblocks}) {
+    const std::string pre = list == &g.noise_res ? G + "noise_res." : G + "resblocks.";
+    for (size_t i = 0; i < list->size(); ++i) {
+      PResBlock1& r = (*list)[i];
+      for (int j = 0; j < 3; ++j) r.ad1[j] = bank.add(pk, pre + std::to_string(i) + ".adain1." + std::to_string(j), r.channels);
+      for (int j = 0; j < 3; ++j) r.ad2[j] = bank.add(pk, pre + std::to_string(i) + ".adain2." + std::to_string(j), r.channels);
+    }
+  }
+  if (pk.ok) bank.pack(pk, sty, &d.bank_wt, &d.bank_b);
+  d.J = bank.J;
+  // noise convs: kernel = 2*stride -> polyphase k = 2 conv; the last one is k = 1
+  for (int i = 0; i < nu; ++i) {
+    const int stride_f0 = i + 1 < nu ? prod_from(cfg.upsample_rates, i + 1, nu) : 1;
+    const HostTensor* w = pk.get(G + "noise_convs." + std::to_string(i) + ".weight");
+    g.noise_stride.push_back(stride_f0);
+    if (w) {
+      const int C_out = (int)w->shape[0], C_in = (int)w->shape[1], K = (int)w->shape[2];
+      if (stride_f0 > 1) {
+        if (K != 2 * stride_f0) { *err = "noise_convs kernel must be 2*stride"; return 1; }
+        std::vector<float> wp = polyphase_strided(w->data.data(), C_out, C_in, stride_f0);
+        g.noise_wt.push_back(pack_split(blob, wp.data(), C_out, C_in * stride_f0, 2));
+      } else {
+        g.noise_wt.push_back(pack_split(blob, w->data.data(), C_out, C_in, K));
+      }
+    } else {
+      g.noise_wt.push_back(SplitW());
+    }
+    g.noise_b.push_back(pk.vec(G + "noise_convs." + std::to_string(i) + ".bias"));
+  }
+  for (int i = 0; i < nu; ++i) {
+    const HostTensor* w = pk.get(G + "ups." + std::to_string(i) + ".weight");  // [C_in][C_out][K]
+    const int u = cfg.upsample_rates[i];
+    if (w) {
+      const int C_in = (int)w->shape[0], C_out = (int)w->shape[1], K = (int)w->shape[2];
+      if (K != 2 * u) { *err = "ups kernel must be 2*stride"; return 1; }
+      std::vector<float> wp = polyphase_convt(w->data.data(), C_in, C_out, u);
+      g.ups_wt.push_back(pack_split(blob, wp.data(), u * C_out, C_in, 2));
+    } else {
+      g.ups_wt.push_back(SplitW());
+    }
+    g.ups_b.push_back(pk.vec(G + "ups." + std::to_string(i) + ".bias"));
+  }
+  g.post = pk.conv(G + "conv_post");
+  if (!ist)
+    for (int i = 0; i <= nu; ++i) g.alphas.push_back(pk.vec(G + "alphas." + std::to_string(i)));
+  if (!pk.ok) {
+    *err = "decoder weight missing: " + pk.missing;
+    return 1;
+  }
+  d.ready = true;
+  e.dec = d;
+  return 0;
+}
+
+int pack_denoiser(st2_engine& e, Blob& blob, std::string* err) {
+  const st2_model_config& cfg = e.cfg;
+  Packer pk{e, blob};
+  PDenoiser d;
+  const std::string N = "denoiser.";
+  d.features = cfg.dn_channels + cfg.dn_embedding;
+  d.time_w = pk.vec(N + "to_time.0.0.weights");
+  d.time_lin = pk.lin_t(N + "to_time.0.1.weight"); d.time_b = pk.vec(N + "to_time.0.1.bias");
+  d.map0 = pk.lin_t(N + "to_mapping.0.weight");    d.map0_b = pk.vec(N + "to_mapping.0.bias");
+  d.map2 = pk.lin_t(N + "to_mapping.2.weight");    d.map2_b = pk.vec(N + "to_mapping.2.bias");
+  const int F = d.features;
+  if (cfg.multispeaker) {
+    d.feat = pk.lin_t(N + "to_features.0.weight"); d.feat_b = pk.vec(N + "to_features.0.bias");
+    // every AdaLayerNorm fc of the net in one [style][J] matrix: per block norm (2F) then norm_context (2F)
+    const int Fc = cfg.dn_context_features, J = cfg.dn_layers * 4 * F;
+    std::vector<float> wt((size_t)Fc * J), b((size_t)J);
+    int off = 0;
+    for (int i = 0; i < cfg.dn_layers; ++i)
+      for (const char* nm : {".attention.norm", ".attention.norm_context"}) {
+        const HostTensor* w = pk.get(N + "blocks." + std::to_string(i) + nm + ".fc.weight");
+        const HostTensor* bb = pk.get(N + "blocks." + std::to_string(i) + nm + ".fc.bias");
+        if (w && bb)
+          for (int j = 0; j < 2 * F; ++j) {
+            for (int k = 0; k < Fc; ++k) wt[(size_t)k * J + off + j] = w->data[(size_t)j * Fc + k];
+            b[(size_t)off + j] = bb->data[(size_t)j];
+          }
+        off += 2 * F;
+      }
+    d.ada_wt = blob.add_f32(wt);
+    d.ada_b = blob.add_f32(b);
+  }
+  for (int i = 0; i < cfg.dn_layers; ++i) {
+    const std::string B = N + "blocks." + std::to_string(i);
+    PBlock b;
+    if (!cfg.multispeaker) {
+      b.n_w = pk.vec(B + ".attention.norm.weight");          b.n_b = pk.vec(B + ".attention.norm.bias");
+      b.nc_w = pk.vec(B + ".attention.norm_context.weight"); b.nc_b = pk.vec(B + ".attention.norm_context.bias");
+    }
+    b.q = pk.conv_w(B + ".attention.to_q.weight");
+    b.kv = pk.conv_w(B + ".attention.to_kv.weight");
+    b.o = pk.conv_w(B + ".attention.attention.to_out.weight"); b.o_b = pk.vec(B + ".attention.attention.to_out.bias");
+    b.f1 = pk.conv_w(B + ".feed_forward.0.weight");            b.f1_b = pk.vec(B + ".feed_forward.0.bias");
+    b.f1_out = b.f1.C_out;
+    b.f2 = pk.conv_w(B + ".feed_forward.2.weight");            b.f2_b = pk.vec(B + ".feed_forward.2.bias");
+    d.blocks.push_back(b);
+  }
+  {  // to_out.1: Conv1d(F, channels, 1) applied to the token mean -> [F][channels] for st2_style_fc
+    const HostTensor* w = pk.get(N + "to_out.1.weight");
+    if (w) {
+      const int O = (int)w->shape[0], I = (int)w->shape[1];
+      std::vector<float> v((size_t)O * I);
+      for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i) v[(size_t)i * O + o] = w->data[(size_t)o * I + i];
+      d.out_t = blob.add_f32(v);
+    }
+    d.out_b = pk.vec(N + "to_out.1.bias");
+  }
+  d.fixed = pk.vec(N + "fixed_embedding.embedding.weight");
+  if (!pk.ok) {
+    *err = "denoiser weight missing: " + pk.missing;
+    return 1;
+  }
+  d.ready = true;
+  e.dn = d;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv dispatch == styletts2_amd.ops.conv1d for split-f16 weights
+// ------------------------------------------------------------------------------------------------------------------
+struct ConvOpt {
+  int dil = 1, pad_left = 0;
+  const float* bias = nullptr;
+  int pro = ST2_PRO_NONE;
+  float slope = 0.f;
+  const float* stats = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  int64_t gb_bs = 0;
+  int gamma_plus_one = 0;
+  const float* alpha = nullptr;
+  View res; int res_shift = 0;
+  View res2;
+  float div = 1.0f;
+  int act = ST2_ACT_NONE, act_split = 0;
+  float act_slope = 0.f;
+  float* stats_out = nullptr;  // want_stats: [B][C_out][2]
+};
+
+float x_scale_for(int pro) {
+  return (pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_COLNORM) ? 8.0f : 1.0f;
+}
+int xs_row_slots(int L) { return XS_HALO + (std::max(L, 1) + 1 + 511) / 512 * 512 + 96; }
+
+void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const View& y, const ConvOpt& o) {
+  st2_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = x.B; d.C_in = x.C; d.C_out = y.C; d.L_in = x.L; d.L_out = y.L; d.ks = w.ks; d.dil = o.dil; d.pad_left = o.pad_left;
+  d.wq = e.P<const void>(w.wq); d.wq_co_pad = w.co_pad; d.wq_cin_pad = w.cin_pad;
+  d.x_scale = x_scale_for(o.pro);
+  d.out_scale = 1.0f / d.x_scale;
+  d.w_row_scale = e.F(w.row_scale);
+  d.bias = o.bias;
+  d.y = y.p; d.y_bs = y.bs; d.y_cs = y.cs;
+  if (o.res.ok()) { d.res = o.res.p; d.res_bs = o.res.bs; d.res_cs = o.res.cs; d.res_shift = o.res_shift; }
+  if (o.res2.ok()) { d.res2 = o.res2.p; d.res2_bs = o.res2.bs; d.res2_cs = o.res2.cs; }
+  d.div = o.div;
+  d.act = o.act; d.act_split = o.act_split; d.act_slope = o.act_slope;
+  if (w.C_in != x.C || w.C_out != y.C) {
+    if (c.rc == 0) { st2_set_error("engine: conv weight is %d->%d, call has %d->%d", w.C_in, w.C_out, x.C, y.C); c.rc = 1; }
+    return;
+  }
+  const bool use_xs = o.pad_left <= XS_HALO && x.L >= XS_MIN_L && (o.pro != ST2_PRO_NONE || x.C >= XS_MIN_C_PLAIN);
+  const int64_t mark = c.a.off;
+  if (use_xs) {
+    const int cg = (x.C + 31) / 32 * 32 / 8;
+    const int Lp = xs_row_slots(x.L);
+    void* xs = c.a.alloc((int64_t)x.B * 2 * cg * Lp * 16);
+    RUN(c, g_be.act_split(x.p, x.bs, x.cs, x.B, x.C, x.L, o.pro, o.slope, o.stats, o.gamma, o.beta, o.gb_bs,
+                          o.gamma_plus_one, o.alpha, d.x_scale, xs, cg, Lp, XS_HALO, c.stream));
+    d.xs = xs; d.xs_cg = cg; d.xs_lp = Lp; d.xs_halo = XS_HALO;
+    float* part = nullptr;
+    int nt = 0;
+    if (o.stats_out) {
+      nt = (y.L + 127) / 128;
+      part = c.a.f32((int64_t)y.B * y.C * nt * 2);
+      d.part = part; d.part_nt = nt;
+    }
+    RUN(c, g_be.conv1d_xs(&d, c.stream));
+    if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
+  } else {
+    d.x = x.p; d.x_bs = x.bs; d.x_cs = x.cs;
+    d.pro = o.pro; d.slope = o.slope;
+    d.stats = o.stats; d.gamma = o.gamma; d.beta = o.beta; d.gb_bs = o.gb_bs; d.gamma_plus_one = o.gamma_plus_one;
+    d.alpha = o.alpha;
+    RUN(c, g_be.conv1d_f16s(&d, c.stream));
+    if (o.stats_out) RUN(c, g_be.instnorm_stats(y.p, y.bs, y.cs, y.B, y.C, y.L, 1e-5f, o.stats_out, c.stream));
+  }
+  c.a.off = mark;  // planes / partial sums are dead once the launches are queued (stream order protects reuse)
+}
+
+float* new_stats(Ctx& c, int B, int C) { return c.a.f32((int64_t)B * C * 2); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// decoder plan == styletts2_amd/decoder.py
+// ------------------------------------------------------------------------------------------------------------------
+struct DecRun {
+  Ctx& c;
+  const st2_engine& e;
+  const float* h;  // style bank output [B][J]
+  int J;
+  const float* gamma(int off) const { return h + off; }
+  const float* beta(int off, int channels) const { return h + off + channels; }
+};
+
+// AdaINResBlock1.forward (Modules/istftnet.py:66-75); the MRF sum / division ride in the last conv's epilogue
+View run_resblock1(DecRun& r, const PResBlock1& p, View x, const float* x_stats, View mrf_acc, bool mrf_last, int n_mrf,
+                   View out) {
+  Ctx& c = r.c;
+  const int C = p.channels, ks = p.ks, B = x.B, L = x.L;
+  const float* st = x_stats;
+  if (!st) {
+    float* s0 = new_stats(c, B, C);
+    RUN(c, g_be.instnorm_stats(x.p, x.bs, x.cs, B, C, L, 1e-5f, s0, c.stream));
+    st = s0;
+  }
+  View xt = new_ncl(c, B, C, L);
+  View ping[2] = {new_ncl(c, B, C, L), new_ncl(c, B, C, L)};
+  float* st2 = new_stats(c, B, C);
+  float* stn[2] = {new_stats(c, B, C), new_stats(c, B, C)};
+  for (int i = 0; i < 3; ++i) {
+    const int d = p.dil[i];
+    ConvOpt o1;
+    o1.dil = d; o1.pad_left = (ks * d - d) / 2; o1.bias = r.e.F(p.c1[i].bias); o1.pro = ST2_PRO_ADAIN_SNAKE;
+    o1.stats = st; o1.gamma = r.gamma(p.ad1[i]); o1.beta = r.beta(p.ad1[i], C); o1.gb_bs = r.J;
+    o1.alpha = r.e.F(p.a1[i]); o1.stats_out = st2;
+    conv(c, r.e, x, p.c1[i].w, xt, o1);
+    const bool last = i == 2;
+    ConvOpt o2;
+    o2.dil = 1; o2.pad_left = (ks - 1) / 2; o2.bias = r.e.F(p.c2[i].bias); o2.pro = ST2_PRO_ADAIN_SNAKE;
+    o2.stats = st2; o2.gamma = r.gamma(p.ad2[i]); o2.beta = r.beta(p.ad2[i], C); o2.gb_bs = r.J;
+    o2.alpha = r.e.F(p.a2[i]); o2.res = x;
+    if (last) {
+      o2.res2 = mrf_acc;
+      o2.div = mrf_last ? (float)n_mrf : 1.0f;
+      conv(c, r.e, xt, p.c2[i].w, out, o2);
+      x = out;
+    } else {
+      o2.stats_out = stn[i & 1];
+      conv(c, r.e, xt, p.c2[i].w, ping[i & 1], o2);
+      x = ping[i & 1];
+      st = stn[i & 1];
+    }
+  }
+  return x;
+}
+
+// AdainResBlk1d.forward (Modules/istftnet.py:435-454): (residual(x, s) + shortcut(x)) / sqrt(2)
+void run_adain_resblk(DecRun& r, const PAdainResBlk& p, const View& x, const View& out) {
+  Ctx& c = r.c;
+  const int B = x.B, L = x.L;
+  const int64_t mark = c.a.off;
+  float* st1 = new_stats(c, B, p.dim_in);
+  RUN(c, g_be.instnorm_stats(x.p, x.bs, x.cs, B, p.dim_in, L, 1e-5f, st1, c.stream));
+  float* st2 = new_stats(c, B, p.dim_out);
+  const int Lo = p.upsample ? 2 * L : L;
+  View t1 = new_ncl(c, B, p.dim_out, Lo);
+  if (p.upsample) {
+    View u = new_ncl(c, B, p.dim_in, 2 * L);
+    RUN(c, g_be.adain_leaky_pool(x.p, x.bs, x.cs, st1, r.gamma(p.n1), r.beta(p.n1, p.dim_in), r.J, 0.2f,
+                                 r.e.F(p.pool_w), r.e.F(p.pool_b), u.p, u.bs, u.cs, B, p.dim_in, L, c.stream));
+    ConvOpt o;
+    o.pad_left = 1; o.bias = r.e.F(p.conv1.bias); o.stats_out = st2;
+    conv(c, r.e, u, p.conv1.w, t1, o);
+  } else {
+    ConvOpt o;
+    o.pad_left = 1; o.bias = r.e.F(p.conv1.bias); o.pro = ST2_PRO_ADAIN_LEAKY; o.slope = 0.2f; o.stats = st1;
+    o.gamma = r.gamma(p.n1); o.beta = r.beta(p.n1, p.dim_in); o.gb_bs = r.J; o.stats_out = st2;
+    conv(c, r.e, x, p.conv1.w, t1, o);
+  }
+  View sc = x;
+  if (p.learned_sc) {  // the 1x1 shortcut commutes with nearest x2 up-sampling: it runs at the low rate
+    sc = new_ncl(c, B, p.dim_out, L);
+    ConvOpt o;
+    conv(c, r.e, x, p.sc.w, sc, o);
+  }
+  ConvOpt o;
+  o.pad_left = 1; o.bias = r.e.F(p.conv2.bias); o.pro = ST2_PRO_ADAIN_LEAKY; o.slope = 0.2f; o.stats = st2;
+  o.gamma = r.gamma(p.n2); o.beta = r.beta(p.n2, p.dim_out); o.gb_bs = r.J; o.res = sc;
+  o.res_shift = p.upsample ? 1 : 0;
+  o.div = (float)sqrt(2.0);  // python passes math.sqrt(2) through a c_float: the same fp32 value
+  conv(c, r.e, t1, p.conv2.w, out, o);
+  c.a.off = mark;
+}
+
+void tap(Ctx& c, const View& v, float* dst) {
+  if (!dst) return;
+  RUN(c, g_be.copy_ncl(v.p, v.bs, v.cs, dst, (int64_t)v.C * v.L, v.L, v.B, v.C, v.L, c.stream));
+}
+
+int decoder_plan(Ctx& c, const st2_engine& e, const float* asr_p, const float* f0_p, const float* n_p, const float* s_p,
+                 const float* sine_noise, const float* har_inject, int B, int T, float* wave,
+                 const st2_decoder_taps* taps) {
+  const st2_model_config& cfg = e.cfg;
+  const PDecoder& d = e.dec;
+  const PGenerator& g = d.gen;
+  const bool ist = cfg.decoder_kind == 0;
+  const int Cin = cfg.dim_in, nu = cfg.n_upsamples, nk = cfg.n_resblock_kernels;
+  const int T2 = 2 * T;
+  st2_decoder_taps notaps;
+  memset(&notaps, 0, sizeof(notaps));
+  if (!taps) taps = &notaps;
+
+  float* h = c.a.f32((int64_t)B * d.J);
+  RUN(c, g_be.style_fc(s_p, B, cfg.style_dim, e.F(d.bank_wt), e.F(d.bank_b), d.J, ST2_ACT_NONE, h, c.stream));
+  DecRun r{c, e, h, d.J};
+
+  View asr = wrap(asr_p, B, Cin, T);
+  View f0 = wrap(f0_p, B, 1, T2), nn = wrap(n_p, B, 1, T2);
+  // [x(1024) | asr_res(64) | F0 | N] lives in one buffer; producers write their channel slices in place
+  View cat = new_ncl(c, B, 1024 + 64 + 2, T, false);
+  View cat0 = new_ncl(c, B, Cin + 2, T, false);
+  RUN(c, g_be.copy_ncl(asr.p, asr.bs, asr.cs, cat0.p, cat0.bs, cat0.cs, B, Cin, T, c.stream));
+  {
+    View a = cat0.rows(Cin, Cin + 1), b = cat0.rows(Cin + 1, Cin + 2);
+    RUN(c, g_be.conv1d_direct(f0.p, f0.bs, f0.cs, e.F(d.f0_w), e.F(d.f0_b), a.p, a.bs, a.cs, B, 1, 1, T2, T, 3, 2, 1, c.stream));
+    RUN(c, g_be.conv1d_direct(nn.p, nn.bs, nn.cs, e.F(d.n_w), e.F(d.n_b), b.p, b.bs, b.cs, B, 1, 1, T2, T, 3, 2, 1, c.stream));
+    View src = cat0.rows(Cin, Cin + 2), dst = cat.rows(1088, 1090);
+    RUN(c, g_be.copy_ncl(src.p, src.bs, src.cs, dst.p, dst.bs, dst.cs, B, 2, T, c.stream));
+  }
+  {
+    ConvOpt o;
+    o.bias = e.F(d.asr_res.bias);
+    conv(c, e, asr, d.asr_res.w, cat.rows(1024, 1088), o);
+  }
+  run_adain_resblk(r, d.encode, cat0, cat.rows(0, 1024));
+  tap(c, cat.rows(0, 1024), taps->encode);
+  View x = new_ncl(c, B, 512, T2);
+  for (int i = 0; i < 4; ++i) {
+    if (d.decode[i].upsample)
+      run_adain_resblk(r, d.decode[i], cat, x);
+    else
+      run_adain_resblk(r, d.decode[i], cat, cat.rows(0, 1024));
+  }
+  tap(c, x, taps->front);
+
+  // ---- generator (istftnet.py:350-380 / hifigan.py:321-347) ---------------------------------------------------------
+  int up_scale = prod_from(cfg.upsample_rates, 0, nu) * (ist ? cfg.gen_istft_hop : 1);
+  const int L = T2 * up_scale;  // samples
+  const int n_fft = cfg.gen_istft_n_fft, hop = cfg.gen_istft_hop;
+  View har;
+  if (har_inject) {
+    har = ist ? wrap(har_inject, B, n_fft + 2, L / hop + 1) : wrap(har_inject, B, 1, L);
+  } else {
+    float* scratch = c.a.f32((int64_t)B * 9 * T2);
+    float* hs = c.a.f32((int64_t)B * L);
+    RUN(c, g_be.har_source(f0_p, B, T2, up_scale, 9, sine_noise, e.F(g.lin_w), e.F(g.lin_b), 0.1f, 0.003f, 10.0f,
+                           24000.0f, scratch, hs, c.stream));
+    if (taps->har_source) RUN(c, g_be.copy_ncl(hs, L, L, taps->har_source, L, L, B, 1, L, c.stream));
+    if (ist) {
+      har = new_ncl(c, B, n_fft + 2, L / hop + 1, false);
+      RUN(c, g_be.stft_mag_phase(hs, B, L, n_fft, hop, har.p, har.bs, har.cs, c.stream));
+    } else {
+      har = wrap(hs, B, 1, L);
+    }
+  }
+  if (ist) tap(c, har, taps->har);
+
+  for (int i = 0; i < nu; ++i) {
+    const int u = cfg.upsample_rates[i], k = cfg.upsample_kernel_sizes[i], C = g.channels[i];
+    const bool last = i + 1 == nu;
+    const int L_in = x.L;
+    int pad, L_raw;
+    if (ist) {
+      pad = (k - u) / 2;
+      L_raw = (L_in - 1) * u - 2 * ((k - u) / 2) + k;
+    } else {
+      pad = u / 2 + u % 2;
+      L_raw = (L_in - 1) * u - 2 * (u / 2 + u % 2) + k + u % 2;
+    }
+    const bool reflect = ist && last;
+    const int L_out = L_raw + (reflect ? 1 : 0);
+    // persistent across the stage: the stage output and the MRF accumulators
+    View x_next = new_ncl(c, B, C, L_out);
+    const int64_t stage_mark = c.a.off;
+    // harmonic-source branch (istftnet.py:361-362 / hifigan.py:330-331)
+    View xs_src = new_ncl(c, B, C, L_out);
+    {
+      const int64_t m = c.a.off;
+      View xs0 = new_ncl(c, B, C, L_out);
+      const int stride_f0 = g.noise_stride[i];
+      ConvOpt o;
+      o.bias = e.F(g.noise_b[i]);
+      if (stride_f0 > 1) {
+        const int pad_f0 = (stride_f0 + 1) / 2;
+        const int L_ns = (har.L + 2 * pad_f0 - 2 * stride_f0) / stride_f0 + 1;
+        View harp = new_ncl(c, B, har.C * stride_f0, L_ns + 1, false);
+        RUN(c, g_be.phase_split(har.p, har.bs, har.cs, B, har.C, har.L, stride_f0, pad_f0, harp.p, harp.bs, harp.cs,
+                                L_ns + 1, c.stream));
+        if (L_ns != L_out && c.rc == 0) { st2_set_error("engine: noise conv length %d != stage length %d", L_ns, L_out); c.rc = 1; }
+        conv(c, e, harp, g.noise_wt[i], xs0, o);
+      } else {
+        conv(c, e, har, g.noise_wt[i], xs0, o);
+      }
+      View nul;
+      run_resblock1(r, g.noise_res[i], xs0, nullptr, nul, false, nk, xs_src);
+      // xs_src was allocated before m: keep it, drop the branch temporaries
+      c.a.off = m;
+    }
+    // up-sampling ConvTranspose1d as polyphase GEMM + interleave (istftnet.py:360,364-368)
+    View xu = new_ncl(c, B, C, L_out);
+    float* st = new_stats(c, B, C);
+    {
+      const int64_t m = c.a.off;
+      View Y = new_ncl(c, B, u * C, L_in + 1);
+      ConvOpt o;
+      o.pad_left = 1;
+      if (ist) { o.pro = ST2_PRO_LEAKY; o.slope = 0.1f; } else { o.pro = ST2_PRO_SNAKE; o.alpha = e.F(g.alphas[i]); }
+      conv(c, e, x, g.ups_wt[i], Y, o);
+      const int nt = (L_out + CVT_TILE - 1) / CVT_TILE;
+      float* part = c.a.f32((int64_t)B * C * nt * 2);
+      RUN(c, g_be.convt_interleave_stats(Y.p, Y.bs, Y.cs, L_in + 1, e.F(g.ups_b[i]), xs_src.p, xs_src.bs, xs_src.cs,
+                                         xu.p, xu.bs, xu.cs, B, C, u, pad, L_raw, reflect ? 1 : 0, part, nt, c.stream));
+      RUN(c, g_be.stats_finalize(part, B * C, nt, L_out, 1e-5f, st, c.stream));
+      c.a.off = m;
+    }
+    // multi-receptive-field fusion (istftnet.py:369-375): ((r0 + r1) + r2) / n in the last convs' epilogues
+    View acc[2] = {new_ncl(c, B, C, L_out), new_ncl(c, B, C, L_out)};
+    View prev;
+    for (int j = 0; j < nk; ++j) {
+      const int64_t m = c.a.off;
+      const bool lastk = j + 1 == nk;
+      View out = lastk ? x_next : acc[j & 1];
+      run_resblock1(r, g.resblocks[(size_t)i * nk + j], xu, st, prev, lastk, nk, out);
+      prev = out;
+      c.a.off = m;
+    }
+    x = x_next;
+    c.a.off = stage_mark;
+    if (i < 4) tap(c, x, taps->stage[i]);
+  }
+  if (ist) {
+    const int nb = n_fft / 2 + 1;
+    View sp = new_ncl(c, B, n_fft + 2, x.L, false);
+    ConvOpt o;
+    o.pad_left = 3; o.bias = e.F(g.post.bias); o.pro = ST2_PRO_LEAKY; o.slope = 0.01f; o.act = ST2_ACT_EXP_SIN;
+    o.act_split = nb;
+    conv(c, e, x, g.post.w, sp, o);
+    tap(c, sp, taps->spec_phase);
+    RUN(c, g_be.istft(sp.p, sp.bs, sp.cs, B, x.L, n_fft, hop, wave, (int64_t)hop * (x.L - 1), c.stream));
+  } else {
+    View w = wrap(wave, B, 1, x.L);
+    ConvOpt o;
+    o.pad_left = 3; o.bias = e.F(g.post.bias); o.pro = ST2_PRO_SNAKE; o.alpha = e.F(g.alphas[(size_t)nu]);
+    o.act = ST2_ACT_TANH;
+    conv(c, e, x, g.post.w, w, o);
+  }
+  return c.rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sampler plan == styletts2_amd/diffusion.py (DiffusionSampler.forward + _Transformer sessions)
+// ------------------------------------------------------------------------------------------------------------------
+struct Sess {
+  Ctx& c;
+  const st2_engine& e;
+  int B, N;
+  bool merged;
+  const int32_t* key_len;
+  View bases[2];
+  int nbases;
+  const float* feat_map;  // [B][F] or null
+  const float* ada;       // [B][layers*4F] or null
+  double scale;  // embedding_scale (classifier-free guidance weight)
+};
+
+// [B][C][N] activation buffer; in the merged layout a strided view of a [C][B*N] block
+View dn_alloc(Sess& s, int C) {
+  View v;
+  v.B = s.B; v.C = C; v.L = s.N;
+  v.p = s.c.a.f32((int64_t)s.B * C * s.N);
+  if (s.merged) { v.bs = s.N; v.cs = s.B * s.N; } else { v.bs = (int64_t)C * s.N; v.cs = s.N; }
+  return v;
+}
+// the view the k=1 convs consume: [1][C][B*N] (merged) or [B][C][N]
+View dn_cv(const Sess& s, const View& t) {
+  if (!s.merged) return t;
+  View v = t;
+  v.B = 1; v.L = s.B * s.N; v.bs = (int64_t)t.C * v.L; v.cs = v.L;
+  return v;
+}
+
+const float* dn_mapping(Sess& s, float c_noise) {
+  Ctx& c = s.c;
+  const st2_engine& e = s.e;
+  const PDenoiser& d = e.dn;
+  const int F = d.features, H2 = e.cfg.dn_channels / 2;
+  float* four = c.a.f32((int64_t)s.B * (1 + 2 * H2));
+  RUN(c, g_be.time_features(c_noise, e.F(d.time_w), H2, s.B, four, c.stream));
+  float* m = c.a.f32((int64_t)s.B * F);
+  RUN(c, g_be.style_fc(four, s.B, 1 + 2 * H2, e.F(d.time_lin), e.F(d.time_b), F, ST2_ACT_GELU, m, c.stream));
+  if (s.feat_map) {
+    float* m2 = c.a.f32((int64_t)s.B * F);
+    RUN(c, g_be.axpbypcz(m, 1.0f, s.feat_map, 1.0f, nullptr, 0.0f, m2, (int64_t)s.B * F, c.stream));
+    m = m2;
+  }
+  float* m3 = c.a.f32((int64_t)s.B * F);
+  RUN(c, g_be.style_fc(m, s.B, F, e.F(d.map0), e.F(d.map0_b), F, ST2_ACT_GELU, m3, c.stream));
+  float* m4 = c.a.f32((int64_t)s.B * F);
+  RUN(c, g_be.style_fc(m3, s.B, F, e.F(d.map2), e.F(d.map2_b), F, ST2_ACT_GELU, m4, c.stream));
+  return m4;
+}
+
+// one denoiser evaluation on base buffer `base`: x [B][C] -> out [B][C]   (_Transformer._run)
+void dn_run(Sess& s, View base, const float* x, const float* m, float* out) {
+  Ctx& c = s.c;
+  const st2_engine& e = s.e;
+  const PDenoiser& d = e.dn;
+  const st2_model_config& cfg = e.cfg;
+  const int B = s.B, N = s.N, Fz = d.features, C = cfg.dn_channels;
+  const int mid = cfg.dn_heads * cfg.dn_head_features;
+  const int64_t mark = c.a.off;
+  View b0 = base.rows(0, C);
+  RUN(c, g_be.broadcast_cols(x, C, b0.p, b0.bs, b0.cs, B, C, N, c.stream));
+  View X = dn_alloc(s, Fz);
+  RUN(c, g_be.add_chanvec(base.p, base.bs, base.cs, m, Fz, X.p, X.bs, X.cs, B, Fz, N, c.stream));
+  const int nblk = (int)d.blocks.size();
+  for (int i = 0; i < nblk; ++i) {
+    const PBlock& b = d.blocks[(size_t)i];
+    float* st = c.a.f32((int64_t)B * N * 2);
+    RUN(c, g_be.colnorm_stats(X.p, X.bs, X.cs, B, Fz, N, 1e-5f, st, c.stream));
+    View qkv = dn_alloc(s, 3 * mid);
+    ConvOpt o1, o2;
+    o1.pro = o2.pro = ST2_PRO_COLNORM;
+    o1.stats = o2.stats = st;  // [B][N][2] == [1][B*N][2] in the merged view
+    if (cfg.multispeaker) {
+      const int64_t J = (int64_t)nblk * 4 * Fz;
+      const float* a = s.ada + (int64_t)4 * Fz * i;
+      o1.gamma = a;          o1.beta = a + Fz;     o1.gb_bs = J; o1.gamma_plus_one = 1;
+      o2.gamma = a + 2 * Fz; o2.beta = a + 3 * Fz; o2.gb_bs = J; o2.gamma_plus_one = 1;
+    } else {
+      o1.gamma = e.F(b.n_w);  o1.beta = e.F(b.n_b);
+      o2.gamma = e.F(b.nc_w); o2.beta = e.F(b.nc_b);
+    }
+    View Xv = dn_cv(s, X), qv = dn_cv(s, qkv);
+    conv(c, e, Xv, b.q, qv.rows(0, mid), o1);
+    conv(c, e, Xv, b.kv, qv.rows(mid, 3 * mid), o2);
+    View att = dn_alloc(s, mid);
+    View q = qkv.rows(0, mid), k = qkv.rows(mid, 2 * mid), v = qkv.rows(2 * mid, 3 * mid);
+    RUN(c, g_be.attention_keylen(q.p, k.p, v.p, q.bs, q.cs, att.p, att.bs, att.cs, B, cfg.dn_heads, cfg.dn_head_features,
+                                 N, (float)pow((double)cfg.dn_head_features, -0.5), s.key_len, c.stream));
+    View X1 = dn_alloc(s, Fz), hmid = dn_alloc(s, b.f1_out), X2 = dn_alloc(s, Fz);
+    ConvOpt oo;
+    oo.bias = e.F(b.o_b); oo.res = dn_cv(s, X);
+    conv(c, e, dn_cv(s, att), b.o, dn_cv(s, X1), oo);
+    ConvOpt of1;
+    of1.bias = e.F(b.f1_b); of1.act = ST2_ACT_GELU;
+    conv(c, e, dn_cv(s, X1), b.f1, dn_cv(s, hmid), of1);
+    ConvOpt of2;
+    of2.bias = e.F(b.f2_b); of2.res = dn_cv(s, X1);
+    conv(c, e, dn_cv(s, hmid), b.f2, dn_cv(s, X2), of2);
+    if (i + 1 < nblk) {
+      View Xn = dn_alloc(s, Fz);
+      RUN(c, g_be.add_chanvec(X2.p, X2.bs, X2.cs, m, Fz, Xn.p, Xn.bs, Xn.cs, B, Fz, N, c.stream));
+      X = Xn;
+    } else {
+      X = X2;
+    }
+  }
+  float* mean = c.a.f32((int64_t)B * Fz);
+  RUN(c, g_be.mean_tokens_len(X.p, X.bs, X.cs, mean, Fz, B, Fz, N, s.key_len, c.stream));
+  RUN(c, g_be.style_fc(mean, B, Fz, e.F(d.out_t), e.F(d.out_b), C, ST2_ACT_NONE, out, c.stream));
+  c.a.off = mark;
+}
+
+// KDiffusion.denoise_fn at one sigma (sampler.py:184-208): out = c_skip * x + c_out * net(c_in * x, c_noise)
+void dn_denoise(Sess& s, const float* x, const double* w4, float* out) {
+  Ctx& c = s.c;
+  const int C = s.e.cfg.dn_channels;
+  const int64_t n = (int64_t)s.B * C;
+  const int64_t mark = c.a.off;
+  const float c_skip = (float)w4[0], c_out = (float)w4[1], c_in = (float)w4[2], c_noise = (float)w4[3];
+  float* x_in = c.a.f32(n);
+  RUN(c, g_be.axpbypcz(x, c_in, nullptr, 0.f, nullptr, 0.f, x_in, n, c.stream));
+  const float* m = dn_mapping(s, c_noise);
+  float* pred = c.a.f32(n);
+  dn_run(s, s.bases[0], x_in, m, pred);
+  if (s.nbases > 1) {  // classifier-free guidance, modules.py:418-423
+    float* pm = c.a.f32(n);
+    dn_run(s, s.bases[1], x_in, m, pm);
+    float* mix = c.a.f32(n);
+    RUN(c, g_be.axpbypcz(pm, (float)(1.0 - s.scale), pred, (float)s.scale, nullptr, 0.f, mix, n, c.stream));
+    pred = mix;
+  }
+  RUN(c, g_be.axpbypcz(x, c_skip, pred, c_out, nullptr, 0.f, out, n, c.stream));
+  c.a.off = mark;
+}
+
+int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* embedding, const float* features,
+                 const float* step_noise, const int32_t* lengths, int B, int N, int steps, double scale,
+                 const double* table, double sigma0, float* out, float* step_taps) {
+  const st2_model_config& cfg = e.cfg;
+  const PDenoiser& d = e.dn;
+  const int C = cfg.dn_channels, E = cfg.dn_embedding, Fz = d.features;
+  Sess s{c, e, B, N, !cfg.multispeaker, lengths, {}, 1, nullptr, nullptr, scale};
+  // session: everything constant across the 2*(steps-1) net calls
+  s.bases[0] = dn_alloc(s, Fz);
+  {
+    View dst = s.bases[0].rows(C, Fz);
+    RUN(c, g_be.tokens_to_channels(embedding, (int64_t)N * E, B, N, E, dst.p, dst.bs, dst.cs, c.stream));
+  }
+  if (scale != 1.0) {
+    s.nbases = 2;
+    s.bases[1] = dn_alloc(s, Fz);
+    View dst = s.bases[1].rows(C, Fz);
+    RUN(c, g_be.tokens_to_channels(e.F(d.fixed), 0, B, N, E, dst.p, dst.bs, dst.cs, c.stream));
+  }
+  if (cfg.multispeaker) {
+    if (!features) { st2_set_error("st2_sampler_run: the multispeaker denoiser needs `features`"); return 1; }
+    float* fm = c.a.f32((int64_t)B * Fz);
+    RUN(c, g_be.style_fc(features, B, cfg.dn_context_features, e.F(d.feat), e.F(d.feat_b), Fz, ST2_ACT_GELU, fm, c.stream));
+    const int J = cfg.dn_layers * 4 * Fz;
+    float* ada = c.a.f32((int64_t)B * J);
+    RUN(c, g_be.style_fc(features, B, cfg.dn_context_features, e.F(d.ada_wt), e.F(d.ada_b), J, ST2_ACT_NONE, ada, c.stream));
+    s.feat_map = fm;
+    s.ada = ada;
+  }
+  const int64_t n = (int64_t)B * C;
+  float* xa = c.a.f32(n);
+  float* xb = c.a.f32(n);
+  float* x = xa;
+  RUN(c, g_be.axpbypcz(noise, (float)sigma0, nullptr, 0.f, nullptr, 0.f, x, n, c.stream));
+  for (int i = 0; i + 1 < steps; ++i) {
+    const double* row = table + (int64_t)i * ST2_SAMPLER_TABLE_COLS;
+    const int64_t mark = c.a.off;
+    float* den = c.a.f32(n);
+    dn_denoise(s, x, row + 0, den);
+    // d = (x - den) / sigma ; x_mid = x + d * (sigma_mid - sigma)
+    const double k = row[8];
+    float* x_mid = c.a.f32(n);
+    RUN(c, g_be.axpbypcz(x, (float)(1.0 + k), den, (float)(-k), nullptr, 0.f, x_mid, n, c.stream));
+    float* den_mid = c.a.f32(n);
+    dn_denoise(s, x_mid, row + 4, den_mid);
+    // d_mid = (x_mid - den_mid) / sigma_mid ; x = x + d_mid * (sigma_down - sigma) + eps * sigma_up
+    const double k2 = row[9];
+    float* d_mid = c.a.f32(n);
+    RUN(c, g_be.axpbypcz(x_mid, (float)k2, den_mid, (float)(-k2), nullptr, 0.f, d_mid, n, c.stream));
+    float* xn = (x == xa) ? xb : xa;
+    RUN(c, g_be.axpbypcz(x, 1.0f, d_mid, 1.0f, step_noise + (int64_t)i * n, (float)row[10], xn, n, c.stream));
+    x = xn;
+    if (step_taps) RUN(c, g_be.axpbypcz(x, 1.0f, nullptr, 0.f, nullptr, 0.f, step_taps + (int64_t)i * n, n, c.stream));
+    c.a.off = mark;
+  }
+  RUN(c, g_be.axpbypcz(x, 1.0f, nullptr, 0.f, nullptr, 0.f, out, n, c.stream));
+  return c.rc;
+}
+
+bool check_cfg(const st2_model_config& c) {
+  return c.n_upsamples >= 1 && c.n_upsamples <= 4 && c.n_resblock_kernels >= 1 && c.n_resblock_kernels <= 4 &&
+         (c.decoder_kind == 0 || c.decoder_kind == 1) && c.dim_in > 0 && c.style_dim > 0 && c.dn_layers >= 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// C entry points
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int st2_debug_set_backend(void* const* table, int32_t entries) {
+  if (!table) {
+    g_be = kHipBackend;
+    return 0;
+  }
+  ST2_REQUIRE(entries == ST2_BACKEND_ENTRIES, "st2_debug_set_backend: %d entries, expected %d", entries,
+              (int)ST2_BACKEND_ENTRIES);
+  for (int i = 0; i < entries; ++i) ST2_REQUIRE(table[i] != nullptr, "st2_debug_set_backend: entry %d is null", i);
+#define SLOT(field, slot) g_be.field = reinterpret_cast<decltype(g_be.field)>(table[slot])
+  SLOT(conv1d_f16s, ST2_BE_CONV1D_F16S); SLOT(conv1d_xs, ST2_BE_CONV1D_XS); SLOT(act_split, ST2_BE_ACT_SPLIT);
+  SLOT(stats_finalize, ST2_BE_STATS_FINALIZE); SLOT(conv1d_direct, ST2_BE_CONV1D_DIRECT);
+  SLOT(phase_split, ST2_BE_PHASE_SPLIT); SLOT(instnorm_stats, ST2_BE_INSTNORM_STATS);
+  SLOT(colnorm_stats, ST2_BE_COLNORM_STATS); SLOT(style_fc, ST2_BE_STYLE_FC);
+  SLOT(convt_interleave_stats, ST2_BE_CONVT_INTERLEAVE_STATS); SLOT(adain_leaky_pool, ST2_BE_ADAIN_LEAKY_POOL);
+  SLOT(har_source, ST2_BE_HAR_SOURCE); SLOT(stft_mag_phase, ST2_BE_STFT_MAG_PHASE); SLOT(istft, ST2_BE_ISTFT);
+  SLOT(attention_keylen, ST2_BE_ATTENTION_KEYLEN); SLOT(add_chanvec, ST2_BE_ADD_CHANVEC);
+  SLOT(mean_tokens_len, ST2_BE_MEAN_TOKENS_LEN); SLOT(axpbypcz, ST2_BE_AXPBYPCZ);
+  SLOT(time_features, ST2_BE_TIME_FEATURES); SLOT(tokens_to_channels, ST2_BE_TOKENS_TO_CHANNELS);
+  SLOT(broadcast_cols, ST2_BE_BROADCAST_COLS); SLOT(copy_ncl, ST2_BE_COPY_NCL);
+  SLOT(dev_alloc, ST2_BE_DEV_ALLOC); SLOT(dev_free, ST2_BE_DEV_FREE); SLOT(upload, ST2_BE_UPLOAD);
+#undef SLOT
+  return 0;
+}
+
+extern "C" int st2_create(const st2_model_config* cfg, st2_engine** out) {
+  ST2_REQUIRE(cfg && out, "st2_create: null argument");
+  ST2_REQUIRE(check_cfg(*cfg), "st2_create: invalid model configuration");
+  st2_engine* e = new (std::nothrow) st2_engine();
+  ST2_REQUIRE(e, "st2_create: out of memory");
+  e->cfg = *cfg;
+  *out = e;
+  return 0;
+}
+
+extern "C" int st2_destroy(st2_engine* e) {
+  if (!e) return 0;
+  if (e->wbase) g_be.dev_free(e->wbase);
+  delete e;
+  return 0;
+}
+
+extern "C" int st2_load_weights(st2_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  ST2_REQUIRE(e && name && data && shape && ndim >= 0 && ndim <= 4, "st2_load_weights: bad arguments");
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    ST2_REQUIRE(shape[i] > 0, "st2_load_weights: %s has a non-positive dimension", name);
+    t.shape.push_back(shape[i]);
+    n *= shape[i];
+  }
+  t.data.assign(data, data + n);
+  e->host[std::string(name)] = std::move(t);
+  return 0;
+}
+
+extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
+  ST2_REQUIRE(e && (which & 3) != 0, "st2_finalize_weights: bad arguments");
+  Blob blob;
+  std::string err;
+  if (which & 1) ST2_REQUIRE(pack_decoder(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+  else e->dec.ready = false;
+  if (which & 2) ST2_REQUIRE(pack_denoiser(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+  else e->dn.ready = false;
+  if (e->wbase) {
+    g_be.dev_free(e->wbase);
+    e->wbase = nullptr;
+  }
+  const int64_t bytes = (int64_t)blob.host.size();
+  void* p = g_be.dev_alloc(bytes);
+  ST2_REQUIRE(p, "st2_finalize_weights: device allocation of %lld B failed", (long long)bytes);
+  if (g_be.upload(p, blob.host.data(), bytes) != 0) {
+    g_be.dev_free(p);
+    st2_set_error("st2_finalize_weights: upload failed");
+    return 1;
+  }
+  e->wbase = static_cast<char*>(p);
+  e->wbytes = bytes;
+  return 0;
+}
+
+extern "C" int64_t st2_decoder_workspace_bytes(st2_engine* e, int32_t B, int32_t T) {
+  if (!e || !e->dec.ready || B <= 0 || T <= 0) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  decoder_plan(c, *e, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, T, nullptr, nullptr);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_decoder_forward(st2_engine* e, const float* asr, const float* f0, const float* n, const float* s,
+                                   const float* sine_noise, const float* har_inject, int32_t B, int32_t T, float* wave,
+                                   void* workspace, int64_t workspace_bytes, const st2_decoder_taps* taps, void* stream) {
+  ST2_REQUIRE(e && e->dec.ready, "st2_decoder_forward: decoder weights not finalized");
+  ST2_REQUIRE(asr && f0 && n && s && wave && workspace && B > 0 && T > 0, "st2_decoder_forward: bad arguments");
+  ST2_REQUIRE(sine_noise || har_inject, "st2_decoder_forward: sine_noise (or har_inject) is required");
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_decoder_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = decoder_plan(c, *e, asr, f0, n, s, sine_noise, har_inject, B, T, wave, taps);
+  ST2_REQUIRE(!c.a.overflow, "st2_decoder_forward: workspace of %lld B is too small (need %lld B, see "
+              "st2_decoder_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
+}
+
+extern "C" int st2_sampler_table(int32_t steps, double sigma_min, double sigma_max, double rho, double sigma_data,
+                                 double* table, double* sigma0) {
+  ST2_REQUIRE(steps >= 2 && table && sigma0 && rho > 0, "st2_sampler_table: bad arguments");
+  std::vector<float> sig((size_t)steps + 1, 0.f);
+  const double rinv = 1.0 / rho;
+  for (int i = 0; i < steps; ++i) {  // KarrasSchedule.forward in fp32 (sampler.py:328-337)
+    const float frac = (float)i / (float)(steps - 1);
+    const float base = (float)pow(sigma_max, rinv) + frac * (float)(pow(sigma_min, rinv) - pow(sigma_max, rinv));
+    sig[(size_t)i] = powf(base, (float)rho);
+  }
+  *sigma0 = (double)sig[0];
+  auto weights = [&](double sigma, double* w4) {  // KDiffusion.get_scale_weights in fp32 (sampler.py:184-191)
+    const float s = (float)sigma, sd = (float)sigma_data;
+    w4[3] = (double)(logf(s) * 0.25f);
+    w4[0] = (double)((sd * sd) / (s * s + sd * sd));
+    w4[1] = (double)(s * sd * (1.0f / sqrtf(sd * sd + s * s)));
+    w4[2] = (double)(1.0f / sqrtf(s * s + sd * sd));
+  };
+  for (int i = 0; i + 1 < steps; ++i) {
+    double* row = table + (int64_t)i * ST2_SAMPLER_TABLE_COLS;
+    const double s = (double)sig[(size_t)i], sn = (double)sig[(size_t)i + 1];
+    const double up = sqrt(sn * sn * (s * s - sn * sn) / (s * s));  // ADPM2Sampler.get_sigmas, rho = 1
+    const double down = sqrt(sn * sn - up * up);
+    const double mid = (s + down) / 2.0;
+    weights(s, row + 0);
+    weights(mid, row + 4);
+    row[8] = (mid - s) / s;
+    row[9] = (down - s) / mid;
+    row[10] = up;
+  }
+  return 0;
+}
+
+extern "C" int64_t st2_sampler_workspace_bytes(st2_engine* e, int32_t B, int32_t N, int32_t steps, double embedding_scale) {
+  if (!e || !e->dn.ready || B <= 0 || N <= 0 || steps < 2) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  std::vector<double> table((size_t)(steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
+  static const float dummy = 0.f;
+  sampler_plan(c, *e, nullptr, nullptr, &dummy, nullptr, nullptr, B, N, steps, embedding_scale, table.data(), 1.0, nullptr,
+               nullptr);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_sampler_run(st2_engine* e, const float* noise, const float* embedding, const float* features,
+                               const float* step_noise, const int32_t* lengths, int32_t B, int32_t N, int32_t steps,
+                               double embedding_scale, const double* table, double sigma0, float* out, void* workspace,
+                               int64_t workspace_bytes, float* step_taps, void* stream) {
+  ST2_REQUIRE(e && e->dn.ready, "st2_sampler_run: denoiser weights not finalized");
+  ST2_REQUIRE(noise && embedding && step_noise && table && out && workspace && B > 0 && N > 0 && steps >= 2,
+              "st2_sampler_run: bad arguments");
+  ST2_REQUIRE(N <= e->cfg.dn_max_length, "st2_sampler_run: N=%d exceeds the fixed-embedding length %d", N,
+              e->cfg.dn_max_length);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_sampler_run: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = sampler_plan(c, *e, noise, embedding, features, step_noise, lengths, B, N, steps, embedding_scale, table,
+                              sigma0, out, step_taps);
+  ST2_REQUIRE(!c.a.overflow, "st2_sampler_run: workspace of %lld B is too small (need %lld B, see "
+              "st2_sampler_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
+}

@@ -143,7 +143,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 @torch.no_grad()
 def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
               ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
-              taps=None, front_stream=None):
+              taps=None, front_stream=None, inputs_on_main=False):
     """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
 
     Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
@@ -157,7 +157,11 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     the decoder (on the current stream) through an event.  A caller that synthesises batch after batch thereby
     overlaps batch k+1's front -- a long chain of small, latency-bound kernels (BiLSTM recurrences on 64 CUs, 100-token
     transformer layers) -- with batch k's decoder, whose big convolutions fill whatever CUs the front leaves idle.
-    Results are identical to the single-stream call.
+    Results are identical to the single-stream call.  The caller's input tensors must be complete when the front
+    stream reaches them: inputs resident from earlier synchronised work (the bench, a server's staging buffers) need
+    nothing; inputs still being produced on the CURRENT stream (a per-call torch.randn, an async H2D copy) need
+    `inputs_on_main=True`, which makes the front stream wait for the current stream first -- at the price of also
+    waiting for the previous call's decoder queued there, i.e. of the overlap.
     """
     kw = dict(input_lengths=input_lengths, noise=noise, diffusion_steps=diffusion_steps,
               embedding_scale=embedding_scale, ref_s=ref_s, alpha=alpha, beta=beta, durations=durations,
@@ -166,7 +170,8 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
         p = prepare(model, sampler, tokens, **kw)
     else:
         main = torch.cuda.current_stream(tokens.device)
-        front_stream.wait_stream(main)  # inputs the caller produced on its stream (per-call randn, H2D copies) are ready
+        if inputs_on_main:
+            front_stream.wait_stream(main)
         with torch.cuda.stream(front_stream):
             p = prepare(model, sampler, tokens, **kw)
             ready = torch.cuda.Event()

@@ -145,7 +145,7 @@ def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
 @pytest.mark.parametrize("pro", [R.PRO_NONE, R.PRO_LEAKY, R.PRO_ADAIN_LEAKY, R.PRO_ADAIN_SNAKE, R.PRO_SNAKE,
                                  R.PRO_COLNORM])
 def test_activate_planes_match_contract(pro):
-    """st2_act_split: hi + lo planes reconstruct 8 * pro(x); halo, tail and channel padding are exact zeros; every
+    """st2_act_split: hi + lo planes reconstruct x_scale * pro(x) (x_scale = ops.x_scale_for(pro)); halo, tail and channel padding are exact zeros; every
     stored half is finite and |lo| <= half an ulp of hi."""
     B, C, L = 2, 70, 333
     x, w, kw = make_conv_case(seed=5, B=B, C_in=C, C_out=8, L=L, ks=1, dil=1, pro=pro)
@@ -155,7 +155,8 @@ def test_activate_planes_match_contract(pro):
     torch.cuda.synchronize()
     d = xs.data.cpu().float()                                   # [B, 2, cg, Lp, 8]
     assert xs.C == C and xs.L == L and d.shape[2] * 8 >= C and d.shape[3] >= L + xs.halo
-    val = (d[:, 0] + d[:, 1]).permute(0, 1, 3, 2).reshape(B, -1, d.shape[3]) / 8.0   # [B, cg*8, Lp]
+    val = (d[:, 0] + d[:, 1]).permute(0, 1, 3, 2).reshape(B, -1, d.shape[3]) / xs.x_scale   # [B, cg*8, Lp]
+    assert xs.x_scale == ops.x_scale_for(pro) == (8.0 if pro in (R.PRO_ADAIN_LEAKY, R.PRO_ADAIN_SNAKE, R.PRO_COLNORM) else 1.0)
     ref = R.activate(x, **{k: v for k, v in kw.items() if k in ("pro", "slope", "stats", "gamma", "beta", "alpha")})
     got = val[:, :C, xs.halo:xs.halo + L]
     assert (got - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
