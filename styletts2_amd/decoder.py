@@ -328,6 +328,11 @@ class Decoder(nn.Module):
                                        upsample_initial_channel, resblock_dilation_sizes, upsample_kernel_sizes)
         self._pk = None
 
+    def __setattr__(self, name, value):
+        if name == "_pk" and value is None:  # every invalidation of the Python-side pack drops the C++ plan's copy too
+            object.__setattr__(self, "_eng", None)
+        super().__setattr__(name, value)
+
     # -- packed-weight cache ---------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._pk = None
@@ -374,6 +379,13 @@ class Decoder(nn.Module):
             raise RuntimeError("the MI355X engine is inference-only; call .eval() (reference: istftnet.py:500-508 "
                                "is the training-only F0/N smoothing)")
         dev = asr.device
+        from . import engine
+        if asr.is_cuda and engine.plan_mode() == "engine" and W.conv_precision() == "f16s":
+            # ONE C-ABI call: the launch plan below exists in C++ (csrc/st2_engine.hip, st2_decoder_forward)
+            eng = self._eng
+            if eng is None or eng.device != dev:
+                eng = self._eng = engine.build_decoder_engine(self, dev)
+            return eng.decoder_forward(asr, F0_curve, N, s, noise=noise, har=har, taps=taps)
         pk = self._pk if (self._pk is not None and self._pk.device == dev) else self._prepare(dev)
         bank = pk.bank
         asr = asr.float().contiguous()

@@ -111,11 +111,39 @@ class DiffusionSampler(nn.Module):
         self.num_steps = num_steps
         self.clamp = clamp
 
+    def step_table(self, num_steps):
+        """The input-independent scalars of the ADPM2 loop in the reference's own arithmetic (fp32 tensors for the
+        schedule and the EDM weights, python floats for sigma_up / down / mid): `st2_sampler_run`'s `table` (11 doubles per
+        step, include/st2.h) and sigma0."""
+        sigmas = self.sigma_schedule(num_steps, None)
+        table = []
+        for i in range(num_steps - 1):
+            sigma, sigma_next = sigmas[i], sigmas[i + 1]
+            s_up, s_down, s_mid = self.sampler.get_sigmas(sigma, sigma_next)
+            sg = float(sigma)
+            table += list(self.diffusion.get_scale_weights(sg)) + list(self.diffusion.get_scale_weights(s_mid))
+            table += [(s_mid - sg) / sg, (s_down - sg) / s_mid, s_up]
+        return table, float(sigmas[0])
+
+    def _engine(self, device):
+        """The C++ plan's handle for this denoiser on `device` (packed once per load; rebuilt when the Python-side
+        packed-weight cache was invalidated by load_state_dict / .to())."""
+        from . import engine
+        net = self.diffusion.net
+        eng = getattr(net, "_engine", None)
+        if eng is None or eng.device != device or getattr(net, "_engine_stale", True):
+            eng = engine.build_denoiser_engine(net, device)
+            net._engine, net._engine_stale = eng, False
+        return eng
+
     @torch.no_grad()
     def forward(self, noise, num_steps=None, step_noise=None, taps=None, **kwargs):
         """`step_noise` [num_steps-1, B, 1, C] (optional) replays the per-step randn_like draws of sampler.py:509."""
         num_steps = num_steps if num_steps is not None else self.num_steps
         assert num_steps is not None, "Parameter `num_steps` must be provided"
+        from . import engine
+        if noise.is_cuda and engine.plan_mode() == "engine" and not kwargs.get("embedding_mask_proba"):
+            return self._forward_engine(noise, num_steps, step_noise, taps, **kwargs)
         sigmas = self.sigma_schedule(num_steps, noise.device)
         noise = noise.float().contiguous()
         sess = self.diffusion.net.open_session(noise, **kwargs)
@@ -136,6 +164,26 @@ class DiffusionSampler(nn.Module):
             x = ops.axpbypcz(x, 1.0, d_mid, 1.0, eps, s_up)
             if taps is not None:
                 taps["step%d" % i] = x
+        return x.clamp(-1.0, 1.0) if self.clamp else x
+
+    def _forward_engine(self, noise, num_steps, step_noise, taps, embedding=None, features=None, embedding_scale=1.0,
+                        lengths=None, embedding_mask_proba=0.0):
+        """One `st2_sampler_run` call: the whole ADPM2 loop is issued by the C++ plan (csrc/st2_engine.hip)."""
+        assert embedding is not None, "the denoiser is conditional: `embedding` is required (modules.py:410)"
+        net = self.diffusion.net
+        B, N, E = embedding.shape
+        assert N <= net.fixed_embedding.max_length, "Input sequence length must be <= max_length"
+        if net.multispeaker:
+            assert features is not None, "context_features exists but no features provided"
+        if step_noise is None:  # the reference's per-step randn_like draws (sampler.py:509)
+            step_noise = torch.randn((num_steps - 1,) + tuple(noise.shape), device=noise.device, dtype=torch.float32)
+        if lengths is not None and not (lengths.dtype == torch.int32 and lengths.device == noise.device):
+            assert int(lengths.min()) >= 1 and int(lengths.max()) <= N
+            lengths = lengths.to(torch.int32).to(noise.device)
+        table, sigma0 = self.step_table(num_steps)
+        x = self._engine(noise.device).sampler_run(noise, embedding, features if net.multispeaker else None, step_noise,
+                                                   None if lengths is None else lengths.contiguous(), num_steps,
+                                                   float(embedding_scale), table, sigma0, taps=taps)
         return x.clamp(-1.0, 1.0) if self.clamp else x
 
 
@@ -171,7 +219,7 @@ class GraphedSampler(nn.Module):
                lengths is not None)
         g = self._graphs.get(key)
         net = self.sampler.diffusion.net
-        if g is not None and g["pk"] is not getattr(net, "_pk", None):
+        if g is not None and g["gen"] != getattr(net, "_pack_gen", 0):
             # the denoiser's packed weights were rebuilt (load_state_dict / .to()): every recorded graph still points
             # at the old, freed pack
             self._graphs.clear()
@@ -217,7 +265,7 @@ class GraphedSampler(nn.Module):
         with torch.cuda.graph(graph):
             st["out"] = run()
         st["graph"] = graph
-        st["pk"] = self.sampler.diffusion.net._pk  # identity of the packed weights the graph's kernels read
+        st["gen"] = getattr(self.sampler.diffusion.net, "_pack_gen", 0)  # generation of the packed weights the graph reads
         return st
 
 
@@ -308,6 +356,12 @@ class _Transformer(nn.Module):
 
     def refresh(self):
         self._pk = None
+
+    def __setattr__(self, name, value):
+        if name == "_pk" and value is None:  # every invalidation of the Python-side pack (load_state_dict, .to(), refresh)
+            object.__setattr__(self, "_engine_stale", True)   # ... makes the C++ plan's packed copy stale too
+            object.__setattr__(self, "_pack_gen", getattr(self, "_pack_gen", 0) + 1)  # ... and recorded graphs
+        super().__setattr__(name, value)
 
     def _prepare(self, device):
         d = lambda t: t.detach().float().contiguous().to(device)

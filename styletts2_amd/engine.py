@@ -1,0 +1,218 @@
+"""Python binding of the module-level C ABI (include/st2.h: st2_create / st2_load_weights / st2_finalize_weights /
+st2_decoder_forward / st2_sampler_run).
+
+The launch plans of `Decoder.forward` (Modules/istftnet.py:499-528, Modules/hifigan.py:446-475) and
+`DiffusionSampler.forward` (Modules/diffusion/sampler.py:573-586) live in C++ (csrc/st2_engine.hip); a module forward is
+ONE ctypes call here: PyTorch supplies the device buffers (inputs, output, one workspace) and the stream, nothing else.
+The per-kernel Python plans (decoder.py, diffusion.py) remain as the tap-point / A-B path: `ST2_PLAN=python` selects
+them, and CPU tensors always take them (the CPU plan tests substitute per-kernel contracts for the HIP wrappers).
+"""
+import ctypes as C
+import math
+import os
+
+import torch
+
+from . import _lib
+from . import weights as W
+
+
+def plan_mode():
+    """"engine" (default): module forwards are single C-ABI calls into the C++ plans; "python": the per-kernel Python
+    plans.  Read from ST2_PLAN at call time."""
+    mode = os.environ.get("ST2_PLAN", "engine")
+    if mode not in ("engine", "python"):
+        raise ValueError("ST2_PLAN must be engine or python, got %r" % mode)
+    return mode
+
+
+def _folded_state(module):
+    """Reference-layout state_dict with every weight-norm pair folded: X.weight_g / X.weight_v -> X.weight."""
+    sd = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_g"):
+            continue
+        if k.endswith(".weight_v"):
+            out[k[:-2]] = W.fold_weight_norm(sd[k[:-1] + "g"].detach().float().cpu(), v.detach().float().cpu())
+        elif torch.is_floating_point(v):
+            out[k] = v.detach().float().cpu()
+    return out
+
+
+class Engine:
+    """One st2_engine handle (packed weights of a decoder and / or a denoiser on the current device)."""
+
+    def __init__(self, cfg):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _lib.check(self.lib.st2_create(C.byref(cfg), C.byref(self.h)), "st2_create")
+        self.device = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.h:
+                self.lib.st2_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def load(self, name, t):
+        t = t.detach().float().cpu().contiguous()
+        shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        _lib.check(self.lib.st2_load_weights(self.h, name.encode(), t.data_ptr(), shape, t.dim()), "st2_load_weights")
+
+    def load_module(self, prefix, module):
+        for k, v in _folded_state(module).items():
+            self.load(prefix + k, v)
+
+    def finalize(self, which, device):
+        if device is not None and torch.device(device).type == "cuda":
+            with torch.cuda.device(device):
+                _lib.check(self.lib.st2_finalize_weights(self.h, which), "st2_finalize_weights")
+        else:
+            _lib.check(self.lib.st2_finalize_weights(self.h, which), "st2_finalize_weights")
+        self.device = device
+
+    # -- decoder ---------------------------------------------------------------------------------------------------
+    def decoder_forward(self, asr, F0, N, s, noise=None, har=None, taps=None):
+        B, Cin, T = asr.shape
+        dev = asr.device
+        cfg = self.cfg
+        rates = [cfg.upsample_rates[i] for i in range(cfg.n_upsamples)]
+        up = math.prod(rates) * (cfg.gen_istft_hop if cfg.decoder_kind == 0 else 1)
+        L = 2 * T * up
+        asr, F0, N, s = (t.float().contiguous() for t in (asr, F0, N, s))
+        if har is None and noise is None:
+            noise = torch.randn(B, L, 9, device=dev, dtype=torch.float32)  # the reference's in-forward randn_like
+        if noise is not None:
+            noise = noise.float().contiguous()
+            assert noise.shape == (B, L, 9)
+        if har is not None:
+            har = har.float().contiguous()
+        wave = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
+        nbytes = self.lib.st2_decoder_workspace_bytes(self.h, B, T)
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_decoder_workspace_bytes failed (weights not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        tp = None
+        if taps is not None:
+            tp = _lib.DecoderTaps()
+            M = L // cfg.gen_istft_hop + 1 if cfg.decoder_kind == 0 else L
+            bufs = {"encode": torch.empty((B, 1024, T), device=dev), "front": torch.empty((B, 512, 2 * T), device=dev)}
+            if har is None:
+                bufs["har_source"] = torch.empty((B, L), device=dev)
+            if cfg.decoder_kind == 0:
+                bufs["har"] = torch.empty((B, cfg.gen_istft_n_fft + 2, M), device=dev)
+                bufs["spec_phase"] = torch.empty((B, cfg.gen_istft_n_fft + 2, M), device=dev)
+            Ls = 2 * T
+            for i in range(cfg.n_upsamples):  # stage lengths as decoder_plan computes them
+                u, k = rates[i], cfg.upsample_kernel_sizes[i]
+                if cfg.decoder_kind == 0:
+                    Ls = (Ls - 1) * u - 2 * ((k - u) // 2) + k + (1 if i + 1 == cfg.n_upsamples else 0)
+                else:
+                    Ls = (Ls - 1) * u - 2 * (u // 2 + u % 2) + k + u % 2
+                bufs["stage%d" % i] = torch.empty((B, cfg.upsample_initial_channel >> (i + 1), Ls), device=dev)
+            for k, v in bufs.items():
+                if k.startswith("stage"):
+                    tp.stage[int(k[5:])] = v.data_ptr()
+                else:
+                    setattr(tp, k, v.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_decoder_forward(self.h, asr.data_ptr(), F0.data_ptr(), N.data_ptr(), s.data_ptr(),
+                                                0 if noise is None else noise.data_ptr(),
+                                                0 if har is None else har.data_ptr(), B, T, wave.data_ptr(),
+                                                ws_ptr, nbytes, None if tp is None else C.byref(tp), stream),
+                   "st2_decoder_forward")
+        if taps is not None:
+            taps.update(bufs)
+            if cfg.decoder_kind == 0:
+                taps["har"] = bufs["har"] if har is None else har
+            else:
+                taps["har"] = (bufs["har_source"] if har is None else har.reshape(B, L)).unsqueeze(1)
+        return wave
+
+    # -- sampler ---------------------------------------------------------------------------------------------------
+    def sampler_run(self, noise, embedding, features, step_noise, lengths, steps, scale, table, sigma0, taps=None):
+        B = noise.shape[0]
+        Cc = self.cfg.dn_channels
+        N = embedding.shape[1]
+        dev = noise.device
+        noise = noise.float().contiguous()
+        embedding = embedding.float().contiguous()
+        if features is not None:
+            features = features.float().contiguous()
+        step_noise = step_noise.float().contiguous()
+        assert step_noise.numel() == (steps - 1) * B * Cc and noise.numel() == B * Cc
+        out = torch.empty((B, 1, Cc), device=dev, dtype=torch.float32)
+        nbytes = self.lib.st2_sampler_workspace_bytes(self.h, B, N, steps, float(scale))
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_sampler_workspace_bytes failed (weights not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        st = torch.empty((steps - 1, B, 1, Cc), device=dev, dtype=torch.float32) if taps is not None else None
+        tab = (C.c_double * len(table))(*table)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_sampler_run(self.h, noise.data_ptr(), embedding.data_ptr(),
+                                            0 if features is None else features.data_ptr(), step_noise.data_ptr(),
+                                            0 if lengths is None else lengths.data_ptr(), B, N, steps, float(scale), tab,
+                                            float(sigma0), out.data_ptr(), ws_ptr, nbytes,
+                                            0 if st is None else st.data_ptr(), stream), "st2_sampler_run")
+        if taps is not None:
+            for i in range(steps - 1):
+                taps["step%d" % i] = st[i]
+        return out
+
+
+def decoder_config(dec):
+    """st2_model_config of a styletts2_amd.decoder.Decoder (denoiser fields left zero)."""
+    g = dec.generator
+    cfg = _lib.ModelConfig()
+    cfg.decoder_kind = 0 if dec.kind == "istftnet" else 1
+    cfg.dim_in = dec.dim_in
+    cfg.style_dim = dec.encode.norm1.fc.weight.shape[1]
+    cfg.upsample_initial_channel = g.channels[0] * 2
+    cfg.n_upsamples = g.num_upsamples
+    for i in range(g.num_upsamples):
+        cfg.upsample_rates[i] = g.rates[i]
+        cfg.upsample_kernel_sizes[i] = g.up_ks[i]
+    cfg.n_resblock_kernels = g.num_kernels
+    for k in range(g.num_kernels):
+        rb = g.resblocks[k]
+        cfg.resblock_kernel_sizes[k] = rb.ks
+        for j in range(3):
+            cfg.resblock_dilations[k][j] = rb.dilation[j]
+    if dec.kind == "istftnet":
+        cfg.gen_istft_n_fft, cfg.gen_istft_hop = g.n_fft, g.hop
+    return cfg
+
+
+def denoiser_config(net):
+    """st2_model_config of a styletts2_amd.diffusion._Transformer (decoder fields are placeholders)."""
+    cfg = _lib.ModelConfig()
+    cfg.decoder_kind, cfg.dim_in, cfg.style_dim, cfg.upsample_initial_channel = 0, 512, 128, 512
+    cfg.n_upsamples, cfg.n_resblock_kernels = 1, 1
+    cfg.multispeaker = 1 if net.multispeaker else 0
+    cfg.dn_layers = len(net.blocks)
+    cfg.dn_heads, cfg.dn_head_features = net.heads, net.head_features
+    cfg.dn_multiplier = net.blocks[0].feed_forward[0].weight.shape[0] // net.features if len(net.blocks) else 0
+    cfg.dn_channels, cfg.dn_embedding = net.channels, net.emb_features
+    cfg.dn_context_features = net.to_features[0].weight.shape[1] if net.multispeaker else 0
+    cfg.dn_max_length = net.fixed_embedding.max_length
+    return cfg
+
+
+def build_decoder_engine(dec, device):
+    eng = Engine(decoder_config(dec))
+    eng.load_module("decoder.", dec)
+    eng.finalize(1, device)
+    return eng
+
+
+def build_denoiser_engine(net, device):
+    eng = Engine(denoiser_config(net))
+    eng.load_module("denoiser.", net)
+    eng.finalize(2, device)
+    return eng
