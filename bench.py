@@ -378,6 +378,15 @@ def main():
     else:
         assert out.shape == (B, 1, int(AUDIO_S_PER_UTT * 24000)) and bool(torch.isfinite(out).all())
     ops.check_status()  # raises if a cooperative BiLSTM group timed out or a split-f16 operand left the f16 range
+    # host issue time of one step (outside the timed region): wall time until the call has queued everything, GPU idle
+    # at the start and not waited for
+    host_issue = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = step()
+        host_issue.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
 
     if rank == 0:
         by_class = timer.by_class()
@@ -397,7 +406,9 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "phonemes": N_PHONEMES,
                        "diffusion_steps": steps_d, "decoder": man["config"]["decoder"]["type"],
                        "audio_s_per_step_per_gpu": audio_s, "parallelism": "utterance-sharded x%d" % world,
-                       "streams": streams, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes},
+                       "streams": streams, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
+                       "plan": os.environ.get("ST2_PLAN", "engine"),
+                       "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,
         }
         if longform:

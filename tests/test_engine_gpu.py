@@ -1,0 +1,131 @@
+"""Module-level C ABI on the GPU: `st2_decoder_forward` / `st2_sampler_run` -- the C++ launch
+plans of csrc/st2_engine.hip -- against the per-kernel Python plans (decoder.py / diffusion.py, ST2_PLAN=python).  Both
+issue the same kernels with the same arguments, so their results must be BITWISE equal; the Python plans are in turn
+held to the oracle by test_decoder_gpu.py / test_sampler_gpu.py.  Also: a whole decoder call captured in a hipGraph
+(the entry point allocates nothing and never synchronises), replayed on new inputs."""
+import os
+
+import pytest
+import torch
+
+from _util import decoder_kwargs, manifest
+from styletts2_amd import engine, models, synth
+from styletts2_amd.decoder import Decoder
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class _plan:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("ST2_PLAN")
+        os.environ["ST2_PLAN"] = self.mode
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("ST2_PLAN", None)
+        else:
+            os.environ["ST2_PLAN"] = self.old
+
+
+def _decoder(tag, wseed=1):
+    dc = manifest(tag)["config"]["decoder"]
+    dec = Decoder(**decoder_kwargs(dc)).eval()
+    synth.init_synthetic_(dec, wseed)
+    return dc, dec.to(DEV)
+
+
+@pytest.mark.parametrize("tag,B,T", [("ljspeech", 2, 10), ("ljspeech", 1, 57), ("libritts", 2, 10), ("libritts", 1, 33),
+                                     ("libritts_istftnet", 3, 16)])
+def test_decoder_engine_equals_python_plan_bitwise(tag, B, T):
+    dc, dec = _decoder(tag)
+    asr, F0, N, s, noise = (t.to(DEV) for t in synth.decoder_inputs(B, T, 5))
+    te, tp = {}, {}
+    with _plan("engine"):
+        assert engine.plan_mode() == "engine"
+        out_e = dec(asr, F0, N, s, noise=noise, taps=te)
+    with _plan("python"):
+        out_p = dec(asr, F0, N, s, noise=noise, taps=tp)
+    torch.cuda.synchronize()
+    assert getattr(dec, "_eng", None) is not None, "the engine path did not run"
+    assert out_e.shape == out_p.shape == (B, 1, 600 * T)
+    for k in ("encode", "front", "har_source", "stage0", "stage1"):
+        assert torch.equal(te[k].reshape(-1), tp[k].reshape(-1)), k
+    assert torch.equal(out_e, out_p)
+    # the harmonic-feature injection path of the tap-point protocol
+    with _plan("engine"):
+        out_e2 = dec(asr, F0, N, s, noise=noise, har=tp["har"])
+    with _plan("python"):
+        out_p2 = dec(asr, F0, N, s, noise=noise, har=tp["har"])
+    assert torch.equal(out_e2, out_p2)
+
+
+def _diffusion(tag, seed=2):
+    man = manifest(tag)
+    args = models.recursive_munch(man["config"])
+    tcls = models.StyleTransformer1d if args.multispeaker else models.Transformer1d
+    tr = tcls(channels=args.style_dim * 2, context_embedding_features=768, context_features=args.style_dim * 2,
+              embedding_max_length=512, **args.diffusion.transformer)
+    diff = models.AudioDiffusionConditional(tr, sigma_data=args.diffusion.dist.sigma_data).eval()
+    synth.init_synthetic_(diff, seed)
+    return man, diff.to(DEV)
+
+
+@pytest.mark.parametrize("tag,B,N,steps,scale,ragged", [("ljspeech", 2, 37, 5, 1.0, False), ("ljspeech", 3, 100, 5, 1.5, False),
+                                                        ("libritts", 2, 64, 10, 1.0, False), ("libritts", 1, 130, 5, 2.0, False),
+                                                        ("ljspeech", 3, 48, 5, 1.0, True), ("libritts", 2, 80, 5, 1.5, True)])
+def test_sampler_engine_equals_python_plan_bitwise(tag, B, N, steps, scale, ragged):
+    man, diff = _diffusion(tag)
+    sampler = models.DiffusionSampler(diff.diffusion, sampler=models.ADPM2Sampler(),
+                                      sigma_schedule=models.KarrasSchedule(sigma_min=0.0001, sigma_max=3.0, rho=9.0),
+                                      clamp=False)
+    g = torch.Generator().manual_seed(N)
+    noise = torch.randn(B, 1, 256, generator=g).to(DEV)
+    emb = torch.randn(B, N, 768, generator=g).to(DEV)
+    step_noise = torch.randn(steps - 1, B, 1, 256, generator=g).to(DEV)
+    kw = dict(embedding=emb, embedding_scale=scale, num_steps=steps, step_noise=step_noise)
+    if man["config"]["multispeaker"]:
+        kw["features"] = torch.randn(B, 256, generator=g).to(DEV)
+    if ragged:
+        kw["lengths"] = torch.tensor([N - 7 * b for b in range(B)], dtype=torch.int32, device=DEV)
+    te, tp = {}, {}
+    with _plan("engine"):
+        out_e = sampler(noise, taps=te, **kw)
+    with _plan("python"):
+        out_p = sampler(noise, taps=tp, **kw)
+    torch.cuda.synchronize()
+    assert out_e.shape == out_p.shape == (B, 1, 256)
+    assert set(te) == set(tp) and len(tp) == steps - 1
+    for k in tp:
+        assert torch.equal(te[k].reshape(-1), tp[k].reshape(-1)), k
+    assert torch.equal(out_e, out_p)
+
+
+@pytest.mark.parametrize("tag", ["ljspeech", "libritts"])
+def test_decoder_forward_is_graph_capturable(tag):
+    """st2_decoder_forward allocates nothing and never synchronises: after one eager call of the shape it is captured
+    whole in a hipGraph (torch.cuda.CUDAGraph on a side stream) and the replay on NEW input values reproduces the eager
+    result bitwise."""
+    dc, dec = _decoder(tag)
+    B, T = 2, 12
+    a0 = [t.to(DEV) for t in synth.decoder_inputs(B, T, 7)]
+    a1 = [t.to(DEV) for t in synth.decoder_inputs(B, T, 8)]
+    with _plan("engine"):
+        ref0 = dec(*a0[:4], noise=a0[4]).clone()
+        ref1 = dec(*a1[:4], noise=a1[4]).clone()
+        static = [t.clone() for t in a0]
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = dec(*static[:4], noise=static[4])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref0)
+        for dst, src in zip(static, a1):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref1)
