@@ -318,6 +318,8 @@ def main():
     B = 1 if longform else PER_GPU_BATCH
     tokens, lengths, noise, durations, ref_s = synthetic_inputs(PER_GPU_BATCH, 1000 + rank)
     tokens, noise = tokens.to(dev), noise.to(dev)
+    durations_dev = durations.to(dev)  # forced durations live on the device: no host -> device copy inside a step
+    frames = N_PHONEMES * FRAMES_PER_PHONEME
     ref_s = ref_s.to(dev) if cfg["multispeaker"] else None
 
     # Two HIP streams: the front of step k+1 (text encoder, PL-BERT, diffusion sampler, duration / prosody predictors:
@@ -351,7 +353,8 @@ def main():
 
         def step():
             return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
-                                      embedding_scale=1.0, ref_s=ref_s, durations=durations, front_stream=front)
+                                      embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
+                                      front_stream=front)
 
     for i in range(a.warmup):
         out = step()
@@ -359,8 +362,8 @@ def main():
         log("warm-up step %d done" % i)
     first_chunk_ms.clear()
     # roofline leg: per-launch HIP events around every split-f16 conv launch, by shape class
-    timer = ops.ConvTimer()
-    ops.set_conv_timer(timer)
+    lib = _lib.load()
+    lib.st2_conv_timing(1)  # C-ABI hook: event pairs inside st2_conv1d_xs itself, so the C++ plans' launches are seen
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
@@ -369,7 +372,7 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
-    ops.set_conv_timer(None)
+    lib.st2_conv_timing(0)
     dt = parallel.max_over_ranks(dt, dev)
     log("timed %d steps: %.1f ms/step" % (a.steps, dt / a.steps * 1e3))
     if longform:
@@ -389,7 +392,14 @@ def main():
     torch.cuda.synchronize()
 
     if rank == 0:
-        by_class = timer.by_class()
+        import ctypes
+        n_rec = lib.st2_conv_timing_read(None, 0)
+        rows = (ctypes.c_double * (6 * max(n_rec, 1)))()
+        _lib.check(0 if lib.st2_conv_timing_read(rows, n_rec) == n_rec else 1, "st2_conv_timing_read")
+        by_class = {}
+        for i in range(n_rec):
+            ks, ci, co, L, b, ms = rows[6 * i:6 * i + 6]
+            by_class.setdefault((int(ks), int(ci), int(co), int(L), int(b)), []).append(ms)
         roof = roofline(by_class)
         roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
         streams = "1" if (a.single_stream or (front is None and not longform)) else \

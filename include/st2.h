@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 9
+#define ST2_ABI_VERSION 10
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -351,6 +351,33 @@ int st2_duration_head(const float* x, int64_t x_bs, int32_t x_cs, const float* w
 int st2_expand_by_durations(const float* x, int64_t x_bs, int32_t x_cs, const int64_t* dur, int32_t B, int32_t C,
                             int32_t N, int32_t T, int32_t shift, float* y, int64_t y_bs, int32_t y_cs, void* stream);
 
+/* ---- reference-audio style path (compute_style, Demo/Inference_LibriTTS.ipynb:100-111) ------------------------- *
+ * The mel front-end (meldataset.py:58-66: torchaudio MelSpectrogram(n_mels 80, n_fft 2048, win 1200, hop 300) ->
+ * (log(1e-5 + mel) + 4) / 4) and StyleEncoder (models.py:139-164) run on the conv kernels above: the windowed DFT is a
+ * k=1 conv [2*(n_fft/2+1)][n_win] over the frame columns, the mel filter bank a k=1 conv [n_mels][n_fft/2+1], every
+ * Conv2d a Conv1d over the width with its kernel rows stacked along the channels (feature maps are stored (h, c, w):
+ * element (b,h,c,w) at x + b*x_bs + h*x_hs + c*x_cs + w, so three consecutive rows ARE the 3C-channel input).  These
+ * entry points are the remaining non-GEMM steps.
+ *   st2_stft_frames:    frames[b][c][m] = wave[b][reflect(m*hop + c - shift)], c < n_win, m < L/hop + 1: the frame
+ *                       columns of torch.stft(center=True, pad_mode="reflect") restricted to the taps where the window
+ *                       (zero padded to n_fft) is non-zero; shift = n_fft/2 - (n_fft - n_win)/2.
+ *   st2_power_spectrum: p[b][k][m] = y[b][k][m]^2 + y[b][K+k][m]^2 (stacked real / imaginary DFT rows).
+ *   st2_log_norm:       x = (log(eps + x) - mean) / std in place.
+ *   st2_dwconv3x3s2:    depthwise Conv2d(C, C, 3, stride 2, padding 1, groups C), w [C][3][3]: LearnedDownSample('half'),
+ *                       models.py:27-42; output map (H-1)/2+1 x (W-1)/2+1.
+ *   st2_avgpool2x2:     DownSample('half'), models.py:72-75: replicate the last column of an odd width, 2x2 average;
+ *                       H even; output H/2 x (W+1)/2. */
+int st2_stft_frames(const float* wave, int64_t w_bs, int32_t B, int32_t L, int32_t n_win, int32_t hop, int32_t shift,
+                    float* frames, int64_t f_bs, int32_t f_cs, void* stream);
+int st2_power_spectrum(const float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t K, int32_t M, float* p,
+                       int64_t p_bs, int32_t p_cs, void* stream);
+int st2_log_norm(float* x, int64_t n, float eps, float mean, float stdv, void* stream);
+int st2_dwconv3x3s2(const float* x, int64_t x_bs, int64_t x_hs, int32_t x_cs, const float* w, const float* bias,
+                    int32_t B, int32_t C, int32_t H, int32_t W, float* y, int64_t y_bs, int64_t y_hs, int32_t y_cs,
+                    void* stream);
+int st2_avgpool2x2(const float* x, int64_t x_bs, int64_t x_hs, int32_t x_cs, int32_t B, int32_t C, int32_t H, int32_t W,
+                   float* y, int64_t y_bs, int64_t y_hs, int32_t y_cs, void* stream);
+
 /* out[i] = a*x[i] + b*y[i] + c*z[i] (z may be NULL): sampler updates, sampler.py:184-208,497-510 */
 int st2_axpbypcz(const float* x, float a, const float* y, float b, const float* z, float c,
                  float* out, int64_t n, void* stream);
@@ -437,6 +464,14 @@ int st2_sampler_run(st2_engine* e, const float* noise, const float* embedding, c
                     const float* step_noise, const int32_t* lengths, int32_t B, int32_t N, int32_t steps,
                     double embedding_scale, const double* table, double sigma0, float* out, void* workspace,
                     int64_t workspace_bytes, float* step_taps, void* stream);
+
+/* ---- measurement hook (bench.py's roofline leg) ------------------------------------------------------------------- *
+ * st2_conv_timing(1) clears and starts, (0) stops recording a HIP event pair around every st2_conv1d_xs launch (C_in >=
+ * 64, L_out >= 256) on its launch stream, whichever plan issues it.  st2_conv_timing_read (after stopping) waits for the
+ * events and fills rows of 6 doubles {ks, C_in, C_out, L_out, B, milliseconds}; returns the number of launches recorded
+ * (rows may be NULL to count), < 0 on error.  Not thread safe; not legal under stream capture. */
+int st2_conv_timing(int enable);
+int st2_conv_timing_read(double* rows, int32_t cap_rows);
 
 /* ---- testing hook ---------------------------------------------------------------------------------------------- *
  * Replaces the kernel / memory entry points the launch plans call by the caller's (an array of ST2_BACKEND_ENTRIES

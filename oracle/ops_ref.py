@@ -348,3 +348,38 @@ def expand_by_durations(x, dur, T, shift=False, out=None):
         out.copy_(y)
         return out
     return y
+
+
+# ---- reference-audio style path (st2_style.hip contracts) ------------------------------------------------------------
+def stft_frames(wave, n_win, hop, shift):
+    B, L = wave.shape
+    M = L // hop + 1
+    idx = torch.arange(M).unsqueeze(0) * hop + torch.arange(n_win).unsqueeze(1) - shift   # [n_win, M]
+    idx = idx.abs()
+    idx = torch.where(idx >= L, 2 * (L - 1) - idx, idx)
+    return wave[:, idx]
+
+
+def power_spectrum(y):
+    K = y.shape[1] // 2
+    return y[:, :K] ** 2 + y[:, K:] ** 2
+
+
+def log_norm_(x, eps, mean, std):
+    x.copy_((torch.log(eps + x) - mean) / std)
+    return x
+
+
+def dwconv3x3s2(x, w, bias, out):
+    B, H, Cc, Wd = x.shape
+    y = F.conv2d(x.permute(0, 2, 1, 3), w.unsqueeze(1), bias, stride=2, padding=1, groups=Cc)   # [B, C, Ho, Wo]
+    out.copy_(y.permute(0, 2, 1, 3))
+    return out
+
+
+def avgpool2x2(x, out):
+    xc = x.permute(0, 2, 1, 3)
+    if xc.shape[-1] % 2 != 0:
+        xc = torch.cat([xc, xc[..., -1:]], dim=-1)
+    out.copy_(F.avg_pool2d(xc, 2).permute(0, 2, 1, 3))
+    return out

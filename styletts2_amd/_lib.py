@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -164,7 +164,18 @@ _SIGNATURES = {
     "st2_sampler_run": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_double, C.POINTER(C.c_double), C.c_double, f32p, C.c_void_p, C.c_int64, f32p,
                                   C.c_void_p]),
+    "st2_conv_timing": (C.c_int, [C.c_int]),
+    "st2_conv_timing_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_debug_set_backend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
+    "st2_stft_frames": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p,
+                                  C.c_int64, C.c_int32, C.c_void_p]),
+    "st2_power_spectrum": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p, C.c_int64,
+                                     C.c_int32, C.c_void_p]),
+    "st2_log_norm": (C.c_int, [f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "st2_dwconv3x3s2": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int32, f32p, f32p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, f32p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "st2_avgpool2x2": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p,
+                                 C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "st2_axpbypcz": (C.c_int, [f32p, C.c_float, f32p, C.c_float, f32p, C.c_float, f32p, C.c_int64, C.c_void_p]),
 }
 

@@ -9,15 +9,18 @@
 // slots that are copied global -> registers -> LDS as 16-byte vectors, double buffered (loads for chunk c+1 are
 // issued at the first k-step of chunk c, written to the other LDS buffer at its last k-step; one barrier per chunk).
 //
-// GEMM structure (as st2_conv1d_f16s.hip): per batch item M = C_out, N = L_out, K = C_in*ks ordered (ci/16, tap,
-// ci%16); product = hi_w*hi_a + hi_w*lo_a + lo_w*hi_a on v_mfma_f32_32x32x16_f16 into one fp32 accumulator; the B
-// fragment is one conflict-free ds_read_b128 per (tap, 32 columns), a tap is a shift of the slot index; the A
-// fragments (weights, L2 resident, every wave owns distinct output rows) go straight from L2 to registers, one
-// k-step ahead.  Wave tile 32 (co) x 128 (l); workgroup = 4 waves as 4x1 / 2x2 / 1x4 over (co, l) by C_out.
+// GEMM structure: per batch item M = C_out, N = L_out, K = C_in*ks ordered (ci/16, tap, ci%16); product =
+// hi_w*hi_a + hi_w*lo_a + lo_w*hi_a on v_mfma_f32_32x32x16_f16 into one fp32 accumulator; the activation fragment is
+// one conflict-free ds_read_b128 per (tap, 32 columns), a tap is a shift of the slot index; the weight fragments (L2
+// resident, every wave owns distinct output rows) go straight from L2 to registers, two k-steps ahead.  The
+// activations are the MFMA's A operand and the weights its B operand, so the accumulator is the TRANSPOSED tile: a
+// lane owns one output row and runs of 4 consecutive positions.  Wave tile 32 (co) x 128 (l); workgroup = 4 waves as
+// 4x1 / 2x2 / 1x4 over (co, l) by C_out.
 //
-// Epilogue: out_scale, bias, residual(s), divide, activation, coalesced fp32 stores -- and, if d.part is given, the
-// per-tile (sum, sum of squares) of the stored values per output channel (half-wave reduce-scatter over the 32
-// column lanes, fixed order) so the next layer's InstanceNorm statistics cost no extra pass over the tensor.
+// Epilogue: out_scale, bias, residual(s), divide, activation, 16-byte fp32 stores / residual loads per lane on interior
+// tiles of aligned tensors -- and, if d.part is given, the per-tile (sum, sum of squares) of the stored values per
+// output channel (a lane's own values + one cross-lane move, fixed order) so the next layer's InstanceNorm statistics
+// cost no extra pass over the tensor.
 #pragma once
 #include "st2_common.h"
 #include "st2_act.h"
@@ -25,34 +28,23 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Instrumentation switches of the micro-benchmark tools/xs_bench.hip (all compiled out of the library, ST2_XS_ABLATE = 0):
+// bit 0 = activation fragments read from LDS once per chunk instead of per k-step, bit 1 = weight fragments loaded once,
+// bit 2 = no epilogue, bit 3 = activations staged once (what does each stream cost on top of the bare MFMA loop?), bit 6
+// = per-workgroup timeline (s_memtime / s_memrealtime at start, k-loop end and exit, HW_ID, XCC_ID) into d.stats.
+#ifndef ST2_XS_ABLATE
+#define ST2_XS_ABLATE 0
+#endif
+#ifndef ST2_XS_NSET
+#define ST2_XS_NSET 3  // weight-fragment register sets = prefetch distance + 1
+#endif
 
 namespace {
 
 constexpr int NT = 256;
-
-// Sum 4 per-lane values over the 32 lanes that share (lane >> 5).  Reduce-scatter: after the exchange rounds lane l
-// holds the total of element 2*bit4(l) + bit3(l) (all 8 lanes of that group hold it).  6 cross-lane moves instead of
-// 20; summation order is fixed (bitwise reproducible).  Done once per group of 4 output rows so that only 2 x 4
-// partial sums are live next to the 64 accumulators (the 2 x 16 of a whole-tile reduction made the 168-VGPR build
-// spill in its epilogue).
-__device__ __forceinline__ float halfwave_reduce4(const float (&s)[4], int l31) {
-  float a2[2];
-  bool up = (l31 & 16) != 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float mine = up ? s[2 + i] : s[i];
-    const float theirs = up ? s[i] : s[2 + i];
-    a2[i] = mine + __shfl_xor(theirs, 16, 64);
-  }
-  up = (l31 & 8) != 0;
-  const float mine = up ? a2[1] : a2[0];
-  const float theirs = up ? a2[0] : a2[1];
-  float a1 = mine + __shfl_xor(theirs, 8, 64);
-  a1 += __shfl_xor(a1, 4, 64);
-  a1 += __shfl_xor(a1, 2, 64);
-  a1 += __shfl_xor(a1, 1, 64);
-  return a1;
-}
+constexpr int ABL = ST2_XS_ABLATE;
 
 // Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
 // one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
@@ -123,19 +115,29 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   const int64_t a_step = (int64_t)2 * d.wq_co_pad * 2;  // h8 units per k-step
   const int nchunk = d.wq_cin_pad / CI_T;
 
-  load_chunk(0);
   constexpr int SPC = S16 * KS;  // k-steps per chunk
-  // Weight fragments run TWO k-steps ahead in three NAMED register sets (set = k-step index within the chunk mod 3,
-  // a compile-time constant after unrolling).  VMEM returns in order, so the first weight wait that also has to
+  unsigned long long tl_t0 = 0, tl_r0 = 0;
+  if constexpr (ABL & 64) {
+    tl_t0 = __builtin_amdgcn_s_memtime();
+    tl_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  load_chunk(0);
+  // Weight fragments run NSET - 1 k-steps ahead in NSET NAMED register sets (set = k-step index within the chunk mod
+  // NSET, a compile-time constant after unrolling).  VMEM returns in order, so the first weight wait that also has to
   // drain the activation loads of the next chunk (issued at k-step 0, after that step's prefetch) is the one of
-  // k-step 3: three k-steps (>= 1100 MFMA cycles per wave) of slack for their HBM latency.
-  h8 a_hi[3], a_lo[3];
-  a_hi[0] = ap[0];
-  a_lo[0] = ap[1];
+  // k-step NSET: NSET k-steps (>= 380 MFMA cycles each per wave) of slack for their HBM latency.  The distance has to
+  // cover an L2 round trip at the pace of a wave that runs with ONE competitor on its SIMD (the third workgroup of
+  // the CU being in its epilogue most of the time): per-workgroup s_memtime stamps showed the matrix pipe idle 23 %
+  // of the cycles with two k-steps of distance.
+  constexpr int NSET = ST2_XS_NSET;
+  h8 a_hi[NSET], a_lo[NSET];
   const int nsteps = nchunk * SPC;
-  if (nsteps > 1) ap += a_step;
-  a_hi[1] = ap[0];
-  a_lo[1] = ap[1];
+#pragma unroll
+  for (int k = 0; k < NSET - 1; ++k) {
+    if (k > 0 && k < nsteps) ap += a_step;
+    a_hi[k] = ap[0];
+    a_lo[k] = ap[1];
+  }
   store_chunk(0);
   __syncthreads();
 
@@ -146,6 +148,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   // Workgroups sharing a CU run out of phase: while this wave is in its k loop, a neighbour's may be in its epilogue
   // (VALU + global memory).  Raised priority for the k loop keeps the matrix pipe fed first (cdna_hip_programming.md
   // T5: pays where waves have different roles); dropped again before the epilogue.
+  h8 abl_bh[TN], abl_bl[TN];  // ABL & 1 only
   __builtin_amdgcn_s_setprio(1);
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
@@ -156,50 +159,110 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
 #pragma unroll
       for (int t = 0; t < KS; ++t) {
         const int i = s * KS + t;           // k-step within the chunk (compile-time after unrolling)
-        const int cur = i % 3, pre = (i + 2) % 3;
-        if (more || i + 2 < SPC) ap += a_step;  // scalar select, no branch around the loads
-        a_hi[pre] = ap[0];                      // prefetch the weights of k-step i + 2
-        a_lo[pre] = ap[1];
-        // next chunk's activations: issued AFTER this step's weight prefetch (see above)
-        if (i == 0) load_chunk(more ? c + 1 : c);
-        // ... and parked in the other LDS buffer at the chunk's last k-step (free since the previous barrier)
-        if (i == SPC - 1) store_chunk(buf ^ 1);
+        const int cur = i % NSET, pre = (i + NSET - 1) % NSET;
+        if constexpr (!(ABL & 2)) {
+          if (more || i + NSET - 1 < SPC) ap += a_step;  // scalar select, no branch around the loads
+          a_hi[pre] = ap[0];                             // prefetch the weights of k-step i + NSET - 1
+          a_lo[pre] = ap[1];
+        } else {
+          a_hi[pre] = a_hi[cur];
+          a_lo[pre] = a_lo[cur];
+        }
+        if constexpr (!(ABL & 8)) {
+          // next chunk's activations: issued AFTER this step's weight prefetch (see above)
+          if (i == 0) load_chunk(more ? c + 1 : c);
+          // ... and parked in the other LDS buffer at the chunk's last k-step (free since the previous barrier)
+          if (i == SPC - 1) store_chunk(buf ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch distance is kept
         const h8 ah = a_hi[cur], al = a_lo[cur];
         const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
         h8 bh[TN], bl[TN];
+        if constexpr (ABL & 1) {
+          if (i == 0) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh[j] = xp[j * 32];
-          bl[j] = xp[plane + j * 32];
+            for (int j = 0; j < TN; ++j) {
+              abl_bh[j] = xp[j * 32];
+              abl_bl[j] = xp[plane + j * 32];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            bh[j] = abl_bh[j];
+            bl[j] = abl_bl[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            bh[j] = xp[j * 32];
+            bl[j] = xp[plane + j * 32];
+          }
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
+        // activations as the MFMA's A operand, weights as B: the accumulator comes out TRANSPOSED -- lane = output row
+        // (co), registers = positions, 4 consecutive l per (r >> 2) -- so the epilogue moves 16 bytes per lane and
+        // instruction (see below); the products and their summation order are the same as with (weights, activations)
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al, acc[j], 0, 0, 0);
       }
     }
-    // the next chunk indexes its steps from 0 again: rotate the two live sets (steps SPC, SPC+1) to sets 0, 1
-    if (SPC % 3 == 1) {
-      const h8 th = a_hi[1], tl = a_lo[1];  // sets (1, 2) -> (0, 1)
-      a_hi[1] = a_hi[2];
-      a_lo[1] = a_lo[2];
-      a_hi[0] = th;
-      a_lo[0] = tl;
-    } else if (SPC % 3 == 2) {
-      const h8 th = a_hi[0], tl = a_lo[0];  // sets (2, 0) -> (0, 1)
-      a_hi[0] = a_hi[2];
-      a_lo[0] = a_lo[2];
-      a_hi[1] = th;
-      a_lo[1] = tl;
+    // the next chunk indexes its steps from 0 again: rotate the live sets (steps SPC .. SPC + NSET - 2) to 0 .. NSET - 2
+    if constexpr (SPC % NSET != 0) {
+      h8 th[NSET], tl[NSET];
+#pragma unroll
+      for (int k = 0; k < NSET; ++k) {
+        th[k] = a_hi[k];
+        tl[k] = a_lo[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NSET; ++k) {
+        a_hi[k] = th[(k + SPC) % NSET];
+        a_lo[k] = tl[(k + SPC) % NSET];
+      }
     }
     __syncthreads();
   }
 
   __builtin_amdgcn_s_setprio(0);
+  unsigned long long tl_t1 = 0;
+  if constexpr (ABL & 64) tl_t1 = __builtin_amdgcn_s_memtime();
+  auto tl_write = [&]() __attribute__((always_inline)) {
+   if constexpr (ABL & 64) {  // micro-benchmark timeline: d.stats (unused by this kernel) carries a uint64 buffer
+    __builtin_amdgcn_s_waitcnt(0);  // stores issued (vmcnt / lgkmcnt drained as far as this counter encodes)
+    if (tid == 0) {
+      unsigned long long* tl = reinterpret_cast<unsigned long long*>(const_cast<float*>(d.stats));
+      const unsigned long long lin = blockIdx.x + gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+      tl[lin * 8 + 0] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |
+                        ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
+      tl[lin * 8 + 1] = tl_t0;
+      tl[lin * 8 + 2] = tl_t1;
+      tl[lin * 8 + 3] = __builtin_amdgcn_s_memtime();
+      tl[lin * 8 + 4] = tl_r0;
+      tl[lin * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  };
+  if constexpr (ABL & 4) {  // keep the accumulators live, store (practically) nothing
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[j][r];
+    if (t == 12345.678f) d.y[tid] = t;
+    tl_write();
+    return;
+  }
   // ---- epilogue ---------------------------------------------------------------------------------------
+  // Accumulator layout (transposed product, see the k loop): lane (l31, kg) owns output row co = m0 + wm*32 + l31 and,
+  // in acc[j][4*q + e], the position l = n0 + wn*32*TN + j*32 + 8*q + 4*kg + e: four CONSECUTIVE positions per (j, q).
+  // Interior tiles of 16-byte aligned tensors therefore store / load 16 bytes per lane and instruction -- 16 stores per
+  // wave tile instead of 64 (the store tail of an MFMA kernel is bound by the number of store instructions, not by
+  // their bytes: cdna_hip_programming.md T21; measured here: the epilogue cost 0.23 ms of a 1.70 ms k = 11 launch and
+  // 0.35 of 0.85 ms at k = 3 with 4-byte stores), bias and weight scale are per lane, and the InstanceNorm partial
+  // sums of a row are a lane's own 64 values plus its kg partner's: one cross-lane move.
   float* yb = d.y + (int64_t)b * d.y_bs;
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
   const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
@@ -207,17 +270,23 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
   const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
   const bool want_part = d.part != nullptr;
-  const int ptile = blockIdx.x * WN + wn;  // 128-column tile index of this wave's partial sums
+  constexpr int NPT = TN / 4;               // 128-column partial-sum tiles per wave tile
+  const int ptile = (blockIdx.x * WN + wn) * NPT;  // first 128-column tile index of this wave's partial sums
+  const int co = m0 + wm * 32 + l31;       // this lane's output row (< wq_co_pad by construction of the packing)
+  const int lw = n0 + wn * (32 * TN) + 4 * kg;  // first position of this lane's (j = 0, q = 0) quad
+  // 16-byte accesses need every row of y / res / res2 to start 16-byte aligned (workgroup-uniform, set by the plans'
+  // padded row pitch); the residual must not be sub-sampled
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.y) | (uintptr_t)(d.y_bs * 4) | (uintptr_t)(d.y_cs * 4)) & 15) == 0 &&
+                      (!rb || (((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0 &&
+                               d.res_shift == 0)) &&
+                      (!r2b || ((reinterpret_cast<uintptr_t>(d.res2) | (uintptr_t)(d.res2_bs * 4) | (uintptr_t)(d.res2_cs * 4)) & 15) == 0);
+  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out && vec_ok;  // workgroup-uniform
   // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
   // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
-  // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
-  // tile but the last along l / co -- of the plain-output convs dispatch ONCE to a build with those terms as
-  // compile-time constants: no bounds tests, one 64-bit address per output row (the four 32-column groups of a lane
-  // are immediate offsets), the row's residual loads issued together ahead of the arithmetic.  Edge tiles and rare
-  // combinations take the generic build (MODE < 0: run-time flags, per-element bounds).
-  const int col0 = n0 + wn * (32 * TN) + l31;
-  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
-  const int rstep = 32 >> d.res_shift;
+  // each waited for on the spot.  So interior tiles -- every tile but the last along l / co -- of aligned tensors
+  // dispatch ONCE to a build with those terms as compile-time constants: no bounds tests, 32-bit offsets from scalar
+  // bases, a column block's residual loads issued together ahead of its arithmetic.  Edge tiles, unaligned tensors and
+  // rare combinations take the generic build (MODE < 0: run-time flags, per-element bounds, 4-byte accesses).
   auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
@@ -225,69 +294,124 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
     const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
     const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
-    float ps[4], pq[4];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const bool rok = FULL || row < d.C_out;
-      const int rowc = FULL ? row : min(row, d.C_out - 1);
-      // 32-bit element offsets from the (scalar) per-batch bases: one VALU mad per row and tensor, and the memory
-      // instructions take the SGPR-base + VGPR-offset form (a batch item is < 2^31 elements, checked at launch)
-      const int yo = rowc * d.y_cs + col0;
-      const int ro = rowc * d.res_cs + (col0 >> d.res_shift);  // used only if use_res
-      const int r2o = rowc * d.res2_cs + col0;                 // used only if use_res2
-      // unconditional load + select (a branch here would split the rows into separate basic blocks); without a bias
-      // the packed weights serve as a valid address
-      const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
-      const float bias_r = d.bias ? braw : 0.f;
-      const float sraw = rsc[row];  // row < wq_co_pad by construction of the packing
-      const float osc_r = d.w_row_scale ? osc * sraw : osc;
-      bool ok[TN];
-      float rv[TN], r2v[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        ok[j] = FULL || (rok && col0 + j * 32 < d.L_out);
-        rv[j] = (use_res && ok[j]) ? rb[ro + j * rstep] : 0.f;
-        r2v[j] = (use_res2 && ok[j]) ? r2b[r2o + j * 32] : 0.f;
+    const bool rok = FULL || co < d.C_out;
+    const int coc = FULL ? co : min(co, d.C_out - 1);
+    // unconditional load + select (a branch here would split the code into separate basic blocks); without a bias the
+    // packed weights serve as a valid address
+    const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[coc];
+    const float bias_r = d.bias ? braw : 0.f;
+    const float sraw = rsc[co];
+    const float osc_r = d.w_row_scale ? osc * sraw : osc;
+    // 32-bit element offsets from the (scalar) per-batch bases (a batch item is < 2^31 elements, checked at launch)
+    const int yo = coc * d.y_cs + lw;
+    const int ro = coc * d.res_cs;   // + (l >> res_shift)
+    const int r2o = coc * d.res2_cs + lw;
+    float s1 = 0.f, s2 = 0.f;
+    float s1d[NPT], s2d[NPT];  // finished 128-column sums
+    auto finish = [&](float v) __attribute__((always_inline)) -> float {
+      if (use_div) v = v / d.div;
+      if constexpr (ACT == ST2_ACT_GELU) {
+        v = gelu_erf(v);
+      } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
+        v = co < d.act_split ? expf(v) : sin_acc(v);
+      } else if constexpr (ACT == ST2_ACT_TANH) {
+        v = tanhf(v);
+      } else if constexpr (ACT == ST2_ACT_LEAKY) {
+        v = leaky(v, d.act_slope);
+      } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
+        v = gelu_tanh(v);
       }
-      float s1 = 0.f, s2 = 0.f;
+      return v;
+    };
+    if constexpr (FULL) {
+      // ALL residual quads of 4 column blocks are requested before the first one is used: 16 x 16 bytes per lane in
+      // flight (64 VGPRs -- the k loop's fragment and staging registers are dead here).  Issued per (j, q) pair they
+      // cost one HBM round trip each, 8 in series per tile: measured 27 000 cycles of epilogue against a 101 000-cycle
+      // k loop (per-workgroup s_memtime stamps, tools/xs_bench.hip), i.e. a fifth of every workgroup slot's time.
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float v = acc[j][r] * osc_r + bias_r;
-        if (use_res) v += rv[j];
-        if (use_res2) v = r2v[j] + v;
-        if (use_div) v = v / d.div;
-        if constexpr (ACT == ST2_ACT_GELU) {
-          v = gelu_erf(v);
-        } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
-          v = row < d.act_split ? expf(v) : sin_acc(v);
-        } else if constexpr (ACT == ST2_ACT_TANH) {
-          v = tanhf(v);
-        } else if constexpr (ACT == ST2_ACT_LEAKY) {
-          v = leaky(v, d.act_slope);
-        } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
-          v = gelu_tanh(v);
+      for (int jh = 0; jh < TN; jh += 4) {
+        f32x4 rv[4][4];
+        if (use_res) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              rv[jj][q] = *reinterpret_cast<const f32x4*>(rb + ro + lw + (jh + jj) * 32 + 8 * q);
         }
-        if (ok[j]) {
-          yb[yo + j * 32] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-      ps[r & 3] = s1;
-      pq[r & 3] = s2;
-      if ((r & 3) == 3) {
-        if (want_part) {  // wave-uniform: the (sum, sumsq) of these 4 rows over the wave's 128 columns
-          const float ts = halfwave_reduce4(ps, l31);
-          const float tq = halfwave_reduce4(pq, l31);
-          const int rr = (r & ~3) + ((l31 >> 4) & 1) * 2 + ((l31 >> 3) & 1);
-          const int prow = m0 + wm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kg;
-          if ((l31 & 7) == 0 && prow < d.C_out && ptile < d.part_nt) {
-            float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + prow) * d.part_nt + ptile;
-            *pp = make_float2(ts, tq);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = jh + jj;
+          f32x4 r2v[4];
+          if (use_res2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r2v[q] = *reinterpret_cast<const f32x4*>(r2b + r2o + j * 32 + 8 * q);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // osc_r is a power of two: acc * osc_r is exact, so the fused form rounds exactly like mul + add
+              float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
+              if (use_res) t += rv[jj][q][e];
+              if (use_res2) t = r2v[q][e] + t;
+              t = finish(t);
+              v[e] = t;
+              s1 += t;
+              s2 = fmaf(t, t, s2);
+            }
+            *reinterpret_cast<f32x4*>(yb + yo + j * 32 + 8 * q) = v;
+          }
+          // pin the running sums here: otherwise the compiler sinks the whole accumulation below the (wave-uniform)
+          // `want_part` test, keeps all 64 stored values alive for it and spills
+          asm volatile("" : "+v"(s1), "+v"(s2));
+          __builtin_amdgcn_sched_barrier(0);
+          if ((j & 3) == 3) {
+            s1d[j >> 2] = s1;
+            s2d[j >> 2] = s2;
+            s1 = 0.f;
+            s2 = 0.f;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int l = lw + j * 32 + 8 * q + e;
+            const bool ok = rok && l < d.L_out;
+            float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
+            if (use_res) t += ok ? rb[ro + (l >> d.res_shift)] : 0.f;
+            if (use_res2) t = (ok ? r2b[r2o + j * 32 + 8 * q + e] : 0.f) + t;
+            t = finish(t);
+            if (ok) {
+              yb[yo + j * 32 + 8 * q + e] = t;
+              s1 += t;
+              s2 = fmaf(t, t, s2);
+            }
+          }
+          asm volatile("" : "+v"(s1), "+v"(s2));
+        }
+        if ((j & 3) == 3) {
+          s1d[j >> 2] = s1;
+          s2d[j >> 2] = s2;
+          s1 = 0.f;
+          s2 = 0.f;
+        }
+      }
+    }
+    if (want_part) {  // wave-uniform: (sum, sumsq) of row co over 128 columns = this lane + its kg partner
+#pragma unroll
+      for (int t = 0; t < NPT; ++t) {
+        const float a1 = s1d[t] + __shfl_xor(s1d[t], 32, 64);
+        const float a2 = s2d[t] + __shfl_xor(s2d[t], 32, 64);
+        if (kg == 0 && co < d.C_out && ptile + t < d.part_nt) {
+          float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + co) * d.part_nt + ptile + t;
+          *pp = make_float2(a1, a2);
+        }
       }
     }
   };
@@ -331,6 +455,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
       epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
       break;
   }
+  tl_write();
 }
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
@@ -388,7 +513,13 @@ namespace st2xs {
 
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
-  if (d.C_out > 64) return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
+  if (d.C_out > 64) {
+    // k >= 7: 32 (co) x 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU: half the weight stream (L2 ->
+    // registers) per FLOP; measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32,
+    // 1.03 vs 1.10 ms at C = 256, L = 8 000; no gain at k = 3 (tools/xs_bench.hip, profiles/r02i_xs_bench_tn8.log)
+    if constexpr (KS >= 7) return launch<KS, CI_T, 4, 1, 8, 2>(d, s);
+    return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
+  }
   if (d.C_out > 32) {                                           // 64 co x 256 l
     if constexpr (CI_T == 16)
       return launch<KS, CI_T, 2, 2, 4, 3>(d, s);

@@ -25,7 +25,9 @@ class WNConv1d(nn.Module):
         self.c_in, self.c_out, self.ks = c_in, c_out, ks
 
     def folded(self):
-        return W.fold_weight_norm(self.weight_g.detach(), self.weight_v.detach())
+        # always on the host in fp32: the C++ engine takes host-folded weights (st2_load_weights) and a device-side
+        # norm differs from ATen-CPU's in the last ulp, which would make the two plans differ bitwise
+        return W.fold_weight_norm(self.weight_g.detach().float().cpu(), self.weight_v.detach().float().cpu())
 
 
 class WNConvTranspose1d(nn.Module):
@@ -39,7 +41,9 @@ class WNConvTranspose1d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(bias_dim))
 
     def folded(self):
-        return W.fold_weight_norm(self.weight_g.detach(), self.weight_v.detach())
+        # always on the host in fp32: the C++ engine takes host-folded weights (st2_load_weights) and a device-side
+        # norm differs from ATen-CPU's in the last ulp, which would make the two plans differ bitwise
+        return W.fold_weight_norm(self.weight_g.detach().float().cpu(), self.weight_v.detach().float().cpu())
 
 
 class PlainConv1d(nn.Module):

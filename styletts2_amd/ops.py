@@ -20,37 +20,6 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class ConvTimer:
-    """Optional per-launch HIP-event timing of the split-f16 conv launches (bench.py's roofline leg).  Events are
-    recorded on the launch stream around every st2_conv1d_xs / st2_conv1d_f16s launch (or only those of one shape
-    class when `key` = (ks, C_in, C_out, L_out) is given) and resolved after the caller synchronises."""
-
-    def __init__(self, ks=None, C_in=None, C_out=None, L_out=None):
-        self.key = None if ks is None else (ks, C_in, C_out, L_out)
-        self.pairs = []   # (class, start event, end event); class = (ks, C_in, C_out, L_out, B)
-
-    def matches(self, d):
-        return self.key is None or (d.ks, d.C_in, d.C_out, d.L_out) == self.key
-
-    def durations_ms(self):
-        return [a.elapsed_time(b) for _, a, b in self.pairs]
-
-    def by_class(self):
-        """{(ks, C_in, C_out, L_out, B): [launch durations in ms]}"""
-        out = {}
-        for cls, a, b in self.pairs:
-            out.setdefault(cls, []).append(a.elapsed_time(b))
-        return out
-
-
-_conv_timer = None
-
-
-def set_conv_timer(timer):
-    global _conv_timer
-    _conv_timer = timer
-
-
 def _chk(t, name, ndim=None):
     if t is None:
         return
@@ -236,14 +205,7 @@ def _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split
 
 
 def _launch_conv(fn, fname, d):
-    if _conv_timer is not None and _conv_timer.matches(d):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(fn(C.byref(d), _stream()), fname)
-        e1.record()
-        _conv_timer.pairs.append(((d.ks, d.C_in, d.C_out, d.L_out, d.B), e0, e1))
-    else:
-        _lib.check(fn(C.byref(d), _stream()), fname)
+    _lib.check(fn(C.byref(d), _stream()), fname)
 
 
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
@@ -714,4 +676,70 @@ def expand_by_durations(x, dur, T, shift=False, out=None):
     _lib.check(lib.st2_expand_by_durations(x.data_ptr(), x.stride(0), x.stride(1), dur.data_ptr(), B, Cc, N, T,
                                            1 if shift else 0, out.data_ptr(), out.stride(0), out.stride(1), _stream()),
                "st2_expand_by_durations")
+    return out
+
+
+# ---- reference-audio style path (st2_style.hip) ----------------------------------------------------------------------
+def stft_frames(wave, n_win, hop, shift):
+    """`st2_stft_frames`: wave [B, L] -> frames [B, n_win, L // hop + 1] (reflect-padded frame columns of torch.stft)."""
+    lib = _lib.load()
+    _chk(wave, "wave", 2)
+    B, L = wave.shape
+    M = L // hop + 1
+    fr = torch.empty((B, n_win, M), device=wave.device, dtype=torch.float32)
+    _lib.check(lib.st2_stft_frames(wave.data_ptr(), wave.stride(0), B, L, n_win, hop, shift, fr.data_ptr(), fr.stride(0),
+                                   fr.stride(1), _stream()), "st2_stft_frames")
+    return fr
+
+
+def power_spectrum(y):
+    """`st2_power_spectrum`: y [B, 2K, M] (real rows then imaginary rows) -> [B, K, M]."""
+    lib = _lib.load()
+    _chk(y, "y", 3)
+    B, K2, M = y.shape
+    assert K2 % 2 == 0
+    p = torch.empty((B, K2 // 2, M), device=y.device, dtype=torch.float32)
+    _lib.check(lib.st2_power_spectrum(y.data_ptr(), y.stride(0), y.stride(1), B, K2 // 2, M, p.data_ptr(), p.stride(0),
+                                      p.stride(1), _stream()), "st2_power_spectrum")
+    return p
+
+
+def log_norm_(x, eps, mean, std):
+    """`st2_log_norm`: x = (log(eps + x) - mean) / std in place (x contiguous)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    assert x.is_contiguous()
+    _lib.check(lib.st2_log_norm(x.data_ptr(), x.numel(), eps, mean, std, _stream()), "st2_log_norm")
+    return x
+
+
+def _chk_map(t, name):
+    _chk(t, name, 4)  # [B, H, C, W] view, W contiguous
+
+
+def dwconv3x3s2(x, w, bias, out):
+    """`st2_dwconv3x3s2`: x [B, H, C, W] (any strides, W contiguous), w [C, 3, 3], bias [C] -> out [B, Ho, C, Wo]."""
+    lib = _lib.load()
+    _chk_map(x, "x")
+    _chk_map(out, "out")
+    _chk(w, "w", 3)
+    _chk(bias, "bias", 1)
+    B, H, Cc, Wd = x.shape
+    assert w.shape == (Cc, 3, 3) and w.is_contiguous()
+    assert out.shape == (B, (H - 1) // 2 + 1, Cc, (Wd - 1) // 2 + 1), (out.shape, x.shape)
+    _lib.check(lib.st2_dwconv3x3s2(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), w.data_ptr(), _ptr(bias), B, Cc,
+                                   H, Wd, out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), _stream()),
+               "st2_dwconv3x3s2")
+    return out
+
+
+def avgpool2x2(x, out):
+    """`st2_avgpool2x2`: x [B, H, C, W] -> out [B, H/2, C, (W+1)/2] (odd widths replicate their last column)."""
+    lib = _lib.load()
+    _chk_map(x, "x")
+    _chk_map(out, "out")
+    B, H, Cc, Wd = x.shape
+    assert out.shape == (B, H // 2, Cc, (Wd + 1) // 2), (out.shape, x.shape)
+    _lib.check(lib.st2_avgpool2x2(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), B, Cc, H, Wd, out.data_ptr(),
+                                  out.stride(0), out.stride(1), out.stride(2), _stream()), "st2_avgpool2x2")
     return out

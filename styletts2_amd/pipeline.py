@@ -39,8 +39,11 @@ def predict_durations(model, d, lj_tail=False, input_lengths=None):
     +5-frame tail lands on each utterance's own last token -- every row is then what the notebook computes for that
     utterance alone."""
     B, N = d.shape[0], d.shape[1]
-    ragged = input_lengths is not None and not bool((input_lengths == N).all())
-    lens = input_lengths.to(torch.int32).to(d.device) if ragged else None
+    if input_lengths is not None and input_lengths.is_cuda:  # device copy of a batch known to be padded
+        lens = input_lengths.to(torch.int32)
+    else:
+        ragged = input_lengths is not None and not bool((input_lengths == N).all())
+        lens = input_lengths.to(torch.int32).to(d.device) if ragged else None
     x = model.predictor.lstm.forward_cm(d.transpose(1, 2).contiguous().float(), lens)   # [B, 512, N]
     lin = model.predictor.duration_proj.linear_layer
     return ops.duration_head(x, lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous(),
@@ -50,7 +53,7 @@ def predict_durations(model, d, lj_tail=False, input_lengths=None):
 @torch.no_grad()
 def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
             ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, lj_tail=None, s_prev=None, t=0.7,
-            taps=None, allow_ragged=False):
+            taps=None, allow_ragged=False, total_frames=None, lengths_dev=None):
     """Everything in front of the decoder: text encoder, PL-BERT, style diffusion, style mixing, duration and
     prosody prediction, alignment expansion.  Returns the decoder's inputs {asr, F0, N, ref} plus the mixed style
     vector `s_pred` [B, 256] (what LFinference hands to the next sentence) and the durations.
@@ -61,15 +64,29 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 
     Utterances of different total duration cannot share a decoder call (its InstanceNorm spans the utterance).  With
     `allow_ragged` the result then carries `groups`: a list of (utterance indices, {asr, F0, N, ref}) per distinct
-    frame count; without it such a batch raises."""
+    frame count; without it such a batch raises.
+
+    Host <-> device traffic: none on a batch without padding and with forced `durations` that are either a host tensor
+    or a device tensor accompanied by `total_frames` (int, or one int per utterance: their row sums).  A pageable
+    host -> device copy blocks the host until the stream has drained, i.e. it would serialise the issue of step k+1 with
+    the execution of step k; so the pad mask of an unpadded batch is created on the device, and a caller that
+    synthesises batch after batch keeps its forced durations on the device."""
     dev = tokens.device
     B, N = tokens.shape
     ops.check_status() if dev.type == "cuda" else None  # device-side conditions raised by the previous call's kernels
     if input_lengths is None:
         input_lengths = torch.full((B,), N, dtype=torch.long)
     input_lengths = input_lengths.detach().cpu().long()
-    text_mask = _pad_mask(input_lengths, N).to(dev)
     ragged_n = not bool((input_lengths == N).all())
+    if ragged_n:  # ONE host -> device copy of the lengths (or none: `lengths_dev` prepared by the caller); the modules
+        #           below take the device copy (text.py _device_lengths) and the mask is built on the device
+        if lengths_dev is None:
+            lengths_dev = input_lengths.to(torch.int32).to(dev)
+        text_mask = torch.arange(N, device=dev).unsqueeze(0) >= lengths_dev.reshape(-1, 1)
+        len_arg = lengths_dev
+    else:
+        text_mask = torch.zeros((B, N), dtype=torch.bool, device=dev)
+        len_arg = input_lengths
     multispeaker = ref_s is not None
     hifigan = model.decoder.kind == "hifigan"
     if lj_tail is None:
@@ -77,7 +94,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     if noise is None:
         noise = torch.randn(B, 1, 256, device=dev)
 
-    t_en = model.text_encoder(tokens, input_lengths, text_mask)                      # [B, 512, N]
+    t_en = model.text_encoder(tokens, len_arg, text_mask)                            # [B, 512, N]
     bert_dur = model.bert(tokens, attention_mask=(~text_mask).int())                 # [B, N, 768]
     d_en = model.bert_encoder(bert_dur).transpose(-1, -2)                            # [B, 512, N]
 
@@ -85,7 +102,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     if multispeaker:
         kw["features"] = ref_s
     if ragged_n:  # the denoiser attends over / averages each utterance's own tokens only (the notebooks run B = 1)
-        kw["lengths"] = input_lengths.to(torch.int32).to(dev)
+        kw["lengths"] = lengths_dev
     s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
     if taps is not None:
         taps["s_pred"] = s_pred
@@ -98,15 +115,19 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
         s = beta * s + (1 - beta) * ref_s[:, 128:]
     s, ref = s.contiguous(), ref.contiguous()
 
-    d = model.predictor.text_encoder(d_en, s, input_lengths, text_mask)              # [B, N, 640]
+    d = model.predictor.text_encoder(d_en, s, len_arg, text_mask)                    # [B, N, 640]
     if durations is None:
-        durations = predict_durations(model, d, lj_tail=lj_tail, input_lengths=input_lengths)
+        durations = predict_durations(model, d, lj_tail=lj_tail, input_lengths=len_arg)
         tot = durations.sum(dim=1).tolist()  # the path's one data-dependent host sync: the frame counts
         ops.check_status() if dev.type == "cuda" else None  # everything up to here has completed: free to look
     else:
         durations = durations.long()
-        tot = durations.sum(dim=1).tolist()  # host tensor in throughput runs: no device sync (forced durations are the
-        #                                      caller's: frames given to pad tokens are expanded like any other)
+        if total_frames is not None:  # the caller knows the row sums: nothing is read back
+            tot = [int(total_frames)] * B if isinstance(total_frames, int) else [int(v) for v in total_frames]
+            assert len(tot) == B
+        else:
+            tot = durations.sum(dim=1).tolist()  # host tensor: no device sync; device tensor: one read-back (forced
+            #                                      durations are the caller's: pad-token frames are expanded like any other)
     durations = durations.to(dev)
     if taps is not None:
         taps["durations"] = durations
@@ -143,7 +164,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 @torch.no_grad()
 def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
               ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
-              taps=None, front_stream=None, inputs_on_main=False):
+              taps=None, front_stream=None, inputs_on_main=False, total_frames=None):
     """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
 
     Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
@@ -165,7 +186,7 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     """
     kw = dict(input_lengths=input_lengths, noise=noise, diffusion_steps=diffusion_steps,
               embedding_scale=embedding_scale, ref_s=ref_s, alpha=alpha, beta=beta, durations=durations,
-              step_noise=step_noise, lj_tail=lj_tail, taps=taps, allow_ragged=True)
+              step_noise=step_noise, lj_tail=lj_tail, taps=taps, allow_ragged=True, total_frames=total_frames)
     if front_stream is None:
         p = prepare(model, sampler, tokens, **kw)
     else:
@@ -224,22 +245,31 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     side = torch.cuda.Stream(dev) if use_streams else None
     if use_streams:
         side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
-    s_prev, waves = None, []
+    # per-sentence inputs are prepared (padded to the bucket, moved to the device) BEFORE the streaming loop: a pageable
+    # host -> device copy inside it would block the host until the issuing stream has drained
+    prepped = []
     for k, tok in enumerate(sentences):
         n = tok.numel()
         tokens = tok.reshape(1, -1)
-        dur_k = durations[k] if durations is not None else None
+        dur_k = durations[k].reshape(1, -1).long() if durations is not None else None
         lengths = None
         if bucket and n % bucket:
             npad = (n + bucket - 1) // bucket * bucket
             tokens = torch.nn.functional.pad(tokens, (0, npad - n))  # token id 0 = pad (text_utils / ipynb:277)
             lengths = torch.LongTensor([n])
             if dur_k is not None:
-                dur_k = torch.nn.functional.pad(dur_k.reshape(1, -1), (0, npad - n))  # pad tokens get no frames
+                dur_k = torch.nn.functional.pad(dur_k, (0, npad - n))  # pad tokens get no frames
+        frames = int(dur_k.sum()) if dur_k is not None and not dur_k.is_cuda else None
+        prepped.append((tokens.to(dev), lengths, None if dur_k is None else dur_k.to(dev), frames,
+                        None if lengths is None else lengths.to(torch.int32).to(dev)))
+    s_prev, waves = None, []
+    for k in range(len(sentences)):
+        tokens, lengths, dur_k, frames, lens_dev = prepped[k]
         noise = noises[k] if noises is not None else None
         kw = dict(input_lengths=lengths, noise=noise, diffusion_steps=diffusion_steps, embedding_scale=embedding_scale,
                   ref_s=ref_s, alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
-                  step_noise=step_noises[k] if step_noises is not None else None, durations=dur_k)
+                  step_noise=step_noises[k] if step_noises is not None else None, durations=dur_k,
+                  total_frames=frames, lengths_dev=lens_dev)
         if use_streams:
             with torch.cuda.stream(side):
                 p = prepare(model, sampler, tokens, **kw)

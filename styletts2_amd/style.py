@@ -5,10 +5,21 @@ recording into `ref_s` [B, 256] for the multi-speaker models (Demo/Inference_Lib
 
 `StyleEncoder` keeps the reference's state_dict layout key for key (models.py:139-164 on top of ResBlk :97-137 and
 LearnedDownSample :27-42, all under old-style `torch.nn.utils.spectral_norm`: `weight_orig` / `weight_u` /
-`weight_v`), so `load_checkpoint` fills it from the published checkpoints.  It runs once per speaker, outside the
-timed text->waveform path, on PyTorch-ROCm ops (F.conv2d / avg_pool2d): plumbing, not a hand-written kernel --
-SURVEY.md marks the row "next".  In eval mode spectral norm is a fixed rescale (no power iteration), folded once per
-load exactly as the reference computes it: sigma = u . (W_mat v), W = weight_orig / sigma.
+`weight_v`), so `load_checkpoint` fills it from the published checkpoints.  In eval mode spectral norm is a fixed
+rescale (no power iteration), folded once per load exactly as the reference computes it: sigma = u . (W_mat v),
+W = weight_orig / sigma.
+
+Both the encoders and the mel front-end run on the engine's HIP kernels (`forward` / `mel_spectrogram_engine`):
+  * feature maps are stored (h, c, w) with one zero row above and below, so three consecutive rows ARE the 3C-channel
+    input of a Conv1d over the width: every 3x3 Conv2d is one split-f16 MFMA `st2_conv1d` per utterance (batch = image
+    rows, LeakyReLU as the conv prologue, residual add and 1/sqrt(2) in the epilogue), the 5x5 valid conv the same with
+    5 stacked rows, the 1x1 shortcut a k=1 conv; the depthwise stride-2 conv and the 2x2 average pool are
+    `st2_dwconv3x3s2` / `st2_avgpool2x2`; AdaptiveAvgPool + LeakyReLU + Linear = `st2_mean_tokens` + a k=1 conv with a
+    LeakyReLU prologue;
+  * mel: `st2_stft_frames` (reflect-padded frame columns) -> windowed DFT as an exact-fp32 MFMA k=1 conv
+    [2050][1200] -> `st2_power_spectrum` -> mel filter bank as a k=1 conv [80][1025] -> `st2_log_norm`.
+`forward_torch` / `mel_spectrogram` are the same maths on PyTorch ops (A-B path, `ST2_STYLE=torch`; the CPU metric
+helper of the parity tests).  There is no silent fallback: CPU tensors raise unless ST2_STYLE=torch.
 
 The mel front-end restates `torchaudio.transforms.MelSpectrogram(n_mels=80, n_fft=2048, win_length=1200,
 hop_length=300)` with torchaudio's defaults (power 2, periodic Hann window zero-padded to n_fft, centre + reflect
@@ -18,10 +29,14 @@ torchaudio is not installed in the build container, so this front-end is "parity
 the encoders themselves are pinned against the reference modules (tests/golden/style_vectors.npz).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ops
+from . import weights as W
 
 MEL_MEAN, MEL_STD = -4.0, 4.0  # meldataset.py:60
 
@@ -42,8 +57,15 @@ class _SNConv2d(nn.Module):
     def folded(self):
         """Eval-mode spectral norm: weight_orig / (u . (W_mat v)); no power iteration (spectral_norm.py compute_weight
         with do_power_iteration=False)."""
-        w = self.weight_orig
+        w = self.weight_orig.detach()
         sigma = torch.dot(self.weight_u, torch.mv(w.reshape(w.shape[0], -1), self.weight_v))
+        return w / sigma
+
+    def folded_host(self):
+        """The same fold on the host in fp32 (what the packed engine weights are built from: identical bits whatever
+        device the module lives on)."""
+        w = self.weight_orig.detach().float().cpu()
+        sigma = torch.dot(self.weight_u.float().cpu(), torch.mv(w.reshape(w.shape[0], -1), self.weight_v.float().cpu()))
         return w / sigma
 
     def forward(self, x):
@@ -104,8 +126,119 @@ class StyleEncoder(nn.Module):
         self.shared = nn.Sequential(*blocks)
         self.unshared = nn.Linear(dim_out, style_dim)
 
+        self._pk = None
+
+    # -- packed-weight cache (invalidated by .to() / load_state_dict, also when a parent module recurses here) ----------
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._pk = None
+        return super().load_state_dict(W.strip_module_prefix(state_dict), *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def refresh(self):
+        self._pk = None
+
+    @staticmethod
+    def _rows_as_channels(w2d):
+        """Conv2d weight [Co][Ci][kh][kw] -> Conv1d weight [Co][kh*Ci][kw] acting on kh stacked image rows (channel
+        index dh*Ci + ci), see the module docstring."""
+        co, ci, kh, kw = w2d.shape
+        return w2d.permute(0, 2, 1, 3).reshape(co, kh * ci, kw).contiguous()
+
+    def _prepare(self, device):
+        d = lambda t: None if t is None else t.detach().float().contiguous().to(device)
+        pk = type("PackedStyleEncoder", (), {})()
+        pk.device = device
+        first = self.shared[0]
+        pk.w0, pk.b0 = d(self._rows_as_channels(first.folded_host())), d(first.bias)            # [C0][3][3], direct conv
+        pk.blocks = []
+        for blk in list(self.shared)[1:5]:
+            b = type("PackedResBlk", (), {})()
+            b.c_in, b.c_out = blk.conv1.weight_orig.shape[1], blk.conv2.weight_orig.shape[0]
+            b.w1 = W.pack_conv_auto(self._rows_as_channels(blk.conv1.folded_host())).to(device)
+            b.b1 = d(blk.conv1.bias)
+            b.w2 = W.pack_conv_auto(self._rows_as_channels(blk.conv2.folded_host())).to(device)
+            b.b2 = d(blk.conv2.bias)
+            b.wd = d(blk.downsample_res.conv.folded_host().reshape(b.c_in, 3, 3))
+            b.bd = d(blk.downsample_res.conv.bias)
+            b.wsc = W.pack_conv_auto(blk.conv1x1.folded_host().reshape(b.c_out, b.c_in, 1)).to(device) \
+                if blk.learned_sc else None
+            pk.blocks.append(b)
+        last = self.shared[6]
+        pk.w5 = W.pack_conv_auto(self._rows_as_channels(last.folded_host())).to(device)          # [C][5*C][5]
+        pk.b5 = d(last.bias)
+        pk.c_last = last.weight_orig.shape[0]
+        pk.wl = W.pack_linear_auto(self.unshared.weight.detach().float().cpu()).to(device)
+        pk.bl = d(self.unshared.bias)
+        self._pk = pk
+        return pk
+
     @torch.no_grad()
     def forward(self, x):
+        """mel [B, 1, 80, T] -> style [B, style_dim] on the HIP kernels (module docstring); ST2_STYLE=torch selects the
+        PyTorch-op path."""
+        if os.environ.get("ST2_STYLE", "engine") == "torch":
+            return self.forward_torch(x)
+        x = x.float()
+        dev = x.device
+        pk = self._pk if (self._pk is not None and self._pk.device == dev) else self._prepare(dev)
+        B, one, H, Wd = x.shape
+        assert one == 1 and H % 16 == 0 and Wd >= 80, "StyleEncoder needs [B, 1, 16k, T >= 80], got %s" % (tuple(x.shape),)
+        new_map = lambda h, c, w: torch.zeros((B, h + 2, c, w), device=dev, dtype=torch.float32)  # zero rows 0 and h+1
+
+        def rows(P, b, k):
+            """Rows h-1 .. h+k-2 of utterance b's padded map stacked along the channels: [H][k*C][W] (overlapping view)."""
+            _, hp, c, w = P.shape
+            return torch.as_strided(P[b], (hp - k + 1, k * c, w), (c * w, w, 1))
+
+        m0 = new_map(H, 1, Wd)
+        ops.copy_ncl(x.reshape(B, H, Wd).contiguous(), m0[:, 1:H + 1, 0])
+        C0 = pk.w0.shape[0]
+        P = new_map(H, C0, Wd)
+        for b in range(B):
+            ops.conv1d_direct(rows(m0, b, 3), pk.w0, pk.b0, 1, 1, out=P[b, 1:H + 1])
+        for blk in pk.blocks:
+            C, Co = blk.c_in, blk.c_out
+            Ho, Wo = H // 2, (Wd + 1) // 2
+            # shortcut: 1x1 conv at full resolution, then the 2x2 average (models.py:118-123)
+            if blk.wsc is not None:
+                S = torch.empty((B, H, Co, Wd), device=dev, dtype=torch.float32)
+                for b in range(B):
+                    ops.conv1d(P[b, 1:H + 1], blk.wsc, Co, 1, out=S[b])
+            else:
+                S = P[:, 1:H + 1]
+            SC = torch.empty((B, Ho, Co, Wo), device=dev, dtype=torch.float32)
+            ops.avgpool2x2(S, SC)
+            # residual: leaky -> conv1 3x3 -> depthwise stride-2 3x3 -> leaky -> conv2 3x3 (models.py:125-135)
+            R1 = torch.empty((B, H, C, Wd), device=dev, dtype=torch.float32)
+            for b in range(B):
+                ops.conv1d(rows(P, b, 3), blk.w1, C, 3, pad_left=1, bias=blk.b1, pro=ops.PRO_LEAKY, slope=0.2, out=R1[b])
+            P2 = new_map(Ho, C, Wo)
+            ops.dwconv3x3s2(R1, blk.wd, blk.bd, P2[:, 1:Ho + 1])
+            Pn = new_map(Ho, Co, Wo)
+            for b in range(B):  # (shortcut + residual) / sqrt(2) in the epilogue
+                ops.conv1d(rows(P2, b, 3), blk.w2, Co, 3, pad_left=1, bias=blk.b2, pro=ops.PRO_LEAKY, slope=0.2,
+                           res=SC[b], div=math.sqrt(2), out=Pn[b, 1:Ho + 1])
+            P, H, Wd = Pn, Ho, Wo
+        # LeakyReLU -> 5x5 valid conv -> global average -> LeakyReLU -> Linear (models.py:151-163)
+        Cl = pk.c_last
+        assert H == 5, "the 5x5 valid conv expects a 5-row map (80 mel bins), got %d" % H
+        Fm = torch.empty((B, Cl, Wd - 4), device=dev, dtype=torch.float32)
+        for b in range(B):
+            ops.conv1d(P[b, 1:6].reshape(1, 5 * P.shape[2], Wd), pk.w5, Cl, 5, pad_left=0, L_out=Wd - 4, bias=pk.b5,
+                       pro=ops.PRO_LEAKY, slope=0.2, out=Fm[b:b + 1])
+        m = ops.mean_tokens(Fm)                                                               # [B, Cl]
+        s = ops.conv1d(m.reshape(B, Cl, 1), pk.wl, self.unshared.out_features, 1, bias=pk.bl, pro=ops.PRO_LEAKY, slope=0.2)
+        return s.reshape(B, -1)
+
+    @torch.no_grad()
+    def forward_torch(self, x):
         h = self.shared(x.float())
         return self.unshared(h.view(h.size(0), -1))
 
@@ -141,11 +274,48 @@ def mel_spectrogram(wave, n_fft=2048, win_length=1200, hop_length=300, n_mels=80
     return (torch.log(1e-5 + mel) - MEL_MEAN) / MEL_STD
 
 
+_MEL_PACK = {}
+
+
+def _mel_pack(device, n_fft, win_length, n_mels):
+    """Exact-fp32 MFMA conv weights of the front-end, built once per device: the windowed DFT restricted to the
+    win_length taps where the zero-padded periodic Hann window is non-zero (rows k <= n_fft/2: w[n] cos(2 pi k n / n_fft),
+    rows n_fft/2 + 1 + k: -w[n] sin(...), n counted in the padded frame) and the mel filter bank, both k=1 convs."""
+    key = (str(device), n_fft, win_length, n_mels)
+    pk = _MEL_PACK.get(key)
+    if pk is None:
+        left = (n_fft - win_length) // 2
+        win = torch.hann_window(win_length, periodic=True, dtype=torch.float64)
+        n = torch.arange(win_length, dtype=torch.float64) + left
+        k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
+        ang = 2.0 * math.pi * torch.outer(k, n) / n_fft
+        dft = torch.cat([torch.cos(ang) * win, -torch.sin(ang) * win]).float()               # [2K, win]
+        fb = mel_filterbank(n_fft // 2 + 1, n_mels).t().contiguous()                         # [n_mels, K]
+        pk = (W.pack_conv(dft.unsqueeze(-1)).to(device), W.pack_conv(fb.unsqueeze(-1)).to(device))
+        _MEL_PACK[key] = pk
+    return pk
+
+
+@torch.no_grad()
+def mel_spectrogram_engine(wave, n_fft=2048, win_length=1200, hop_length=300, n_mels=80):
+    """`mel_spectrogram` on the HIP kernels: wave [B, L] -> [B, 80, 1 + L // 300] (module docstring)."""
+    wave = wave.float().contiguous()
+    dft_w, fb_w = _mel_pack(wave.device, n_fft, win_length, n_mels)
+    K = n_fft // 2 + 1
+    frames = ops.stft_frames(wave, win_length, hop_length, n_fft // 2 - (n_fft - win_length) // 2)
+    spec = ops.conv1d(frames, dft_w, 2 * K, 1)
+    mel = ops.conv1d(ops.power_spectrum(spec), fb_w, n_mels, 1)
+    return ops.log_norm_(mel, 1e-5, MEL_MEAN, MEL_STD)
+
+
 @torch.no_grad()
 def compute_style(model, wave):
     """`compute_style` of Demo/Inference_LibriTTS.ipynb:100-111 minus the file I/O: wave [L] or [B, L] at 24 kHz
     (already trimmed; the notebook trims with librosa.effects.trim(top_db=30) on the host) -> ref_s [B, 256]."""
     if wave.dim() == 1:
         wave = wave.unsqueeze(0)
-    mel = mel_spectrogram(wave).unsqueeze(1)                       # [B, 1, 80, T]
+    if os.environ.get("ST2_STYLE", "engine") == "torch":
+        mel = mel_spectrogram(wave).unsqueeze(1)                   # [B, 1, 80, T]
+    else:
+        mel = mel_spectrogram_engine(wave).unsqueeze(1)
     return torch.cat([model.style_encoder(mel), model.predictor_encoder(mel)], dim=1)

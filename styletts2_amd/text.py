@@ -21,6 +21,8 @@ def _device_lengths(lengths, n, device):
     already holds -- the reference reads `input_lengths.cpu()` at the same place, models.py:314)."""
     if lengths is None:
         return None
+    if lengths.is_cuda:  # already the device copy of a batch the caller knows to be padded (pipeline.prepare)
+        return lengths if lengths.dtype == torch.int32 else lengths.to(torch.int32)
     lc = lengths.detach().cpu()
     if bool((lc == n).all()):
         return None

@@ -10,7 +10,7 @@ from styletts2_amd import ops
 _NAMES = ["conv1d", "conv1d_direct", "phase_split", "instnorm_stats", "colnorm_stats", "style_fc", "convt_interleave",
           "adain_leaky_pool", "har_source", "stft_mag_phase", "istft", "attention", "colnorm_apply", "lstm_bidir", "add_chanvec", "mean_tokens",
           "axpbypcz", "time_features", "tokens_to_channels", "broadcast_cols", "copy_ncl", "duration_head",
-          "expand_by_durations"]
+          "expand_by_durations", "stft_frames", "power_spectrum", "log_norm_", "dwconv3x3s2", "avgpool2x2"]
 
 
 @contextlib.contextmanager

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from _plan_on_cpu import ops_on_cpu
 from _util import GOLDEN, manifest
 from styletts2_amd import models, style, synth, text_utils
 
@@ -23,9 +24,32 @@ def test_style_encoder_matches_reference_vectors(tag):
     synth.init_spectral_norm_(enc, c["seed"])
     g = torch.Generator().manual_seed(c["seed"])
     x = torch.randn(c["B"], 1, 80, c["T"], generator=g) * 0.8 - 0.2
-    out = enc(x).numpy()
+    out = enc.forward_torch(x).numpy()  # the PyTorch-op path (A-B path of the engine plan)
     assert out.shape == gold.shape
     assert np.abs(out - gold).max() < 2e-6 * max(1.0, np.abs(gold).max())
+    # the engine's launch plan (row-stacked Conv1d form of every Conv2d, (h, c, w) maps, pooled shortcut in the conv
+    # epilogue) with the per-kernel CPU contracts substituted for the HIP wrappers
+    with ops_on_cpu():
+        plan = enc(x).numpy()
+    assert plan.shape == gold.shape
+    assert np.abs(plan - gold).max() < 1e-5 * max(1.0, np.abs(gold).max()), np.abs(plan - gold).max()
+
+
+def test_style_encoder_engine_refuses_cpu_tensors():
+    enc = style.StyleEncoder(dim_in=16, style_dim=32, max_conv_dim=64).eval()
+    with pytest.raises(Exception, match="HIP device|no CPU path"):
+        enc(torch.randn(1, 1, 80, 83))
+
+
+def test_mel_engine_plan_matches_torch_stft():
+    """Frame gather + windowed DFT as a k=1 conv + power + filter bank + log on the CPU contracts vs torch.stft."""
+    g = torch.Generator().manual_seed(5)
+    wave = torch.randn(2, 24000, generator=g) * 0.1 + 0.3 * torch.sin(torch.arange(24000) * 0.05)
+    ref = style.mel_spectrogram(wave)
+    with ops_on_cpu():
+        out = style.mel_spectrogram_engine(wave)
+    assert out.shape == ref.shape == (2, 80, 81)
+    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
 
 
 def test_mel_frontend_properties():
@@ -58,10 +82,17 @@ def test_compute_style_and_builder_wiring():
     synth.init_spectral_norm_(model.style_encoder, 3)
     synth.init_spectral_norm_(model.predictor_encoder, 4)
     wave = torch.randn(2, 24000 * 2, generator=torch.Generator().manual_seed(0)) * 0.1
-    ref_s = style.compute_style(model, wave)
+    with ops_on_cpu():
+        ref_s = style.compute_style(model, wave)
+        one = style.compute_style(model, wave[0])
     assert ref_s.shape == (2, 256) and bool(torch.isfinite(ref_s).all())
-    one = style.compute_style(model, wave[0])
-    assert torch.allclose(one, ref_s[:1], atol=1e-6)
+    assert torch.allclose(one, ref_s[:1], atol=1e-5)
+    os.environ["ST2_STYLE"] = "torch"
+    try:
+        ref_t = style.compute_style(model, wave)
+    finally:
+        del os.environ["ST2_STYLE"]
+    assert torch.allclose(ref_s, ref_t, atol=2e-4), (ref_s - ref_t).abs().max()
 
 
 def test_text_cleaner_table():

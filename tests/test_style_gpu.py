@@ -1,0 +1,94 @@
+"""Reference-audio style path on the GPU: the HIP kernels of csrc/st2_style.hip against their
+contracts, StyleEncoder on the engine against the golden vectors produced by the unmodified reference module
+(oracle/golden_style.py -> tests/golden/style_vectors.npz), the mel front-end against torch.stft on the CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLDEN, manifest
+from oracle import ops_ref as R
+from styletts2_amd import models, ops, style, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CASES = {"small": dict(dim_in=16, style_dim=32, max_conv_dim=64, B=3, T=83, seed=21),
+         "libritts": dict(dim_in=64, style_dim=128, max_conv_dim=512, B=2, T=120, seed=22)}
+
+
+def test_style_kernels_match_contracts():
+    g = torch.Generator().manual_seed(3)
+    wave = torch.randn(2, 7013, generator=g)
+    fr = ops.stft_frames(wave.to(DEV), 1200, 300, 600)
+    assert torch.equal(fr.cpu(), R.stft_frames(wave, 1200, 300, 600))          # pure gather: bit-exact
+    y = torch.randn(2, 2 * 37, 50, generator=g)
+    p = ops.power_spectrum(y.to(DEV))
+    assert torch.equal(p.cpu(), R.power_spectrum(y))                           # one rounding per op, contraction off
+    x = torch.rand(3, 80, 41, generator=g) * 10
+    got = ops.log_norm_(x.to(DEV).clone(), 1e-5, -4.0, 4.0)
+    assert (got.cpu() - R.log_norm_(x.clone(), 1e-5, -4.0, 4.0)).abs().max().item() < 1e-6
+    for (B, H, C, W) in [(2, 8, 5, 33), (1, 80, 16, 83), (2, 10, 64, 11)]:
+        big = torch.randn(B, H + 2, C, W, generator=g)                         # strided interior view of a padded map
+        xm = big[:, 1:H + 1]
+        w, bias = torch.randn(C, 3, 3, generator=g), torch.randn(C, generator=g)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        ref = R.dwconv3x3s2(xm, w, bias, torch.empty(B, Ho, C, Wo))
+        out = ops.dwconv3x3s2(big.to(DEV)[:, 1:H + 1], w.to(DEV), bias.to(DEV), torch.empty(B, Ho, C, Wo, device=DEV))
+        assert (out.cpu() - ref).abs().max().item() < 1e-5
+        refp = R.avgpool2x2(xm, torch.empty(B, H // 2, C, (W + 1) // 2))
+        outp = ops.avgpool2x2(big.to(DEV)[:, 1:H + 1], torch.empty(B, H // 2, C, (W + 1) // 2, device=DEV))
+        assert (outp.cpu() - refp).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["small", "libritts"])
+def test_style_encoder_engine_matches_reference_vectors(tag):
+    c = CASES[tag]
+    gold = np.load(os.path.join(GOLDEN, "style_vectors.npz"))["style_" + tag]
+    enc = style.StyleEncoder(dim_in=c["dim_in"], style_dim=c["style_dim"], max_conv_dim=c["max_conv_dim"]).eval()
+    synth.init_spectral_norm_(enc, c["seed"])
+    g = torch.Generator().manual_seed(c["seed"])
+    x = torch.randn(c["B"], 1, 80, c["T"], generator=g) * 0.8 - 0.2
+    out = enc.to(DEV)(x.to(DEV))
+    torch.cuda.synchronize()
+    ops.check_status()
+    out = out.cpu().numpy()
+    assert out.shape == gold.shape
+    err = np.abs(out - gold).max()
+    assert err < 1e-5 * max(1.0, np.abs(gold).max()), err
+    # a 10 s reference recording's map (801 frames): the xs conv path (rows >= 256 columns) against the PyTorch ops
+    xl = torch.randn(1, 1, 80, 801, generator=g) * 0.8 - 0.2
+    ref = enc.cpu().forward_torch(xl)
+    got = enc.to(DEV)(xl.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_mel_frontend_engine_matches_torch_stft():
+    g = torch.Generator().manual_seed(5)
+    t = torch.arange(48000) / 24000.0
+    wave = torch.randn(2, 48000, generator=g) * 0.05 + 0.4 * torch.sin(2 * torch.pi * 220.0 * t) * torch.exp(-t)
+    ref = style.mel_spectrogram(wave)
+    out = style.mel_spectrogram_engine(wave.to(DEV)).cpu()
+    assert out.shape == ref.shape == (2, 80, 161)
+    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
+    full = style.mel_spectrogram_engine((wave * 2.4).clamp(-1, 1).to(DEV)).cpu()   # full-scale input: |X|^2 ~ 1e5
+    assert (full - style.mel_spectrogram((wave * 2.4).clamp(-1, 1))).abs().max().item() < 2e-4
+
+
+def test_compute_style_engine_vs_torch_path():
+    man = manifest("libritts")
+    args = models.recursive_munch(man["config"])
+    model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))
+    synth.init_spectral_norm_(model.style_encoder, 3)
+    synth.init_spectral_norm_(model.predictor_encoder, 4)
+    wave = torch.randn(2, 24000 * 3, generator=torch.Generator().manual_seed(0)) * 0.1
+    os.environ["ST2_STYLE"] = "torch"
+    try:
+        ref = style.compute_style(model, wave)
+    finally:
+        del os.environ["ST2_STYLE"]
+    model.style_encoder.to(DEV)
+    model.predictor_encoder.to(DEV)
+    out = style.compute_style(model, wave.to(DEV))
+    assert out.shape == (2, 256)
+    assert (out.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

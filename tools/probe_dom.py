@@ -15,13 +15,16 @@ dev = "cuda"
 B, Cc, L, ks = int(os.environ.get("PROBE_B", "32")), 128, 48001, 11
 reps = int(os.environ.get("PROBE_REPS", "2"))
 g = torch.Generator(device=dev).manual_seed(0)
-x = torch.randn(B, Cc, L, device=dev, generator=g)
+# PROBE_PITCH=1 (default): rows start 128-byte aligned (pitch = L rounded up to 32 floats), the layout of the C++ plan's
+# workspace (st2_engine.hip pitch_of); 0 = dense rows (L = 48001 is odd: every row start is misaligned)
+pitch = (L + 31) // 32 * 32 if os.environ.get("PROBE_PITCH", "1") == "1" else L
+x = torch.randn(B, Cc, pitch, device=dev, generator=g)[:, :, :L]
 w = torch.randn(Cc, Cc, ks, device=dev, generator=g) / math.sqrt(Cc * ks)
 wt = weights.pack_conv_f16s(w).to(dev)
 bias = torch.randn(Cc, device=dev, generator=g)
 h = torch.randn(B, 2 * Cc, device=dev, generator=g) * 0.3
 alpha = torch.rand(Cc, device=dev, generator=g) + 0.5
-out = torch.empty_like(x)
+out = torch.empty((B, Cc, pitch), device=dev)[:, :, :L]
 st = ops.instnorm_stats(x)
 
 
@@ -42,9 +45,12 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / (6 * reps)
+print("probe_dom: row pitch %d floats" % pitch)
 print("probe_dom: B=%d mean launch %.4f ms, %.1f algorithmic TFLOP/s" % (B, ms, 2.0 * B * Cc * Cc * ks * L / ms / 1e9))
+xc, dst = x.contiguous(), torch.empty((B, Cc, L), device=dev)  # calibration kernels on dense tensors of known size
+torch.cuda.synchronize()
 for _ in range(reps):
-    out.copy_(x)
-    ops.instnorm_stats(x, out=st)
+    dst.copy_(xc)
+    ops.instnorm_stats(xc, out=st)
 torch.cuda.synchronize()
 print("probe_dom: bytes(x)=%d" % (x.numel() * 4))
