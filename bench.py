@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="issue every step on one stream (no front/decoder overlap)")
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
+    ap.add_argument("--graph-front", action="store_true", help="longform: hipGraph around the whole front of a sentence")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
@@ -332,6 +333,10 @@ def main():
         front.wait_stream(torch.cuda.current_stream(dev))
 
     first_chunk_ms = []
+    # configs[4]: the diffusion sampler of every sentence replays one hipGraph per 16-token bucket (make_sampler(graph=True));
+    # --graph-front extends the capture to the whole device-only front of a sentence (pipeline.GraphedFront: measured
+    # neutral on this box -- a single sentence is bound by the latency of its kernel chain, not by host issue)
+    lf_front = pipeline.GraphedFront(model, sampler) if (longform and a.graph_front) else None
     if longform:
         sents = [tokens[i % PER_GPU_BATCH, :n].clone() for i, n in enumerate(LONGFORM_SENTENCES)]
         durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
@@ -346,7 +351,7 @@ def main():
                     first_chunk_ms.append((time.perf_counter() - t_start) * 1e3)
             waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                 durations=durs, overlap=not a.single_stream, bucket=16,
-                                                on_chunk=on_chunk)
+                                                on_chunk=on_chunk, front=lf_front)
             return waves
     else:
         audio_s = B * AUDIO_S_PER_UTT

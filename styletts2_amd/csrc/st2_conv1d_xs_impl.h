@@ -517,7 +517,11 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
     // k >= 7: 32 (co) x 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU: half the weight stream (L2 ->
     // registers) per FLOP; measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32,
     // 1.03 vs 1.10 ms at C = 256, L = 8 000; no gain at k = 3 (tools/xs_bench.hip, profiles/r02i_xs_bench_tn8.log)
-    if constexpr (KS >= 7) return launch<KS, CI_T, 4, 1, 8, 2>(d, s);
+    // ... when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a single utterance
+    // (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs
+    if constexpr (KS >= 7) {
+      if ((int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024) return launch<KS, CI_T, 4, 1, 8, 2>(d, s);
+    }
     return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
   }
   if (d.C_out > 32) {                                           // 64 co x 256 l

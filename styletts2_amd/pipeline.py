@@ -51,9 +51,116 @@ def predict_durations(model, d, lj_tail=False, input_lengths=None):
 
 
 @torch.no_grad()
+def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, *, diffusion_steps,
+                embedding_scale, alpha, beta, t, predict, lj_tail, taps=None):
+    """The device-only part of the front: text encoder, PL-BERT, style diffusion, style mixing, duration encoder and
+    (when `predict`) the duration head.  No host read of device data, no host -> device copy, no random draw: every
+    input is a device tensor (`lengths_dev` int32 [B] for a right-padded batch, else None and `lengths_host` decides on
+    the host), so the whole function is legal under stream capture (`GraphedFront`)."""
+    dev = tokens.device
+    B, N = tokens.shape
+    if lengths_dev is not None:  # mask built on the device; the modules take the device copy (text.py _device_lengths)
+        text_mask = torch.arange(N, device=dev).unsqueeze(0) >= lengths_dev.reshape(-1, 1)
+        len_arg = lengths_dev
+    else:
+        text_mask = torch.zeros((B, N), dtype=torch.bool, device=dev)
+        len_arg = lengths_host
+    t_en = model.text_encoder(tokens, len_arg, text_mask)                            # [B, 512, N]
+    bert_dur = model.bert(tokens, attention_mask=(~text_mask).int())                 # [B, N, 768]
+    d_en = model.bert_encoder(bert_dur).transpose(-1, -2)                            # [B, 512, N]
+    kw = dict(embedding=bert_dur, embedding_scale=embedding_scale, num_steps=diffusion_steps, step_noise=step_noise)
+    if ref_s is not None:
+        kw["features"] = ref_s
+    if lengths_dev is not None:  # the denoiser attends over / averages each utterance's own tokens only
+        kw["lengths"] = lengths_dev
+    s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
+    if taps is not None:
+        taps["s_pred"] = s_pred
+    if s_prev is not None:
+        s_pred = t * s_prev + (1 - t) * s_pred  # convex combination of previous and current style
+    s = s_pred[:, 128:]
+    ref = s_pred[:, :128]
+    if ref_s is not None:
+        ref = alpha * ref + (1 - alpha) * ref_s[:, :128]
+        s = beta * s + (1 - beta) * ref_s[:, 128:]
+    s, ref = s.contiguous(), ref.contiguous()
+    d = model.predictor.text_encoder(d_en, s, len_arg, text_mask)                    # [B, N, 640]
+    dur = predict_durations(model, d, lj_tail=lj_tail, input_lengths=len_arg) if predict else None
+    return dict(t_en=t_en, d=d, s=s, ref=ref, durations=dur)
+
+
+class GraphedFront:
+    """hipGraph replay of `_front_core` (BASELINE.json configs[4]: latency-bound sentence-by-sentence synthesis).  The
+    front of one sentence is ~600 launches of 5-40 us kernels issued from Python (~6 ms of host time against ~4 ms of
+    device time at B = 1): the host, not the GPU, paces a passage.  One graph per signature (batch, padded tokens,
+    diffusion steps, guidance scale, speaker / carry-over / padding / duration-prediction flags, mixing weights); the
+    first call with a new signature runs eagerly once and records, later calls copy their inputs into static buffers,
+    replay and return CLONES of the outputs (the next replay may start while the decoder still reads them).  The
+    per-step diffusion noise is always an explicit input (drawn here when the caller gives none)."""
+
+    def __init__(self, model, sampler, max_graphs=32):
+        self.model = model
+        self.sampler = getattr(sampler, "sampler", sampler)  # a GraphedSampler's eager sampler: one graph, not two nested
+        self.max_graphs = max_graphs
+        self._graphs = {}
+
+    def _generation(self):
+        return getattr(self.sampler.diffusion.net, "_pack_gen", 0)
+
+    @torch.no_grad()
+    def __call__(self, tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, **kw):
+        dev = tokens.device
+        B, N = tokens.shape
+        steps = kw["diffusion_steps"]
+        if step_noise is None:
+            step_noise = torch.randn((steps - 1, B, 1, noise.shape[-1]), device=dev, dtype=torch.float32)
+        key = (dev.index, B, N, steps, float(kw["embedding_scale"]), ref_s is not None, s_prev is not None,
+               lengths_dev is not None, bool(kw["predict"]), bool(kw["lj_tail"]), float(kw["alpha"]), float(kw["beta"]),
+               float(kw["t"]))
+        g = self._graphs.get(key)
+        if g is not None and g["gen"] != self._generation():  # packed weights were rebuilt: recorded pointers are stale
+            self._graphs.clear()
+            g = None
+        if g is None:
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            g = self._graphs[key] = self._capture(tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, kw)
+        st = g["static"]
+        for name, val in (("tokens", tokens), ("lengths_dev", lengths_dev), ("noise", noise), ("step_noise", step_noise),
+                          ("ref_s", ref_s), ("s_prev", s_prev)):
+            if val is not None:
+                st[name].copy_(val.reshape(st[name].shape))
+        g["graph"].replay()
+        return {k: (None if v is None else v.clone()) for k, v in g["out"].items()}
+
+    def _capture(self, tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, kw):
+        clone = lambda v: None if v is None else v.detach().clone()
+        st = dict(tokens=clone(tokens), lengths_dev=clone(lengths_dev), noise=clone(noise.float()),
+                  step_noise=clone(step_noise.float()), ref_s=clone(ref_s), s_prev=clone(s_prev))
+        lh = None if lengths_host is None else lengths_host.clone()
+
+        def run():
+            return _front_core(self.model, self.sampler, st["tokens"], lh, st["lengths_dev"], st["noise"],
+                               st["step_noise"], st["ref_s"], st["s_prev"], **kw)
+
+        dev = tokens.device
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            run()  # eager warm-up on a side stream: weight packing, kernel attributes, allocator warm-up
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = run()
+        return dict(graph=graph, static=st, out=out, gen=self._generation())
+
+
+@torch.no_grad()
 def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
             ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, lj_tail=None, s_prev=None, t=0.7,
-            taps=None, allow_ragged=False, total_frames=None, lengths_dev=None):
+            taps=None, allow_ragged=False, total_frames=None, lengths_dev=None, front=None):
     """Everything in front of the decoder: text encoder, PL-BERT, style diffusion, style mixing, duration and
     prosody prediction, alignment expansion.  Returns the decoder's inputs {asr, F0, N, ref} plus the mixed style
     vector `s_pred` [B, 256] (what LFinference hands to the next sentence) and the durations.
@@ -70,7 +177,10 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     or a device tensor accompanied by `total_frames` (int, or one int per utterance: their row sums).  A pageable
     host -> device copy blocks the host until the stream has drained, i.e. it would serialise the issue of step k+1 with
     the execution of step k; so the pad mask of an unpadded batch is created on the device, and a caller that
-    synthesises batch after batch keeps its forced durations on the device."""
+    synthesises batch after batch keeps its forced durations on the device.
+
+    `front` (a `GraphedFront`): the device-only part (`_front_core`) is replayed from a hipGraph instead of being issued
+    kernel by kernel."""
     dev = tokens.device
     B, N = tokens.shape
     ops.check_status() if dev.type == "cuda" else None  # device-side conditions raised by the previous call's kernels
@@ -78,46 +188,26 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
         input_lengths = torch.full((B,), N, dtype=torch.long)
     input_lengths = input_lengths.detach().cpu().long()
     ragged_n = not bool((input_lengths == N).all())
-    if ragged_n:  # ONE host -> device copy of the lengths (or none: `lengths_dev` prepared by the caller); the modules
-        #           below take the device copy (text.py _device_lengths) and the mask is built on the device
-        if lengths_dev is None:
-            lengths_dev = input_lengths.to(torch.int32).to(dev)
-        text_mask = torch.arange(N, device=dev).unsqueeze(0) >= lengths_dev.reshape(-1, 1)
-        len_arg = lengths_dev
-    else:
-        text_mask = torch.zeros((B, N), dtype=torch.bool, device=dev)
-        len_arg = input_lengths
+    if ragged_n and lengths_dev is None:  # ONE host -> device copy of the lengths (none if the caller prepared it)
+        lengths_dev = input_lengths.to(torch.int32).to(dev)
+    if not ragged_n:
+        lengths_dev = None
     multispeaker = ref_s is not None
     hifigan = model.decoder.kind == "hifigan"
     if lj_tail is None:
         lj_tail = not multispeaker
     if noise is None:
         noise = torch.randn(B, 1, 256, device=dev)
-
-    t_en = model.text_encoder(tokens, len_arg, text_mask)                            # [B, 512, N]
-    bert_dur = model.bert(tokens, attention_mask=(~text_mask).int())                 # [B, N, 768]
-    d_en = model.bert_encoder(bert_dur).transpose(-1, -2)                            # [B, 512, N]
-
-    kw = dict(embedding=bert_dur, embedding_scale=embedding_scale, num_steps=diffusion_steps, step_noise=step_noise)
-    if multispeaker:
-        kw["features"] = ref_s
-    if ragged_n:  # the denoiser attends over / averages each utterance's own tokens only (the notebooks run B = 1)
-        kw["lengths"] = lengths_dev
-    s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
-    if taps is not None:
-        taps["s_pred"] = s_pred
-    if s_prev is not None:
-        s_pred = t * s_prev + (1 - t) * s_pred  # convex combination of previous and current style
-    s = s_pred[:, 128:]
-    ref = s_pred[:, :128]
-    if multispeaker:
-        ref = alpha * ref + (1 - alpha) * ref_s[:, :128]
-        s = beta * s + (1 - beta) * ref_s[:, 128:]
-    s, ref = s.contiguous(), ref.contiguous()
-
-    d = model.predictor.text_encoder(d_en, s, len_arg, text_mask)                    # [B, N, 640]
+    ckw = dict(diffusion_steps=diffusion_steps, embedding_scale=embedding_scale, alpha=alpha, beta=beta, t=t,
+               predict=durations is None, lj_tail=lj_tail)
+    if front is not None and dev.type == "cuda" and taps is None:
+        f = front(tokens, input_lengths, lengths_dev, noise, step_noise, ref_s, s_prev, **ckw)
+    else:
+        f = _front_core(model, sampler, tokens, input_lengths, lengths_dev, noise, step_noise, ref_s, s_prev, taps=taps,
+                        **ckw)
+    t_en, d, s, ref = f["t_en"], f["d"], f["s"], f["ref"]
     if durations is None:
-        durations = predict_durations(model, d, lj_tail=lj_tail, input_lengths=len_arg)
+        durations = f["durations"]
         tot = durations.sum(dim=1).tolist()  # the path's one data-dependent host sync: the frame counts
         ops.check_status() if dev.type == "cuda" else None  # everything up to here has completed: free to look
     else:
@@ -164,7 +254,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 @torch.no_grad()
 def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
               ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
-              taps=None, front_stream=None, inputs_on_main=False, total_frames=None):
+              taps=None, front_stream=None, inputs_on_main=False, total_frames=None, front=None):
     """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
 
     Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
@@ -186,7 +276,8 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     """
     kw = dict(input_lengths=input_lengths, noise=noise, diffusion_steps=diffusion_steps,
               embedding_scale=embedding_scale, ref_s=ref_s, alpha=alpha, beta=beta, durations=durations,
-              step_noise=step_noise, lj_tail=lj_tail, taps=taps, allow_ragged=True, total_frames=total_frames)
+              step_noise=step_noise, lj_tail=lj_tail, taps=taps, allow_ragged=True, total_frames=total_frames,
+              front=front)
     if front_stream is None:
         p = prepare(model, sampler, tokens, **kw)
     else:
@@ -217,7 +308,7 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
 @torch.no_grad()
 def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, t=0.7, diffusion_steps=5,
                     embedding_scale=1.0, noises=None, step_noises=None, sine_noises=None, durations=None, trim=None,
-                    overlap=True, on_chunk=None, bucket=0):
+                    overlap=True, on_chunk=None, bucket=0, front=None):
     """Long-form synthesis (BASELINE.json configs[4]; Demo/Inference_LibriTTS.ipynb LFinference + its driver loop,
     Demo/Inference_LJSpeech.ipynb "Long-form generation"): `sentences` is a list of token tensors [N_i] (id 0
     prepended); each sentence is synthesised with the previous sentence's mixed style carried over
@@ -269,7 +360,7 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         kw = dict(input_lengths=lengths, noise=noise, diffusion_steps=diffusion_steps, embedding_scale=embedding_scale,
                   ref_s=ref_s, alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
                   step_noise=step_noises[k] if step_noises is not None else None, durations=dur_k,
-                  total_frames=frames, lengths_dev=lens_dev)
+                  total_frames=frames, lengths_dev=lens_dev, front=front)
         if use_streams:
             with torch.cuda.stream(side):
                 p = prepare(model, sampler, tokens, **kw)

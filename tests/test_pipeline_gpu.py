@@ -279,3 +279,42 @@ def test_two_stream_inference_is_bitwise_the_single_stream_result():
     side.wait_stream(torch.cuda.current_stream())
     out = run(side)
     assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
+@pytest.mark.parametrize("tag,predict", [("libritts", False), ("ljspeech", True)])
+def test_graphed_front_is_bitwise_the_eager_front(tag, predict):
+    """pipeline.GraphedFront: the device-only front of a sentence (text encoder, PL-BERT, sampler, style mixing,
+    duration encoder, optionally the duration head) replayed from ONE hipGraph per bucket == issued kernel by kernel,
+    through the bucketed long-form loop (right-padded token rows, style carry-over, both stream modes)."""
+    man, model, sds = _model(tag)
+    g = torch.Generator().manual_seed(13)
+    lens, steps = [9, 14, 12, 7, 16], 3
+    sentences = [torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, 178, (n - 1,), generator=g)]) for n in lens]
+    noises = [torch.randn(1, 1, 256, generator=g) for _ in lens]
+    step_noises = [torch.randn(steps - 1, 1, 1, 256, generator=g) for _ in lens]
+    durs = None if predict else [torch.full((1, n), 2, dtype=torch.long) for n in lens]
+    multi = man["config"]["multispeaker"]
+    ref_s = torch.randn(1, 256, generator=g).to(DEV) if multi else None
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model, graph=True)
+    front = pipeline.GraphedFront(model, sampler)
+    d = lambda xs: [x.to(DEV) for x in xs]
+    sine = None if predict else d([torch.randn(1, 600 * 2 * n, 9, generator=g) for n in lens])
+    kw = dict(ref_s=ref_s, t=0.7, diffusion_steps=steps, noises=d(noises), step_noises=d(step_noises),
+              sine_noises=sine, durations=durs, bucket=8)
+    if predict:  # the decoder draws its own SineGen noise per call: compare the style chain and the shapes only
+        torch.manual_seed(0)
+    w_e, s_e = pipeline.synthesize_long(model, sampler, d(sentences), overlap=False, **kw)
+    if predict:
+        torch.manual_seed(0)
+    w_g, s_g = pipeline.synthesize_long(model, sampler, d(sentences), overlap=False, front=front, **kw)
+    w_o, s_o = pipeline.synthesize_long(model, sampler, d(sentences), overlap=True, front=front, **kw)
+    torch.cuda.synchronize()
+    # one graph per signature: (bucket 8 | 16) x (first sentence: no carried style) x (exactly 16 tokens: no padding)
+    assert 2 <= len(front._graphs) <= 4, len(front._graphs)
+    assert torch.equal(s_e, s_g) and torch.equal(s_e, s_o)
+    assert [w.shape for w in w_e] == [w.shape for w in w_g] == [w.shape for w in w_o]
+    if not predict:
+        assert all(torch.equal(a, b) for a, b in zip(w_e, w_g)) and all(torch.equal(a, b) for a, b in zip(w_e, w_o))
+    assert all(bool(torch.isfinite(w).all()) for w in w_g)
