@@ -43,6 +43,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The accumulator array must only
+// ever be indexed by constants (a run-time index would move all of it to scratch); `#pragma unroll` is a request the
+// optimizer may decline for a large body, this is not.
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 constexpr int NT = 256;
 constexpr int ABL = ST2_XS_ABLATE;
 
@@ -310,7 +321,16 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     float s1d[NPT], s2d[NPT];  // finished 128-column sums
     auto finish = [&](float v) __attribute__((always_inline)) -> float {
       if (use_div) v = v / d.div;
-      if constexpr (ACT == ST2_ACT_GELU) {
+      if constexpr (ACT == -1) {  // generic build: one body for every activation (run-time switch, wave-uniform)
+        switch (d.act) {
+          case ST2_ACT_GELU: v = gelu_erf(v); break;
+          case ST2_ACT_EXP_SIN: v = co < d.act_split ? expf(v) : sin_acc(v); break;
+          case ST2_ACT_TANH: v = tanhf(v); break;
+          case ST2_ACT_LEAKY: v = leaky(v, d.act_slope); break;
+          case ST2_ACT_GELU_TANH: v = gelu_tanh(v); break;
+          default: break;
+        }
+      } else if constexpr (ACT == ST2_ACT_GELU) {
         v = gelu_erf(v);
       } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
         v = co < d.act_split ? expf(v) : sin_acc(v);
@@ -375,33 +395,28 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
         }
       }
     } else {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int l = lw + j * 32 + 8 * q + e;
-            const bool ok = rok && l < d.L_out;
-            float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
-            if (use_res) t += ok ? rb[ro + (l >> d.res_shift)] : 0.f;
-            if (use_res2) t = (ok ? r2b[r2o + j * 32 + 8 * q + e] : 0.f) + t;
-            t = finish(t);
-            if (ok) {
-              yb[yo + j * 32 + 8 * q + e] = t;
-              s1 += t;
-              s2 = fmaf(t, t, s2);
-            }
-          }
-          asm volatile("" : "+v"(s1), "+v"(s2));
+      static_for<TN * 16>([&](auto idx_tag) __attribute__((always_inline)) {
+        constexpr int idx = decltype(idx_tag)::value;
+        constexpr int j = idx / 16, q = (idx % 16) / 4, e = idx % 4;
+        const int l = lw + j * 32 + 8 * q + e;
+        const bool ok = rok && l < d.L_out;
+        float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
+        if (use_res) t += ok ? rb[ro + (l >> d.res_shift)] : 0.f;
+        if (use_res2) t = (ok ? r2b[r2o + j * 32 + 8 * q + e] : 0.f) + t;
+        t = finish(t);
+        if (ok) {
+          yb[yo + j * 32 + 8 * q + e] = t;
+          s1 += t;
+          s2 = fmaf(t, t, s2);
         }
-        if ((j & 3) == 3) {
+        if constexpr (e == 3) asm volatile("" : "+v"(s1), "+v"(s2));
+        if constexpr (idx % 64 == 63) {
           s1d[j >> 2] = s1;
           s2d[j >> 2] = s2;
           s1 = 0.f;
           s2 = 0.f;
         }
-      }
+      });
     }
     if (want_part) {  // wave-uniform: (sum, sumsq) of row co over 128 columns = this lane + its kg partner
 #pragma unroll
@@ -418,7 +433,6 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
-    if (!full_tile) return epilogue_as(act_tag, std::integral_constant<int, -1>{});
     if constexpr (ACT == ST2_ACT_NONE) {
       switch (mode) {
         case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
@@ -431,10 +445,16 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
         default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
       }
     } else {
-      if (mode == 0) return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-      return epilogue_as(act_tag, std::integral_constant<int, -1>{});
+      return epilogue_as(act_tag, std::integral_constant<int, 0>{});
     }
   };
+  // edge tiles, unaligned tensors, an activation combined with residual / divide: ONE generic body (the 64 predicated
+  // element blocks of a generic build are the bulk of this kernel's code)
+  if (!full_tile || (d.act != ST2_ACT_NONE && (rb || r2b || d.div != 1.0f))) {
+    epilogue_as(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+    tl_write();
+    return;
+  }
   switch (d.act) {
     case ST2_ACT_GELU:
       epilogue(std::integral_constant<int, ST2_ACT_GELU>{});

@@ -101,7 +101,7 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
     objdump, readelf = os.path.join(tools, "llvm-objdump"), os.path.join(tools, "llvm-readelf")
     if not (os.path.exists(objdump) and os.path.exists(readelf)):
         pytest.skip("ROCm LLVM binutils not installed")
-    objs = [os.path.join(ROOT, "styletts2_amd", "csrc", "build", "st2_conv1d_xs_k%d.o" % i) for i in range(3)]
+    objs = [os.path.join(ROOT, "styletts2_amd", "csrc", "build", "st2_conv1d_xs_k%d.o" % i) for i in range(4)]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("objects not built (run __graft_entry__.build())")
     seen = 0
@@ -115,10 +115,15 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
         kernels = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)(?:.|\n)*?\.vgpr_count:\s+(\d+)"
                              r"\n\s+\.vgpr_spill_count:\s+(\d+)", notes)
         for name, priv, vgpr, spill in kernels:
+            if "conv1d_xs_kernel" not in name:
+                continue
+            # every build of the family keeps its epilogue in registers: the 3-workgroups-per-CU builds within 168 VGPRs,
+            # the 2-workgroups-per-CU builds (32 x 256 wave tiles, narrow layers) within 256
+            assert int(spill) == 0 and int(priv) == 0, "%s spills %s VGPRs (%s B scratch)" % (name, spill, priv)
             if "conv1d_xs_kernel_o3" not in name:
+                assert int(vgpr) <= 256, "%s uses %s VGPRs" % (name, vgpr)
                 continue
             seen += 1
-            assert int(spill) == 0 and int(priv) == 0, "%s spills %s VGPRs (%s B scratch)" % (name, spill, priv)
             assert int(vgpr) <= 168, "%s uses %s VGPRs: 2 workgroups per CU, not 3" % (name, vgpr)
         dis = subprocess.check_output([objdump, "-d", co], text=True)
         in_o3 = False
