@@ -291,7 +291,8 @@ def main():
         return
 
     from _util import manifest
-    from styletts2_amd import _lib, models, ops, pipeline, synth
+    from styletts2_amd import _lib, models, ops, pipeline
+    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

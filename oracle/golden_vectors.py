@@ -8,8 +8,11 @@ import os
 import numpy as np
 import torch
 
-from oracle import ref_harness as RH
-from styletts2_amd import synth
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import synth  # noqa: E402  tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from oracle import ref_harness as RH  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 KEYS = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]

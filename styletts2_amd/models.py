@@ -4,9 +4,9 @@
     model = build_model(recursive_munch(config["model_params"]), text_aligner, pitch_extractor, plbert)
 
 returns a Munch with the reference's keys.  Hot-path entries (decoder, diffusion, predictor, text_encoder, bert,
-bert_encoder) are engine-backed nn.Modules with the reference's call signatures and state_dict layouts; the
-training-only entries (discriminators, aligner, pitch extractor) and -- this round -- the reference-audio style
-encoders are explicit placeholders that raise if called ("Scope").
+bert_encoder, and the reference-audio style encoders style_encoder / predictor_encoder) are engine-backed nn.Modules
+with the reference's call signatures and state_dict layouts; the training-only entries (discriminators, aligner, pitch
+extractor) are explicit placeholders that raise if called ("Scope").
 """
 import torch
 import torch.nn as nn

@@ -1,10 +1,12 @@
 """Text side of the path: TextEncoder (models.py:284-345), PL-BERT wrapper (Utils/PLBERT/util.py:6-12) and the
 ProsodyPredictor with its DurationEncoder (models.py:440-582).
 
-Every conv and every BiLSTM here runs on the HIP kernels (TextEncoder k=5 convs and F0/N AdainResBlk1d stacks on
-`st2_conv1d`; LSTM input projections on `st2_conv1d`, recurrences on `st2_lstm_bidir`).  The small per-token
-LayerNorm / LeakyReLU / masking glue and the ALBERT encoder (HF transformers on hipBLASLt) are PyTorch-ROCm
-plumbing this round.  State_dict layouts are the reference's, key for key.
+Every conv, every BiLSTM and the whole ALBERT encoder run on the HIP kernels: TextEncoder k=5 convs, F0/N AdainResBlk1d
+stacks and every Linear (token-merged k=1 convs) on the split-f16 MFMA convs, LayerNorm / AdaLayerNorm + LeakyReLU +
+masking on `st2_colnorm_stats` / `st2_colnorm_apply`, LSTM input projections as k=1 convs and the recurrences on
+`st2_lstm_bidir_coop`, PL-BERT attention on `st2_attention_keylen` (ST2_BERT=hf selects the HF forward for A-B runs).
+What is left to PyTorch-ROCm is glue: embedding gathers, the style concatenation of the duration encoder and
+`bert_encoder`'s nn.Linear.  State_dict layouts are the reference's, key for key.
 """
 import torch
 import torch.nn as nn

@@ -42,7 +42,8 @@ def test_c_host_builds_against_the_header(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,B,T", [("ljspeech", 2, 24), ("libritts", 1, 31)])
 def test_c_host_matches_python_binding_bitwise(tmp_path, tag, B, T):
-    from styletts2_amd import engine, synth
+    from styletts2_amd import engine
+    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
     from styletts2_amd.decoder import Decoder
     exe = _build(tmp_path)
     dc = manifest(tag)["config"]["decoder"]

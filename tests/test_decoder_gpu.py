@@ -5,7 +5,7 @@ import torch
 
 from _util import MEL_L1_TOL, WAVE_RMS_TOL, decoder_kwargs, manifest, mel_l1, phase_err_weighted, rms
 from oracle import st2_oracle as O
-from styletts2_amd import synth
+import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.decoder import Decoder
 
 pytestmark = pytest.mark.gpu

@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from _util import decoder_kwargs, manifest
-from styletts2_amd import engine, models, synth
+from styletts2_amd import engine, models
+import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.decoder import Decoder
 
 pytestmark = pytest.mark.gpu

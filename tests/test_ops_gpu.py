@@ -386,7 +386,8 @@ def test_plbert_engine_matches_hf():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from _util import manifest
     from transformers import AlbertModel
-    from styletts2_amd import models, synth
+    from styletts2_amd import models
+    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
     bert = models.load_plbert(manifest("ljspeech")["plbert"]).eval()
     synth.init_synthetic_(bert, 15)
     B, N = 4, 100

@@ -10,7 +10,8 @@ import torch
 
 from _plan_on_cpu import ops_on_cpu
 from _util import GOLDEN, manifest
-from styletts2_amd import models, style, synth, text_utils
+from styletts2_amd import models, style, text_utils
+import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 
 CASES = {"small": dict(dim_in=16, style_dim=32, max_conv_dim=64, B=3, T=83, seed=21),
          "libritts": dict(dim_in=64, style_dim=128, max_conv_dim=512, B=2, T=120, seed=22)}

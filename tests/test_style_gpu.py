@@ -9,7 +9,8 @@ import torch
 
 from _util import GOLDEN, manifest
 from oracle import ops_ref as R
-from styletts2_amd import models, ops, style, synth
+from styletts2_amd import models, ops, style
+import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 
 from _util import manifest
-from styletts2_amd import models, pipeline, synth
+from styletts2_amd import models, pipeline
+import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 
 dev = "cuda"
 B = int(os.environ.get("PROBE_B", "32"))
