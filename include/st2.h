@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 10
+#define ST2_ABI_VERSION 11
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -114,6 +114,12 @@ typedef struct st2_conv_desc {
   /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
      part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) over the 128 columns of that tile */
   float* part; int32_t part_nt;
+  /* st2_conv1d_f16s only, optional: workspace for split-K launches.  A layer whose grid leaves most of the chip idle and
+     whose k loop is long (C_in >= 8 chunks, < 128 workgroups: the 1024 -> 2048 Linears of the denoiser over the ~100
+     tokens of one utterance) runs as up to 8 K slices per tile + a fixed-order reduction that applies the epilogue; the
+     split is a function of the geometry alone (every plan picks the same one: results are reproducible bit for bit) and
+     needs ksplit * B * C_out * L_out * 4 bytes here.  NULL / too small = no split. */
+  void* splitk_ws; int64_t splitk_ws_bytes;
 } st2_conv_desc;
 
 int st2_conv1d(const st2_conv_desc* d, void* stream);
@@ -133,6 +139,9 @@ int st2_conv1d(const st2_conv_desc* d, void* stream);
  *   f16 range; d.w_row_scale = 1 / w_scale[co]).  Operands are clamped to the f16 range (ST2_STATUS_F16_RANGE).
  * Replaces the same reference call sites as st2_conv1d (decoder / vocoder convolutions, denoiser Linears). */
 int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
+/* Bytes of d.splitk_ws the launch described by *d would use (0 = this geometry is not split): the caller allocates that
+ * much (any alignment >= 16) and sets d.splitk_ws / d.splitk_ws_bytes before calling st2_conv1d_f16s. */
+int64_t st2_conv1d_f16s_splitk_bytes(const st2_conv_desc* d);
 int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
 int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
 /* sizeof(st2_conv_desc) as the library was compiled: lets a binding verify its struct mirror. */

@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -47,6 +47,7 @@ class ConvDesc(C.Structure):
         ("w_row_scale", f32p),
         ("xs", f32p), ("xs_cg", C.c_int32), ("xs_lp", C.c_int32), ("xs_halo", C.c_int32),
         ("part", f32p), ("part_nt", C.c_int32),
+        ("splitk_ws", f32p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -88,6 +89,7 @@ _SIGNATURES = {
     "st2_status": (C.c_int, [C.c_int]),
     "st2_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "st2_conv1d_f16s_splitk_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
     "st2_conv1d_xs": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

@@ -14,6 +14,12 @@ extern "C" int st2_conv1d_f16s_chunk(int ks) { return ks <= 3 ? 32 : 16; }
 
 extern "C" int st2_conv1d_f16s_co_block(int C_out) { return C_out > 64 ? 128 : (C_out > 32 ? 64 : 32); }
 
+extern "C" int64_t st2_conv1d_f16s_splitk_bytes(const st2_conv_desc* dp) {
+  if (!dp || dp->B <= 0 || dp->C_in <= 0 || dp->C_out <= 0 || dp->L_out <= 0) return 0;
+  const int s = ksplit_for_geometry(*dp);
+  return s > 1 ? (int64_t)s * dp->B * dp->C_out * dp->L_out * 4 : 0;
+}
+
 extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(dp != nullptr, "st2_conv1d_f16s: null descriptor");
   const st2_conv_desc& d = *dp;

@@ -27,6 +27,7 @@
 #pragma once
 #include "st2_common.h"
 #include "st2_act.h"
+#include <algorithm>
 #include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -42,7 +43,7 @@ struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
 };
 
 template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d, int* status) {
+__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d, int* status, int ksplit, float* part) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
@@ -63,7 +64,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
   const int wn = wave % WN;
   const int n0 = blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
-  const int b = blockIdx.z;
+  // split-K launches (ksplit > 1): grid.z = B * ksplit, slice `ksl` accumulates the chunks [c_begin, c_end) of the input
+  // channels and stores its scaled partial sums to part[ksl][b][co][l]; splitk_reduce_kernel adds the slices in a fixed
+  // order and applies the epilogue
+  const int b = blockIdx.z / ksplit;
+  const int ksl = blockIdx.z - b * ksplit;
 
   const int XW = BN + (KS - 1) * d.dil;  // staged positions
   // LDS: [2 buffers][2 planes hi/lo][CG][XW] slots of 16 B, then the channel parameter table
@@ -208,15 +213,18 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
   const int co_a = m0 + wm * 32 + l31;  // < wq_co_pad by construction of the packing
   const h8* ap = reinterpret_cast<const h8*>(d.wq) + ((int64_t)kg * d.wq_co_pad + co_a) * 2;
   const int64_t a_step = (int64_t)2 * d.wq_co_pad * 2;  // h8 units per k-step
-  const int nchunk = C_pad / CI_T;
+  const int nchunk_all = C_pad / CI_T;
+  const int c_begin = (int)((int64_t)ksl * nchunk_all / ksplit);
+  const int nchunk = (int)((int64_t)(ksl + 1) * nchunk_all / ksplit) - c_begin;  // chunks of this slice (>= 1)
+  constexpr int SPC = S16 * KS;  // k-steps per chunk
+  ap += (int64_t)c_begin * SPC * a_step;
 
-  load_chunk(0);
+  load_chunk(c_begin * CI_T);
   if (has_par) __syncthreads();  // parameter table visible
-  store_chunk(0, 0);
+  store_chunk(c_begin * CI_T, 0);
   // weight fragments are double buffered in two NAMED register sets indexed by the (compile-time) parity of the
   // k-step inside the chunk; with one set hipcc re-uses the registers and sinks the prefetch to ~4 MFMAs ahead
   // of its consumer
-  constexpr int SPC = S16 * KS;  // k-steps per chunk
   h8 a_hi[2], a_lo[2];
   a_hi[0] = ap[0];
   a_lo[0] = ap[1];
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
         a_lo[nxt] = ap[1];
         // next chunk's activations: issued AFTER the weight prefetch so that the in-order vmcnt wait of the next
         // k-step does not have to drain these (possibly HBM-latency) loads
-        if (s == 0 && t == 0) load_chunk((c + 1) * CI_T);
+        if (s == 0 && t == 0) load_chunk((c_begin + c + 1) * CI_T);
         __builtin_amdgcn_sched_barrier(0x786);  // neither VMEM nor MFMA crosses: the prefetch stays a full k-step ahead
         const h8 ah = a_hi[cur], al = a_lo[cur];
         const h8* xp = xbuf + (2 * s) * XW + t * d.dil;
@@ -265,11 +273,27 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
       a_hi[0] = a_hi[1];
       a_lo[0] = a_lo[1];
     }
-    if (more) store_chunk((c + 1) * CI_T, buf ^ 1);
+    if (more) store_chunk((c_begin + c + 1) * CI_T, buf ^ 1);
     __syncthreads();
   }
 
   __builtin_amdgcn_s_setprio(0);
+  if (ksplit > 1) {  // partial sums of this K slice, scaled, dense [ksplit][B][C_out][L_out]
+    const float* rsc1 = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
+    float* pb = part + ((int64_t)ksl * d.B + b) * d.C_out * d.L_out;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const float sraw = rsc1[row];
+      const float osc_r = d.w_row_scale ? d.out_scale * sraw : d.out_scale;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (32 * TN) + l31 + j * 32;
+        if (row < d.C_out && col < d.L_out) pb[(int64_t)row * d.L_out + col] = acc[j][r] * osc_r;
+      }
+    }
+    return;
+  }
   // ---- epilogue ---------------------------------------------------------------------------------------
   float* yb = d.y + (int64_t)b * d.y_bs;
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
@@ -384,6 +408,55 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
   }
 }
 
+// Second half of a split-K conv: y = epi(bias + sum over the K slices, in slice order), one thread per output element.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const st2_conv_desc d, int ksplit, const float* part) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  const int b = blockIdx.z;
+  if (l >= d.L_out) return;
+  const int64_t slice = (int64_t)d.B * d.C_out * d.L_out;
+  const float* p = part + ((int64_t)b * d.C_out + co) * d.L_out + l;
+  float a = p[0];
+  for (int s = 1; s < ksplit; ++s) a += p[s * slice];
+  float v = a + (d.bias ? d.bias[co] : 0.f);
+  if (d.res) v += d.res[(int64_t)b * d.res_bs + (int64_t)co * d.res_cs + (l >> d.res_shift)];
+  if (d.res2) v = d.res2[(int64_t)b * d.res2_bs + (int64_t)co * d.res2_cs + l] + v;
+  if (d.div != 1.0f) v = v / d.div;
+  switch (d.act) {
+    case ST2_ACT_GELU: v = gelu_erf(v); break;
+    case ST2_ACT_EXP_SIN: v = co < d.act_split ? expf(v) : sin_acc(v); break;
+    case ST2_ACT_TANH: v = tanhf(v); break;
+    case ST2_ACT_LEAKY: v = leaky(v, d.act_slope); break;
+    case ST2_ACT_GELU_TANH: v = gelu_tanh(v); break;
+    default: break;
+  }
+  d.y[(int64_t)b * d.y_bs + (int64_t)co * d.y_cs + l] = v;
+}
+
+// K slices of a launch: layers whose grid leaves most of the chip idle AND whose k loop is long run as `ksplit`
+// workgroups per tile + a reduction (a 1024 -> 2048 Linear over 100 tokens is 8-16 workgroups walking 32-64 chunks in
+// series, ~70 us; at B = 1 these launches are half of a sentence's time).  A function of the geometry only, so every
+// plan picks the same split (bitwise-equal results); 1 when the caller provides no (or too small a) workspace.
+inline int ksplit_for_geometry(const st2_conv_desc& d) {
+  const int CI_T = d.ks <= 3 ? 32 : 16;
+  const int BM = d.C_out > 64 ? 128 : (d.C_out > 32 ? 64 : 32);
+  const int BN = d.C_out > 64 ? 128 : (d.C_out > 32 ? 256 : 512);
+  const int nchunk = (d.C_in + CI_T - 1) / CI_T;
+  const int64_t wgs = (int64_t)st2_cdiv(d.L_out, BN) * st2_cdiv(d.C_out, BM) * d.B;
+  // measured (profiles/r02v_*, r02w_*): with 256 workgroups (B = 32 x 8 co-blocks) a 4-way split LOSES 4-6 % on the
+  // LibriTTS configurations (the reduction re-reads 4 x the output), with 8-16 (B = 1) an 8-way split takes the
+  // long-form passage from 181 to 118 ms -- so only launches below half a round of the chip are split, up to ~256 slices
+  if (nchunk < 8 || wgs >= 128) return 1;
+  int s = (int)std::min<int64_t>(8, 256 / wgs);
+  s = std::min(s, nchunk / 4);
+  return std::max(s, 1);
+}
+inline int pick_ksplit(const st2_conv_desc& d) {
+  const int s = ksplit_for_geometry(d);
+  if (s <= 1 || !d.splitk_ws || (int64_t)s * d.B * d.C_out * d.L_out * 4 > d.splitk_ws_bytes) return 1;
+  return s;
+}
+
 template <int KS, int CI_T, int WM, int WN, int TN>
 int launch(const st2_conv_desc& d, hipStream_t s) {
   constexpr int BM = 32 * WM;
@@ -405,10 +478,19 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  const int ksplit = pick_ksplit(d);
+  ST2_REQUIRE((int64_t)d.B * ksplit <= 65535, "st2_conv1d_f16s: grid too large");
   // rows beyond C_out inside the last co block are computed on zero weights and not stored
-  dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B);
-  hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, st2_status_device_ptr());
+  dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B * ksplit);
+  float* part = ksplit > 1 ? reinterpret_cast<float*>(d.splitk_ws) : nullptr;
+  hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, st2_status_device_ptr(),
+                     ksplit, part);
   ST2_CHECK_LAUNCH("st2_conv1d_f16s");
+  if (ksplit > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(st2_cdiv(d.L_out, 256), d.C_out, d.B), dim3(256), 0, s, d, ksplit,
+                       part);
+    ST2_CHECK_LAUNCH("st2_conv1d_f16s (split-K reduction)");
+  }
   return 0;
 }
 

@@ -656,6 +656,11 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     d.pro = o.pro; d.slope = o.slope;
     d.stats = o.stats; d.gamma = o.gamma; d.beta = o.beta; d.gb_bs = o.gb_bs; d.gamma_plus_one = o.gamma_plus_one;
     d.alpha = o.alpha;
+    const int64_t skb = st2_conv1d_f16s_splitk_bytes(&d);  // skinny layers run split-K inside the workspace
+    if (skb > 0) {
+      d.splitk_ws = c.a.alloc(skb);
+      d.splitk_ws_bytes = skb;
+    }
     RUN(c, g_be.conv1d_f16s(&d, c.stream));
     if (o.stats_out) RUN(c, g_be.instnorm_stats(y.p, y.bs, y.cs, y.B, y.C, y.L, 1e-5f, o.stats_out, c.stream));
   }

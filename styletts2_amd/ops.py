@@ -274,6 +274,12 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         assert alpha.numel() == C_in and alpha.is_contiguous()
         d.alpha = alpha.data_ptr()
     _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope)
+    ws = None
+    if split:  # skinny layers (few workgroups, long k loop) run split-K: the library says how much workspace it wants
+        nb = lib.st2_conv1d_f16s_splitk_bytes(C.byref(d))
+        if nb > 0:
+            ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)  # caching allocator: stream- and capture-safe
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
     _launch_conv(fn, fname, d)
     if want_stats:
         return out, instnorm_stats(out)

@@ -86,6 +86,10 @@ F16S_EXTRA_CASES = [
     dict(B=1, C_in=256, C_out=1280, L=161, ks=2, dil=1, pro=R.PRO_LEAKY, pad_left=1, L_out=162),
     dict(B=2, C_in=64, C_out=1, L=700, ks=7, dil=1, pro=R.PRO_SNAKE, act=R.ACT_TANH),
     dict(B=1, C_in=17, C_out=33, L=129, ks=5, dil=2, pro=R.PRO_NONE),
+    # split-K launches of st2_conv1d_f16s (few workgroups, long k loop): every epilogue term through the reduction kernel
+    dict(B=3, C_in=2048, C_out=1024, L=100, ks=1, dil=1, pro=R.PRO_NONE, res=True, res2=True, div=2.0),
+    dict(B=1, C_in=1000, C_out=300, L=112, ks=1, dil=1, pro=R.PRO_COLNORM, res=True, act=R.ACT_GELU),
+    dict(B=1, C_in=1024, C_out=2048, L=87, ks=1, dil=1, pro=R.PRO_COLNORM, act=R.ACT_GELU_TANH),
 ]
 
 
