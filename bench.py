@@ -266,7 +266,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="issue every step on one stream (no front/decoder overlap)")
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
-    ap.add_argument("--graph-front", action="store_true", help="longform: hipGraph around the whole front of a sentence")
+    ap.add_argument("--eager-front", action="store_true",
+                    help="issue the device-only front of a step / sentence (text encoder, PL-BERT, sampler, duration "
+                         "encoder) kernel by kernel from Python instead of replaying it from one hipGraph")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
@@ -334,10 +336,11 @@ def main():
         front.wait_stream(torch.cuda.current_stream(dev))
 
     first_chunk_ms = []
-    # configs[4]: the diffusion sampler of every sentence replays one hipGraph per 16-token bucket (make_sampler(graph=True));
-    # --graph-front extends the capture to the whole device-only front of a sentence (pipeline.GraphedFront: measured
-    # neutral on this box -- a single sentence is bound by the latency of its kernel chain, not by host issue)
-    lf_front = pipeline.GraphedFront(model, sampler) if (longform and a.graph_front) else None
+    # The device-only front of a step / sentence (text encoder, PL-BERT, diffusion sampler, style mixing, duration
+    # encoder: ~600 launches of 5-70 us kernels) is replayed from ONE hipGraph per shape (pipeline.GraphedFront; captured
+    # during the warm-up steps): host issue time per step 6.0 -> 1.8 ms, throughput +0.7-1.3 % (profiles/r02x_*).  The
+    # per-step random draws stay outside the graph.  --eager-front issues it kernel by kernel.
+    lf_front = None if a.eager_front else pipeline.GraphedFront(model, sampler)
     if longform:
         sents = [tokens[i % PER_GPU_BATCH, :n].clone() for i, n in enumerate(LONGFORM_SENTENCES)]
         durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
@@ -360,7 +363,7 @@ def main():
         def step():
             return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
                                       embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
-                                      front_stream=front)
+                                      front_stream=front, front=lf_front)
 
     for i in range(a.warmup):
         out = step()
@@ -423,7 +426,7 @@ def main():
                        "diffusion_steps": steps_d, "decoder": man["config"]["decoder"]["type"],
                        "audio_s_per_step_per_gpu": audio_s, "parallelism": "utterance-sharded x%d" % world,
                        "streams": streams, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
-                       "plan": os.environ.get("ST2_PLAN", "engine"),
+                       "plan": os.environ.get("ST2_PLAN", "engine"), "graphed_front": not a.eager_front,
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,
         }

@@ -110,11 +110,15 @@ class DiffusionSampler(nn.Module):
         self.sigma_schedule = sigma_schedule
         self.num_steps = num_steps
         self.clamp = clamp
+        self._tables = {}
 
     def step_table(self, num_steps):
         """The input-independent scalars of the ADPM2 loop in the reference's own arithmetic (fp32 tensors for the
         schedule and the EDM weights, python floats for sigma_up / down / mid): `st2_sampler_run`'s `table` (11 doubles per
         step, include/st2.h) and sigma0."""
+        cached = self._tables.get(num_steps)  # input independent: computed once per step count
+        if cached is not None:
+            return cached
         sigmas = self.sigma_schedule(num_steps, None)
         table = []
         for i in range(num_steps - 1):
@@ -123,7 +127,8 @@ class DiffusionSampler(nn.Module):
             sg = float(sigma)
             table += list(self.diffusion.get_scale_weights(sg)) + list(self.diffusion.get_scale_weights(s_mid))
             table += [(s_mid - sg) / sg, (s_down - sg) / s_mid, s_up]
-        return table, float(sigmas[0])
+        self._tables[num_steps] = (table, float(sigmas[0]))
+        return self._tables[num_steps]
 
     def _engine(self, device):
         """The C++ plan's handle for this denoiser on `device` (packed once per load; rebuilt when the Python-side

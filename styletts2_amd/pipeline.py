@@ -100,7 +100,9 @@ class GraphedFront:
 
     def __init__(self, model, sampler, max_graphs=32):
         self.model = model
-        self.sampler = getattr(sampler, "sampler", sampler)  # a GraphedSampler's eager sampler: one graph, not two nested
+        from .diffusion import GraphedSampler
+        # a GraphedSampler's eager sampler: one graph, not two nested (DiffusionSampler.sampler is the ADPM2 object)
+        self.sampler = sampler.sampler if isinstance(sampler, GraphedSampler) else sampler
         self.max_graphs = max_graphs
         self._graphs = {}
 
