@@ -109,6 +109,22 @@ class GraphedFront:
     def _generation(self):
         return getattr(self.sampler.diffusion.net, "_pack_gen", 0)
 
+    def _pack_refs(self):
+        """(module, packed-weight cache) of every front module as of now.  A graph keeps these references -- the device
+        memory its kernels read stays allocated -- and is stale as soon as a module holds a different cache object
+        (load_state_dict / .to() / refresh() rebuild the packs)."""
+        refs = []
+        for key in ("text_encoder", "bert", "predictor"):
+            for m in self.model[key].modules():
+                pk = getattr(m, "_pk", None)
+                if pk is not None:
+                    refs.append((m, pk))
+        return refs
+
+    @staticmethod
+    def _stale(g):
+        return any(getattr(m, "_pk", None) is not pk for m, pk in g["packs"])
+
     @torch.no_grad()
     def __call__(self, tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, **kw):
         dev = tokens.device
@@ -120,7 +136,7 @@ class GraphedFront:
                lengths_dev is not None, bool(kw["predict"]), bool(kw["lj_tail"]), float(kw["alpha"]), float(kw["beta"]),
                float(kw["t"]))
         g = self._graphs.get(key)
-        if g is not None and g["gen"] != self._generation():  # packed weights were rebuilt: recorded pointers are stale
+        if g is not None and (g["gen"] != self._generation() or self._stale(g)):  # packed weights were rebuilt
             self._graphs.clear()
             g = None
         if g is None:
@@ -156,7 +172,7 @@ class GraphedFront:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = run()
-        return dict(graph=graph, static=st, out=out, gen=self._generation())
+        return dict(graph=graph, static=st, out=out, gen=self._generation(), packs=self._pack_refs())
 
 
 @torch.no_grad()

@@ -128,7 +128,10 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
 
 @pytest.mark.parametrize("B,C_in,C_out,L,ks,dil,res", [(2, 128, 128, 2500, 11, 5, True), (1, 256, 256, 515, 3, 1, False),
                                                        (2, 64, 64, 777, 7, 3, True), (1, 32, 22, 1300, 7, 1, False),
-                                                       (2, 128, 128, 48001, 11, 1, True)])
+                                                       (2, 128, 128, 48001, 11, 1, True),
+                                                       # >= 1024 workgroups at 256-column tiles: the 32 x 256 wave-tile
+                                                       # builds (k = 7 / 11), two partial-sum tiles per wave
+                                                       (6, 128, 128, 48001, 11, 3, True), (16, 256, 256, 8000, 7, 1, True)])
 def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
     """want_stats: InstanceNorm statistics of the conv OUTPUT from the epilogue's per-tile partial sums
     (st2_conv1d_xs part + st2_stats_finalize) against the fp64 reduction of the stored tensor."""

@@ -319,3 +319,12 @@ def test_graphed_front_is_bitwise_the_eager_front(tag, predict):
     if not predict:
         assert all(torch.equal(a, b) for a, b in zip(w_e, w_g)) and all(torch.equal(a, b) for a, b in zip(w_e, w_o))
     assert all(bool(torch.isfinite(w).all()) for w in w_g)
+    # a weight reload rebuilds the packed caches the recorded graphs point at: they must be dropped, not replayed
+    old_graphs = dict(front._graphs)
+    model.text_encoder.load_state_dict({k: v.clone() for k, v in model.text_encoder.state_dict().items()})
+    if predict:
+        torch.manual_seed(0)
+    w_r, s_r = pipeline.synthesize_long(model, sampler, d(sentences), overlap=False, front=front, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(s_r, s_e)
+    assert all(front._graphs[k] is not old_graphs.get(k) for k in front._graphs)
