@@ -25,14 +25,11 @@
 //   * wave tile = 32 (co) x 32*TN (l): TN accumulators of 16 registers.  Waves are arranged WM x WN over
 //     (co, l): 4x1 for C_out >= 96, 2x2 for C_out in (32, 96), 1x4 for C_out <= 32.
 #pragma once
-#include "st2_common.h"
-#include "st2_act.h"
+#include "st2_conv_epilogue.h"
 #include <algorithm>
-#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef st2_f32x16 f32x16;
 
 namespace {
 
@@ -262,11 +259,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
           bl[j] = xp[plane + j * 32];
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[j], 0, 0, 0);
+        // activations as the MFMA's A operand, weights as B: the accumulator is the transposed tile the shared
+        // epilogue expects (st2_conv_epilogue.h): lane = output row, registers = runs of 4 consecutive positions
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al, acc[j], 0, 0, 0);
       }
     }
     if (SPC & 1) {  // odd step count: next chunk's step 0 reads set 0
@@ -281,131 +280,21 @@ __global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc 
   if (ksplit > 1) {  // partial sums of this K slice, scaled, dense [ksplit][B][C_out][L_out]
     const float* rsc1 = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
     float* pb = part + ((int64_t)ksl * d.B + b) * d.C_out * d.L_out;
+    const int row = m0 + wm * 32 + l31;  // transposed accumulator: this lane's output row
+    const float sraw = rsc1[row];
+    const float osc_r = d.w_row_scale ? d.out_scale * sraw : d.out_scale;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const float sraw = rsc1[row];
-      const float osc_r = d.w_row_scale ? d.out_scale * sraw : d.out_scale;
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (32 * TN) + l31 + j * 32;
+      for (int r = 0; r < 16; ++r) {
+        const int col = n0 + wn * (32 * TN) + j * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
         if (row < d.C_out && col < d.L_out) pb[(int64_t)row * d.L_out + col] = acc[j][r] * osc_r;
       }
     }
     return;
   }
-  // ---- epilogue ---------------------------------------------------------------------------------------
-  float* yb = d.y + (int64_t)b * d.y_bs;
-  const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
-  const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
-  const float osc = d.out_scale;
-  // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
-  const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
-  // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
-  // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
-  // each waited for on the spot (measured: the epilogue then costs as much as the k loop).  So interior tiles -- every
-  // tile but the last along l / co -- of the plain-output convs dispatch ONCE to a build with those terms as
-  // compile-time constants: no bounds tests, one 64-bit address per output row (the four 32-column groups of a lane
-  // are immediate offsets), the row's residual loads issued together ahead of the arithmetic.  Edge tiles and rare
-  // combinations take the generic build (MODE < 0: run-time flags, per-element bounds).
-  const int col0 = n0 + wn * (32 * TN) + l31;
-  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out;  // workgroup-uniform
-  const int rstep = 32 >> d.res_shift;
-  auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_tag)::value;
-    constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
-    constexpr bool FULL = MODE >= 0;
-    const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
-    const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
-    const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const bool rok = FULL || row < d.C_out;
-      const int rowc = FULL ? row : min(row, d.C_out - 1);
-      // 32-bit element offsets from the (scalar) per-batch bases: one VALU mad per row and tensor, and the memory
-      // instructions take the SGPR-base + VGPR-offset form (a batch item is < 2^31 elements, checked at launch)
-      const int yo = rowc * d.y_cs + col0;
-      const int ro = rowc * d.res_cs + (col0 >> d.res_shift);  // used only if use_res
-      const int r2o = rowc * d.res2_cs + col0;                 // used only if use_res2
-      // unconditional load + select (a branch here would split the rows into separate basic blocks); without a bias
-      // the packed weights serve as a valid address
-      const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[rowc];
-      const float bias_r = d.bias ? braw : 0.f;
-      const float sraw = rsc[row];  // row < wq_co_pad by construction of the packing
-      const float osc_r = d.w_row_scale ? osc * sraw : osc;
-      bool ok[TN];
-      float rv[TN], r2v[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        ok[j] = FULL || (rok && col0 + j * 32 < d.L_out);
-        rv[j] = (use_res && ok[j]) ? rb[ro + j * rstep] : 0.f;
-        r2v[j] = (use_res2 && ok[j]) ? r2b[r2o + j * 32] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float v = acc[j][r] * osc_r + bias_r;
-        if (use_res) v += rv[j];
-        if (use_res2) v = r2v[j] + v;
-        if (use_div) v = v / d.div;
-        if constexpr (ACT == ST2_ACT_GELU) {
-          v = gelu_erf(v);
-        } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
-          v = row < d.act_split ? expf(v) : sin_acc(v);
-        } else if constexpr (ACT == ST2_ACT_TANH) {
-          v = tanhf(v);
-        } else if constexpr (ACT == ST2_ACT_LEAKY) {
-          v = leaky(v, d.act_slope);
-        } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
-          v = gelu_tanh(v);
-        }
-        if (ok[j]) {
-          yb[yo + j * 32] = v;
-        }
-      }
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four rows of loads in flight at a time (VGPR budget)
-    }
-  };
-  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_tag)::value;
-    const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
-    if (!full_tile) return epilogue_as(act_tag, std::integral_constant<int, -1>{});
-    if constexpr (ACT == ST2_ACT_NONE) {
-      switch (mode) {
-        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{});
-        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{});
-        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{});
-        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{});
-        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{});
-        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{});
-        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
-      }
-    } else {
-      if (mode == 0) return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-      return epilogue_as(act_tag, std::integral_constant<int, -1>{});
-    }
-  };
-  switch (d.act) {
-    case ST2_ACT_GELU:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
-      break;
-    case ST2_ACT_EXP_SIN:
-      epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
-      break;
-    case ST2_ACT_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
-      break;
-    case ST2_ACT_LEAKY:
-      epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
-      break;
-    case ST2_ACT_GELU_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
-      break;
-    default:
-      epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
-      break;
-  }
+  // ---- epilogue (st2_conv_epilogue.h: shared with the xs kernel; emits the InstanceNorm partial sums on request) ----
+  st2_conv_epilogue<TN, WM, WN>(d, acc, b, m0, n0, wm, wn, l31, kg);
 }
 
 // Second half of a split-K conv: y = epi(bias + sum over the K slices, in slice order), one thread per output element.
@@ -478,7 +367,9 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const int ksplit = pick_ksplit(d);
+  if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_f16s: part_nt=%d < %d tiles", d.part_nt,
+                          st2_cdiv(d.L_out, 128));
+  const int ksplit = d.part ? 1 : pick_ksplit(d);  // the reduction kernel does not emit statistics
   ST2_REQUIRE((int64_t)d.B * ksplit <= 65535, "st2_conv1d_f16s: grid too large");
   // rows beyond C_out inside the last co block are computed on zero weights and not stored
   dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B * ksplit);

@@ -22,13 +22,10 @@
 // output channel (a lane's own values + one cross-lane move, fixed order) so the next layer's InstanceNorm statistics
 // cost no extra pass over the tensor.
 #pragma once
-#include "st2_common.h"
-#include "st2_act.h"
-#include <type_traits>
+#include "st2_conv_epilogue.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef st2_f32x16 f32x16;
 
 // Instrumentation switches of the micro-benchmark tools/xs_bench.hip (all compiled out of the library, ST2_XS_ABLATE = 0):
 // bit 0 = activation fragments read from LDS once per chunk instead of per k-step, bit 1 = weight fragments loaded once,
@@ -42,17 +39,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 namespace {
-
-// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The accumulator array must only
-// ever be indexed by constants (a run-time index would move all of it to scratch); `#pragma unroll` is a request the
-// optimizer may decline for a large body, this is not.
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 
 constexpr int NT = 256;
 constexpr int ABL = ST2_XS_ABLATE;
@@ -266,215 +252,8 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
     tl_write();
     return;
   }
-  // ---- epilogue ---------------------------------------------------------------------------------------
-  // Accumulator layout (transposed product, see the k loop): lane (l31, kg) owns output row co = m0 + wm*32 + l31 and,
-  // in acc[j][4*q + e], the position l = n0 + wn*32*TN + j*32 + 8*q + 4*kg + e: four CONSECUTIVE positions per (j, q).
-  // Interior tiles of 16-byte aligned tensors therefore store / load 16 bytes per lane and instruction -- 16 stores per
-  // wave tile instead of 64 (the store tail of an MFMA kernel is bound by the number of store instructions, not by
-  // their bytes: cdna_hip_programming.md T21; measured here: the epilogue cost 0.23 ms of a 1.70 ms k = 11 launch and
-  // 0.35 of 0.85 ms at k = 3 with 4-byte stores), bias and weight scale are per lane, and the InstanceNorm partial
-  // sums of a row are a lane's own 64 values plus its kg partner's: one cross-lane move.
-  float* yb = d.y + (int64_t)b * d.y_bs;
-  const float* rb = d.res ? d.res + (int64_t)b * d.res_bs : nullptr;
-  const float* r2b = d.res2 ? d.res2 + (int64_t)b * d.res2_bs : nullptr;
-  const float osc = d.out_scale;
-  // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
-  const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
-  const bool want_part = d.part != nullptr;
-  constexpr int NPT = TN / 4;               // 128-column partial-sum tiles per wave tile
-  const int ptile = (blockIdx.x * WN + wn) * NPT;  // first 128-column tile index of this wave's partial sums
-  const int co = m0 + wm * 32 + l31;       // this lane's output row (< wq_co_pad by construction of the packing)
-  const int lw = n0 + wn * (32 * TN) + 4 * kg;  // first position of this lane's (j = 0, q = 0) quad
-  // 16-byte accesses need every row of y / res / res2 to start 16-byte aligned (workgroup-uniform, set by the plans'
-  // padded row pitch); the residual must not be sub-sampled
-  const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.y) | (uintptr_t)(d.y_bs * 4) | (uintptr_t)(d.y_cs * 4)) & 15) == 0 &&
-                      (!rb || (((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0 &&
-                               d.res_shift == 0)) &&
-                      (!r2b || ((reinterpret_cast<uintptr_t>(d.res2) | (uintptr_t)(d.res2_bs * 4) | (uintptr_t)(d.res2_cs * 4)) & 15) == 0);
-  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out && vec_ok;  // workgroup-uniform
-  // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
-  // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
-  // each waited for on the spot.  So interior tiles -- every tile but the last along l / co -- of aligned tensors
-  // dispatch ONCE to a build with those terms as compile-time constants: no bounds tests, 32-bit offsets from scalar
-  // bases, a column block's residual loads issued together ahead of its arithmetic.  Edge tiles, unaligned tensors and
-  // rare combinations take the generic build (MODE < 0: run-time flags, per-element bounds, 4-byte accesses).
-  auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_tag)::value;
-    constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
-    constexpr bool FULL = MODE >= 0;
-    const bool use_res = FULL ? (MODE & 1) != 0 : rb != nullptr;
-    const bool use_res2 = FULL ? (MODE & 2) != 0 : r2b != nullptr;
-    const bool use_div = FULL ? (MODE & 4) != 0 : d.div != 1.0f;
-    const bool rok = FULL || co < d.C_out;
-    const int coc = FULL ? co : min(co, d.C_out - 1);
-    // unconditional load + select (a branch here would split the code into separate basic blocks); without a bias the
-    // packed weights serve as a valid address
-    const float braw = (d.bias ? d.bias : reinterpret_cast<const float*>(d.wq))[coc];
-    const float bias_r = d.bias ? braw : 0.f;
-    const float sraw = rsc[co];
-    const float osc_r = d.w_row_scale ? osc * sraw : osc;
-    // 32-bit element offsets from the (scalar) per-batch bases (a batch item is < 2^31 elements, checked at launch)
-    const int yo = coc * d.y_cs + lw;
-    const int ro = coc * d.res_cs;   // + (l >> res_shift)
-    const int r2o = coc * d.res2_cs + lw;
-    float s1 = 0.f, s2 = 0.f;
-    float s1d[NPT], s2d[NPT];  // finished 128-column sums
-    auto finish = [&](float v) __attribute__((always_inline)) -> float {
-      if (use_div) v = v / d.div;
-      if constexpr (ACT == -1) {  // generic build: one body for every activation (run-time switch, wave-uniform)
-        switch (d.act) {
-          case ST2_ACT_GELU: v = gelu_erf(v); break;
-          case ST2_ACT_EXP_SIN: v = co < d.act_split ? expf(v) : sin_acc(v); break;
-          case ST2_ACT_TANH: v = tanhf(v); break;
-          case ST2_ACT_LEAKY: v = leaky(v, d.act_slope); break;
-          case ST2_ACT_GELU_TANH: v = gelu_tanh(v); break;
-          default: break;
-        }
-      } else if constexpr (ACT == ST2_ACT_GELU) {
-        v = gelu_erf(v);
-      } else if constexpr (ACT == ST2_ACT_EXP_SIN) {
-        v = co < d.act_split ? expf(v) : sin_acc(v);
-      } else if constexpr (ACT == ST2_ACT_TANH) {
-        v = tanhf(v);
-      } else if constexpr (ACT == ST2_ACT_LEAKY) {
-        v = leaky(v, d.act_slope);
-      } else if constexpr (ACT == ST2_ACT_GELU_TANH) {
-        v = gelu_tanh(v);
-      }
-      return v;
-    };
-    if constexpr (FULL) {
-      // ALL residual quads of 4 column blocks are requested before the first one is used: 16 x 16 bytes per lane in
-      // flight (64 VGPRs -- the k loop's fragment and staging registers are dead here).  Issued per (j, q) pair they
-      // cost one HBM round trip each, 8 in series per tile: measured 27 000 cycles of epilogue against a 101 000-cycle
-      // k loop (per-workgroup s_memtime stamps, tools/xs_bench.hip), i.e. a fifth of every workgroup slot's time.
-#pragma unroll
-      for (int jh = 0; jh < TN; jh += 4) {
-        f32x4 rv[4][4];
-        if (use_res) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              rv[jj][q] = *reinterpret_cast<const f32x4*>(rb + ro + lw + (jh + jj) * 32 + 8 * q);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = jh + jj;
-          f32x4 r2v[4];
-          if (use_res2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r2v[q] = *reinterpret_cast<const f32x4*>(r2b + r2o + j * 32 + 8 * q);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // osc_r is a power of two: acc * osc_r is exact, so the fused form rounds exactly like mul + add
-              float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
-              if (use_res) t += rv[jj][q][e];
-              if (use_res2) t = r2v[q][e] + t;
-              t = finish(t);
-              v[e] = t;
-              s1 += t;
-              s2 = fmaf(t, t, s2);
-            }
-            *reinterpret_cast<f32x4*>(yb + yo + j * 32 + 8 * q) = v;
-          }
-          // pin the running sums here: otherwise the compiler sinks the whole accumulation below the (wave-uniform)
-          // `want_part` test, keeps all 64 stored values alive for it and spills
-          asm volatile("" : "+v"(s1), "+v"(s2));
-          __builtin_amdgcn_sched_barrier(0);
-          if ((j & 3) == 3) {
-            s1d[j >> 2] = s1;
-            s2d[j >> 2] = s2;
-            s1 = 0.f;
-            s2 = 0.f;
-          }
-        }
-      }
-    } else {
-      static_for<TN * 16>([&](auto idx_tag) __attribute__((always_inline)) {
-        constexpr int idx = decltype(idx_tag)::value;
-        constexpr int j = idx / 16, q = (idx % 16) / 4, e = idx % 4;
-        const int l = lw + j * 32 + 8 * q + e;
-        const bool ok = rok && l < d.L_out;
-        float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
-        if (use_res) t += ok ? rb[ro + (l >> d.res_shift)] : 0.f;
-        if (use_res2) t = (ok ? r2b[r2o + j * 32 + 8 * q + e] : 0.f) + t;
-        t = finish(t);
-        if (ok) {
-          yb[yo + j * 32 + 8 * q + e] = t;
-          s1 += t;
-          s2 = fmaf(t, t, s2);
-        }
-        if constexpr (e == 3) asm volatile("" : "+v"(s1), "+v"(s2));
-        if constexpr (idx % 64 == 63) {
-          s1d[j >> 2] = s1;
-          s2d[j >> 2] = s2;
-          s1 = 0.f;
-          s2 = 0.f;
-        }
-      });
-    }
-    if (want_part) {  // wave-uniform: (sum, sumsq) of row co over 128 columns = this lane + its kg partner
-#pragma unroll
-      for (int t = 0; t < NPT; ++t) {
-        const float a1 = s1d[t] + __shfl_xor(s1d[t], 32, 64);
-        const float a2 = s2d[t] + __shfl_xor(s2d[t], 32, 64);
-        if (kg == 0 && co < d.C_out && ptile + t < d.part_nt) {
-          float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + co) * d.part_nt + ptile + t;
-          *pp = make_float2(a1, a2);
-        }
-      }
-    }
-  };
-  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_tag)::value;
-    const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
-    if constexpr (ACT == ST2_ACT_NONE) {
-      switch (mode) {
-        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{});
-        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{});
-        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{});
-        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{});
-        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{});
-        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{});
-        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
-      }
-    } else {
-      return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-    }
-  };
-  // edge tiles, unaligned tensors, an activation combined with residual / divide: ONE generic body (the 64 predicated
-  // element blocks of a generic build are the bulk of this kernel's code)
-  if (!full_tile || (d.act != ST2_ACT_NONE && (rb || r2b || d.div != 1.0f))) {
-    epilogue_as(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
-    tl_write();
-    return;
-  }
-  switch (d.act) {
-    case ST2_ACT_GELU:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
-      break;
-    case ST2_ACT_EXP_SIN:
-      epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
-      break;
-    case ST2_ACT_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
-      break;
-    case ST2_ACT_LEAKY:
-      epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
-      break;
-    case ST2_ACT_GELU_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
-      break;
-    default:
-      epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
-      break;
-  }
+  // ---- epilogue (st2_conv_epilogue.h: shared with the fused kernel) --------------------------------------
+  st2_conv_epilogue<TN, WM, WN>(d, acc, b, m0, n0, wm, wn, l31, kg);
   tl_write();
 }
 

@@ -78,6 +78,7 @@ Backend g_be = kHipBackend;
 // workspace arena, views
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int XS_HALO = 32;        // == styletts2_amd.ops.XS_HALO
+constexpr int FUSED_MAX_C = 64, FUSED_K3_MAX_C = 128;  // ops.prefer_fused
 constexpr int XS_MIN_L = 256;      // shorter rows stay on the fused kernel
 constexpr int XS_MIN_C_PLAIN = 64;  // prologue-free convs take the xs pair from this many input channels on
 constexpr int CVT_TILE = 1024;     // positions per st2_convt_interleave_stats partial sum
@@ -633,7 +634,10 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     if (c.rc == 0) { st2_set_error("engine: conv weight is %d->%d, call has %d->%d", w.C_in, w.C_out, x.C, y.C); c.rc = 1; }
     return;
   }
-  const bool use_xs = o.pad_left <= XS_HALO && x.L >= XS_MIN_L && (o.pro != ST2_PRO_NONE || x.C >= XS_MIN_C_PLAIN);
+  // == styletts2_amd.ops.prefer_fused: HBM-bound layers (C <= 64; k = 3 at C <= 128) skip the activation pass
+  const bool prefer_fused = o.pro != ST2_PRO_NONE && (x.C <= FUSED_MAX_C || (w.ks <= 3 && x.C <= FUSED_K3_MAX_C));
+  const bool use_xs = o.pad_left <= XS_HALO && x.L >= XS_MIN_L && (o.pro != ST2_PRO_NONE || x.C >= XS_MIN_C_PLAIN) &&
+                      !prefer_fused;
   const int64_t mark = c.a.off;
   if (use_xs) {
     const int cg = (x.C + 31) / 32 * 32 / 8;
@@ -656,13 +660,21 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     d.pro = o.pro; d.slope = o.slope;
     d.stats = o.stats; d.gamma = o.gamma; d.beta = o.beta; d.gb_bs = o.gb_bs; d.gamma_plus_one = o.gamma_plus_one;
     d.alpha = o.alpha;
-    const int64_t skb = st2_conv1d_f16s_splitk_bytes(&d);  // skinny layers run split-K inside the workspace
-    if (skb > 0) {
-      d.splitk_ws = c.a.alloc(skb);
-      d.splitk_ws_bytes = skb;
+    float* part = nullptr;
+    int nt = 0;
+    if (o.stats_out) {  // statistics of the output from the epilogue's per-tile partial sums
+      nt = (y.L + 127) / 128;
+      part = c.a.f32((int64_t)y.B * y.C * nt * 2);
+      d.part = part; d.part_nt = nt;
+    } else {
+      const int64_t skb = st2_conv1d_f16s_splitk_bytes(&d);  // skinny layers run split-K inside the workspace
+      if (skb > 0) {
+        d.splitk_ws = c.a.alloc(skb);
+        d.splitk_ws_bytes = skb;
+      }
     }
     RUN(c, g_be.conv1d_f16s(&d, c.stream));
-    if (o.stats_out) RUN(c, g_be.instnorm_stats(y.p, y.bs, y.cs, y.B, y.C, y.L, 1e-5f, o.stats_out, c.stream));
+    if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
   }
   c.a.off = mark;  // planes / partial sums are dead once the launches are queued (stream order protects reuse)
 }

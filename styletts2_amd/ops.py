@@ -75,9 +75,19 @@ def check_status():
 
 
 XS_HALO = 32  # zero columns in front of every xs row (>= the largest pad_left on the path: 25)
+FUSED_MAX_C, FUSED_K3_MAX_C = 64, 128  # see prefer_fused()
 XS_MIN_L = 256  # shorter rows stay on the fused kernel: an xs row is >= 640 slots
 XS_MIN_C_PLAIN = 64  # prologue-free convs take the xs pair too from this many input channels on (the split pass is
 #                      then cheap next to the conv; measured 39 us vs 80 us per denoiser Linear at B*N = 3200)
+
+
+def prefer_fused(pro, C_in, ks):
+    """Layers whose xs pair is HBM-bound take the fused kernel instead (prologue arithmetic on the VALU beside the MFMAs,
+    no activation pass: 12 instead of 20 bytes per element): the narrow HiFi-GAN stages (C <= 64) and the k = 3 resblock
+    convs at C = 128.  Measured per layer at B = 32 (tools/probe_conv.py, profiles/r02y_probe_conv_b32.log): fused / pair =
+    0.80-0.96 at C = 64, 0.86-0.91 at C = 32, 0.89-0.92 at C = 128 k = 3; 1.04-1.19 everywhere else.  The same rule lives in
+    csrc/st2_engine.hip (conv())."""
+    return pro != PRO_NONE and (C_in <= FUSED_MAX_C or (ks <= 3 and C_in <= FUSED_K3_MAX_C))
 
 
 def conv_path():
@@ -221,7 +231,7 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     B, C_in, L_in = x.shape
     split = isinstance(wt, SplitConvWeight)
     if (split and pad_left <= XS_HALO and L_in >= XS_MIN_L and (pro != PRO_NONE or C_in >= XS_MIN_C_PLAIN)
-            and conv_path() == "xs"):
+            and conv_path() == "xs" and not prefer_fused(pro, C_in, ks)):
         xs = activate(x, pro=pro, slope=slope, stats=stats, gamma=gamma, beta=beta,
                                     gamma_plus_one=gamma_plus_one, alpha=alpha)
         return conv1d_xs(xs, wt, C_out, ks, dil=dil, pad_left=pad_left, L_out=L_out, bias=bias, out=out, res=res,
@@ -274,15 +284,19 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         assert alpha.numel() == C_in and alpha.is_contiguous()
         d.alpha = alpha.data_ptr()
     _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope)
-    ws = None
-    if split:  # skinny layers (few workgroups, long k loop) run split-K: the library says how much workspace it wants
+    ws = part = None
+    if split and want_stats:  # InstanceNorm statistics of the output from the epilogue's per-tile partial sums
+        nt = (L_out + 127) // 128
+        part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
+        d.part, d.part_nt = part.data_ptr(), nt
+    elif split:  # skinny layers (few workgroups, long k loop) run split-K: the library says how much workspace it wants
         nb = lib.st2_conv1d_f16s_splitk_bytes(C.byref(d))
         if nb > 0:
             ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)  # caching allocator: stream- and capture-safe
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
     _launch_conv(fn, fname, d)
     if want_stats:
-        return out, instnorm_stats(out)
+        return out, (stats_finalize(part, L_out) if part is not None else instnorm_stats(out))
     return out
 
 

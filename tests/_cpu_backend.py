@@ -80,8 +80,21 @@ def conv1d_f16s(dp, stream):
     kw = _epilogue_kwargs(d)
     kw.update(_prologue_kwargs(d.pro, d.slope, d.stats, d.gamma, d.beta, d.gb_bs, d.gamma_plus_one, d.alpha, d.B, d.C_in,
                                d.L_in))
-    R._conv1d(x, _weight(d), d.C_out, d.ks, **kw)
+    y = R._conv1d(x, _weight(d), d.C_out, d.ks, **kw)
+    _emit_part(d, y)
     return 0
+
+
+def _emit_part(d, y):
+    """Per-128-column (sum, sum of squares) of the stored output, the contract of d.part (st2.h)."""
+    if d.part:
+        nt = d.part_nt
+        part = _t(d.part, (d.B, d.C_out, nt, 2), (d.C_out * nt * 2, nt * 2, 2, 1))
+        yd = torch.zeros(d.B, d.C_out, nt * 128, dtype=torch.float64)
+        yd[:, :, :d.L_out] = y.double()
+        yd = yd.reshape(d.B, d.C_out, nt, 128)
+        part[..., 0] = yd.sum(-1).float()
+        part[..., 1] = (yd * yd).sum(-1).float()
 
 
 def act_split(x, x_bs, x_cs, B, Cc, L, pro, slope, stats, gamma, beta, gb_bs, gamma_plus_one, alpha, x_scale, xs, xs_cg,
@@ -111,14 +124,7 @@ def conv1d_xs(dp, stream):
     assert float(planes[:, :, :, :d.xs_halo].float().abs().max()) == 0.0, "halo must be zero"
     kw = _epilogue_kwargs(d)
     y = R._conv1d(u.contiguous(), _weight(d), d.C_out, d.ks, **kw)
-    if d.part:
-        nt = d.part_nt
-        part = _t(d.part, (d.B, d.C_out, nt, 2), (d.C_out * nt * 2, nt * 2, 2, 1))
-        yd = torch.zeros(d.B, d.C_out, nt * 128, dtype=torch.float64)
-        yd[:, :, :d.L_out] = y.double()
-        yd = yd.reshape(d.B, d.C_out, nt, 128)
-        part[..., 0] = yd.sum(-1).float()
-        part[..., 1] = (yd * yd).sum(-1).float()
+    _emit_part(d, y)
     return 0
 
 
