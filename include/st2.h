@@ -45,10 +45,13 @@ int st2_device_info(int dev, char* name, int cap);
  *                            65504) and was clamped to +-65504 (st2_act_split, st2_conv1d_f16s): the result is finite
  *                            but not the fp32 conv's; re-run that layer with a smaller x_scale or on st2_conv1d;
  *   ST2_STATUS_LSTM_TIMEOUT  a bounded spin of st2_lstm_bidir_coop expired (a group's workgroups were not
- *                            co-resident in time): the outputs of that call are invalid.
+ *                            co-resident in time): the outputs of that call are invalid;
+ *   ST2_STATUS_DURATION_SUM  a row of the durations handed to st2_expand_by_durations does not sum to T (caller-supplied
+ *                            durations with a wrong `total_frames`): frames past the sum repeat the last phoneme.
  * st2_status(clear != 0) returns the word and atomically clears it.  Returns < 0 if no HIP device is usable. */
 #define ST2_STATUS_F16_RANGE 1
 #define ST2_STATUS_LSTM_TIMEOUT 2
+#define ST2_STATUS_DURATION_SUM 4
 int st2_status(int clear);
 
 /* ---- fused Conv1d (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32) ------------ *

@@ -19,7 +19,7 @@ ABI_VERSION = 11
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
-STATUS_F16_RANGE, STATUS_LSTM_TIMEOUT = 1, 2
+STATUS_F16_RANGE, STATUS_LSTM_TIMEOUT, STATUS_DURATION_SUM = 1, 2, 4
 ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY, ACT_GELU_TANH = range(6)
 
 

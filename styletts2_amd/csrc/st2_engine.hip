@@ -1022,7 +1022,9 @@ void dn_run(Sess& s, View base, const float* x, const float* m, float* out) {
       o1.gamma = e.F(b.n_w);  o1.beta = e.F(b.n_b);
       o2.gamma = e.F(b.nc_w); o2.beta = e.F(b.nc_b);
     }
-    View Xv = dn_cv(s, X), qv = dn_cv(s, qkv);
+    // the multispeaker net's AdaLayerNorm affine is per utterance: its q / kv convs run on the [B][F][N] view of the
+    // same (token-merged) storage; everything else -- o, f1, f2: three quarters of the FLOPs -- runs merged in both nets
+    View Xv = cfg.multispeaker ? X : dn_cv(s, X), qv = cfg.multispeaker ? qkv : dn_cv(s, qkv);
     conv(c, e, Xv, b.q, qv.rows(0, mid), o1);
     conv(c, e, Xv, b.kv, qv.rows(mid, 3 * mid), o2);
     View att = dn_alloc(s, mid);
@@ -1082,7 +1084,7 @@ int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* e
   const st2_model_config& cfg = e.cfg;
   const PDenoiser& d = e.dn;
   const int C = cfg.dn_channels, E = cfg.dn_embedding, Fz = d.features;
-  Sess s{c, e, B, N, !cfg.multispeaker, lengths, {}, 1, nullptr, nullptr, scale};
+  Sess s{c, e, B, N, true, lengths, {}, 1, nullptr, nullptr, scale};  // token-merged storage for both denoisers
   // session: everything constant across the 2*(steps-1) net calls
   s.bases[0] = dn_alloc(s, Fz);
   {

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void duration_head_kernel(const float* __restri
 __global__ __launch_bounds__(256) void expand_by_durations_kernel(const float* __restrict__ x, int64_t x_bs, int x_cs,
                                                                   const long long* __restrict__ dur, int N, int C,
                                                                   int T, int shift, float* __restrict__ y,
-                                                                  int64_t y_bs, int y_cs) {
+                                                                  int64_t y_bs, int y_cs, int* status) {
   __shared__ int cum[512];
   const int b = blockIdx.y;
   const long long* db = dur + (int64_t)b * N;
@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256) void expand_by_durations_kernel(const float* _
     }
   }
   __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0 && cum[N - 1] != T)
+    st2_raise_status(status, ST2_STATUS_DURATION_SUM);  // the caller's durations do not sum to the frame count it gave
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   const int ts = shift ? max(t - 1, 0) : t;
@@ -200,7 +202,7 @@ extern "C" int st2_expand_by_durations(const float* x, int64_t x_bs, int32_t x_c
   ST2_REQUIRE(B <= 65535, "st2_expand_by_durations: grid too large");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(expand_by_durations_kernel, dim3(st2_cdiv(T, 256), B, st2_cdiv(C, 64)), dim3(256), 0, s, x, x_bs, x_cs,
-                     reinterpret_cast<const long long*>(dur), N, C, T, shift, y, y_bs, y_cs);
+                     reinterpret_cast<const long long*>(dur), N, C, T, shift, y, y_bs, y_cs, st2_status_device_ptr());
   ST2_CHECK_LAUNCH("st2_expand_by_durations");
   return 0;
 }

@@ -432,11 +432,12 @@ class _Transformer(nn.Module):
             embedding = torch.where(mask, fixed, embedding)
         C = self.channels
 
-        # Token-merged layout (single-speaker net): storage is [F, B*N] -- channel-major over ALL tokens of the batch --
-        # so every Linear is ONE k=1 conv over B*N contiguous columns (25 full 128-column tiles at B=32, N=100 instead
-        # of 32 x one 78%-full tile), while attention / norm statistics / the mapping add see the same memory as
-        # [B, F, N] through strides.  The multi-speaker net keeps [B, F, N]: its AdaLayerNorm affine is per utterance.
-        s.merged = not self.multispeaker
+        # Token-merged layout: storage is [F, B*N] -- channel-major over ALL tokens of the batch -- so every Linear is ONE
+        # k=1 conv over B*N contiguous columns (25 full 128-column tiles at B=32, N=100 instead of 32 x one 78%-full
+        # tile), while attention / norm statistics / the mapping add see the same memory as [B, F, N] through strides.
+        # The multi-speaker net's AdaLayerNorm affine is per utterance: its q / kv convs take the [B, F, N] view of the same
+        # storage, the other three Linears of a block (three quarters of the FLOPs) run merged like the single-speaker net's.
+        s.merged = True
 
         def base(e):  # channel-major [x | embedding] buffer; rows < C are rewritten on every net call
             buf = self._alloc(s, self.features)
@@ -489,7 +490,7 @@ class _Transformer(nn.Module):
         nblk = len(pk.blocks)
         for i, b in enumerate(pk.blocks):
             st = ops.colnorm_stats(X)
-            stv = st.view(1, B * N, 2) if s.merged else st
+            stv = st if self.multispeaker else st.view(1, B * N, 2)
             qkv = A(3 * mid)
             if self.multispeaker:
                 o = 4 * Fz * i
@@ -500,8 +501,9 @@ class _Transformer(nn.Module):
             else:
                 kw1 = dict(gamma=b.n_w, beta=b.n_b)
                 kw2 = dict(gamma=b.nc_w, beta=b.nc_b)
-            ops.conv1d(V(X), b.q, mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=V(qkv)[:, :mid], **kw1)
-            ops.conv1d(V(X), b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=V(qkv)[:, mid:], **kw2)
+            Vq = (lambda t: t) if self.multispeaker else V  # per-utterance affine: [B, F, N] view of the merged storage
+            ops.conv1d(Vq(X), b.q, mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=Vq(qkv)[:, :mid], **kw1)
+            ops.conv1d(Vq(X), b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=Vq(qkv)[:, mid:], **kw2)
             att = ops.attention(qkv[:, :mid], qkv[:, mid:2 * mid], qkv[:, 2 * mid:], self.heads,
                                 self.head_features ** -0.5, out=A(mid), key_len=s.key_len)
             X1, hmid, X2 = A(Fz), A(b.f1_out), A(Fz)

@@ -71,6 +71,9 @@ def check_status():
     if st & _lib.STATUS_LSTM_TIMEOUT:
         msgs.append("a cooperative BiLSTM group timed out (its workgroups were not co-resident in time): outputs of "
                     "that call are invalid; set ST2_LSTM=single")
+    if st & _lib.STATUS_DURATION_SUM:
+        msgs.append("a row of the supplied durations does not sum to the frame count given with it (`total_frames`): the "
+                    "alignment of that call repeated its last phoneme")
     raise _lib.St2Error("device-side status 0x%x: %s" % (st, "; ".join(msgs)))
 
 

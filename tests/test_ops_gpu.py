@@ -544,6 +544,14 @@ def test_expand_by_durations_is_the_one_hot_matmul(shift):
             aln[b, i, c:c + int(dur[b, i])] = 1
             c += int(dur[b, i])
     assert torch.equal(R.expand_by_durations(x, dur, T), x @ aln)
+    torch.cuda.synchronize()
+    assert ops.status() == 0
+    if not shift:  # a frame count that is not the durations' row sum is reported, never silent
+        ops.expand_by_durations(g(x), g(dur), T + 3, shift=False)
+        torch.cuda.synchronize()
+        with pytest.raises(Exception, match="durations does not sum"):
+            ops.check_status()
+        assert ops.status() == 0  # cleared by the check
 
 
 def test_duration_head_matches_contract():
