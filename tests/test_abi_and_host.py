@@ -134,3 +134,39 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
                 assert "scratch_" not in line, line
         os.remove(co)
     assert seen >= 9, "expected the o3 builds of every kernel size, saw %d" % seen
+
+
+def test_splitk_workspace_query_is_a_function_of_the_geometry():
+    """st2_conv1d_f16s_splitk_bytes (host-only): skinny launches -- < 128 workgroups and >= 8 K chunks -- are split into
+    up to 8 slices (~256 workgroups in total), everything else is not; both plans size their workspace with this call."""
+    import ctypes as C
+    lib = _lib.load()
+
+    def q(B, C_in, C_out, L, ks):
+        d = _lib.ConvDesc()
+        d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil = B, C_in, C_out, L, L, ks, 1
+        return lib.st2_conv1d_f16s_splitk_bytes(C.byref(d))
+
+    assert q(1, 1024, 2048, 100, 1) == 8 * 1 * 2048 * 100 * 4        # 16 workgroups, 32 chunks -> 8 slices
+    assert q(1, 2048, 1024, 112, 1) == 8 * 1 * 1024 * 112 * 4
+    assert q(4, 1024, 1024, 100, 1) == 8 * 4 * 1024 * 100 * 4        # 32 workgroups -> 256 / 32 = 8 slices
+    assert q(8, 1024, 1024, 100, 1) == 4 * 8 * 1024 * 100 * 4        # 64 workgroups -> 4 slices
+    assert q(32, 1024, 1024, 100, 1) == 0                            # 256 workgroups: a split loses (measured)
+    assert q(1, 128, 1024, 100, 1) == 0                              # 4 chunks: nothing to split
+    assert q(1, 512, 512, 37, 5) == 8 * 512 * 37 * 4                 # k = 5: 16-channel chunks
+    assert q(0, 0, 0, 0, 1) == 0
+
+
+def test_conv_routing_rule_is_the_same_in_both_plans():
+    """ops.prefer_fused (Python plans) and conv() in csrc/st2_engine.hip (C++ plans) must route a layer to the same
+    kernel, or the plans stop being bitwise equal: the constants are compared at the source level."""
+    from styletts2_amd import ops
+    src = open(os.path.join(ROOT, "styletts2_amd", "csrc", "st2_engine.hip")).read()
+    m = re.search(r"FUSED_MAX_C = (\d+), FUSED_K3_MAX_C = (\d+)", src)
+    assert m and (int(m.group(1)), int(m.group(2))) == (ops.FUSED_MAX_C, ops.FUSED_K3_MAX_C)
+    m = re.search(r"XS_MIN_L = (\d+)", src)
+    assert m and int(m.group(1)) == ops.XS_MIN_L
+    m = re.search(r"XS_MIN_C_PLAIN = (\d+)", src)
+    assert m and int(m.group(1)) == ops.XS_MIN_C_PLAIN
+    assert ops.prefer_fused(ops.PRO_ADAIN_SNAKE, 64, 11) and ops.prefer_fused(ops.PRO_ADAIN_SNAKE, 128, 3)
+    assert not ops.prefer_fused(ops.PRO_ADAIN_SNAKE, 128, 7) and not ops.prefer_fused(ops.PRO_NONE, 32, 3)
