@@ -233,6 +233,9 @@ def roofline(by_class):
             "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": traffic, "traffic_note": note,
             "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 products per fp32-class multiply",
+            "ceiling_note": "a bare MFMA loop of this kernel (everything else compiled out) reaches 0.586 of `peak` on "
+                            "random operands on MI355X: the shader clock is power-limited to 1.46 GHz (2.18 GHz on zero "
+                            "operands); profiles/r02_conv_kernel_study.md",
             "mfma_tflops_executed": dom["achieved"] * F16S_PRODUCTS,
             "launches_timed": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
             "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
