@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 11
+#define ST2_ABI_VERSION 12
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -424,6 +424,8 @@ typedef struct st2_model_config {
   int32_t dn_embedding;            /* PL-BERT hidden size (768) */
   int32_t dn_context_features;     /* width of `features` (256), multispeaker only */
   int32_t dn_max_length;           /* fixed-embedding table length (512) */
+  /* prosody predictor: models.py:440-466, Configs/config.yml `hidden_dim` */
+  int32_t pred_hidden;             /* d_hid of ProsodyPredictor (512); 0 = predictor not used */
 } st2_model_config;
 
 int st2_create(const st2_model_config* cfg, st2_engine** out);
@@ -434,7 +436,8 @@ int st2_destroy(st2_engine* e);
  * ConvTranspose1d is C_in), replacing X.weight_g / X.weight_v.  `data` is a HOST pointer to fp32, C-contiguous. */
 int st2_load_weights(st2_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 /* Packs everything loaded so far (split-f16 conv layouts, polyphase ConvTranspose / strided-conv forms, concatenated
- * AdaIN fc matrix) and uploads it in one device allocation.  which: 1 = decoder, 2 = denoiser, 3 = both.
+ * AdaIN fc matrix) and uploads it in one device allocation.  which: bit 0 = decoder, bit 1 = denoiser, bit 2 = prosody
+ * predictor (names prefixed "predictor.": shared.*, F0.*, N.*, F0_proj.*, N_proj.*).
  * Synchronous; call once after the last st2_load_weights (again after loading new weights). */
 int st2_finalize_weights(st2_engine* e, int32_t which);
 
@@ -477,6 +480,18 @@ int st2_sampler_run(st2_engine* e, const float* noise, const float* embedding, c
                     double embedding_scale, const double* table, double sigma0, float* out, void* workspace,
                     int64_t workspace_bytes, float* step_taps, void* stream);
 
+/* Alignment expansion + ProsodyPredictor.F0Ntrain (Demo/Inference_LJSpeech.ipynb:303-311, models.py:497-510), i.e. what
+ * sits between the duration predictor and Decoder.forward:
+ *   asr[B][dim_in][T]  = t_en[B][dim_in][N] expanded by `durations` (int64 [B][N], rows summing to T),
+ *   (f0, n)[B][2T]     = F0Ntrain(d expanded the same way, s),  d_cm [B][pred_hidden + style_dim][N] = the duration
+ *                        encoder's output channel-major, s [B][style_dim] the prosodic style;
+ * shift = 1 applies the HiFi-GAN one-frame right shift (Demo/Inference_LibriTTS.ipynb:306-319).  Same memory / stream
+ * contract as st2_decoder_forward; its outputs are exactly that call's inputs. */
+int64_t st2_prosody_workspace_bytes(st2_engine* e, int32_t B, int32_t N, int32_t T);
+int st2_prosody_forward(st2_engine* e, const float* d_cm, const float* t_en, const int64_t* durations, const float* s,
+                        int32_t B, int32_t N, int32_t T, int32_t shift, float* asr, float* f0, float* n, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
 /* ---- measurement hook (bench.py's roofline leg) ------------------------------------------------------------------- *
  * st2_conv_timing(1) clears and starts, (0) stops recording a HIP event pair around every st2_conv1d_xs launch (C_in >=
  * 64, L_out >= 256) on its launch stream, whichever plan issues it.  st2_conv_timing_read (after stopping) waits for the
@@ -495,7 +510,8 @@ enum st2_backend_slot {
   ST2_BE_PHASE_SPLIT, ST2_BE_INSTNORM_STATS, ST2_BE_COLNORM_STATS, ST2_BE_STYLE_FC, ST2_BE_CONVT_INTERLEAVE_STATS,
   ST2_BE_ADAIN_LEAKY_POOL, ST2_BE_HAR_SOURCE, ST2_BE_STFT_MAG_PHASE, ST2_BE_ISTFT, ST2_BE_ATTENTION_KEYLEN,
   ST2_BE_ADD_CHANVEC, ST2_BE_MEAN_TOKENS_LEN, ST2_BE_AXPBYPCZ, ST2_BE_TIME_FEATURES, ST2_BE_TOKENS_TO_CHANNELS,
-  ST2_BE_BROADCAST_COLS, ST2_BE_COPY_NCL,
+  ST2_BE_BROADCAST_COLS, ST2_BE_COPY_NCL, ST2_BE_EXPAND_BY_DURATIONS,
+  ST2_BE_LSTM_BIDIR,  /* st2_lstm_bidir's arguments with (void* scratch, int64_t scratch_bytes) inserted before `stream` */
   ST2_BE_DEV_ALLOC,   /* void* (*)(int64_t bytes) */
   ST2_BE_DEV_FREE,    /* void (*)(void*) */
   ST2_BE_UPLOAD,      /* int (*)(void* dst, const void* src, int64_t bytes): synchronous host -> device copy */

@@ -48,6 +48,11 @@ struct Backend {
   decltype(&st2_tokens_to_channels) tokens_to_channels;
   decltype(&st2_broadcast_cols) broadcast_cols;
   decltype(&st2_copy_ncl) copy_ncl;
+  decltype(&st2_expand_by_durations) expand_by_durations;
+  // bidirectional LSTM recurrence with a scratch buffer: the HIP entry tries the cooperative kernel and falls back to
+  // the single-CU one when the device cannot hold its workgroups co-resident (same policy as ops.lstm_bidir)
+  int (*lstm_bidir)(const float*, int64_t, int32_t, const float*, const int32_t*, int32_t, int32_t, int32_t, float*, int64_t,
+                    int32_t, void*, int64_t, void*);
   void* (*dev_alloc)(int64_t);
   void (*dev_free)(void*);
   int (*upload)(void*, const void*, int64_t);
@@ -66,12 +71,25 @@ int hip_upload(void* d, const void* s, int64_t n) {
   return hipMemcpy(d, s, (size_t)n, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
 }
 
+int hip_lstm(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths, int32_t B, int32_t H,
+             int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* scratch, int64_t scratch_bytes, void* stream) {
+  static bool coop_refused = false;
+  if (scratch && scratch_bytes > 0 && !coop_refused) {
+    if (st2_lstm_bidir_coop(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream) == 0)
+      return 0;
+    const char* msg = st2_last_error();
+    if (!msg || !strstr(msg, "co-resident")) return 1;
+    coop_refused = true;  // nothing was launched: the single-CU kernel, now and from here on
+  }
+  return st2_lstm_bidir(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, stream);
+}
+
 const Backend kHipBackend = {st2_conv1d_f16s, st2_conv1d_xs, st2_act_split, st2_stats_finalize, st2_conv1d_direct,
                              st2_phase_split, st2_instnorm_stats, st2_colnorm_stats, st2_style_fc,
                              st2_convt_interleave_stats, st2_adain_leaky_pool, st2_har_source, st2_stft_mag_phase,
                              st2_istft, st2_attention_keylen, st2_add_chanvec, st2_mean_tokens_len, st2_axpbypcz,
                              st2_time_features, st2_tokens_to_channels, st2_broadcast_cols, st2_copy_ncl,
-                             hip_alloc, hip_free, hip_upload};
+                             st2_expand_by_durations, hip_lstm, hip_alloc, hip_free, hip_upload};
 Backend g_be = kHipBackend;
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -298,6 +316,22 @@ struct PDenoiser {
   std::vector<PBlock> blocks;
 };
 
+struct PLstm {  // nn.LSTM(1 layer, bidirectional): input projection as a k = 1 conv, recurrence weights transposed
+  SplitW w_ih;          // [8H][I]: forward gates then reverse gates
+  int64_t bias = -1;    // [8H] = b_ih + b_hh per direction
+  int64_t whh_t = -1;   // [2][H][4H]
+  int H = 0;
+};
+
+struct PPredictor {  // ProsodyPredictor.F0Ntrain (models.py:497-510)
+  bool ready = false;
+  int J = 0;
+  int64_t bank_wt = -1, bank_b = -1;
+  PLstm shared;
+  PAdainResBlk f0[3], n[3];
+  int64_t f0p_w = -1, f0p_b = -1, np_w = -1, np_b = -1;
+};
+
 }  // namespace
 
 struct st2_engine {
@@ -307,6 +341,7 @@ struct st2_engine {
   int64_t wbytes = 0;
   PDecoder dec;
   PDenoiser dn;
+  PPredictor pred;
   template <class T>
   T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
   const float* F(int64_t off) const { return P<const float>(off); }
@@ -1137,6 +1172,112 @@ int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* e
   return c.rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// prosody plan == the notebooks' alignment expansion + ProsodyPredictor.F0Ntrain (styletts2_amd/text.py, pipeline.py)
+// ------------------------------------------------------------------------------------------------------------------
+PLstm pack_lstm(Packer& pk, const std::string& prefix) {
+  PLstm l;
+  const HostTensor* wf = pk.get(prefix + ".weight_ih_l0");
+  const HostTensor* wr = pk.get(prefix + ".weight_ih_l0_reverse");
+  const HostTensor* hf = pk.get(prefix + ".weight_hh_l0");
+  const HostTensor* hr = pk.get(prefix + ".weight_hh_l0_reverse");
+  const HostTensor* bif = pk.get(prefix + ".bias_ih_l0");
+  const HostTensor* bhf = pk.get(prefix + ".bias_hh_l0");
+  const HostTensor* bir = pk.get(prefix + ".bias_ih_l0_reverse");
+  const HostTensor* bhr = pk.get(prefix + ".bias_hh_l0_reverse");
+  if (!wf || !wr || !hf || !hr || !bif || !bhf || !bir || !bhr) return l;
+  const int G4 = (int)wf->shape[0], I = (int)wf->shape[1], H = G4 / 4;
+  l.H = H;
+  std::vector<float> w((size_t)2 * G4 * I);  // cat([W_ih, W_ih_reverse]) as a k = 1 conv weight [8H][I][1]
+  std::copy(wf->data.begin(), wf->data.end(), w.begin());
+  std::copy(wr->data.begin(), wr->data.end(), w.begin() + (size_t)G4 * I);
+  l.w_ih = pack_split(pk.blob, w.data(), 2 * G4, I, 1);
+  std::vector<float> b((size_t)2 * G4);
+  for (int i = 0; i < G4; ++i) {
+    b[(size_t)i] = bif->data[(size_t)i] + bhf->data[(size_t)i];
+    b[(size_t)G4 + i] = bir->data[(size_t)i] + bhr->data[(size_t)i];
+  }
+  l.bias = pk.blob.add_f32(b);
+  std::vector<float> t((size_t)2 * H * G4);  // stack([W_hh.t(), W_hh_reverse.t()]): [2][H][4H]
+  for (int dir = 0; dir < 2; ++dir) {
+    const HostTensor* h = dir ? hr : hf;
+    for (int r = 0; r < G4; ++r)
+      for (int k = 0; k < H; ++k) t[((size_t)dir * H + k) * G4 + r] = h->data[(size_t)r * H + k];
+  }
+  l.whh_t = pk.blob.add_f32(t);
+  return l;
+}
+
+int pack_predictor(st2_engine& e, Blob& blob, std::string* err) {
+  const st2_model_config& cfg = e.cfg;
+  Packer pk{e, blob};
+  PPredictor p;
+  Bank bank;
+  const std::string P = "predictor.";
+  const int dh = cfg.pred_hidden;
+  if (dh <= 0) { *err = "st2_model_config.pred_hidden is not set"; return 1; }
+  p.shared = pack_lstm(pk, P + "shared");
+  // registration order of text.ProsodyPredictor._prepare: F0[0..2] then N[0..2], norm1 then norm2 each
+  const int din[3] = {dh, dh, dh / 2}, dout[3] = {dh, dh / 2, dh / 2};
+  for (int path = 0; path < 2; ++path) {
+    for (int i = 0; i < 3; ++i) {
+      const std::string pre = P + (path ? "N." : "F0.") + std::to_string(i);
+      PAdainResBlk& r = path ? p.n[i] : p.f0[i];
+      r = pack_adain_resblk(pk, pre, din[i], dout[i], i == 1);
+      r.n1 = bank.add(pk, pre + ".norm1", din[i]);
+      r.n2 = bank.add(pk, pre + ".norm2", dout[i]);
+    }
+  }
+  p.f0p_w = pk.vec(P + "F0_proj.weight"); p.f0p_b = pk.vec(P + "F0_proj.bias");
+  p.np_w = pk.vec(P + "N_proj.weight");   p.np_b = pk.vec(P + "N_proj.bias");
+  if (!pk.ok) { *err = "missing predictor parameter " + pk.missing; return 1; }
+  p.J = bank.J;
+  bank.pack(pk, cfg.style_dim, &p.bank_wt, &p.bank_b);
+  p.ready = true;
+  e.pred = p;
+  return 0;
+}
+
+// asr[B][dim_in][T] = expand(t_en), (F0, N)[B][2T] = F0Ntrain(expand(d), s); d_cm [B][pred_hidden + style_dim][N] is the
+// duration encoder's output channel-major, dur int64 [B][N] with rows summing to T
+int prosody_plan(Ctx& c, const st2_engine& e, const float* d_cm, const float* t_en, const int64_t* dur, const float* s_p,
+                 int B, int N, int T, int shift, float* asr, float* f0, float* nn) {
+  const st2_model_config& cfg = e.cfg;
+  const PPredictor& p = e.pred;
+  const int dh = cfg.pred_hidden, Cd = dh + cfg.style_dim, Ct = cfg.dim_in;
+  View en = new_ncl(c, B, Cd, T, false);
+  RUN(c, g_be.expand_by_durations(d_cm, (int64_t)Cd * N, N, dur, B, Cd, N, T, shift, en.p, en.bs, en.cs, c.stream));
+  RUN(c, g_be.expand_by_durations(t_en, (int64_t)Ct * N, N, dur, B, Ct, N, T, shift, asr, (int64_t)Ct * T, T, c.stream));
+  // shared BiLSTM: input projection of every frame as one k = 1 conv, then the recurrence
+  const int H = p.shared.H;
+  View G = new_ncl(c, B, 8 * H, T, false);
+  {
+    ConvOpt o;
+    o.bias = e.F(p.shared.bias);
+    conv(c, e, en, p.shared.w_ih, G, o);
+  }
+  View y = new_ncl(c, B, 2 * H, T, false);
+  const int64_t sb = st2_lstm_coop_scratch_bytes(B);
+  void* scratch = sb > 0 ? c.a.alloc(sb) : nullptr;
+  RUN(c, g_be.lstm_bidir(G.p, G.bs, G.cs, e.F(p.shared.whh_t), nullptr, B, H, T, y.p, y.bs, y.cs, scratch, sb, c.stream));
+  float* h = c.a.f32((int64_t)B * p.J);
+  RUN(c, g_be.style_fc(s_p, B, cfg.style_dim, e.F(p.bank_wt), e.F(p.bank_b), p.J, ST2_ACT_NONE, h, c.stream));
+  DecRun r{c, e, h, p.J};
+  for (int path = 0; path < 2; ++path) {
+    const PAdainResBlk* blks = path ? p.n : p.f0;
+    View t = y;
+    for (int i = 0; i < 3; ++i) {
+      View out = new_ncl(c, B, blks[i].dim_out, blks[i].upsample ? 2 * t.L : t.L, false);
+      run_adain_resblk(r, blks[i], t, out);
+      t = out;
+    }
+    float* dst = path ? nn : f0;
+    RUN(c, g_be.conv1d_direct(t.p, t.bs, t.cs, e.F(path ? p.np_w : p.f0p_w), e.F(path ? p.np_b : p.f0p_b), dst,
+                              (int64_t)t.L, t.L, B, t.C, 1, t.L, t.L, 1, 1, 0, c.stream));
+  }
+  return c.rc;
+}
+
 bool check_cfg(const st2_model_config& c) {
   return c.n_upsamples >= 1 && c.n_upsamples <= 4 && c.n_resblock_kernels >= 1 && c.n_resblock_kernels <= 4 &&
          (c.decoder_kind == 0 || c.decoder_kind == 1) && c.dim_in > 0 && c.style_dim > 0 && c.dn_layers >= 0;
@@ -1166,6 +1307,7 @@ extern "C" int st2_debug_set_backend(void* const* table, int32_t entries) {
   SLOT(mean_tokens_len, ST2_BE_MEAN_TOKENS_LEN); SLOT(axpbypcz, ST2_BE_AXPBYPCZ);
   SLOT(time_features, ST2_BE_TIME_FEATURES); SLOT(tokens_to_channels, ST2_BE_TOKENS_TO_CHANNELS);
   SLOT(broadcast_cols, ST2_BE_BROADCAST_COLS); SLOT(copy_ncl, ST2_BE_COPY_NCL);
+  SLOT(expand_by_durations, ST2_BE_EXPAND_BY_DURATIONS); SLOT(lstm_bidir, ST2_BE_LSTM_BIDIR);
   SLOT(dev_alloc, ST2_BE_DEV_ALLOC); SLOT(dev_free, ST2_BE_DEV_FREE); SLOT(upload, ST2_BE_UPLOAD);
 #undef SLOT
   return 0;
@@ -1203,13 +1345,15 @@ extern "C" int st2_load_weights(st2_engine* e, const char* name, const float* da
 }
 
 extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
-  ST2_REQUIRE(e && (which & 3) != 0, "st2_finalize_weights: bad arguments");
+  ST2_REQUIRE(e && (which & 7) != 0, "st2_finalize_weights: bad arguments");
   Blob blob;
   std::string err;
   if (which & 1) ST2_REQUIRE(pack_decoder(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   else e->dec.ready = false;
   if (which & 2) ST2_REQUIRE(pack_denoiser(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   else e->dn.ready = false;
+  if (which & 4) ST2_REQUIRE(pack_predictor(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+  else e->pred.ready = false;
   if (e->wbase) {
     g_be.dev_free(e->wbase);
     e->wbase = nullptr;
@@ -1250,6 +1394,33 @@ extern "C" int st2_decoder_forward(st2_engine* e, const float* asr, const float*
   const int rc = decoder_plan(c, *e, asr, f0, n, s, sine_noise, har_inject, B, T, wave, taps);
   ST2_REQUIRE(!c.a.overflow, "st2_decoder_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_decoder_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
+}
+
+extern "C" int64_t st2_prosody_workspace_bytes(st2_engine* e, int32_t B, int32_t N, int32_t T) {
+  if (!e || !e->pred.ready || B <= 0 || N <= 0 || T <= 0) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  prosody_plan(c, *e, nullptr, nullptr, nullptr, nullptr, B, N, T, 0, nullptr, nullptr, nullptr);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_prosody_forward(st2_engine* e, const float* d_cm, const float* t_en, const int64_t* durations,
+                                   const float* s, int32_t B, int32_t N, int32_t T, int32_t shift, float* asr, float* f0,
+                                   float* n, void* workspace, int64_t workspace_bytes, void* stream) {
+  ST2_REQUIRE(e && e->pred.ready, "st2_prosody_forward: predictor weights not finalized");
+  ST2_REQUIRE(d_cm && t_en && durations && s && asr && f0 && n && workspace && B > 0 && N > 0 && T > 0,
+              "st2_prosody_forward: bad arguments");
+  ST2_REQUIRE(N <= 512, "st2_prosody_forward: N=%d tokens exceed the 512 of PL-BERT's position table", N);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_prosody_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = prosody_plan(c, *e, d_cm, t_en, durations, s, B, N, T, shift, asr, f0, n);
+  ST2_REQUIRE(!c.a.overflow, "st2_prosody_forward: workspace of %lld B is too small (need %lld B, see "
+              "st2_prosody_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
   return rc;
 }
 

@@ -1,5 +1,5 @@
 """Python binding of the module-level C ABI (include/st2.h: st2_create / st2_load_weights / st2_finalize_weights /
-st2_decoder_forward / st2_sampler_run).
+st2_decoder_forward / st2_sampler_run / st2_prosody_forward).
 
 The launch plans of `Decoder.forward` (Modules/istftnet.py:499-528, Modules/hifigan.py:446-475) and
 `DiffusionSampler.forward` (Modules/diffusion/sampler.py:573-586) live in C++ (csrc/st2_engine.hip); a module forward is
@@ -134,6 +134,30 @@ class Engine:
                 taps["har"] = (bufs["har_source"] if har is None else har.reshape(B, L)).unsqueeze(1)
         return wave
 
+    # -- prosody (alignment expansion + F0Ntrain) --------------------------------------------------------------------
+    def prosody_forward(self, d_cm, t_en, durations, s, T, shift=False):
+        """d_cm [B, d_hid + sty, N], t_en [B, dim_in, N], durations int64 [B, N] (rows summing to T), s [B, sty] ->
+        (asr [B, dim_in, T], F0 [B, 2T], N [B, 2T]): one `st2_prosody_forward` call."""
+        B, Cd, N = d_cm.shape
+        dev = d_cm.device
+        d_cm, t_en, s = (t.float().contiguous() for t in (d_cm, t_en, s))
+        durations = durations.long().contiguous()
+        assert t_en.shape == (B, self.cfg.dim_in, N) and durations.shape == (B, N)
+        assert Cd == self.cfg.pred_hidden + self.cfg.style_dim and s.shape == (B, self.cfg.style_dim)
+        asr = torch.empty((B, self.cfg.dim_in, T), device=dev, dtype=torch.float32)
+        f0 = torch.empty((B, 2 * T), device=dev, dtype=torch.float32)
+        nn_ = torch.empty((B, 2 * T), device=dev, dtype=torch.float32)
+        nbytes = self.lib.st2_prosody_workspace_bytes(self.h, B, N, T)
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_prosody_workspace_bytes failed (predictor weights not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_prosody_forward(self.h, d_cm.data_ptr(), t_en.data_ptr(), durations.data_ptr(), s.data_ptr(),
+                                                B, N, T, 1 if shift else 0, asr.data_ptr(), f0.data_ptr(), nn_.data_ptr(),
+                                                ws_ptr, nbytes, stream), "st2_prosody_forward")
+        return asr, f0, nn_
+
     # -- sampler ---------------------------------------------------------------------------------------------------
     def sampler_run(self, noise, embedding, features, step_noise, lengths, steps, scale, table, sigma0, taps=None):
         B = noise.shape[0]
@@ -164,6 +188,27 @@ class Engine:
             for i in range(steps - 1):
                 taps["step%d" % i] = st[i]
         return out
+
+
+def predictor_config(pred, dim_in):
+    """st2_model_config of a styletts2_amd.text.ProsodyPredictor (F0Ntrain only; decoder / denoiser fields are placeholders)."""
+    cfg = _lib.ModelConfig()
+    cfg.decoder_kind, cfg.dim_in, cfg.upsample_initial_channel = 0, dim_in, 512
+    cfg.n_upsamples, cfg.n_resblock_kernels = 1, 1
+    cfg.style_dim = pred.F0[0].norm1.fc.weight.shape[1]
+    cfg.pred_hidden = pred.shared.hidden_size * 2
+    return cfg
+
+
+def build_predictor_engine(pred, device, dim_in=512):
+    """Engine handle holding the prosody predictor's F0Ntrain weights (st2_prosody_forward)."""
+    eng = Engine(predictor_config(pred, dim_in))
+    sd = _folded_state(pred)
+    for k, v in sd.items():
+        if k.split(".")[0] in ("shared", "F0", "N", "F0_proj", "N_proj"):
+            eng.load("predictor." + k, v)
+    eng.finalize(4, device)
+    return eng
 
 
 def decoder_config(dec):

@@ -254,6 +254,19 @@ def copy_ncl(x, x_bs, x_cs, y, y_bs, y_cs, B, Cc, L, stream):
     return 0
 
 
+def expand_by_durations(x, x_bs, x_cs, dur, B, Cc, N, T, shift, y, y_bs, y_cs, stream):
+    d = _t(dur, (B, N), (N, 1), torch.int64)
+    _ncl(y, y_bs, y_cs, B, Cc, T).copy_(R.expand_by_durations(_ncl(x, x_bs, x_cs, B, Cc, N), d, T, shift=bool(shift)))
+    return 0
+
+
+def lstm_bidir(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream):
+    lens = _t(lengths, (B,), (1,), torch.int32) if lengths else None
+    R.lstm_bidir(_ncl(G, g_bs, g_cs, B, 8 * H, N), _t(whh_t, (2, H, 4 * H), (H * 4 * H, 4 * H, 1)), lens,
+                 out=_ncl(Y, y_bs, y_cs, B, 2 * H, N))
+    return 0
+
+
 def dev_alloc(nbytes):
     buf = C.create_string_buffer(int(nbytes) + 512)
     addr = (C.addressof(buf) + 255) & ~255
@@ -272,6 +285,9 @@ def upload(dst, src, nbytes):
 
 _MEM_TYPES = {"dev_alloc": C.CFUNCTYPE(C.c_void_p, C.c_int64), "dev_free": C.CFUNCTYPE(None, C.c_void_p),
               "upload": C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)}
+_p, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
+# slots whose signature is not that of the C-ABI entry point of the same name
+_SPECIAL_TYPES = {"lstm_bidir": C.CFUNCTYPE(C.c_int, _p, _i64, _i32, _p, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p)}
 
 
 def _guard(fn):
@@ -294,6 +310,8 @@ def install():
     for i, name in enumerate(_lib.BACKEND_SLOTS):
         if name in _MEM_TYPES:
             cb = _MEM_TYPES[name](globals()[name])
+        elif name in _SPECIAL_TYPES:
+            cb = _SPECIAL_TYPES[name](_guard(globals()[name]))
         else:
             res, args = _lib._SIGNATURES["st2_" + name]
             cb = C.CFUNCTYPE(res, *args)(_guard(globals()[name]))

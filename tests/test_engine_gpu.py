@@ -130,3 +130,31 @@ def test_decoder_forward_is_graph_capturable(tag):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref1)
+
+
+@pytest.mark.parametrize("B,N,shift", [(2, 23, False), (3, 40, True)])
+def test_prosody_engine_equals_python_plan_bitwise(B, N, shift):
+    """st2_prosody_forward (C++ plan: alignment expansion + ProsodyPredictor.F0Ntrain) against the per-kernel Python
+    plan (pipeline.expand_by_durations + predictor.F0Ntrain): same kernels, same arguments -> bitwise equal."""
+    from styletts2_amd import pipeline
+    from styletts2_amd.text import ProsodyPredictor
+    pred = ProsodyPredictor(style_dim=128, d_hid=512, nlayers=3, max_dur=50).eval()
+    synth.init_synthetic_(pred, 7)
+    pred = pred.to(DEV)
+    g = torch.Generator().manual_seed(B * 100 + N)
+    d_cm = torch.randn(B, 640, N, generator=g).to(DEV)
+    t_en = torch.randn(B, 512, N, generator=g).to(DEV)
+    s = torch.randn(B, 128, generator=g).to(DEV)
+    dur = torch.randint(1, 9, (B, N), generator=g)
+    T = int(dur.sum(dim=1).max())
+    for b in range(B):
+        dur[b, -1] += T - int(dur[b].sum())
+    dur = dur.to(DEV)
+    en = pipeline.expand_by_durations(d_cm, dur, T, shift=shift)
+    asr_p = pipeline.expand_by_durations(t_en, dur, T, shift=shift)
+    f0_p, n_p = pred.F0Ntrain(en, s)
+    eng = engine.build_predictor_engine(pred, torch.device(DEV))
+    asr_e, f0_e, n_e = eng.prosody_forward(d_cm, t_en, dur, s, T, shift=shift)
+    torch.cuda.synchronize()
+    assert torch.equal(asr_e, asr_p)
+    assert torch.equal(f0_e, f0_p) and torch.equal(n_e, n_p)

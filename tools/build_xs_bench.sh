@@ -3,7 +3,7 @@
 set -eu
 cd "$(dirname "$0")/.."
 mkdir -p tools/bin
-MASKS=${*:-0 1 2 4 8 15}
+MASKS=${*:-0 1 2 4 8 15 64}
 for m in $MASKS; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-function -Iinclude \
       -Istyletts2_amd/csrc -DST2_XS_ABLATE=$m tools/xs_bench.hip -o tools/bin/xs_bench_$m ) &
