@@ -368,6 +368,10 @@ def main():
                                       embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
                                       front_stream=front, front=lf_front)
 
+    if lf_front is not None:  # set-up, not a warm-up step: the hipGraph of the front is recorded here (one eager pass + the
+        out = step()          # capture), so that --warmup 0 does not put a capture inside the timed region
+        torch.cuda.synchronize()
+        log("front graph recorded")
     for i in range(a.warmup):
         out = step()
         torch.cuda.synchronize()
