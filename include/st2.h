@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 12
+#define ST2_ABI_VERSION 13
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -349,6 +349,10 @@ int st2_broadcast_cols(const float* x, int64_t x_bs, float* y, int64_t y_bs, int
 int st2_copy_ncl(const float* x, int64_t x_bs, int32_t x_cs, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
                  int32_t L, void* stream);
 
+/* x[b][c][l] = 0 for l >= len[b] (int32 [B] on the device): the masked_fill_ the reference applies after every block of
+ * the text-side modules (models.py:308-312, 547-556). */
+int st2_mask_tail(float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, const int32_t* len, void* stream);
+
 /* ---- duration head and alignment expansion (the notebooks' glue between predictor and decoder) ----------------- *
  * st2_duration_head: x [B][K][N] channel-major output of the duration BiLSTM, w [J][K] / bias [J] = duration_proj
  * (models.py:450-451); dur[b][n] (int64) = max(1, round(sum_j sigmoid(w_j . x[b,:,n] + bias_j))), 0 for n >= len[b]
@@ -492,6 +496,19 @@ int st2_prosody_forward(st2_engine* e, const float* d_cm, const float* t_en, con
                         int32_t B, int32_t N, int32_t T, int32_t shift, float* asr, float* f0, float* n, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
+/* DurationEncoder.forward + the duration head (models.py:536-569, 450-451; Demo/Inference_LJSpeech.ipynb:294-301): from
+ * d_en [B][pred_hidden][N] (bert_encoder's output, channel-major) and the prosodic style s [B][style_dim] to
+ *   d_cm [B][pred_hidden + style_dim][N]  the duration encoder's output (channel-major; st2_prosody_forward's input),
+ *   durations int64 [B][N] (may be NULL)  max(1, round(sum sigmoid(duration_proj(lstm(d))))), 0 at pad tokens, + `tail`
+ *                                         frames on every utterance's last token (5 in the LJSpeech notebook).
+ * `lengths` (int32 [B] on the device, or NULL) = token counts of a right-padded batch (packed-sequence BiLSTMs, masked
+ * LayerNorm outputs).  Weights: "predictor.text_encoder.*", "predictor.lstm.*", "predictor.duration_proj.linear_layer.*"
+ * (st2_finalize_weights bit 2 packs them with the rest of the predictor when they were loaded). */
+int64_t st2_duration_workspace_bytes(st2_engine* e, int32_t B, int32_t N);
+int st2_duration_forward(st2_engine* e, const float* d_en, const float* s, const int32_t* lengths, int32_t B, int32_t N,
+                         int32_t tail, float* d_cm, int64_t* durations, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+
 /* ---- measurement hook (bench.py's roofline leg) ------------------------------------------------------------------- *
  * st2_conv_timing(1) clears and starts, (0) stops recording a HIP event pair around every st2_conv1d_xs launch (C_in >=
  * 64, L_out >= 256) on its launch stream, whichever plan issues it.  st2_conv_timing_read (after stopping) waits for the
@@ -512,6 +529,7 @@ enum st2_backend_slot {
   ST2_BE_ADD_CHANVEC, ST2_BE_MEAN_TOKENS_LEN, ST2_BE_AXPBYPCZ, ST2_BE_TIME_FEATURES, ST2_BE_TOKENS_TO_CHANNELS,
   ST2_BE_BROADCAST_COLS, ST2_BE_COPY_NCL, ST2_BE_EXPAND_BY_DURATIONS,
   ST2_BE_LSTM_BIDIR,  /* st2_lstm_bidir's arguments with (void* scratch, int64_t scratch_bytes) inserted before `stream` */
+  ST2_BE_COLNORM_APPLY, ST2_BE_DURATION_HEAD, ST2_BE_MASK_TAIL,
   ST2_BE_DEV_ALLOC,   /* void* (*)(int64_t bytes) */
   ST2_BE_DEV_FREE,    /* void (*)(void*) */
   ST2_BE_UPLOAD,      /* int (*)(void* dst, const void* src, int64_t bytes): synchronous host -> device copy */

@@ -53,6 +53,9 @@ struct Backend {
   // the single-CU one when the device cannot hold its workgroups co-resident (same policy as ops.lstm_bidir)
   int (*lstm_bidir)(const float*, int64_t, int32_t, const float*, const int32_t*, int32_t, int32_t, int32_t, float*, int64_t,
                     int32_t, void*, int64_t, void*);
+  decltype(&st2_colnorm_apply) colnorm_apply;
+  decltype(&st2_duration_head) duration_head;
+  decltype(&st2_mask_tail) mask_tail;
   void* (*dev_alloc)(int64_t);
   void (*dev_free)(void*);
   int (*upload)(void*, const void*, int64_t);
@@ -89,7 +92,8 @@ const Backend kHipBackend = {st2_conv1d_f16s, st2_conv1d_xs, st2_act_split, st2_
                              st2_convt_interleave_stats, st2_adain_leaky_pool, st2_har_source, st2_stft_mag_phase,
                              st2_istft, st2_attention_keylen, st2_add_chanvec, st2_mean_tokens_len, st2_axpbypcz,
                              st2_time_features, st2_tokens_to_channels, st2_broadcast_cols, st2_copy_ncl,
-                             st2_expand_by_durations, hip_lstm, hip_alloc, hip_free, hip_upload};
+                             st2_expand_by_durations, hip_lstm, st2_colnorm_apply, st2_duration_head, st2_mask_tail,
+                             hip_alloc, hip_free, hip_upload};
 Backend g_be = kHipBackend;
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -323,6 +327,15 @@ struct PLstm {  // nn.LSTM(1 layer, bidirectional): input projection as a k = 1 
   int H = 0;
 };
 
+struct PDuration {  // DurationEncoder (models.py:517-569) + duration LSTM + duration_proj (models.py:450-451)
+  bool ready = false;
+  std::vector<PLstm> lstms;             // nlayers
+  std::vector<int64_t> ada_wt, ada_b;   // AdaLayerNorm fc per layer: [style][2C] (st2_style_fc layout), [2C]
+  PLstm dur_lstm;
+  int64_t proj_w = -1, proj_b = -1;     // duration_proj.linear_layer: [max_dur][d_hid], [max_dur]
+  int max_dur = 0;
+};
+
 struct PPredictor {  // ProsodyPredictor.F0Ntrain (models.py:497-510)
   bool ready = false;
   int J = 0;
@@ -342,6 +355,7 @@ struct st2_engine {
   PDecoder dec;
   PDenoiser dn;
   PPredictor pred;
+  PDuration dur;
   template <class T>
   T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
   const float* F(int64_t off) const { return P<const float>(off); }
@@ -1278,6 +1292,79 @@ int prosody_plan(Ctx& c, const st2_engine& e, const float* d_cm, const float* t_
   return c.rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// duration plan == DurationEncoder.forward + pipeline.predict_durations (styletts2_amd/text.py, pipeline.py)
+// ------------------------------------------------------------------------------------------------------------------
+int pack_duration(st2_engine& e, Blob& blob, std::string* err) {
+  Packer pk{e, blob};
+  PDuration d;
+  const std::string T = "predictor.text_encoder.lstms.";
+  for (int i = 0; pk.has(T + std::to_string(2 * i) + ".weight_ih_l0"); ++i) {
+    d.lstms.push_back(pack_lstm(pk, T + std::to_string(2 * i)));
+    d.ada_wt.push_back(pk.lin_t(T + std::to_string(2 * i + 1) + ".fc.weight"));
+    d.ada_b.push_back(pk.vec(T + std::to_string(2 * i + 1) + ".fc.bias"));
+  }
+  if (d.lstms.empty()) { *err = "missing predictor parameter predictor.text_encoder.lstms.0.weight_ih_l0"; return 1; }
+  d.dur_lstm = pack_lstm(pk, "predictor.lstm");
+  const HostTensor* pw = pk.get("predictor.duration_proj.linear_layer.weight");
+  d.proj_w = pk.vec("predictor.duration_proj.linear_layer.weight");
+  d.proj_b = pk.vec("predictor.duration_proj.linear_layer.bias");
+  if (!pk.ok || !pw) { *err = "missing predictor parameter " + pk.missing; return 1; }
+  d.max_dur = (int)pw->shape[0];
+  d.ready = true;
+  e.dur = d;
+  return 0;
+}
+
+View lstm_run(Ctx& c, const st2_engine& e, const PLstm& l, const View& x, const int32_t* lens) {
+  View G = new_ncl(c, x.B, 8 * l.H, x.L, false);
+  ConvOpt o;
+  o.bias = e.F(l.bias);
+  conv(c, e, x, l.w_ih, G, o);
+  View y = new_ncl(c, x.B, 2 * l.H, x.L, false);
+  const int64_t sb = st2_lstm_coop_scratch_bytes(x.B);
+  void* scratch = sb > 0 ? c.a.alloc(sb) : nullptr;
+  RUN(c, g_be.lstm_bidir(G.p, G.bs, G.cs, e.F(l.whh_t), lens, x.B, l.H, x.L, y.p, y.bs, y.cs, scratch, sb, c.stream));
+  return y;
+}
+
+int duration_plan(Ctx& c, const st2_engine& e, const float* d_en, const float* s_p, const int32_t* lens, int B, int N,
+                  int tail, float* d_cm, int64_t* durations) {
+  const st2_model_config& cfg = e.cfg;
+  const PDuration& d = e.dur;
+  const int dh = cfg.pred_hidden, sty = cfg.style_dim, Cd = dh + sty;
+  const int nl = (int)d.lstms.size();
+  View h = new_ncl(c, B, Cd, N, false);
+  {  // [x | style broadcast over the tokens], pad positions zeroed
+    View src = wrap(d_en, B, dh, N), dst = h.rows(0, dh), st = h.rows(dh, Cd);
+    RUN(c, g_be.copy_ncl(src.p, src.bs, src.cs, dst.p, dst.bs, dst.cs, B, dh, N, c.stream));
+    RUN(c, g_be.broadcast_cols(s_p, sty, st.p, st.bs, st.cs, B, sty, N, c.stream));
+    if (lens) RUN(c, g_be.mask_tail(h.p, h.bs, h.cs, B, Cd, N, lens, c.stream));
+  }
+  for (int i = 0; i < nl; ++i) {
+    View y = lstm_run(c, e, d.lstms[(size_t)i], h, lens);  // [B][dh][N]
+    // AdaLayerNorm (models.py:418-438): (1 + gamma) * LayerNorm_c(y) + beta, gamma | beta = fc(style)
+    float* gb = c.a.f32((int64_t)B * 2 * dh);
+    RUN(c, g_be.style_fc(s_p, B, sty, e.F(d.ada_wt[(size_t)i]), e.F(d.ada_b[(size_t)i]), 2 * dh, ST2_ACT_NONE, gb, c.stream));
+    float* st = c.a.f32((int64_t)B * N * 2);
+    RUN(c, g_be.colnorm_stats(y.p, y.bs, y.cs, B, dh, N, 1e-5f, st, c.stream));
+    const bool last = i + 1 == nl;
+    View nh = last ? wrap(d_cm, B, Cd, N) : new_ncl(c, B, Cd, N, false);
+    View top = nh.rows(0, dh), bot = nh.rows(dh, Cd);
+    RUN(c, g_be.colnorm_apply(y.p, y.bs, y.cs, st, gb, gb + dh, 2 * dh, 1, ST2_ACT_NONE, 0.f, lens, top.p, top.bs, top.cs, B,
+                              dh, N, c.stream));
+    RUN(c, g_be.broadcast_cols(s_p, sty, bot.p, bot.bs, bot.cs, B, sty, N, c.stream));
+    if (lens) RUN(c, g_be.mask_tail(bot.p, bot.bs, bot.cs, B, sty, N, lens, c.stream));
+    h = nh;
+  }
+  if (durations) {
+    View x = lstm_run(c, e, d.dur_lstm, h, lens);
+    RUN(c, g_be.duration_head(x.p, x.bs, x.cs, e.F(d.proj_w), e.F(d.proj_b), B, dh, d.max_dur, N, lens, tail, durations,
+                              nullptr, c.stream));
+  }
+  return c.rc;
+}
+
 bool check_cfg(const st2_model_config& c) {
   return c.n_upsamples >= 1 && c.n_upsamples <= 4 && c.n_resblock_kernels >= 1 && c.n_resblock_kernels <= 4 &&
          (c.decoder_kind == 0 || c.decoder_kind == 1) && c.dim_in > 0 && c.style_dim > 0 && c.dn_layers >= 0;
@@ -1308,6 +1395,7 @@ extern "C" int st2_debug_set_backend(void* const* table, int32_t entries) {
   SLOT(time_features, ST2_BE_TIME_FEATURES); SLOT(tokens_to_channels, ST2_BE_TOKENS_TO_CHANNELS);
   SLOT(broadcast_cols, ST2_BE_BROADCAST_COLS); SLOT(copy_ncl, ST2_BE_COPY_NCL);
   SLOT(expand_by_durations, ST2_BE_EXPAND_BY_DURATIONS); SLOT(lstm_bidir, ST2_BE_LSTM_BIDIR);
+  SLOT(colnorm_apply, ST2_BE_COLNORM_APPLY); SLOT(duration_head, ST2_BE_DURATION_HEAD); SLOT(mask_tail, ST2_BE_MASK_TAIL);
   SLOT(dev_alloc, ST2_BE_DEV_ALLOC); SLOT(dev_free, ST2_BE_DEV_FREE); SLOT(upload, ST2_BE_UPLOAD);
 #undef SLOT
   return 0;
@@ -1354,6 +1442,9 @@ extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
   else e->dn.ready = false;
   if (which & 4) ST2_REQUIRE(pack_predictor(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   else e->pred.ready = false;
+  e->dur.ready = false;
+  if ((which & 4) && e->host.count("predictor.text_encoder.lstms.0.weight_ih_l0"))
+    ST2_REQUIRE(pack_duration(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   if (e->wbase) {
     g_be.dev_free(e->wbase);
     e->wbase = nullptr;
@@ -1394,6 +1485,33 @@ extern "C" int st2_decoder_forward(st2_engine* e, const float* asr, const float*
   const int rc = decoder_plan(c, *e, asr, f0, n, s, sine_noise, har_inject, B, T, wave, taps);
   ST2_REQUIRE(!c.a.overflow, "st2_decoder_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_decoder_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
+}
+
+extern "C" int64_t st2_duration_workspace_bytes(st2_engine* e, int32_t B, int32_t N) {
+  if (!e || !e->dur.ready || B <= 0 || N <= 0) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  static int64_t dummy_dur;
+  duration_plan(c, *e, nullptr, nullptr, nullptr, B, N, 0, nullptr, &dummy_dur);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_duration_forward(st2_engine* e, const float* d_en, const float* s, const int32_t* lengths, int32_t B,
+                                    int32_t N, int32_t tail, float* d_cm, int64_t* durations, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  ST2_REQUIRE(e && e->dur.ready, "st2_duration_forward: duration-encoder weights not finalized");
+  ST2_REQUIRE(d_en && s && d_cm && workspace && B > 0 && N > 0 && tail >= 0, "st2_duration_forward: bad arguments");
+  ST2_REQUIRE(N <= 512, "st2_duration_forward: N=%d tokens exceed the 512 of PL-BERT's position table", N);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_duration_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = duration_plan(c, *e, d_en, s, lengths, B, N, tail, d_cm, durations);
+  ST2_REQUIRE(!c.a.overflow, "st2_duration_forward: workspace of %lld B is too small (need %lld B, see "
+              "st2_duration_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
   return rc;
 }
 

@@ -143,7 +143,27 @@ __global__ __launch_bounds__(256) void expand_by_durations_kernel(const float* _
   for (int c = blockIdx.z * 64; c < c_hi; ++c) yb[(int64_t)c * y_cs] = xb[(int64_t)c * x_cs];
 }
 
+// x[b][c][l] = 0 for l >= len[b]  (the masked_fill_ of the text-side modules, models.py:308-312, 547-556)
+__global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ x, int64_t x_bs, int x_cs, int L,
+                                                        const int* __restrict__ len) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int b = blockIdx.z;
+  if (l >= L || l < len[b]) return;
+  x[(int64_t)b * x_bs + (int64_t)c * x_cs + l] = 0.f;
+}
+
 }  // namespace
+
+extern "C" int st2_mask_tail(float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, const int32_t* len,
+                             void* stream) {
+  ST2_REQUIRE(x && len && B > 0 && C > 0 && L > 0, "st2_mask_tail: bad arguments");
+  ST2_REQUIRE(B <= 65535 && C <= 65535, "st2_mask_tail: grid too large");
+  hipLaunchKernelGGL(mask_tail_kernel, dim3(st2_cdiv(L, 256), C, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     x_bs, x_cs, L, len);
+  ST2_CHECK_LAUNCH("st2_mask_tail");
+  return 0;
+}
 
 extern "C" int st2_time_features(float t, const float* w, int32_t H2, int32_t B, float* out, void* stream) {
   ST2_REQUIRE(w && out && H2 > 0 && B > 0, "st2_time_features: bad arguments");

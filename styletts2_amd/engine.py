@@ -158,6 +158,31 @@ class Engine:
                                                 ws_ptr, nbytes, stream), "st2_prosody_forward")
         return asr, f0, nn_
 
+    # -- duration stage (DurationEncoder + duration LSTM + head) -------------------------------------------------------
+    def duration_forward(self, d_en, s, lengths=None, tail=0, want_durations=True):
+        """d_en [B, d_hid, N] (bert_encoder output, channel-major), s [B, sty], lengths int32 [B] on the device or None ->
+        (d_cm [B, d_hid + sty, N], durations int64 [B, N] or None): one `st2_duration_forward` call."""
+        B, dh, N = d_en.shape
+        dev = d_en.device
+        d_en, s = d_en.float().contiguous(), s.float().contiguous()
+        assert dh == self.cfg.pred_hidden and s.shape == (B, self.cfg.style_dim)
+        if lengths is not None:
+            lengths = lengths.to(torch.int32).contiguous()
+            assert lengths.device == dev and lengths.numel() == B
+        d_cm = torch.empty((B, dh + self.cfg.style_dim, N), device=dev, dtype=torch.float32)
+        dur = torch.empty((B, N), device=dev, dtype=torch.int64) if want_durations else None
+        nbytes = self.lib.st2_duration_workspace_bytes(self.h, B, N)
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_duration_workspace_bytes failed (duration-encoder weights not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_duration_forward(self.h, d_en.data_ptr(), s.data_ptr(),
+                                                 0 if lengths is None else lengths.data_ptr(), B, N, int(tail),
+                                                 d_cm.data_ptr(), 0 if dur is None else dur.data_ptr(), ws_ptr, nbytes,
+                                                 stream), "st2_duration_forward")
+        return d_cm, dur
+
     # -- sampler ---------------------------------------------------------------------------------------------------
     def sampler_run(self, noise, embedding, features, step_noise, lengths, steps, scale, table, sigma0, taps=None):
         B = noise.shape[0]
@@ -201,11 +226,12 @@ def predictor_config(pred, dim_in):
 
 
 def build_predictor_engine(pred, device, dim_in=512):
-    """Engine handle holding the prosody predictor's F0Ntrain weights (st2_prosody_forward)."""
+    """Engine handle holding the whole prosody predictor: duration encoder + duration head (st2_duration_forward) and
+    F0Ntrain (st2_prosody_forward)."""
     eng = Engine(predictor_config(pred, dim_in))
     sd = _folded_state(pred)
     for k, v in sd.items():
-        if k.split(".")[0] in ("shared", "F0", "N", "F0_proj", "N_proj"):
+        if k.split(".")[0] in ("shared", "F0", "N", "F0_proj", "N_proj", "text_encoder", "lstm", "duration_proj"):
             eng.load("predictor." + k, v)
     eng.finalize(4, device)
     return eng

@@ -267,6 +267,32 @@ def lstm_bidir(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, s
     return 0
 
 
+def colnorm_apply(x, x_bs, x_cs, stats, gamma, beta, gb_bs, gamma_plus_one, act, slope, length, y, y_bs, y_cs, B, Cc, L,
+                  stream):
+    lens = _t(length, (B,), (1,), torch.int32) if length else None
+    R.colnorm_apply(_ncl(x, x_bs, x_cs, B, Cc, L), _t(stats, (B, L, 2), (L * 2, 2, 1)), _gb(gamma, gb_bs, B, Cc),
+                    _gb(beta, gb_bs, B, Cc), gamma_plus_one=bool(gamma_plus_one), act=act, slope=slope, lengths=lens,
+                    out=_ncl(y, y_bs, y_cs, B, Cc, L))
+    return 0
+
+
+def duration_head(x, x_bs, x_cs, w, bias, B, K, J, N, length, tail, dur, dsum, stream):
+    lens = _t(length, (B,), (1,), torch.int32) if length else None
+    d, sums = R.duration_head(_ncl(x, x_bs, x_cs, B, K, N), _t(w, (J, K), (K, 1)), _t(bias, (J,), (1,)), lengths=lens,
+                              tail=tail, want_sums=True)
+    _t(dur, (B, N), (N, 1), torch.int64).copy_(d)
+    if dsum:
+        _t(dsum, (B, N), (N, 1)).copy_(sums)
+    return 0
+
+
+def mask_tail(x, x_bs, x_cs, B, Cc, L, length, stream):
+    lens = _t(length, (B,), (1,), torch.int32)
+    xv = _ncl(x, x_bs, x_cs, B, Cc, L)
+    xv.masked_fill_(torch.arange(L).view(1, 1, L) >= lens.view(-1, 1, 1), 0.0)
+    return 0
+
+
 def dev_alloc(nbytes):
     buf = C.create_string_buffer(int(nbytes) + 512)
     addr = (C.addressof(buf) + 255) & ~255
