@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 13
+#define ST2_ABI_VERSION 14
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -349,6 +349,10 @@ int st2_broadcast_cols(const float* x, int64_t x_bs, float* y, int64_t y_bs, int
 int st2_copy_ncl(const float* x, int64_t x_bs, int32_t x_cs, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
                  int32_t L, void* stream);
 
+/* y[b][e][n] = n < len[b] ? table[tokens[b][n]][e] : 0  (tokens int64 [B][N], table [V][E]; len int32 [B] or NULL; token
+ * ids outside [0, V) give 0): nn.Embedding + transpose + masked_fill of TextEncoder.forward (models.py:302-306). */
+int st2_embed_tokens(const int64_t* tokens, int32_t B, int32_t N, const float* table, int32_t V, int32_t E,
+                     const int32_t* len, float* y, int64_t y_bs, int32_t y_cs, void* stream);
 /* x[b][c][l] = 0 for l >= len[b] (int32 [B] on the device): the masked_fill_ the reference applies after every block of
  * the text-side modules (models.py:308-312, 547-556). */
 int st2_mask_tail(float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, const int32_t* len, void* stream);
@@ -441,7 +445,7 @@ int st2_destroy(st2_engine* e);
 int st2_load_weights(st2_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 /* Packs everything loaded so far (split-f16 conv layouts, polyphase ConvTranspose / strided-conv forms, concatenated
  * AdaIN fc matrix) and uploads it in one device allocation.  which: bit 0 = decoder, bit 1 = denoiser, bit 2 = prosody
- * predictor (names prefixed "predictor.": shared.*, F0.*, N.*, F0_proj.*, N_proj.*).
+ * predictor (names prefixed "predictor."), bit 3 = text encoder ("text_encoder.").
  * Synchronous; call once after the last st2_load_weights (again after loading new weights). */
 int st2_finalize_weights(st2_engine* e, int32_t which);
 
@@ -496,6 +500,13 @@ int st2_prosody_forward(st2_engine* e, const float* d_cm, const float* t_en, con
                         int32_t B, int32_t N, int32_t T, int32_t shift, float* asr, float* f0, float* n, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
+/* TextEncoder.forward (models.py:284-345): tokens int64 [B][N] (id 0 = pad), lengths int32 [B] or NULL ->
+ * t_en [B][dim_in][N]: Embedding -> depth x [weight-norm Conv1d k5 -> LayerNorm over channels -> LeakyReLU(0.2) -> mask] ->
+ * BiLSTM.  Weights: "text_encoder.*" with the weight-norm pairs folded (st2_finalize_weights bit 3). */
+int64_t st2_text_workspace_bytes(st2_engine* e, int32_t B, int32_t N);
+int st2_text_forward(st2_engine* e, const int64_t* tokens, const int32_t* lengths, int32_t B, int32_t N, float* t_en,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
 /* DurationEncoder.forward + the duration head (models.py:536-569, 450-451; Demo/Inference_LJSpeech.ipynb:294-301): from
  * d_en [B][pred_hidden][N] (bert_encoder's output, channel-major) and the prosodic style s [B][style_dim] to
  *   d_cm [B][pred_hidden + style_dim][N]  the duration encoder's output (channel-major; st2_prosody_forward's input),
@@ -529,7 +540,7 @@ enum st2_backend_slot {
   ST2_BE_ADD_CHANVEC, ST2_BE_MEAN_TOKENS_LEN, ST2_BE_AXPBYPCZ, ST2_BE_TIME_FEATURES, ST2_BE_TOKENS_TO_CHANNELS,
   ST2_BE_BROADCAST_COLS, ST2_BE_COPY_NCL, ST2_BE_EXPAND_BY_DURATIONS,
   ST2_BE_LSTM_BIDIR,  /* st2_lstm_bidir's arguments with (void* scratch, int64_t scratch_bytes) inserted before `stream` */
-  ST2_BE_COLNORM_APPLY, ST2_BE_DURATION_HEAD, ST2_BE_MASK_TAIL,
+  ST2_BE_COLNORM_APPLY, ST2_BE_DURATION_HEAD, ST2_BE_MASK_TAIL, ST2_BE_EMBED_TOKENS,
   ST2_BE_DEV_ALLOC,   /* void* (*)(int64_t bytes) */
   ST2_BE_DEV_FREE,    /* void (*)(void*) */
   ST2_BE_UPLOAD,      /* int (*)(void* dst, const void* src, int64_t bytes): synchronous host -> device copy */

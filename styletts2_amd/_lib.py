@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -79,7 +79,7 @@ BACKEND_SLOTS = ["conv1d_f16s", "conv1d_xs", "act_split", "stats_finalize", "con
                  "instnorm_stats", "colnorm_stats", "style_fc", "convt_interleave_stats", "adain_leaky_pool",
                  "har_source", "stft_mag_phase", "istft", "attention_keylen", "add_chanvec", "mean_tokens_len",
                  "axpbypcz", "time_features", "tokens_to_channels", "broadcast_cols", "copy_ncl", "expand_by_durations",
-                 "lstm_bidir", "colnorm_apply", "duration_head", "mask_tail", "dev_alloc", "dev_free",
+                 "lstm_bidir", "colnorm_apply", "duration_head", "mask_tail", "embed_tokens", "dev_alloc", "dev_free",
                  "upload"]  # enum st2_backend_slot
 
 _SIGNATURES = {
@@ -162,6 +162,11 @@ _SIGNATURES = {
     "st2_decoder_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "st2_decoder_forward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_int32, f32p,
                                       C.c_void_p, C.c_int64, C.POINTER(DecoderTaps), C.c_void_p]),
+    "st2_embed_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_int32, C.c_int32, C.c_void_p, f32p, C.c_int64,
+                                   C.c_int32, C.c_void_p]),
+    "st2_text_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "st2_text_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p, C.c_int64,
+                                   C.c_void_p]),
     "st2_mask_tail": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "st2_duration_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "st2_duration_forward": (C.c_int, [C.c_void_p, f32p, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, f32p,

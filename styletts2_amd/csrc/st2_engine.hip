@@ -56,6 +56,7 @@ struct Backend {
   decltype(&st2_colnorm_apply) colnorm_apply;
   decltype(&st2_duration_head) duration_head;
   decltype(&st2_mask_tail) mask_tail;
+  decltype(&st2_embed_tokens) embed_tokens;
   void* (*dev_alloc)(int64_t);
   void (*dev_free)(void*);
   int (*upload)(void*, const void*, int64_t);
@@ -93,7 +94,7 @@ const Backend kHipBackend = {st2_conv1d_f16s, st2_conv1d_xs, st2_act_split, st2_
                              st2_istft, st2_attention_keylen, st2_add_chanvec, st2_mean_tokens_len, st2_axpbypcz,
                              st2_time_features, st2_tokens_to_channels, st2_broadcast_cols, st2_copy_ncl,
                              st2_expand_by_durations, hip_lstm, st2_colnorm_apply, st2_duration_head, st2_mask_tail,
-                             hip_alloc, hip_free, hip_upload};
+                             st2_embed_tokens, hip_alloc, hip_free, hip_upload};
 Backend g_be = kHipBackend;
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -336,6 +337,15 @@ struct PDuration {  // DurationEncoder (models.py:517-569) + duration LSTM + dur
   int max_dur = 0;
 };
 
+struct PText {  // TextEncoder (models.py:284-345)
+  bool ready = false;
+  int64_t emb = -1;
+  int V = 0, C = 0;
+  std::vector<PConv> convs;
+  std::vector<int64_t> ln_g, ln_b;
+  PLstm lstm;
+};
+
 struct PPredictor {  // ProsodyPredictor.F0Ntrain (models.py:497-510)
   bool ready = false;
   int J = 0;
@@ -356,6 +366,7 @@ struct st2_engine {
   PDenoiser dn;
   PPredictor pred;
   PDuration dur;
+  PText text;
   template <class T>
   T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
   const float* F(int64_t off) const { return P<const float>(off); }
@@ -1365,6 +1376,55 @@ int duration_plan(Ctx& c, const st2_engine& e, const float* d_en, const float* s
   return c.rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// text-encoder plan == TextEncoder.forward (styletts2_amd/text.py)
+// ------------------------------------------------------------------------------------------------------------------
+int pack_text(st2_engine& e, Blob& blob, std::string* err) {
+  Packer pk{e, blob};
+  PText t;
+  const std::string T = "text_encoder.";
+  const HostTensor* emb = pk.get(T + "embedding.weight");
+  if (!emb || emb->shape.size() != 2) { *err = "missing text-encoder parameter text_encoder.embedding.weight"; return 1; }
+  t.V = (int)emb->shape[0];
+  t.C = (int)emb->shape[1];
+  t.emb = blob.add_f32(emb->data);
+  for (int i = 0; pk.has(T + "cnn." + std::to_string(i) + ".0.weight"); ++i) {
+    const std::string p = T + "cnn." + std::to_string(i);
+    t.convs.push_back(pk.conv(p + ".0"));
+    t.ln_g.push_back(pk.vec(p + ".1.gamma"));
+    t.ln_b.push_back(pk.vec(p + ".1.beta"));
+  }
+  t.lstm = pack_lstm(pk, T + "lstm");
+  if (!pk.ok || t.convs.empty()) { *err = "missing text-encoder parameter " + pk.missing; return 1; }
+  t.ready = true;
+  e.text = t;
+  return 0;
+}
+
+int text_plan(Ctx& c, const st2_engine& e, const int64_t* tokens, const int32_t* lens, int B, int N, float* t_en) {
+  const PText& t = e.text;
+  View h = new_ncl(c, B, t.C, N, false);
+  RUN(c, g_be.embed_tokens(tokens, B, N, e.F(t.emb), t.V, t.C, lens, h.p, h.bs, h.cs, c.stream));
+  for (size_t i = 0; i < t.convs.size(); ++i) {
+    const PConv& pc = t.convs[i];
+    View y = new_ncl(c, B, pc.c_out, N, false);
+    ConvOpt o;
+    o.pad_left = (pc.ks - 1) / 2; o.bias = e.F(pc.bias);
+    conv(c, e, h, pc.w, y, o);
+    // LayerNorm over channels + LeakyReLU(0.2) + masked_fill in one pass (models.py:270-282, 308-312)
+    float* st = c.a.f32((int64_t)B * N * 2);
+    RUN(c, g_be.colnorm_stats(y.p, y.bs, y.cs, B, pc.c_out, N, 1e-5f, st, c.stream));
+    View z = new_ncl(c, B, pc.c_out, N, false);
+    RUN(c, g_be.colnorm_apply(y.p, y.bs, y.cs, st, e.F(t.ln_g[i]), e.F(t.ln_b[i]), 0, 0, ST2_ACT_LEAKY, 0.2f, lens, z.p, z.bs,
+                              z.cs, B, pc.c_out, N, c.stream));
+    h = z;
+  }
+  View y = lstm_run(c, e, t.lstm, h, lens);  // outputs past a sequence's end are zero (packed-sequence semantics)
+  View dst = wrap(t_en, B, 2 * t.lstm.H, N);
+  RUN(c, g_be.copy_ncl(y.p, y.bs, y.cs, dst.p, dst.bs, dst.cs, B, 2 * t.lstm.H, N, c.stream));
+  return c.rc;
+}
+
 bool check_cfg(const st2_model_config& c) {
   return c.n_upsamples >= 1 && c.n_upsamples <= 4 && c.n_resblock_kernels >= 1 && c.n_resblock_kernels <= 4 &&
          (c.decoder_kind == 0 || c.decoder_kind == 1) && c.dim_in > 0 && c.style_dim > 0 && c.dn_layers >= 0;
@@ -1396,6 +1456,7 @@ extern "C" int st2_debug_set_backend(void* const* table, int32_t entries) {
   SLOT(broadcast_cols, ST2_BE_BROADCAST_COLS); SLOT(copy_ncl, ST2_BE_COPY_NCL);
   SLOT(expand_by_durations, ST2_BE_EXPAND_BY_DURATIONS); SLOT(lstm_bidir, ST2_BE_LSTM_BIDIR);
   SLOT(colnorm_apply, ST2_BE_COLNORM_APPLY); SLOT(duration_head, ST2_BE_DURATION_HEAD); SLOT(mask_tail, ST2_BE_MASK_TAIL);
+  SLOT(embed_tokens, ST2_BE_EMBED_TOKENS);
   SLOT(dev_alloc, ST2_BE_DEV_ALLOC); SLOT(dev_free, ST2_BE_DEV_FREE); SLOT(upload, ST2_BE_UPLOAD);
 #undef SLOT
   return 0;
@@ -1433,7 +1494,7 @@ extern "C" int st2_load_weights(st2_engine* e, const char* name, const float* da
 }
 
 extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
-  ST2_REQUIRE(e && (which & 7) != 0, "st2_finalize_weights: bad arguments");
+  ST2_REQUIRE(e && (which & 15) != 0, "st2_finalize_weights: bad arguments");
   Blob blob;
   std::string err;
   if (which & 1) ST2_REQUIRE(pack_decoder(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
@@ -1445,6 +1506,8 @@ extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
   e->dur.ready = false;
   if ((which & 4) && e->host.count("predictor.text_encoder.lstms.0.weight_ih_l0"))
     ST2_REQUIRE(pack_duration(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+  if (which & 8) ST2_REQUIRE(pack_text(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+  else e->text.ready = false;
   if (e->wbase) {
     g_be.dev_free(e->wbase);
     e->wbase = nullptr;
@@ -1485,6 +1548,30 @@ extern "C" int st2_decoder_forward(st2_engine* e, const float* asr, const float*
   const int rc = decoder_plan(c, *e, asr, f0, n, s, sine_noise, har_inject, B, T, wave, taps);
   ST2_REQUIRE(!c.a.overflow, "st2_decoder_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_decoder_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
+}
+
+extern "C" int64_t st2_text_workspace_bytes(st2_engine* e, int32_t B, int32_t N) {
+  if (!e || !e->text.ready || B <= 0 || N <= 0) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  text_plan(c, *e, nullptr, nullptr, B, N, nullptr);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_text_forward(st2_engine* e, const int64_t* tokens, const int32_t* lengths, int32_t B, int32_t N,
+                                float* t_en, void* workspace, int64_t workspace_bytes, void* stream) {
+  ST2_REQUIRE(e && e->text.ready, "st2_text_forward: text-encoder weights not finalized");
+  ST2_REQUIRE(tokens && t_en && workspace && B > 0 && N > 0, "st2_text_forward: bad arguments");
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_text_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = text_plan(c, *e, tokens, lengths, B, N, t_en);
+  ST2_REQUIRE(!c.a.overflow, "st2_text_forward: workspace of %lld B is too small (need %lld B, see st2_text_workspace_bytes)",
+              (long long)workspace_bytes, (long long)c.a.peak);
   return rc;
 }
 

@@ -153,7 +153,47 @@ __global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ x, i
   x[(int64_t)b * x_bs + (int64_t)c * x_cs + l] = 0.f;
 }
 
+// y[b][e][n] = n < len[b] ? table[tok[b][n]][e] : 0: nn.Embedding + transpose + masked_fill of TextEncoder.forward
+// (models.py:302-306).  32 tokens x 32 features per tile through LDS: table rows are read along e, y is written along n.
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
+                                                           int V, int E, int N, const int* __restrict__ len,
+                                                           float* __restrict__ y, int64_t y_bs, int y_cs) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, e0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int nlen = len ? len[b] : N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, e = e0 + tx;
+    float v = 0.f;
+    if (n < N && n < nlen && e < E) {
+      const long long t = tok[(int64_t)b * N + n];
+      if (t >= 0 && t < V) v = table[t * E + e];
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+  float* yb = y + (int64_t)b * y_bs;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = e0 + ty + 8 * i, n = n0 + tx;
+    if (n < N && e < E) yb[(int64_t)e * y_cs + n] = tile[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace
+
+extern "C" int st2_embed_tokens(const int64_t* tokens, int32_t B, int32_t N, const float* table, int32_t V, int32_t E,
+                                const int32_t* len, float* y, int64_t y_bs, int32_t y_cs, void* stream) {
+  ST2_REQUIRE(tokens && table && y && B > 0 && N > 0 && V > 0 && E > 0, "st2_embed_tokens: bad arguments");
+  ST2_REQUIRE(B <= 65535, "st2_embed_tokens: grid too large");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(st2_cdiv(N, 32), st2_cdiv(E, 32), B), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(tokens), table, V, E, N, len, y,
+                     y_bs, y_cs);
+  ST2_CHECK_LAUNCH("st2_embed_tokens");
+  return 0;
+}
 
 extern "C" int st2_mask_tail(float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, const int32_t* len,
                              void* stream) {

@@ -158,6 +158,26 @@ class Engine:
                                                 ws_ptr, nbytes, stream), "st2_prosody_forward")
         return asr, f0, nn_
 
+    # -- text encoder --------------------------------------------------------------------------------------------------
+    def text_forward(self, tokens, lengths=None):
+        """tokens int64 [B, N], lengths int32 [B] on the device or None -> t_en [B, dim_in, N]: one `st2_text_forward` call."""
+        B, N = tokens.shape
+        dev = tokens.device
+        tokens = tokens.long().contiguous()
+        if lengths is not None:
+            lengths = lengths.to(torch.int32).contiguous()
+            assert lengths.device == dev and lengths.numel() == B
+        t_en = torch.empty((B, self.cfg.dim_in, N), device=dev, dtype=torch.float32)
+        nbytes = self.lib.st2_text_workspace_bytes(self.h, B, N)
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_text_workspace_bytes failed (text-encoder weights not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_text_forward(self.h, tokens.data_ptr(), 0 if lengths is None else lengths.data_ptr(), B, N,
+                                             t_en.data_ptr(), ws_ptr, nbytes, stream), "st2_text_forward")
+        return t_en
+
     # -- duration stage (DurationEncoder + duration LSTM + head) -------------------------------------------------------
     def duration_forward(self, d_en, s, lengths=None, tail=0, want_durations=True):
         """d_en [B, d_hid, N] (bert_encoder output, channel-major), s [B, sty], lengths int32 [B] on the device or None ->
@@ -234,6 +254,18 @@ def build_predictor_engine(pred, device, dim_in=512):
         if k.split(".")[0] in ("shared", "F0", "N", "F0_proj", "N_proj", "text_encoder", "lstm", "duration_proj"):
             eng.load("predictor." + k, v)
     eng.finalize(4, device)
+    return eng
+
+
+def build_text_engine(text_encoder, device):
+    """Engine handle holding the text encoder (st2_text_forward)."""
+    cfg = _lib.ModelConfig()
+    cfg.decoder_kind, cfg.upsample_initial_channel, cfg.style_dim = 0, 512, 128
+    cfg.n_upsamples, cfg.n_resblock_kernels = 1, 1
+    cfg.dim_in = text_encoder.embedding.weight.shape[1]
+    eng = Engine(cfg)
+    eng.load_module("text_encoder.", text_encoder)
+    eng.finalize(8, device)
     return eng
 
 
