@@ -158,3 +158,61 @@ def test_prosody_engine_equals_python_plan_bitwise(B, N, shift):
     torch.cuda.synchronize()
     assert torch.equal(asr_e, asr_p)
     assert torch.equal(f0_e, f0_p) and torch.equal(n_e, n_p)
+
+
+def _close(a, b, rel):
+    scale = max(1.0, float(b.abs().max()))
+    return float((a - b).abs().max()) <= rel * scale
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_text_plan_engine_equals_python_plan(ragged):
+    """st2_text_forward (C++ plan) against text.TextEncoder.forward (per-kernel Python plan): the same conv / colnorm /
+    LSTM kernels with the same arguments, the embedding gather + mask in `st2_embed_tokens` instead of torch indexing."""
+    from styletts2_amd.text import TextEncoder
+    enc = TextEncoder(channels=512, kernel_size=5, depth=3, n_symbols=178).eval()
+    synth.init_synthetic_(enc, 9)
+    enc = enc.to(DEV)
+    B, N = 3, 37
+    g = torch.Generator().manual_seed(6)
+    tokens = torch.randint(1, 178, (B, N), generator=g)
+    lengths = torch.tensor([N, N - 9, N - 2]) if ragged else torch.full((B,), N)
+    mask = torch.arange(N).unsqueeze(0) >= lengths.unsqueeze(1)
+    tokens = tokens.masked_fill(mask, 0).to(DEV)
+    ref = enc(tokens, lengths, mask.to(DEV))
+    eng = engine.build_text_engine(enc, torch.device(DEV))
+    out = eng.text_forward(tokens, lengths.to(torch.int32).to(DEV) if ragged else None)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    print("text plan max |diff| = %.3e (bitwise: %s)" % (float((out - ref).abs().max()), torch.equal(out, ref)))
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("ragged,tail", [(False, 5), (True, 0)])
+def test_duration_plan_engine_matches_python_plan(ragged, tail):
+    """st2_duration_forward (C++ plan) against DurationEncoder.forward + pipeline.predict_durations.  The AdaLayerNorm
+    style projections are a library kernel in the C++ plan and a torch GEMM in the Python plan, so d_cm is compared at
+    fp32 rounding level; the integer durations must be identical."""
+    from styletts2_amd import pipeline
+    from styletts2_amd.text import ProsodyPredictor
+    pred = ProsodyPredictor(style_dim=128, d_hid=512, nlayers=3, max_dur=50).eval()
+    synth.init_synthetic_(pred, 7)
+    pred = pred.to(DEV)
+    B, N = 3, 29
+    g = torch.Generator().manual_seed(17)
+    d_en = torch.randn(B, 512, N, generator=g).to(DEV)
+    s = torch.randn(B, 128, generator=g).to(DEV)
+    lengths = torch.tensor([N, N - 7, N - 1]) if ragged else torch.full((B,), N)
+    mask = torch.arange(N).unsqueeze(0) >= lengths.unsqueeze(1)
+    d_p = pred.text_encoder(d_en, s, lengths, mask.to(DEV))                       # [B, N, 640]
+    holder = type("M", (), {"predictor": pred})()
+    dur_p = pipeline.predict_durations(holder, d_p, lj_tail=tail == 5, input_lengths=lengths)
+    eng = engine.build_predictor_engine(pred, torch.device(DEV))
+    d_e, dur_e = eng.duration_forward(d_en, s, lengths.to(torch.int32).to(DEV) if ragged else None, tail=tail)
+    torch.cuda.synchronize()
+    print("duration plan max |diff| = %.3e, durations equal: %s" % (float((d_e - d_p.transpose(1, 2)).abs().max()),
+                                                                    torch.equal(dur_e, dur_p)))
+    assert _close(d_e, d_p.transpose(1, 2), 2e-5)
+    assert dur_e.dtype == torch.int64 and torch.equal(dur_e, dur_p)
+    if ragged:
+        assert int(dur_e[1, N - 7:].sum()) == 0
