@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 14
+#define ST2_ABI_VERSION 15
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -349,10 +349,13 @@ int st2_broadcast_cols(const float* x, int64_t x_bs, float* y, int64_t y_bs, int
 int st2_copy_ncl(const float* x, int64_t x_bs, int32_t x_cs, float* y, int64_t y_bs, int32_t y_cs, int32_t B, int32_t C,
                  int32_t L, void* stream);
 
-/* y[b][e][n] = n < len[b] ? table[tokens[b][n]][e] : 0  (tokens int64 [B][N], table [V][E]; len int32 [B] or NULL; token
- * ids outside [0, V) give 0): nn.Embedding + transpose + masked_fill of TextEncoder.forward (models.py:302-306). */
+/* y[b][e][n] = n < len[b] ? (table[tokens[b][n]][e] + add[e]) + pos[n][e] : 0  (tokens int64 [B][N], table [V][E]; add [E]
+ * and pos [>= N][E] optional; len int32 [B] or NULL; token ids outside [0, V) contribute 0): nn.Embedding + transpose +
+ * masked_fill of TextEncoder.forward (models.py:302-306), and -- with add = token-type row 0, pos = the position table --
+ * the embedding sum of the ALBERT model behind PL-BERT (Utils/PLBERT/util.py:6-12; HF AlbertEmbeddings). */
 int st2_embed_tokens(const int64_t* tokens, int32_t B, int32_t N, const float* table, int32_t V, int32_t E,
-                     const int32_t* len, float* y, int64_t y_bs, int32_t y_cs, void* stream);
+                     const float* add, const float* pos, const int32_t* len, float* y, int64_t y_bs, int32_t y_cs,
+                     void* stream);
 /* x[b][c][l] = 0 for l >= len[b] (int32 [B] on the device): the masked_fill_ the reference applies after every block of
  * the text-side modules (models.py:308-312, 547-556). */
 int st2_mask_tail(float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, const int32_t* len, void* stream);
@@ -434,6 +437,9 @@ typedef struct st2_model_config {
   int32_t dn_max_length;           /* fixed-embedding table length (512) */
   /* prosody predictor: models.py:440-466, Configs/config.yml `hidden_dim` */
   int32_t pred_hidden;             /* d_hid of ProsodyPredictor (512); 0 = predictor not used */
+  /* PL-BERT: Utils/PLBERT/config.yml model_params (an HF AlbertConfig; widths are read from the weights' shapes) */
+  int32_t bert_layers;             /* num_hidden_layers (12; ALBERT: one shared weight set); 0 = PL-BERT not used */
+  float bert_ln_eps;               /* layer_norm_eps (1e-12) */
 } st2_model_config;
 
 int st2_create(const st2_model_config* cfg, st2_engine** out);
@@ -445,7 +451,8 @@ int st2_destroy(st2_engine* e);
 int st2_load_weights(st2_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 /* Packs everything loaded so far (split-f16 conv layouts, polyphase ConvTranspose / strided-conv forms, concatenated
  * AdaIN fc matrix) and uploads it in one device allocation.  which: bit 0 = decoder, bit 1 = denoiser, bit 2 = prosody
- * predictor (names prefixed "predictor."), bit 3 = text encoder ("text_encoder.").
+ * predictor (names prefixed "predictor."), bit 3 = text encoder ("text_encoder."), bit 4 = PL-BERT ("bert.", the HF
+ * AlbertModel keys) with the `bert_encoder` Linear ("bert_encoder.weight" / ".bias") when it was loaded.
  * Synchronous; call once after the last st2_load_weights (again after loading new weights). */
 int st2_finalize_weights(st2_engine* e, int32_t which);
 
@@ -519,6 +526,51 @@ int64_t st2_duration_workspace_bytes(st2_engine* e, int32_t B, int32_t N);
 int st2_duration_forward(st2_engine* e, const float* d_en, const float* s, const int32_t* lengths, int32_t B, int32_t N,
                          int32_t tail, float* d_cm, int64_t* durations, void* workspace, int64_t workspace_bytes,
                          void* stream);
+
+/* PL-BERT forward (Utils/PLBERT/util.py:6-12: HF AlbertModel(...).last_hidden_state): tokens int64 [B][N], lengths int32
+ * [B] or NULL (valid keys of a right-padded batch = the attention mask of utils.py:42-46 `length_to_mask`) ->
+ * hidden_cm [B][hidden][N], the last hidden state CHANNEL-major (transpose of the reference's [B][N][hidden]).
+ * Token-merged storage inside ([C][B*N]): every Linear is one k = 1 split-f16 conv over B*N columns (q|k|v fused), the
+ * embedding LayerNorm rides in the mapping conv's prologue, gelu_new in the FFN conv's epilogue.  Weights: "bert.*"
+ * (st2_finalize_weights bit 4); cfg.bert_layers / bert_ln_eps. */
+int64_t st2_bert_workspace_bytes(st2_engine* e, int32_t B, int32_t N);
+int st2_bert_forward(st2_engine* e, const int64_t* tokens, const int32_t* lengths, int32_t B, int32_t N, float* hidden_cm,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Everything the notebooks' `inference` cell does between the phoneme ids and the alignment (Demo/Inference_LJSpeech.ipynb:
+ * 268-301, Demo/Inference_LibriTTS.ipynb:258-305; LFinference's style carry-over, Inference_LJSpeech.ipynb:409-446) in ONE
+ * call: text encoder, PL-BERT, bert_encoder, the style-diffusion sampler (ADPM2 over st2_sampler_table's rows), the style
+ * mixing, the duration encoder and (when `durations` is given) the duration head.
+ *   s_pred  = sampler(noise, embedding = bert, features = ref_s)            [B][2*style_dim]
+ *   s_pred  = t * s_prev + (1 - t) * s_pred                                 when s_prev != NULL
+ *   ref | s = s_pred[:, :style_dim] | s_pred[:, style_dim:]
+ *   ref     = alpha * ref + (1 - alpha) * ref_s[:, :style_dim];  s = beta * s + (1 - beta) * ref_s[:, style_dim:]   (ref_s)
+ * All pointers are device memory; NULL = absent where marked optional.  Needs every weight group of bits 1-4 finalized.
+ * Same memory / stream / graph-capture contract as st2_decoder_forward; the outputs feed st2_prosody_forward (after the
+ * host has read the frame counts off `durations`) and st2_decoder_forward (`ref`). */
+typedef struct st2_front_args {
+  const int64_t* tokens;     /* [B][N] */
+  const int32_t* lengths;    /* [B] or NULL */
+  const float* noise;        /* [B][2*style_dim] */
+  const float* step_noise;   /* [steps-1][B][2*style_dim] */
+  const float* ref_s;        /* [B][2*style_dim]: reference style (multispeaker models), or NULL */
+  const float* s_prev;       /* [B][2*style_dim]: previous sentence's s_pred_out (long-form), or NULL */
+  int32_t B, N, steps;
+  int32_t tail;              /* frames added to every utterance's last token (5 in the LJSpeech notebook) */
+  double embedding_scale;
+  const double* table;       /* HOST: st2_sampler_table(steps, ...) rows */
+  double sigma0;
+  double alpha, beta, t;     /* style mixing weights (0.3 / 0.7 / 0.7 in the notebooks) */
+  float* t_en;               /* out [B][dim_in][N] */
+  float* d_cm;               /* out [B][pred_hidden + style_dim][N] */
+  float* s;                  /* out [B][style_dim]  prosodic style */
+  float* ref;                /* out [B][style_dim]  acoustic style (the decoder's `s`) */
+  float* s_pred_out;         /* out [B][2*style_dim] = ref | s after mixing (the next sentence's s_prev), or NULL */
+  int64_t* durations;        /* out [B][N], or NULL when the caller supplies its own durations */
+} st2_front_args;
+int st2_sizeof_front_args(void);
+int64_t st2_front_workspace_bytes(st2_engine* e, const st2_front_args* a);
+int st2_front_forward(st2_engine* e, const st2_front_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- measurement hook (bench.py's roofline leg) ------------------------------------------------------------------- *
  * st2_conv_timing(1) clears and starts, (0) stops recording a HIP event pair around every st2_conv1d_xs launch (C_in >=

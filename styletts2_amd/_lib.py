@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -65,7 +65,19 @@ class ModelConfig(C.Structure):
         ("dn_multiplier", C.c_int32), ("dn_channels", C.c_int32), ("dn_embedding", C.c_int32),
         ("dn_context_features", C.c_int32), ("dn_max_length", C.c_int32),
         ("pred_hidden", C.c_int32),
+        ("bert_layers", C.c_int32), ("bert_ln_eps", C.c_float),
     ]
+
+
+class FrontArgs(C.Structure):
+    """Mirror of `st2_front_args`."""
+    _fields_ = [("tokens", C.c_void_p), ("lengths", C.c_void_p), ("noise", C.c_void_p), ("step_noise", C.c_void_p),
+                ("ref_s", C.c_void_p), ("s_prev", C.c_void_p),
+                ("B", C.c_int32), ("N", C.c_int32), ("steps", C.c_int32), ("tail", C.c_int32),
+                ("embedding_scale", C.c_double), ("table", C.POINTER(C.c_double)), ("sigma0", C.c_double),
+                ("alpha", C.c_double), ("beta", C.c_double), ("t", C.c_double),
+                ("t_en", C.c_void_p), ("d_cm", C.c_void_p), ("s", C.c_void_p), ("ref", C.c_void_p),
+                ("s_pred_out", C.c_void_p), ("durations", C.c_void_p)]
 
 
 class DecoderTaps(C.Structure):
@@ -162,8 +174,14 @@ _SIGNATURES = {
     "st2_decoder_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "st2_decoder_forward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_int32, f32p,
                                       C.c_void_p, C.c_int64, C.POINTER(DecoderTaps), C.c_void_p]),
-    "st2_embed_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_int32, C.c_int32, C.c_void_p, f32p, C.c_int64,
-                                   C.c_int32, C.c_void_p]),
+    "st2_embed_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_int32, C.c_int32, f32p, f32p, C.c_void_p, f32p,
+                                   C.c_int64, C.c_int32, C.c_void_p]),
+    "st2_bert_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "st2_bert_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p, C.c_int64,
+                                   C.c_void_p]),
+    "st2_sizeof_front_args": (C.c_int, []),
+    "st2_front_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(FrontArgs)]),
+    "st2_front_forward": (C.c_int, [C.c_void_p, C.POINTER(FrontArgs), C.c_void_p, C.c_int64, C.c_void_p]),
     "st2_text_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "st2_text_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p, C.c_int64,
                                    C.c_void_p]),
@@ -227,6 +245,9 @@ def load():
     if lib.st2_sizeof_conv_desc() != C.sizeof(ConvDesc):
         raise St2Error("st2_conv_desc layout mismatch: library %d B, binding %d B"
                        % (lib.st2_sizeof_conv_desc(), C.sizeof(ConvDesc)))
+    if lib.st2_sizeof_front_args() != C.sizeof(FrontArgs):
+        raise St2Error("st2_front_args layout mismatch: library %d B, binding %d B"
+                       % (lib.st2_sizeof_front_args(), C.sizeof(FrontArgs)))
     _lib = lib
     return lib
 

@@ -346,6 +346,15 @@ struct PText {  // TextEncoder (models.py:284-345)
   PLstm lstm;
 };
 
+struct PBert {  // PL-BERT: HF AlbertModel, one shared layer (Utils/PLBERT/util.py:6-20) + the bert_encoder Linear (models.py:689)
+  int64_t word = -1, pos = -1, tok0 = -1, eln_w = -1, eln_b = -1;
+  int V = 0, P = 0, E = 0, H = 0, I = 0;
+  SplitW map, qkv, dense, ffn, out, enc;
+  int64_t map_b = -1, qkv_b = -1, dense_b = -1, aln_w = -1, aln_b = -1, ffn_b = -1, out_b = -1, fln_w = -1, fln_b = -1,
+          enc_b = -1;
+  bool has_enc = false, ready = false;
+};
+
 struct PPredictor {  // ProsodyPredictor.F0Ntrain (models.py:497-510)
   bool ready = false;
   int J = 0;
@@ -367,6 +376,7 @@ struct st2_engine {
   PPredictor pred;
   PDuration dur;
   PText text;
+  PBert bert;
   template <class T>
   T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
   const float* F(int64_t off) const { return P<const float>(off); }
@@ -1138,8 +1148,8 @@ void dn_denoise(Sess& s, const float* x, const double* w4, float* out) {
   c.a.off = mark;
 }
 
-int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* embedding, const float* features,
-                 const float* step_noise, const int32_t* lengths, int B, int N, int steps, double scale,
+int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* embedding, const View* emb_cm,
+                 const float* features, const float* step_noise, const int32_t* lengths, int B, int N, int steps, double scale,
                  const double* table, double sigma0, float* out, float* step_taps) {
   const st2_model_config& cfg = e.cfg;
   const PDenoiser& d = e.dn;
@@ -1149,7 +1159,10 @@ int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* e
   s.bases[0] = dn_alloc(s, Fz);
   {
     View dst = s.bases[0].rows(C, Fz);
-    RUN(c, g_be.tokens_to_channels(embedding, (int64_t)N * E, B, N, E, dst.p, dst.bs, dst.cs, c.stream));
+    if (emb_cm)  // already channel-major on the device (front plan: PL-BERT's merged output)
+      RUN(c, g_be.copy_ncl(emb_cm->p, emb_cm->bs, emb_cm->cs, dst.p, dst.bs, dst.cs, B, E, N, c.stream));
+    else
+      RUN(c, g_be.tokens_to_channels(embedding, (int64_t)N * E, B, N, E, dst.p, dst.bs, dst.cs, c.stream));
   }
   if (scale != 1.0) {
     s.nbases = 2;
@@ -1339,7 +1352,7 @@ View lstm_run(Ctx& c, const st2_engine& e, const PLstm& l, const View& x, const 
   return y;
 }
 
-int duration_plan(Ctx& c, const st2_engine& e, const float* d_en, const float* s_p, const int32_t* lens, int B, int N,
+int duration_plan(Ctx& c, const st2_engine& e, const View& d_en, const float* s_p, const int32_t* lens, int B, int N,
                   int tail, float* d_cm, int64_t* durations) {
   const st2_model_config& cfg = e.cfg;
   const PDuration& d = e.dur;
@@ -1347,7 +1360,7 @@ int duration_plan(Ctx& c, const st2_engine& e, const float* d_en, const float* s
   const int nl = (int)d.lstms.size();
   View h = new_ncl(c, B, Cd, N, false);
   {  // [x | style broadcast over the tokens], pad positions zeroed
-    View src = wrap(d_en, B, dh, N), dst = h.rows(0, dh), st = h.rows(dh, Cd);
+    View src = d_en, dst = h.rows(0, dh), st = h.rows(dh, Cd);
     RUN(c, g_be.copy_ncl(src.p, src.bs, src.cs, dst.p, dst.bs, dst.cs, B, dh, N, c.stream));
     RUN(c, g_be.broadcast_cols(s_p, sty, st.p, st.bs, st.cs, B, sty, N, c.stream));
     if (lens) RUN(c, g_be.mask_tail(h.p, h.bs, h.cs, B, Cd, N, lens, c.stream));
@@ -1404,7 +1417,7 @@ int pack_text(st2_engine& e, Blob& blob, std::string* err) {
 int text_plan(Ctx& c, const st2_engine& e, const int64_t* tokens, const int32_t* lens, int B, int N, float* t_en) {
   const PText& t = e.text;
   View h = new_ncl(c, B, t.C, N, false);
-  RUN(c, g_be.embed_tokens(tokens, B, N, e.F(t.emb), t.V, t.C, lens, h.p, h.bs, h.cs, c.stream));
+  RUN(c, g_be.embed_tokens(tokens, B, N, e.F(t.emb), t.V, t.C, nullptr, nullptr, lens, h.p, h.bs, h.cs, c.stream));
   for (size_t i = 0; i < t.convs.size(); ++i) {
     const PConv& pc = t.convs[i];
     View y = new_ncl(c, B, pc.c_out, N, false);
@@ -1422,6 +1435,177 @@ int text_plan(Ctx& c, const st2_engine& e, const int64_t* tokens, const int32_t*
   View y = lstm_run(c, e, t.lstm, h, lens);  // outputs past a sequence's end are zero (packed-sequence semantics)
   View dst = wrap(t_en, B, 2 * t.lstm.H, N);
   RUN(c, g_be.copy_ncl(y.p, y.bs, y.cs, dst.p, dst.bs, dst.cs, B, 2 * t.lstm.H, N, c.stream));
+  return c.rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PL-BERT plan == CustomAlbert.forward_engine (styletts2_amd/text.py); front plan == pipeline._front_core
+// ------------------------------------------------------------------------------------------------------------------
+int pack_bert(st2_engine& e, Blob& blob, std::string* err) {
+  Packer pk{e, blob};
+  PBert b;
+  const std::string R = "bert.", L = R + "encoder.albert_layer_groups.0.albert_layers.0.";
+  const HostTensor* w = pk.get(R + "embeddings.word_embeddings.weight");
+  const HostTensor* p = pk.get(R + "embeddings.position_embeddings.weight");
+  const HostTensor* tt = pk.get(R + "embeddings.token_type_embeddings.weight");
+  const HostTensor* q = pk.get(L + "attention.query.weight");
+  const HostTensor* k = pk.get(L + "attention.key.weight");
+  const HostTensor* v = pk.get(L + "attention.value.weight");
+  const HostTensor* qb = pk.get(L + "attention.query.bias");
+  const HostTensor* kb = pk.get(L + "attention.key.bias");
+  const HostTensor* vb = pk.get(L + "attention.value.bias");
+  if (!pk.ok || w->shape.size() != 2 || p->shape.size() != 2 || tt->shape.size() != 2 || q->shape.size() != 2) {
+    *err = "missing PL-BERT parameter " + pk.missing;
+    return 1;
+  }
+  b.V = (int)w->shape[0]; b.E = (int)w->shape[1]; b.P = (int)p->shape[0]; b.H = (int)q->shape[0];
+  if (p->shape[1] != b.E || tt->shape[1] != b.E || q->shape[1] != b.H || k->numel() != q->numel() ||
+      v->numel() != q->numel() || b.H % 64 != 0 || e.cfg.bert_layers <= 0) {
+    *err = "PL-BERT: inconsistent shapes (64-wide heads, one shared layer) or cfg.bert_layers == 0";
+    return 1;
+  }
+  b.word = blob.add_f32(w->data);
+  b.pos = blob.add_f32(p->data);
+  b.tok0 = blob.add_f32(std::vector<float>(tt->data.begin(), tt->data.begin() + b.E));  // token_type_ids == 0 everywhere
+  b.eln_w = pk.vec(R + "embeddings.LayerNorm.weight"); b.eln_b = pk.vec(R + "embeddings.LayerNorm.bias");
+  b.map = pk.conv_w(R + "encoder.embedding_hidden_mapping_in.weight");
+  b.map_b = pk.vec(R + "encoder.embedding_hidden_mapping_in.bias");
+  {  // q | k | v as one 3H-row Linear
+    const size_t HH = (size_t)b.H * b.H;
+    std::vector<float> cat(3 * HH), bias((size_t)3 * b.H);
+    std::copy(q->data.begin(), q->data.end(), cat.begin());
+    std::copy(k->data.begin(), k->data.end(), cat.begin() + HH);
+    std::copy(v->data.begin(), v->data.end(), cat.begin() + 2 * HH);
+    std::copy(qb->data.begin(), qb->data.end(), bias.begin());
+    std::copy(kb->data.begin(), kb->data.end(), bias.begin() + b.H);
+    std::copy(vb->data.begin(), vb->data.end(), bias.begin() + 2 * b.H);
+    b.qkv = pack_split(blob, cat.data(), 3 * b.H, b.H, 1);
+    b.qkv_b = blob.add_f32(bias);
+  }
+  b.dense = pk.conv_w(L + "attention.dense.weight");      b.dense_b = pk.vec(L + "attention.dense.bias");
+  b.aln_w = pk.vec(L + "attention.LayerNorm.weight");     b.aln_b = pk.vec(L + "attention.LayerNorm.bias");
+  b.ffn = pk.conv_w(L + "ffn.weight");                    b.ffn_b = pk.vec(L + "ffn.bias");
+  b.out = pk.conv_w(L + "ffn_output.weight");             b.out_b = pk.vec(L + "ffn_output.bias");
+  b.fln_w = pk.vec(L + "full_layer_layer_norm.weight");   b.fln_b = pk.vec(L + "full_layer_layer_norm.bias");
+  b.I = b.ffn.C_out;
+  if (pk.has("bert_encoder.weight")) {
+    b.enc = pk.conv_w("bert_encoder.weight");
+    b.enc_b = pk.vec("bert_encoder.bias");
+    b.has_enc = true;
+  }
+  if (!pk.ok) { *err = "missing PL-BERT parameter " + pk.missing; return 1; }
+  b.ready = true;
+  e.bert = b;
+  return 0;
+}
+
+// -> the last hidden state as a [B][H][N] view of token-merged storage ([H][B*N]); lives in the arena
+View bert_plan(Ctx& c, const st2_engine& e, const int64_t* tokens, const int32_t* lens, int B, int N) {
+  const PBert& p = e.bert;
+  const float eps = e.cfg.bert_ln_eps;
+  const int H = p.H, heads = H / 64;
+  Sess s{c, e, B, N, true, lens, {}, 0, nullptr, nullptr, 1.0};
+  View X = dn_alloc(s, H), Xn = dn_alloc(s, H);
+  {
+    const int64_t mark = c.a.off;
+    View E = dn_alloc(s, p.E);
+    RUN(c, g_be.embed_tokens(tokens, B, N, e.F(p.word), p.V, p.E, e.F(p.tok0), e.F(p.pos), nullptr, E.p, E.bs, E.cs,
+                             c.stream));
+    float* st = c.a.f32((int64_t)B * N * 2);
+    RUN(c, g_be.colnorm_stats(E.p, E.bs, E.cs, B, p.E, N, eps, st, c.stream));
+    ConvOpt o;  // embedding LayerNorm in the prologue of the E -> H mapping
+    o.bias = e.F(p.map_b); o.pro = ST2_PRO_COLNORM; o.stats = st; o.gamma = e.F(p.eln_w); o.beta = e.F(p.eln_b);
+    conv(c, e, dn_cv(s, E), p.map, dn_cv(s, X), o);
+    c.a.off = mark;
+  }
+  for (int l = 0; l < e.cfg.bert_layers; ++l) {
+    const int64_t mark = c.a.off;
+    View qkv = dn_alloc(s, 3 * H);
+    {
+      ConvOpt o;
+      o.bias = e.F(p.qkv_b);
+      conv(c, e, dn_cv(s, X), p.qkv, dn_cv(s, qkv), o);
+    }
+    View ctx = dn_alloc(s, H);
+    View q = qkv.rows(0, H), k = qkv.rows(H, 2 * H), v = qkv.rows(2 * H, 3 * H);
+    RUN(c, g_be.attention_keylen(q.p, k.p, v.p, q.bs, q.cs, ctx.p, ctx.bs, ctx.cs, B, heads, 64, N, 0.125f, lens, c.stream));
+    View Y = dn_alloc(s, H);
+    {
+      ConvOpt o;
+      o.bias = e.F(p.dense_b); o.res = dn_cv(s, X);
+      conv(c, e, dn_cv(s, ctx), p.dense, dn_cv(s, Y), o);
+    }
+    float* st1 = c.a.f32((int64_t)B * N * 2);
+    RUN(c, g_be.colnorm_stats(Y.p, Y.bs, Y.cs, B, H, N, eps, st1, c.stream));
+    View X1 = dn_alloc(s, H);
+    RUN(c, g_be.colnorm_apply(Y.p, Y.bs, Y.cs, st1, e.F(p.aln_w), e.F(p.aln_b), 0, 0, ST2_ACT_NONE, 0.f, nullptr, X1.p, X1.bs,
+                              X1.cs, B, H, N, c.stream));
+    View Hm = dn_alloc(s, p.I);
+    {
+      ConvOpt o;
+      o.bias = e.F(p.ffn_b); o.act = ST2_ACT_GELU_TANH;
+      conv(c, e, dn_cv(s, X1), p.ffn, dn_cv(s, Hm), o);
+    }
+    View Z = dn_alloc(s, H);
+    {
+      ConvOpt o;
+      o.bias = e.F(p.out_b); o.res = dn_cv(s, X1);
+      conv(c, e, dn_cv(s, Hm), p.out, dn_cv(s, Z), o);
+    }
+    float* st2 = c.a.f32((int64_t)B * N * 2);
+    RUN(c, g_be.colnorm_stats(Z.p, Z.bs, Z.cs, B, H, N, eps, st2, c.stream));
+    RUN(c, g_be.colnorm_apply(Z.p, Z.bs, Z.cs, st2, e.F(p.fln_w), e.F(p.fln_b), 0, 0, ST2_ACT_NONE, 0.f, nullptr, Xn.p, Xn.bs,
+                              Xn.cs, B, H, N, c.stream));
+    std::swap(X, Xn);
+    c.a.off = mark;
+  }
+  return X;
+}
+
+int front_plan(Ctx& c, const st2_engine& e, const st2_front_args& a) {
+  const st2_model_config& cfg = e.cfg;
+  const int B = a.B, N = a.N, sty = cfg.style_dim, C2 = cfg.dn_channels, dh = cfg.pred_hidden;
+  text_plan(c, e, a.tokens, a.lengths, B, N, a.t_en);
+  View X = bert_plan(c, e, a.tokens, a.lengths, B, N);
+  Sess s0{c, e, B, N, true, a.lengths, {}, 0, nullptr, nullptr, 1.0};
+  View D = dn_alloc(s0, dh);  // bert_encoder: Linear(H -> hidden_dim) over the merged tokens == d_en channel-major
+  {
+    ConvOpt o;
+    o.bias = e.F(e.bert.enc_b);
+    conv(c, e, dn_cv(s0, X), e.bert.enc, dn_cv(s0, D), o);
+  }
+  const int64_t n = (int64_t)B * C2;
+  float* sp = c.a.f32(n);
+  {
+    const int64_t mark = c.a.off;
+    if (sampler_plan(c, e, a.noise, nullptr, &X, a.ref_s, a.step_noise, a.lengths, B, N, a.steps, a.embedding_scale, a.table,
+                     a.sigma0, sp, nullptr) != 0 && c.rc == 0)
+      c.rc = 1;
+    c.a.off = mark;
+  }
+  const float* cur = sp;
+  if (a.s_prev) {  // LFinference: convex combination of the previous and the current style
+    float* m = c.a.f32(n);
+    RUN(c, g_be.axpbypcz(a.s_prev, (float)a.t, cur, (float)(1.0 - a.t), nullptr, 0.f, m, n, c.stream));
+    cur = m;
+  }
+  const float* ref_src = cur;
+  const float* s_src = cur + sty;
+  if (a.ref_s) {  // Demo/Inference_LibriTTS.ipynb:289-290
+    float* ma = c.a.f32(n);
+    float* mb = c.a.f32(n);
+    RUN(c, g_be.axpbypcz(cur, (float)a.alpha, a.ref_s, (float)(1.0 - a.alpha), nullptr, 0.f, ma, n, c.stream));
+    RUN(c, g_be.axpbypcz(cur, (float)a.beta, a.ref_s, (float)(1.0 - a.beta), nullptr, 0.f, mb, n, c.stream));
+    ref_src = ma;
+    s_src = mb + sty;
+  }
+  RUN(c, g_be.copy_ncl(ref_src, C2, sty, a.ref, sty, sty, B, 1, sty, c.stream));
+  RUN(c, g_be.copy_ncl(s_src, C2, sty, a.s, sty, sty, B, 1, sty, c.stream));
+  if (a.s_pred_out) {
+    RUN(c, g_be.copy_ncl(ref_src, C2, sty, a.s_pred_out, C2, sty, B, 1, sty, c.stream));
+    RUN(c, g_be.copy_ncl(s_src, C2, sty, a.s_pred_out + sty, C2, sty, B, 1, sty, c.stream));
+  }
+  duration_plan(c, e, D, a.s, a.lengths, B, N, a.tail, a.d_cm, a.durations);
   return c.rc;
 }
 
@@ -1494,7 +1678,7 @@ extern "C" int st2_load_weights(st2_engine* e, const char* name, const float* da
 }
 
 extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
-  ST2_REQUIRE(e && (which & 15) != 0, "st2_finalize_weights: bad arguments");
+  ST2_REQUIRE(e && (which & 31) != 0, "st2_finalize_weights: bad arguments");
   Blob blob;
   std::string err;
   if (which & 1) ST2_REQUIRE(pack_decoder(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
@@ -1508,6 +1692,8 @@ extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
     ST2_REQUIRE(pack_duration(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   if (which & 8) ST2_REQUIRE(pack_text(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   else e->text.ready = false;
+  if (which & 16) ST2_REQUIRE(pack_bert(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+  else e->bert.ready = false;
   if (e->wbase) {
     g_be.dev_free(e->wbase);
     e->wbase = nullptr;
@@ -1575,13 +1761,92 @@ extern "C" int st2_text_forward(st2_engine* e, const int64_t* tokens, const int3
   return rc;
 }
 
+extern "C" int64_t st2_bert_workspace_bytes(st2_engine* e, int32_t B, int32_t N) {
+  if (!e || !e->bert.ready || B <= 0 || N <= 0) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  bert_plan(c, *e, nullptr, nullptr, B, N);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_bert_forward(st2_engine* e, const int64_t* tokens, const int32_t* lengths, int32_t B, int32_t N,
+                                float* hidden_cm, void* workspace, int64_t workspace_bytes, void* stream) {
+  ST2_REQUIRE(e && e->bert.ready, "st2_bert_forward: PL-BERT weights not finalized");
+  ST2_REQUIRE(tokens && hidden_cm && workspace && B > 0 && N > 0, "st2_bert_forward: bad arguments");
+  ST2_REQUIRE(N <= e->bert.P, "st2_bert_forward: N=%d tokens exceed the %d rows of the position table", N, e->bert.P);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_bert_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  View X = bert_plan(c, *e, tokens, lengths, B, N);
+  View dst = wrap(hidden_cm, B, e->bert.H, N);
+  RUN(c, g_be.copy_ncl(X.p, X.bs, X.cs, dst.p, dst.bs, dst.cs, B, e->bert.H, N, c.stream));
+  ST2_REQUIRE(!c.a.overflow, "st2_bert_forward: workspace of %lld B is too small (need %lld B, see st2_bert_workspace_bytes)",
+              (long long)workspace_bytes, (long long)c.a.peak);
+  return c.rc;
+}
+
+extern "C" int st2_sizeof_front_args(void) { return (int)sizeof(st2_front_args); }
+
+namespace {
+const char* front_ready(const st2_engine* e) {
+  if (!e) return "null engine";
+  if (!e->text.ready) return "text-encoder weights not finalized (bit 3)";
+  if (!e->bert.ready || !e->bert.has_enc) return "PL-BERT / bert_encoder weights not finalized (bit 4)";
+  if (!e->dn.ready) return "denoiser weights not finalized (bit 1)";
+  if (!e->dur.ready) return "duration-encoder weights not finalized (bit 2)";
+  if (e->cfg.dn_channels != 2 * e->cfg.style_dim) return "cfg.dn_channels != 2 * cfg.style_dim";
+  if (e->cfg.dn_embedding != e->bert.H) return "cfg.dn_embedding != PL-BERT hidden size";
+  if (e->bert.enc.C_out != e->cfg.pred_hidden) return "bert_encoder width != cfg.pred_hidden";
+  return nullptr;
+}
+}  // namespace
+
+extern "C" int64_t st2_front_workspace_bytes(st2_engine* e, const st2_front_args* a) {
+  if (front_ready(e) || !a || a->B <= 0 || a->N <= 0 || a->steps < 2) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  std::vector<double> table((size_t)(a->steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
+  static const float dummy = 0.f;
+  static int64_t dummy_dur;
+  st2_front_args q = *a;  // only B, N, steps, embedding_scale and which optional pointers are set matter for the size
+  q.table = table.data();
+  if (e->cfg.multispeaker) q.ref_s = &dummy;
+  if (a->durations) q.durations = &dummy_dur;
+  front_plan(c, *e, q);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_front_forward(st2_engine* e, const st2_front_args* a, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  const char* why = front_ready(e);
+  ST2_REQUIRE(!why, "st2_front_forward: %s", why);
+  ST2_REQUIRE(a && a->tokens && a->noise && a->step_noise && a->table && a->t_en && a->d_cm && a->s && a->ref && workspace &&
+              a->B > 0 && a->N > 0 && a->steps >= 2 && a->tail >= 0, "st2_front_forward: bad arguments");
+  ST2_REQUIRE(!e->cfg.multispeaker || a->ref_s, "st2_front_forward: the multispeaker denoiser needs ref_s");
+  ST2_REQUIRE(a->N <= e->bert.P && a->N <= e->cfg.dn_max_length && a->N <= 512,
+              "st2_front_forward: N=%d tokens exceed the position / fixed-embedding tables", a->N);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_front_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = front_plan(c, *e, *a);
+  ST2_REQUIRE(!c.a.overflow, "st2_front_forward: workspace of %lld B is too small (need %lld B, see "
+              "st2_front_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
+}
+
 extern "C" int64_t st2_duration_workspace_bytes(st2_engine* e, int32_t B, int32_t N) {
   if (!e || !e->dur.ready || B <= 0 || N <= 0) return -1;
   Ctx c;
   c.dry = true;
   c.a.dry = true;
   static int64_t dummy_dur;
-  duration_plan(c, *e, nullptr, nullptr, nullptr, B, N, 0, nullptr, &dummy_dur);
+  duration_plan(c, *e, wrap(nullptr, B, e->cfg.pred_hidden, N), nullptr, nullptr, B, N, 0, nullptr, &dummy_dur);
   return c.a.peak + 256;
 }
 
@@ -1596,7 +1861,7 @@ extern "C" int st2_duration_forward(st2_engine* e, const float* d_en, const floa
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  const int rc = duration_plan(c, *e, d_en, s, lengths, B, N, tail, d_cm, durations);
+  const int rc = duration_plan(c, *e, wrap(d_en, B, e->cfg.pred_hidden, N), s, lengths, B, N, tail, d_cm, durations);
   ST2_REQUIRE(!c.a.overflow, "st2_duration_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_duration_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
   return rc;
@@ -1669,7 +1934,7 @@ extern "C" int64_t st2_sampler_workspace_bytes(st2_engine* e, int32_t B, int32_t
   c.a.dry = true;
   std::vector<double> table((size_t)(steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
   static const float dummy = 0.f;
-  sampler_plan(c, *e, nullptr, nullptr, &dummy, nullptr, nullptr, B, N, steps, embedding_scale, table.data(), 1.0, nullptr,
+  sampler_plan(c, *e, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, B, N, steps, embedding_scale, table.data(), 1.0, nullptr,
                nullptr);
   return c.a.peak + 256;
 }
@@ -1688,7 +1953,7 @@ extern "C" int st2_sampler_run(st2_engine* e, const float* noise, const float* e
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  const int rc = sampler_plan(c, *e, noise, embedding, features, step_noise, lengths, B, N, steps, embedding_scale, table,
+  const int rc = sampler_plan(c, *e, noise, embedding, nullptr, features, step_noise, lengths, B, N, steps, embedding_scale, table,
                               sigma0, out, step_taps);
   ST2_REQUIRE(!c.a.overflow, "st2_sampler_run: workspace of %lld B is too small (need %lld B, see "
               "st2_sampler_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);

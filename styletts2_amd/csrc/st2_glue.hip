@@ -153,10 +153,12 @@ __global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ x, i
   x[(int64_t)b * x_bs + (int64_t)c * x_cs + l] = 0.f;
 }
 
-// y[b][e][n] = n < len[b] ? table[tok[b][n]][e] : 0: nn.Embedding + transpose + masked_fill of TextEncoder.forward
-// (models.py:302-306).  32 tokens x 32 features per tile through LDS: table rows are read along e, y is written along n.
+// y[b][e][n] = n < len[b] ? (table[tok[b][n]][e] + add[e]) + pos[n][e] : 0: nn.Embedding + transpose + masked_fill of
+// TextEncoder.forward (models.py:302-306; add = pos = null) and the word + token-type + position sum of the ALBERT
+// embeddings (PL-BERT).  32 tokens x 32 features per tile through LDS: table rows are read along e, y is written along n.
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
-                                                           int V, int E, int N, const int* __restrict__ len,
+                                                           int V, int E, int N, const float* __restrict__ add,
+                                                           const float* __restrict__ pos, const int* __restrict__ len,
                                                            float* __restrict__ y, int64_t y_bs, int y_cs) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
@@ -170,6 +172,8 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __re
     if (n < N && n < nlen && e < E) {
       const long long t = tok[(int64_t)b * N + n];
       if (t >= 0 && t < V) v = table[t * E + e];
+      if (add) v += add[e];
+      if (pos) v += pos[(int64_t)n * E + e];
     }
     tile[ty + 8 * i][tx] = v;
   }
@@ -185,12 +189,13 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* __re
 }  // namespace
 
 extern "C" int st2_embed_tokens(const int64_t* tokens, int32_t B, int32_t N, const float* table, int32_t V, int32_t E,
-                                const int32_t* len, float* y, int64_t y_bs, int32_t y_cs, void* stream) {
+                                const float* add, const float* pos, const int32_t* len, float* y, int64_t y_bs,
+                                int32_t y_cs, void* stream) {
   ST2_REQUIRE(tokens && table && y && B > 0 && N > 0 && V > 0 && E > 0, "st2_embed_tokens: bad arguments");
   ST2_REQUIRE(B <= 65535, "st2_embed_tokens: grid too large");
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(st2_cdiv(N, 32), st2_cdiv(E, 32), B), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(tokens), table, V, E, N, len, y,
-                     y_bs, y_cs);
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(tokens), table, V, E, N, add,
+                     pos, len, y, y_bs, y_cs);
   ST2_CHECK_LAUNCH("st2_embed_tokens");
   return 0;
 }

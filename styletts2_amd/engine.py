@@ -178,6 +178,66 @@ class Engine:
                                              t_en.data_ptr(), ws_ptr, nbytes, stream), "st2_text_forward")
         return t_en
 
+    # -- PL-BERT ---------------------------------------------------------------------------------------------------------
+    def bert_forward(self, tokens, lengths=None):
+        """tokens int64 [B, N], lengths int32 [B] on the device or None -> last hidden state [B, N, hidden] (a transposed
+        view of the channel-major buffer `st2_bert_forward` fills)."""
+        B, N = tokens.shape
+        dev = tokens.device
+        tokens = tokens.long().contiguous()
+        if lengths is not None:
+            lengths = lengths.to(torch.int32).contiguous()
+            assert lengths.device == dev and lengths.numel() == B
+        out = torch.empty((B, self.cfg.dn_embedding, N), device=dev, dtype=torch.float32)
+        nbytes = self.lib.st2_bert_workspace_bytes(self.h, B, N)
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_bert_workspace_bytes failed (PL-BERT weights not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_bert_forward(self.h, tokens.data_ptr(), 0 if lengths is None else lengths.data_ptr(), B, N,
+                                             out.data_ptr(), ws_ptr, nbytes, stream), "st2_bert_forward")
+        return out.transpose(1, 2)
+
+    # -- the whole front (tokens -> t_en, d, s, ref, durations) ---------------------------------------------------------------
+    def front_forward(self, tokens, noise, step_noise, table, sigma0, *, lengths=None, ref_s=None, s_prev=None,
+                      embedding_scale=1.0, alpha=0.3, beta=0.7, t=0.7, predict=True, tail=0):
+        """One `st2_front_forward` call (== pipeline._front_core): tokens int64 [B, N], noise [B, 1, 256] or [B, 256],
+        step_noise [steps-1, B, 1, 256]; (table, sigma0) = DiffusionSampler.step_table(steps).  Returns a dict with t_en
+        [B, dim_in, N], d_cm [B, d_hid + sty, N], s, ref [B, sty], s_pred [B, 2 sty] (ref | s) and durations int64 [B, N]
+        (None unless `predict`)."""
+        cfg = self.cfg
+        B, N = tokens.shape
+        dev = tokens.device
+        C2 = cfg.dn_channels
+        steps = step_noise.shape[0] + 1
+        f = lambda v: None if v is None else v.float().contiguous()
+        tokens = tokens.long().contiguous()
+        noise, step_noise, ref_s, s_prev = f(noise), f(step_noise), f(ref_s), f(s_prev)
+        assert noise.numel() == B * C2 and step_noise.numel() == (steps - 1) * B * C2 and len(table) == (steps - 1) * 11
+        if lengths is not None:
+            lengths = lengths.to(torch.int32).contiguous()
+            assert lengths.device == dev and lengths.numel() == B
+        new = lambda *shape, dtype=torch.float32: torch.empty(shape, device=dev, dtype=dtype)
+        out = dict(t_en=new(B, cfg.dim_in, N), d_cm=new(B, cfg.pred_hidden + cfg.style_dim, N), s=new(B, cfg.style_dim),
+                   ref=new(B, cfg.style_dim), s_pred=new(B, C2),
+                   durations=new(B, N, dtype=torch.int64) if predict else None)
+        ptr = lambda v: None if v is None else v.data_ptr()
+        tab = (C.c_double * len(table))(*table)
+        a = _lib.FrontArgs(tokens=ptr(tokens), lengths=ptr(lengths), noise=ptr(noise), step_noise=ptr(step_noise),
+                           ref_s=ptr(ref_s), s_prev=ptr(s_prev), B=B, N=N, steps=steps, tail=int(tail),
+                           embedding_scale=float(embedding_scale), table=tab, sigma0=float(sigma0), alpha=float(alpha),
+                           beta=float(beta), t=float(t), t_en=ptr(out["t_en"]), d_cm=ptr(out["d_cm"]), s=ptr(out["s"]),
+                           ref=ptr(out["ref"]), s_pred_out=ptr(out["s_pred"]), durations=ptr(out["durations"]))
+        nbytes = self.lib.st2_front_workspace_bytes(self.h, C.byref(a))
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_front_workspace_bytes failed (a weight group is not finalized?)")
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_front_forward(self.h, C.byref(a), ws_ptr, nbytes, stream), "st2_front_forward")
+        return out
+
     # -- duration stage (DurationEncoder + duration LSTM + head) -------------------------------------------------------
     def duration_forward(self, d_en, s, lengths=None, tail=0, want_durations=True):
         """d_en [B, d_hid, N] (bert_encoder output, channel-major), s [B, sty], lengths int32 [B] on the device or None ->
@@ -266,6 +326,43 @@ def build_text_engine(text_encoder, device):
     eng = Engine(cfg)
     eng.load_module("text_encoder.", text_encoder)
     eng.finalize(8, device)
+    return eng
+
+
+def _bert_fields(cfg, bert):
+    cfg.bert_layers, cfg.bert_ln_eps = bert.config.num_hidden_layers, bert.config.layer_norm_eps
+    assert bert.config.num_hidden_groups == 1 and bert.config.inner_group_num == 1, "PL-BERT shares one ALBERT layer"
+    assert bert.config.hidden_act == "gelu_new" and bert.config.hidden_size // bert.config.num_attention_heads == 64
+
+
+def build_bert_engine(bert, device):
+    """Engine handle holding PL-BERT (st2_bert_forward)."""
+    cfg = _lib.ModelConfig()
+    cfg.decoder_kind, cfg.dim_in, cfg.upsample_initial_channel, cfg.style_dim = 0, 512, 512, 128
+    cfg.n_upsamples, cfg.n_resblock_kernels = 1, 1
+    cfg.dn_embedding = bert.config.hidden_size
+    _bert_fields(cfg, bert)
+    eng = Engine(cfg)
+    eng.load_module("bert.", bert)
+    eng.finalize(16, device)
+    return eng
+
+
+def build_front_engine(model, device):
+    """Engine handle holding everything in front of the alignment -- text encoder, PL-BERT + bert_encoder, style
+    denoiser, prosody predictor (duration encoder / head and F0Ntrain): st2_front_forward, st2_prosody_forward."""
+    net = model.diffusion.diffusion.net
+    cfg = denoiser_config(net)
+    pc = predictor_config(model.predictor, model.text_encoder.embedding.weight.shape[1])
+    cfg.dim_in, cfg.style_dim, cfg.pred_hidden = pc.dim_in, pc.style_dim, pc.pred_hidden
+    _bert_fields(cfg, model.bert)
+    eng = Engine(cfg)
+    eng.load_module("text_encoder.", model.text_encoder)
+    eng.load_module("bert.", model.bert)
+    eng.load_module("bert_encoder.", model.bert_encoder)
+    eng.load_module("denoiser.", net)
+    eng.load_module("predictor.", model.predictor)
+    eng.finalize(2 | 4 | 8 | 16, device)
     return eng
 
 

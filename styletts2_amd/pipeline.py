@@ -10,6 +10,8 @@ Differences from the notebooks, all host-side:
   * optional `durations=` forces the per-phoneme durations (throughput runs use 4 frames / phoneme so that
     every utterance is exactly 10 s) and removes the only data-dependent host sync.
 """
+import os
+
 import torch
 
 from . import ops
@@ -51,6 +53,19 @@ def predict_durations(model, d, lj_tail=False, input_lengths=None):
 
 
 @torch.no_grad()
+def _front_engine(model, dev):
+    """The st2_engine handle behind ST2_FRONT=engine, packed once per (weights, device): rebuilt when a front module's
+    parameters were reloaded (in-place version counters) or moved (storage addresses)."""
+    from . import engine
+    mods = [model.text_encoder, model.bert, model.bert_encoder, model.diffusion.diffusion.net, model.predictor]
+    stamp = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+    cached = getattr(model.predictor, "_front_engine", None)
+    if cached is None or cached[0] != stamp or cached[1].device != dev:
+        cached = (stamp, engine.build_front_engine(model, dev))
+        model.predictor._front_engine = cached
+    return cached[1]
+
+
 def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, *, diffusion_steps,
                 embedding_scale, alpha, beta, t, predict, lj_tail, taps=None):
     """The device-only part of the front: text encoder, PL-BERT, style diffusion, style mixing, duration encoder and
@@ -59,6 +74,18 @@ def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_n
     the host), so the whole function is legal under stream capture (`GraphedFront`)."""
     dev = tokens.device
     B, N = tokens.shape
+    if os.environ.get("ST2_FRONT", "python") == "engine":  # the same stages as ONE C-ABI call (csrc/st2_engine.hip front_plan)
+        from .diffusion import GraphedSampler
+        smp = sampler.sampler if isinstance(sampler, GraphedSampler) else sampler
+        if lengths_dev is None and lengths_host is not None and not bool((lengths_host == N).all()):
+            lengths_dev = lengths_host.to(torch.int32).to(dev)
+        if step_noise is None:
+            step_noise = torch.randn((diffusion_steps - 1, B, 1, noise.shape[-1]), device=dev, dtype=torch.float32)
+        table, sigma0 = smp.step_table(diffusion_steps)
+        o = _front_engine(model, dev).front_forward(tokens, noise, step_noise, table, sigma0, lengths=lengths_dev, ref_s=ref_s,
+                                                    s_prev=s_prev, embedding_scale=embedding_scale, alpha=alpha, beta=beta,
+                                                    t=t, predict=predict, tail=5 if lj_tail else 0)
+        return dict(t_en=o["t_en"], d=o["d_cm"].transpose(1, 2), s=o["s"], ref=o["ref"], durations=o["durations"])
     if lengths_dev is not None:  # mask built on the device; the modules take the device copy (text.py _device_lengths)
         text_mask = torch.arange(N, device=dev).unsqueeze(0) >= lengths_dev.reshape(-1, 1)
         len_arg = lengths_dev

@@ -293,9 +293,14 @@ def mask_tail(x, x_bs, x_cs, B, Cc, L, length, stream):
     return 0
 
 
-def embed_tokens(tokens, B, N, table, V, E, length, y, y_bs, y_cs, stream):
+def embed_tokens(tokens, B, N, table, V, E, add, pos, length, y, y_bs, y_cs, stream):
     tok = _t(tokens, (B, N), (N, 1), torch.int64)
-    emb = _t(table, (V, E), (E, 1))[tok].transpose(1, 2)                     # [B, E, N]
+    emb = _t(table, (V, E), (E, 1))[tok]                                     # [B, N, E]
+    if add:
+        emb = emb + _t(add, (E,), (1,))
+    if pos:
+        emb = emb + _t(pos, (N, E), (E, 1)).unsqueeze(0)
+    emb = emb.transpose(1, 2)                                                # [B, E, N]
     if length:
         lens = _t(length, (B,), (1,), torch.int32)
         emb = emb.masked_fill(torch.arange(N).view(1, 1, N) >= lens.view(-1, 1, 1), 0.0)

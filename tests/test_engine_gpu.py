@@ -216,3 +216,69 @@ def test_duration_plan_engine_matches_python_plan(ragged, tail):
     assert dur_e.dtype == torch.int64 and torch.equal(dur_e, dur_p)
     if ragged:
         assert int(dur_e[1, N - 7:].sum()) == 0
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_bert_plan_engine_equals_python_plan_bitwise(ragged):
+    """st2_bert_forward (C++ plan) against CustomAlbert.forward_engine (per-kernel Python plan): same kernels, same
+    arguments; the embedding sum comes from `st2_embed_tokens` (word + type, then + position: the Python plan's order)."""
+    man = manifest("ljspeech")
+    bert = models.load_plbert(man["plbert"]).eval()
+    synth.init_synthetic_(bert, 15)
+    bert = bert.to(DEV)
+    B, N = 3, 41
+    g = torch.Generator().manual_seed(12)
+    tokens = torch.randint(1, 178, (B, N), generator=g)
+    lengths = torch.tensor([N, N - 11, N - 1]) if ragged else torch.full((B,), N)
+    mask = torch.arange(N).unsqueeze(0) >= lengths.unsqueeze(1)
+    tokens = tokens.masked_fill(mask, 0).to(DEV)
+    ref = bert.forward_engine(tokens, (~mask).int().to(DEV))
+    eng = engine.build_bert_engine(bert, torch.device(DEV))
+    out = eng.bert_forward(tokens, lengths.to(torch.int32).to(DEV))
+    torch.cuda.synchronize()
+    print("bert plan max |diff| = %.3e (bitwise: %s)" % (float((out - ref).abs().max()), torch.equal(out, ref)))
+    assert torch.equal(out, ref)
+    if not ragged:  # no lengths == every key valid
+        assert torch.equal(eng.bert_forward(tokens, None), ref)
+
+
+@pytest.mark.parametrize("tag,ragged,carry", [("ljspeech", True, True), ("libritts", False, False)])
+def test_front_plan_engine_matches_python_front(tag, ragged, carry):
+    """st2_front_forward (one C-ABI call) against pipeline._front_core (per-kernel Python plan + torch glue).  The two
+    differ only where the Python front uses a torch GEMM / elementwise op (bert_encoder Linear, AdaLayerNorm style
+    projections, the style mixing): compared at fp32 rounding level; the integer durations must be identical."""
+    from styletts2_amd import pipeline
+    man = manifest(tag)
+    args = models.recursive_munch(man["config"])
+    model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))
+    for i, k in enumerate(["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]):
+        synth.init_synthetic_(model[k], 10 + i)
+        model[k].eval().to(DEV)
+    B, N, steps = 3, 33, 4
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randint(1, 178, (B, N), generator=g)
+    lengths = torch.LongTensor([N, N - 8, N - 1] if ragged else [N] * B)
+    tokens = tokens.masked_fill(torch.arange(N).unsqueeze(0) >= lengths.unsqueeze(1), 0).to(DEV)
+    noise = torch.randn(B, 1, 256, generator=g).to(DEV)
+    step_noise = torch.randn(steps - 1, B, 1, 256, generator=g).to(DEV)
+    ref_s = torch.randn(B, 256, generator=g).to(DEV) if man["config"]["multispeaker"] else None
+    s_prev = torch.randn(B, 256, generator=g).to(DEV) if carry else None
+    sampler = models.make_sampler(model)
+    kw = dict(diffusion_steps=steps, embedding_scale=1.5, alpha=0.3, beta=0.7, t=0.7, predict=True, lj_tail=tag == "ljspeech")
+    lens_dev = lengths.to(torch.int32).to(DEV) if ragged else None
+    outs = {}
+    for mode in ("python", "engine"):
+        os.environ["ST2_FRONT"] = mode
+        try:
+            outs[mode] = pipeline._front_core(model, sampler, tokens, lengths, lens_dev, noise, step_noise, ref_s, s_prev, **kw)
+        finally:
+            os.environ.pop("ST2_FRONT", None)
+    torch.cuda.synchronize()
+    p, e = outs["python"], outs["engine"]
+    for k in ("t_en", "d", "s", "ref"):
+        diff = float((p[k] - e[k]).abs().max())
+        print("%s: max |diff| = %.3e of %.3e" % (k, diff, float(p[k].abs().max())))
+    assert torch.equal(p["t_en"], e["t_en"])
+    for k in ("d", "s", "ref"):
+        assert _close(e[k], p[k], 5e-5), k
+    assert torch.equal(p["durations"], e["durations"])
