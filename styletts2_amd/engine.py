@@ -366,6 +366,43 @@ def build_front_engine(model, device):
     return eng
 
 
+def model_config(model):
+    """st2_model_config of a whole styletts2_amd model dict (decoder + denoiser + predictor + text encoder + PL-BERT)."""
+    cfg = decoder_config(model.decoder)
+    dn = denoiser_config(model.diffusion.diffusion.net)
+    for k in ("multispeaker", "dn_layers", "dn_heads", "dn_head_features", "dn_multiplier", "dn_channels", "dn_embedding",
+              "dn_context_features", "dn_max_length"):
+        setattr(cfg, k, getattr(dn, k))
+    cfg.pred_hidden = model.predictor.shared.hidden_size * 2
+    assert cfg.dim_in == model.text_encoder.embedding.weight.shape[1]
+    _bert_fields(cfg, model.bert)
+    return cfg
+
+
+MODEL_PREFIXES = (("text_encoder.", "text_encoder"), ("bert.", "bert"), ("bert_encoder.", "bert_encoder"),
+                  ("predictor.", "predictor"), ("decoder.", "decoder"))
+
+
+def model_state(model):
+    """name -> folded fp32 tensor of everything st2_load_weights wants for the text -> waveform path."""
+    out = {}
+    for prefix, key in MODEL_PREFIXES:
+        for k, v in _folded_state(model[key]).items():
+            out[prefix + k] = v
+    for k, v in _folded_state(model.diffusion.diffusion.net).items():
+        out["denoiser." + k] = v
+    return out
+
+
+def build_model_engine(model, device):
+    """ONE engine handle for the whole text -> waveform path: st2_front_forward, st2_prosody_forward, st2_decoder_forward."""
+    eng = Engine(model_config(model))
+    for k, v in model_state(model).items():
+        eng.load(k, v)
+    eng.finalize(31, device)
+    return eng
+
+
 def decoder_config(dec):
     """st2_model_config of a styletts2_amd.decoder.Decoder (denoiser fields left zero)."""
     g = dec.generator

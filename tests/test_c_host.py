@@ -73,3 +73,102 @@ def test_c_host_matches_python_binding_bitwise(tmp_path, tag, B, T):
     wave_py = dec(asr.cuda(), F0.cuda(), N.cuda(), s.cuda(), noise=noise.cuda()).cpu()
     assert bool(torch.isfinite(wave_c).all())
     assert torch.equal(wave_c, wave_py)
+
+
+TTS_SRC = os.path.join(ROOT, "tools", "st2_c_tts.c")
+
+
+def _build_tts(tmp_path):
+    global SRC
+    keep, SRC = SRC, TTS_SRC
+    try:
+        exe = _build(tmp_path)
+    finally:
+        SRC = keep
+    return exe
+
+
+def test_c_tts_host_builds_against_the_header(tmp_path):
+    """CPU box: the text -> waveform C host compiles as C11 against include/st2.h and links (st2_front_forward,
+    st2_prosody_forward, st2_decoder_forward, st2_sampler_table are exported)."""
+    exe = _build_tts(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,N", [("ljspeech", 9), ("libritts", 11)])
+def test_c_tts_host_matches_python_bitwise(tmp_path, tag, N):
+    """Phoneme ids -> waveform by tools/st2_c_tts.c (plain C: st2_front_forward, one read-back of the durations,
+    st2_prosody_forward, st2_decoder_forward) == the same three calls through the Python binding == pipeline.inference
+    with the C++ front (ST2_FRONT=engine), on the same weights, tokens and noise."""
+    from styletts2_amd import engine, models, pipeline
+    import synth
+    exe = _build_tts(tmp_path)
+    man = manifest(tag)
+    model = models.build_model(models.recursive_munch(man["config"]), None, None, models.load_plbert(man["plbert"]))
+    for i, k in enumerate(["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]):
+        synth.init_synthetic_(model[k], 10 + i)
+        model[k].eval()
+    multi, hifigan = bool(man["config"]["multispeaker"]), man["config"]["decoder"]["type"] == "hifigan"
+    B, steps, tail = 1, 3, 0 if multi else 5
+    T_max = 50 * N + tail
+    g = torch.Generator().manual_seed(21)
+    tokens = torch.randint(1, 178, (B, N), generator=g)
+    tokens[:, 0] = 0
+    noise = torch.randn(B, 1, 256, generator=g)
+    step_noise = torch.randn(steps - 1, B, 1, 256, generator=g)
+    ref_s = torch.randn(B, 256, generator=g) if multi else None
+    pool = torch.randn(B, 600 * T_max, 9, generator=g)
+    sampler = models.make_sampler(model)
+    table, sigma0 = sampler.step_table(steps)
+    cfg = engine.model_config(model)
+    bundle = os.path.join(str(tmp_path), "tts.bin")
+    f32 = lambda t: t.contiguous().numpy().astype("<f4").tobytes()
+    with open(bundle, "wb") as f:
+        f.write(bytes(cfg))
+        f.write(struct.pack("<8i", B, N, steps, tail, int(hifigan), int(multi), T_max, 1))
+        f.write(struct.pack("<3d", 1.0, 0.3, 0.7))
+        f.write(struct.pack("<d", sigma0) + struct.pack("<%dd" % len(table), *table))
+        state = engine.model_state(model)
+        f.write(struct.pack("<i", len(state)))
+        for name, t in state.items():
+            nm = name.encode()
+            f.write(struct.pack("<i", len(nm)) + nm)
+            f.write(struct.pack("<i", t.dim()) + struct.pack("<%dq" % t.dim(), *t.shape))
+            f.write(f32(t))
+        f.write(tokens.numpy().astype("<i8").tobytes())
+        f.write(f32(noise) + f32(step_noise))
+        if multi:
+            f.write(f32(ref_s))
+        f.write(f32(pool))
+    out = os.path.join(str(tmp_path), "tts_out.bin")
+    r = subprocess.run([exe, bundle, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    raw = np.fromfile(out, dtype=np.uint8)
+    dur_c = torch.from_numpy(raw[:B * N * 8].view("<i8").copy()).reshape(B, N)
+    T = int(dur_c.sum())
+    wave_c = torch.from_numpy(raw[B * N * 8:].view("<f4").copy()).reshape(B, 1, 600 * T)
+    assert 0 < T <= T_max and bool(torch.isfinite(wave_c).all())
+    # the same three calls through the Python binding
+    for k in ("decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"):
+        model[k].to("cuda")
+    d = lambda t: None if t is None else t.cuda()
+    eng = engine.build_model_engine(model, torch.device("cuda"))
+    fr = eng.front_forward(d(tokens), d(noise), d(step_noise), table, sigma0, ref_s=d(ref_s), tail=tail)
+    assert torch.equal(fr["durations"].cpu(), dur_c)
+    asr, F0, Nn = eng.prosody_forward(fr["d_cm"], fr["t_en"], fr["durations"], fr["s"], T, shift=hifigan)
+    sine = pool[:, :600 * T].cuda()
+    wave_py = eng.decoder_forward(asr, F0, Nn, fr["ref"], noise=sine).cpu()
+    assert torch.equal(wave_c, wave_py)
+    # ... and the product pipeline with the C++ front
+    os.environ["ST2_FRONT"] = "engine"
+    try:
+        wave_pl = pipeline.inference(model, sampler, d(tokens), None, d(noise), diffusion_steps=steps, ref_s=d(ref_s),
+                                     step_noise=d(step_noise), sine_noise=sine, lj_tail=not multi)
+    finally:
+        os.environ.pop("ST2_FRONT", None)
+    wave_pl = wave_pl[0] if isinstance(wave_pl, list) else wave_pl
+    diff = float((wave_pl.cpu().reshape(-1) - wave_c.reshape(-1)).abs().max())
+    print("pipeline (ST2_FRONT=engine) vs C host: max |diff| = %.3e" % diff)
+    assert diff == 0.0
