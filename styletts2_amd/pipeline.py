@@ -148,8 +148,12 @@ class GraphedFront:
                     refs.append((m, pk))
         return refs
 
-    @staticmethod
-    def _stale(g):
+    def _engine_mode(self):
+        return os.environ.get("ST2_FRONT", "python") == "engine"
+
+    def _stale(self, g, dev):
+        if g["engine"] is not None or self._engine_mode():  # recorded over / now running on the C++ front: same handle?
+            return not self._engine_mode() or _front_engine(self.model, dev) is not g["engine"]
         return any(getattr(m, "_pk", None) is not pk for m, pk in g["packs"])
 
     @torch.no_grad()
@@ -163,7 +167,7 @@ class GraphedFront:
                lengths_dev is not None, bool(kw["predict"]), bool(kw["lj_tail"]), float(kw["alpha"]), float(kw["beta"]),
                float(kw["t"]))
         g = self._graphs.get(key)
-        if g is not None and (g["gen"] != self._generation() or self._stale(g)):  # packed weights were rebuilt
+        if g is not None and (g["gen"] != self._generation() or self._stale(g, dev)):  # packed weights were rebuilt
             self._graphs.clear()
             g = None
         if g is None:
@@ -199,7 +203,10 @@ class GraphedFront:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = run()
-        return dict(graph=graph, static=st, out=out, gen=self._generation(), packs=self._pack_refs())
+        # the graph's kernels read the packed weights: keep the Python caches / the C++ engine handle they live in alive,
+        # and compare identities at replay (a reload or .to() rebuilds them)
+        eng = _front_engine(self.model, dev) if self._engine_mode() else None
+        return dict(graph=graph, static=st, out=out, gen=self._generation(), packs=self._pack_refs(), engine=eng)
 
 
 @torch.no_grad()
