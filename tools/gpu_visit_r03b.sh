@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 3, visit b: the Toom-Cook F(3,3) conv experiment (tools/wino_bench.hip) -- correctness
+# against the host fp64 conv first, then timing next to the production kernel on the same box.
+#   bash tools/build_xs_bench.sh 0 && gpurun --timeout 600 -- 'bash tools/gpu_visit_r03b.sh r03b'
+set -u
+TAG=${1:-r03b}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+echo "== wino check"; timeout 300 tools/bin/wino_bench check > $OUT/wino_check.log 2>&1; echo rc=$?; cat $OUT/wino_check.log
+for k in 11 7; do
+  echo "== production kernel k=$k (C=128, L=48001, B=32)"; timeout 120 tools/bin/xs_bench_0 $k 1 128 48001 32 1 1 10 | tee -a $OUT/xs_bench.log
+  for tn in 2 1; do
+    echo "== F(3,3) k=$k TN=$tn"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 $tn | tee -a $OUT/wino_bench.log
+  done
+done
+echo "== C=256, L=8000"; timeout 120 tools/bin/xs_bench_0 11 1 256 8000 32 1 1 10 | tee -a $OUT/xs_bench.log; timeout 120 tools/bin/wino_bench 11 256 8000 32 10 2 | tee -a $OUT/wino_bench.log

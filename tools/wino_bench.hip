@@ -1,0 +1,592 @@
+// EXPERIMENT (not part of the library): Toom-Cook F(3, 3) form of the split-f16 MFMA conv for the vocoder's long
+// undilated filters (k = 11 -> four 3-tap groups, k = 7 -> three), DESIGN.md section 7 item 0.  Stand-alone binary: plain
+// hipMalloc buffers, its own CPU fp64 check, HIP events.  Written at the end of round 2 without GPU minutes left -- the
+// first thing to run in round 3:
+//
+//   tools/bin/wino_bench check           small shapes (edge tiles included) against a direct fp64 conv on the host
+//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2]   timing of the transform pass and the conv
+//                                          (TN = 32-tile blocks per wave: 2 -> 2 workgroups / CU, 1 -> 3 workgroups / CU)
+//
+// Maths (points 0, 1, -1, 2, inf; verified on the CPU by tools/winograd_numerics.py):
+//   y[3T + i] = sum_j w[j] a[3T + i + j - pad],  w zero-padded to 3G taps, group g = taps 3g .. 3g + 2
+//   V_p[ci][T'] = sum_n BT[p][n] a[ci][3T' - pad + n]                (input transform, fp32, then hi / lo f16 split)
+//   U_{g,p}[co][ci] = sum_r Gm[p][r] w[co][ci][3g + r]               (weight transform, fp64 at pack time)
+//   Y_p[co][T]  = sum_{g, ci} U_{g,p}[co][ci] V_p[ci][T + g]         (5 independent G-tap convs over the TILE index: MFMA)
+//   y[co][3T + i] = sum_p AT[i][p] Y_p[co][T]                        (inverse transform on the fp32 accumulators)
+// i.e. 5 G / 3 MFMA-multiplies per output instead of 3 G - 1 (k = 11: 6.67 vs 11, k = 7: 5 vs 7).
+//
+// Kernel structure = csrc/st2_conv1d_xs_impl.h with "taps" t = g * 5 + p: the packed-weight layout (st2.h) is reused with
+// ks_eff = 5 G, the chunk image in LDS has one row set per point, the accumulators are acc[p][j] (transposed tile: lane =
+// output row, registers = runs of 4 consecutive TILES = 12 consecutive outputs -> three 16-byte stores).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../styletts2_amd/csrc/st2_act.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                  \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+constexpr int P = 5;        // Winograd points
+constexpr int NT = 256;     // threads per workgroup
+constexpr int CI_T = 16;    // input channels per chunk (one MFMA k-step per (g, p))
+constexpr int CG = CI_T / 8;
+
+struct WArgs {
+  // transformed activation planes: vs[b][plane (hi, lo)][p][cg][Lt] slots of 8 channels x f16
+  const h8* vs; int cg_tot; int Lt;
+  // packed weights, st2.h layout with ks_eff = 5 G: [(i16 * ks_eff + t) * 2 + kg][co_pad][hi8 | lo8]
+  const h8* wq; int co_pad, cin_pad;
+  const float* row_scale; const float* bias;
+  float out_scale;
+  float* y; int64_t y_bs; int y_cs;
+  const float* res; int64_t res_bs; int res_cs;
+  float* part; int part_nt;   // per (b, co, tile block of 96 TN outputs): (sum, sum of squares) of the stored values
+  int C_out, L_out;
+};
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv over tiles: workgroup = 4 waves along co (128 output rows) x 32 TN tiles (= 96 TN outputs)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, int TN>
+__global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArgs d) {  // TN = 1: <= 168 VGPRs, 3 workgroups / CU
+  constexpr int BT_ = 32 * TN;            // tiles per workgroup
+  constexpr int XW = BT_ + G - 1;         // staged tile slots per image row
+  constexpr int ROWS = 2 * P * CG;        // image rows per chunk: (plane, point, channel group)
+  constexpr int S = ROWS * XW;
+  constexpr int NS = (S + NT - 1) / NT;
+  constexpr int LBUF = NS * NT;
+  constexpr int SPC = G * P;              // k-steps per chunk
+  constexpr int NSET = 3;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  h8* lds = reinterpret_cast<h8*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;  // = co block of 32 within the workgroup
+  const int kg = lane >> 5;
+  const int l31 = lane & 31;
+  const int t0 = blockIdx.x * BT_;        // first tile
+  const int m0 = blockIdx.y * 128;
+  const int b = blockIdx.z;
+
+  const int64_t pstride = (int64_t)d.cg_tot * d.Lt;      // slots per (plane, point)
+  const int64_t plane_stride = (int64_t)P * pstride;     // slots per plane
+  const h8* vsb = d.vs + (int64_t)b * 2 * plane_stride + t0;
+  int soff[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int slot = tid + i * NT;
+    const int row = slot / XW;
+    const int col = slot - row * XW;
+    const int pl = row / (P * CG), rem = row % (P * CG), p = rem / CG, g8 = rem % CG;
+    soff[i] = slot < S ? (int)(pl * plane_stride + p * pstride + (int64_t)g8 * d.Lt + col) : 0;
+  }
+  h8 xr[NS];
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    const h8* src = vsb + (int64_t)c * CG * d.Lt;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xr[i] = src[soff[i]];
+  };
+  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+    h8* dst = lds + (size_t)buf * LBUF;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) dst[tid + i * NT] = xr[i];
+  };
+
+  f32x16 acc[P][TN];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
+
+  const int co_a = m0 + wave * 32 + l31;  // < co_pad by construction of the packing
+  const h8* ap = d.wq + ((int64_t)kg * d.co_pad + co_a) * 2;
+  const int64_t a_step = (int64_t)2 * d.co_pad * 2;
+  const int nchunk = d.cin_pad / CI_T;
+  const int nsteps = nchunk * SPC;
+
+  load_chunk(0);
+  h8 a_hi[NSET], a_lo[NSET];
+#pragma unroll
+  for (int k = 0; k < NSET - 1; ++k) {
+    if (k > 0 && k < nsteps) ap += a_step;
+    a_hi[k] = ap[0];
+    a_lo[k] = ap[1];
+  }
+  store_chunk(0);
+  __syncthreads();
+
+  __builtin_amdgcn_s_setprio(1);
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunk;
+    const h8* xbuf = lds + (size_t)buf * LBUF + l31;
+    static_for<SPC>([&](auto i_tag) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_tag)::value;
+      constexpr int g = i / P, p = i % P;
+      constexpr int cur = i % NSET, pre = (i + NSET - 1) % NSET;
+      if (more || i + NSET - 1 < SPC) ap += a_step;
+      a_hi[pre] = ap[0];
+      a_lo[pre] = ap[1];
+      if constexpr (i == 0) load_chunk(more ? c + 1 : c);
+      if constexpr (i == SPC - 1) store_chunk(buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0x786);
+      const h8 ah = a_hi[cur], al = a_lo[cur];
+      // image rows of point p: hi plane row (p * CG + kg), lo plane row ((P + p) * CG + kg); a tap group is a shift by g tiles
+      const h8* xp = xbuf + (p * CG + kg) * XW + g;
+      h8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = xp[j * 32];
+        bl[j] = xp[P * CG * XW + j * 32];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah, acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah, acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al, acc[p][j], 0, 0, 0);
+    });
+    if constexpr (SPC % NSET != 0) {  // the next chunk indexes its steps from 0 again: rotate the live sets
+      h8 th[NSET], tl[NSET];
+#pragma unroll
+      for (int k = 0; k < NSET; ++k) {
+        th[k] = a_hi[k];
+        tl[k] = a_lo[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NSET; ++k) {
+        a_hi[k] = th[(k + SPC) % NSET];
+        a_lo[k] = tl[(k + SPC) % NSET];
+      }
+    }
+    __syncthreads();
+  }
+  __builtin_amdgcn_s_setprio(0);
+
+  // ---- epilogue: inverse transform, scale, bias, residual, store, statistics ------------------------------------------
+  // lane (l31, kg) owns output row co and, in acc[p][j][4 q + e], tile T = t0 + 32 j + 8 q + 4 kg + e: the four tiles of a
+  // (j, q) are 12 consecutive outputs starting at 3 (t0 + 32 j + 8 q + 4 kg)
+  const int co = m0 + wave * 32 + l31;
+  const bool rok = co < d.C_out;
+  const int coc = rok ? co : d.C_out - 1;
+  const float osc_r = d.out_scale * d.row_scale[co];
+  const float bias_r = d.bias ? d.bias[coc] : 0.f;
+  float* yb = d.y + (int64_t)b * d.y_bs + (int64_t)coc * d.y_cs;
+  const float* rb = d.res ? d.res + (int64_t)b * d.res_bs + (int64_t)coc * d.res_cs : nullptr;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.y) | (uintptr_t)(d.y_bs * 4) | (uintptr_t)(d.y_cs * 4)) & 15) == 0 &&
+                      (!d.res || ((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0);
+  const bool full = vec_ok && m0 + 128 <= d.C_out && 3 * (t0 + BT_) <= d.L_out;  // workgroup-uniform
+  float s1 = 0.f, s2 = 0.f;
+  static_for<TN * 4>([&](auto jq_tag) __attribute__((always_inline)) {
+    constexpr int j = decltype(jq_tag)::value / 4, q = decltype(jq_tag)::value % 4;
+    const int l0 = 3 * (t0 + 32 * j + 8 * q + 4 * kg);
+    float o[12];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float Y0 = acc[0][j][4 * q + e], Y1 = acc[1][j][4 * q + e], Y2 = acc[2][j][4 * q + e],
+                  Y3 = acc[3][j][4 * q + e], Y4 = acc[4][j][4 * q + e];
+      o[3 * e + 0] = (Y0 + Y1) + (Y2 + Y3);
+      o[3 * e + 1] = (Y1 - Y2) + 2.f * Y3;
+      o[3 * e + 2] = (Y1 + Y2) + (4.f * Y3 + Y4);
+    }
+    if (full) {
+      f32x4 rv[3];
+      if (rb) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) rv[v] = *reinterpret_cast<const f32x4*>(rb + l0 + 4 * v);
+      }
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(o[4 * v + e], osc_r, bias_r);
+          if (rb) t += rv[v][e];
+          w[e] = t;
+          s1 += t;
+          s2 = fmaf(t, t, s2);
+        }
+        *reinterpret_cast<f32x4*>(yb + l0 + 4 * v) = w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) {
+        const int l = l0 + e;
+        const bool ok = rok && l < d.L_out;
+        float t = fmaf(o[e], osc_r, bias_r);
+        if (rb) t += ok ? rb[l] : 0.f;
+        if (ok) {
+          yb[l] = t;
+          s1 += t;
+          s2 = fmaf(t, t, s2);
+        }
+      }
+    }
+    asm volatile("" : "+v"(s1), "+v"(s2));
+  });
+  if (d.part) {
+    const float a1 = s1 + __shfl_xor(s1, 32, 64);
+    const float a2 = s2 + __shfl_xor(s2, 32, 64);
+    if (kg == 0 && rok && (int)blockIdx.x < d.part_nt) {
+      float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + co) * d.part_nt + blockIdx.x;
+      *pp = make_float2(a1, a2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// activation + input transform pass: x fp32 [B][C][L] -> vs (see WArgs).  Workgroup = (256 tiles, one group of 8 channels,
+// one batch item): the 770 input positions it needs are activated ONCE into LDS (coalesced reads along l), then every
+// thread transforms its tile's 5 inputs x 8 channels and writes 5 points x (hi, lo) 16-byte slots (contiguous per wave).
+// ---------------------------------------------------------------------------------------------------------------------
+struct AArgs {
+  const float* x; int64_t x_bs; int x_cs;
+  int C, L, pad;
+  int pro;  // 0 = none, 1 = AdaIN + Snake (st2_actsplit.hip ST2_PRO_ADAIN_SNAKE)
+  const float* stats; const float* gamma; const float* beta; int64_t gb_bs; const float* alpha;
+  float x_scale;
+  h8* vs; int cg_tot; int Lt;
+};
+
+constexpr int AT_TILES = 256;
+constexpr int AT_POS = 3 * AT_TILES + 2;   // input positions per workgroup
+constexpr int AT_PITCH = AT_POS + 1;       // odd pitch: the 8 channel rows start in different banks
+
+template <int PRO>
+__global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
+  __shared__ float sa[8 * AT_PITCH];
+  const int tile0 = blockIdx.x * AT_TILES;
+  const int cg = blockIdx.y;
+  const int b = blockIdx.z;
+  const int p0 = 3 * tile0 - a.pad;  // first input position of the workgroup
+  for (int idx = threadIdx.x; idx < 8 * AT_POS; idx += 256) {
+    const int e = idx / AT_POS, i = idx - e * AT_POS;
+    const int l = p0 + i;
+    const int ci = cg * 8 + e;
+    float u = 0.f;
+    if (l >= 0 && l < a.L && ci < a.C) {
+      u = a.x[(int64_t)b * a.x_bs + (int64_t)ci * a.x_cs + l];
+      if constexpr (PRO == 1) {
+        const float* st = a.stats + ((int64_t)b * a.C + ci) * 2;
+        const float g = 1.0f + a.gamma[(int64_t)b * a.gb_bs + ci];
+        const float bt = a.beta[(int64_t)b * a.gb_bs + ci];
+        float w = (u - st[0]) * st[1];
+        w = g * w + bt;
+        const float al = a.alpha[ci];
+        u = snake(w, al, 1.0f / al);
+      }
+      u *= a.x_scale;
+    }
+    sa[e * AT_PITCH + i] = u;  // zero outside the tensor: F.conv1d pads the ACTIVATED tensor
+  }
+  __syncthreads();
+  const int T = tile0 + threadIdx.x;
+  if (T >= a.Lt) return;
+  h8 hi[P], lo[P];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float* s = sa + e * AT_PITCH + 3 * threadIdx.x;
+    const float d0 = s[0], d1 = s[1], d2 = s[2], d3 = s[3], d4 = s[4];
+    float v[P];
+    v[0] = (2.f * d0 - d1) + (d3 - 2.f * d2);
+    v[1] = (d3 - d2) - 2.f * d1;
+    v[2] = (2.f * d1 + d3) - 3.f * d2;
+    v[3] = d3 - d1;
+    v[4] = (2.f * d1 - d2) + (d4 - 2.f * d3);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float uc = st2_clamp_f16(v[p]);
+      const _Float16 h = (_Float16)uc;
+      hi[p][e] = h;
+      lo[p][e] = (_Float16)(uc - (float)h);
+    }
+  }
+  const int64_t pstride = (int64_t)a.cg_tot * a.Lt;
+  h8* dst = a.vs + (int64_t)b * 2 * P * pstride + (int64_t)cg * a.Lt + T;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    dst[p * pstride] = hi[p];
+    dst[(P + p) * pstride] = lo[p];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static uint32_t rng_state = 12345u;
+static float frand() {  // uniform in [-1, 1)
+  rng_state = rng_state * 1664525u + 1013904223u;
+  return ((int)((rng_state >> 8) & 0xffff) - 32768) * (1.f / 32768.f);
+}
+
+struct Packed {
+  std::vector<_Float16> q;
+  std::vector<float> row_scale;
+  int co_pad, cin_pad, ks_eff;
+};
+
+// U_{g,p} = sum_r Gm[p][r] w[3g + r] in fp64, then csrc/st2_engine.hip pack_split with ks = 5 G (per-row power-of-two scale,
+// hi / lo f16, [(i16 * ks + t) * 2 + kg][co_pad][16])
+static Packed pack_w3(const std::vector<float>& w, int C_out, int C_in, int K, int G) {
+  static const double Gm[5][3] = {{0.5, 0, 0}, {-0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0, 0, 1}};
+  Packed r;
+  r.ks_eff = P * G;
+  r.cin_pad = (C_in + 15) / 16 * 16;
+  r.co_pad = (C_out + 127) / 128 * 128;
+  r.q.assign((size_t)(r.cin_pad / 16) * r.ks_eff * 2 * r.co_pad * 16, (_Float16)0.0f);
+  r.row_scale.assign((size_t)r.co_pad, 1.0f);
+  std::vector<float> u((size_t)C_in * r.ks_eff);
+  for (int co = 0; co < C_out; ++co) {
+    float amax = 0.f;
+    for (int ci = 0; ci < C_in; ++ci)
+      for (int g = 0; g < G; ++g)
+        for (int p = 0; p < P; ++p) {
+          double s = 0.0;
+          for (int rr = 0; rr < 3; ++rr) {
+            const int j = 3 * g + rr;
+            if (j < K) s += Gm[p][rr] * (double)w[((size_t)co * C_in + ci) * K + j];
+          }
+          const float v = (float)s;
+          u[(size_t)ci * r.ks_eff + g * P + p] = v;
+          amax = std::fmax(amax, std::fabs(v));
+        }
+    float scale = 1.0f;
+    if (amax > 0.f) {
+      int e = 0;
+      (void)frexpf(amax, &e);
+      scale = ldexpf(1.0f, 14 - e);
+    }
+    r.row_scale[co] = 1.0f / scale;
+    for (int ci = 0; ci < C_in; ++ci)
+      for (int t = 0; t < r.ks_eff; ++t) {
+        const float v = u[(size_t)ci * r.ks_eff + t] * scale;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int i16 = ci / 16, kg = (ci % 16) / 8, e8 = ci % 8;
+        const size_t base = ((((size_t)i16 * r.ks_eff + t) * 2 + kg) * r.co_pad + co) * 16;
+        r.q[base + e8] = hi;
+        r.q[base + 8 + e8] = lo;
+      }
+  }
+  return r;
+}
+
+static double snake_ref(double v, double al) {
+  const double s = std::sin(al * v);
+  return v + s * s / al;
+}
+
+template <int G, int TN>
+static int launch_conv(const WArgs& d, int B) {
+  constexpr int BT_ = 32 * TN;
+  constexpr int XW = BT_ + G - 1;
+  constexpr int NS = (2 * P * CG * XW + NT - 1) / NT;
+  const size_t smem = (size_t)2 * NS * NT * 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w3_kernel<G, TN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           160 * 1024));
+    attr_done = true;
+  }
+  const int n_tiles = (d.L_out + 2) / 3;
+  dim3 grid((n_tiles + BT_ - 1) / BT_, (d.C_out + 127) / 128, B);
+  hipLaunchKernelGGL((conv_w3_kernel<G, TN>), grid, dim3(NT), smem, 0, d);
+  CK(hipGetLastError());
+  return 0;
+}
+
+template <int TN>
+static int run_case(int K, int C, int L, int B, int reps, bool check, bool adain) {
+  const int G = (K + 2) / 3;
+  const int pad = (K - 1) / 2;
+  const int n_tiles = (L + 2) / 3;
+  const int BT_ = 32 * TN;
+  const int Lt = (n_tiles + BT_ - 1) / BT_ * BT_ + 8;   // every workgroup stages BT_ + G - 1 <= BT_ + 3 tiles
+  const int cg_tot = (C + 15) / 16 * 16 / 8;
+  const int pitch = (L + 31) / 32 * 32;
+  const int nblk = (n_tiles + BT_ - 1) / BT_;
+
+  std::vector<float> hx((size_t)B * C * pitch), hres((size_t)B * C * pitch), hw((size_t)C * C * K), hb(C), hst((size_t)B * C * 2),
+      hga((size_t)B * C), hbe((size_t)B * C), hal(C);
+  rng_state = 777u + K * 131 + L;
+  for (auto& v : hx) v = 1.5f * frand();
+  for (auto& v : hres) v = frand();
+  const float wsc = 1.0f / std::sqrt((float)(C * K));
+  for (auto& v : hw) v = 1.7f * wsc * frand();
+  for (auto& v : hb) v = 0.3f * frand();
+  for (size_t i = 0; i < hst.size(); i += 2) { hst[i] = 0.2f * frand(); hst[i + 1] = 1.0f + 0.3f * frand(); }
+  for (auto& v : hga) v = 0.3f * frand();
+  for (auto& v : hbe) v = 0.3f * frand();
+  for (auto& v : hal) v = 1.0f + 0.5f * frand();
+
+  Packed pk = pack_w3(hw, C, C, K, G);
+  float *x, *res, *y, *bias, *rsc, *part, *st, *ga, *be, *al;
+  _Float16* wq;
+  h8* vs;
+  const size_t vs_slots = (size_t)B * 2 * P * cg_tot * Lt;
+  CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&res, hres.size() * 4)); CK(hipMalloc(&y, hx.size() * 4));
+  CK(hipMalloc(&bias, (size_t)pk.co_pad * 4)); CK(hipMalloc(&rsc, (size_t)pk.co_pad * 4));
+  CK(hipMalloc(&part, (size_t)B * C * nblk * 8)); CK(hipMalloc(&wq, pk.q.size() * 2)); CK(hipMalloc(&vs, vs_slots * 16));
+  CK(hipMalloc(&st, hst.size() * 4)); CK(hipMalloc(&ga, hga.size() * 4)); CK(hipMalloc(&be, hbe.size() * 4));
+  CK(hipMalloc(&al, hal.size() * 4));
+  CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(res, hres.data(), hres.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, (size_t)pk.co_pad * 4));
+  CK(hipMemcpy(bias, hb.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(rsc, pk.row_scale.data(), (size_t)pk.co_pad * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(wq, pk.q.data(), pk.q.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(st, hst.data(), hst.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(ga, hga.data(), hga.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(be, hbe.data(), hbe.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(al, hal.data(), hal.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(vs, 0, vs_slots * 16));
+  CK(hipMemset(y, 0, hx.size() * 4));
+
+  AArgs a;
+  a.x = x; a.x_bs = (int64_t)C * pitch; a.x_cs = pitch; a.C = C; a.L = L; a.pad = pad; a.pro = adain ? 1 : 0;
+  a.stats = st; a.gamma = ga; a.beta = be; a.gb_bs = C; a.alpha = al; a.x_scale = 8.f;
+  a.vs = vs; a.cg_tot = cg_tot; a.Lt = Lt;
+  WArgs d;
+  memset(&d, 0, sizeof(d));
+  d.vs = vs; d.cg_tot = cg_tot; d.Lt = Lt;
+  d.wq = reinterpret_cast<const h8*>(wq); d.co_pad = pk.co_pad; d.cin_pad = pk.cin_pad;
+  d.row_scale = rsc; d.bias = bias; d.out_scale = 1.f / 8.f;
+  d.y = y; d.y_bs = (int64_t)C * pitch; d.y_cs = pitch;
+  d.res = res; d.res_bs = (int64_t)C * pitch; d.res_cs = pitch;
+  d.part = part; d.part_nt = nblk;
+  d.C_out = C; d.L_out = L;
+
+  auto run_act = [&]() -> int {
+    dim3 grid((Lt + AT_TILES - 1) / AT_TILES, cg_tot, B);
+    if (adain) hipLaunchKernelGGL((act_w3_kernel<1>), grid, dim3(256), 0, 0, a);
+    else hipLaunchKernelGGL((act_w3_kernel<0>), grid, dim3(256), 0, 0, a);
+    CK(hipGetLastError());
+    return 0;
+  };
+  auto run_conv = [&]() -> int { return G == 4 ? launch_conv<4, TN>(d, B) : launch_conv<3, TN>(d, B); };
+  if (run_act() || run_conv()) return 1;
+  CK(hipDeviceSynchronize());
+
+  if (check) {
+    std::vector<float> hy(hx.size()), hpart((size_t)B * C * nblk * 2);
+    CK(hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hpart.data(), part, hpart.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<double> act((size_t)C * L);
+    double err = 0.0, ymax = 0.0, perr = 0.0, pmax = 0.0;
+    for (int b = 0; b < B; ++b) {
+      for (int ci = 0; ci < C; ++ci)
+        for (int l = 0; l < L; ++l) {
+          double u = hx[((size_t)b * C + ci) * pitch + l];
+          if (adain) {
+            const double w = (u - hst[((size_t)b * C + ci) * 2]) * hst[((size_t)b * C + ci) * 2 + 1];
+            u = snake_ref((1.0 + hga[(size_t)b * C + ci]) * w + hbe[(size_t)b * C + ci], hal[ci]);
+          }
+          act[(size_t)ci * L + l] = u;
+        }
+      for (int co = 0; co < C; ++co) {
+        std::vector<double> row(L, (double)hb[co]);
+        for (int ci = 0; ci < C; ++ci)
+          for (int j = 0; j < K; ++j) {
+            const double wv = hw[((size_t)co * C + ci) * K + j];
+            const int lo = std::max(0, pad - j), hi = std::min(L, L + pad - j);
+            const double* ar = act.data() + (size_t)ci * L + (j - pad);
+            for (int l = lo; l < hi; ++l) row[l] += wv * ar[l];
+          }
+        std::vector<double> s1(nblk, 0.0), s2(nblk, 0.0);
+        for (int l = 0; l < L; ++l) {
+          const double ref = row[l] + hres[((size_t)b * C + co) * pitch + l];
+          const double got = hy[((size_t)b * C + co) * pitch + l];
+          err = std::fmax(err, std::fabs(got - ref));
+          ymax = std::fmax(ymax, std::fabs(ref));
+          s1[l / (3 * BT_)] += got;
+          s2[l / (3 * BT_)] += got * got;
+        }
+        for (int t = 0; t < nblk; ++t) {
+          const float* pp = hpart.data() + (((size_t)b * C + co) * nblk + t) * 2;
+          perr = std::fmax(perr, std::fmax(std::fabs(pp[0] - s1[t]), std::fabs(pp[1] - s2[t])));
+          pmax = std::fmax(pmax, std::fmax(std::fabs(s1[t]), std::fabs(s2[t])));
+        }
+      }
+    }
+    const bool ok = err < 2e-5 * ymax && perr < 1e-4 * pmax;
+    printf("wino check TN=%d k=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums %.3e of %.3e  -> %s\n", TN, K, C, L,
+           B, (int)adain, err, ymax, perr, pmax, ok ? "OK" : "MISMATCH");
+    return ok ? 0 : 1;
+  }
+
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float ms_act = 0.f, ms_conv = 0.f;
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i)
+    if (run_act()) return 1;
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms_act, e0, e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i)
+    if (run_conv()) return 1;
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms_conv, e0, e1));
+  ms_act /= reps;
+  ms_conv /= reps;
+  const double flop = 2.0 * B * C * (double)C * K * L;
+  printf("wino_bench TN=%d k=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + planes written), conv %.4f ms = "
+         "%.1f algorithmic TFLOP/s (%.3f of 833)\n", TN, K, C, L, B, (int)adain, ms_act,
+         ((double)B * C * L * 4 + (double)vs_slots * 16) / ms_act / 1e9, ms_conv, flop / ms_conv / 1e9,
+         flop / ms_conv / 1e9 / (2500.0 / 3));
+  return 0;
+}
+
+template <int TN>
+static int check_all() {
+  int bad = 0;
+  bad |= run_case<TN>(11, 128, 1000, 2, 1, true, false);   // edge tiles along l
+  bad |= run_case<TN>(11, 128, 1152, 1, 1, true, true);    // interior tiles only, AdaIN + Snake prologue
+  bad |= run_case<TN>(7, 128, 777, 2, 1, true, true);
+  bad |= run_case<TN>(7, 256, 389, 1, 1, true, false);     // two co blocks
+  bad |= run_case<TN>(11, 96, 500, 1, 1, true, false);     // C_out < 128: row guard
+  return bad;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "check")) {
+    const int bad = check_all<2>() | check_all<1>();
+    printf(bad ? "wino check: FAILED\n" : "wino check: all cases OK\n");
+    return bad;
+  }
+  auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
+  const int K = arg(1, 11), C = arg(2, 128), L = arg(3, 48001), B = arg(4, 32), reps = arg(5, 10), tn = arg(6, 2);
+  if (K != 7 && K != 11) { fprintf(stderr, "k must be 7 or 11\n"); return 2; }
+  return tn == 1 ? run_case<1>(K, C, L, B, reps, false, true) : run_case<2>(K, C, L, B, reps, false, true);
+}
