@@ -3,6 +3,7 @@
 // hipMalloc buffers, its own CPU fp64 check, HIP events.  Written at the end of round 2 without GPU minutes left -- the
 // first thing to run in round 3:
 //
+//   tools/bin/wino_bench selftest        no GPU: host emulation of the kernels' data flow through the same checker
 //   tools/bin/wino_bench check           small shapes (edge tiles included) against a direct fp64 conv on the host
 //   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2]   timing of the transform pass and the conv
 //                                          (TN = 32-tile blocks per wave: 2 -> 2 workgroups / CU, 1 -> 3 workgroups / CU)
@@ -423,8 +424,136 @@ static int launch_conv(const WArgs& d, int B) {
   return 0;
 }
 
+static int check_result(int TN, int K, int C, int L, int B, bool adain, int pitch, int nblk, const std::vector<float>& hx,
+                        const std::vector<float>& hres, const std::vector<float>& hw, const std::vector<float>& hb,
+                        const std::vector<float>& hst, const std::vector<float>& hga, const std::vector<float>& hbe,
+                        const std::vector<float>& hal, const std::vector<float>& hy, const std::vector<float>& hpart, bool host) {
+  const int pad = (K - 1) / 2, BT_ = 32 * TN;
+    std::vector<double> act((size_t)C * L);
+    double err = 0.0, ymax = 0.0, perr = 0.0, pmax = 0.0;
+    for (int b = 0; b < B; ++b) {
+      for (int ci = 0; ci < C; ++ci)
+        for (int l = 0; l < L; ++l) {
+          double u = hx[((size_t)b * C + ci) * pitch + l];
+          if (adain) {
+            const double w = (u - hst[((size_t)b * C + ci) * 2]) * hst[((size_t)b * C + ci) * 2 + 1];
+            u = snake_ref((1.0 + hga[(size_t)b * C + ci]) * w + hbe[(size_t)b * C + ci], hal[ci]);
+          }
+          act[(size_t)ci * L + l] = u;
+        }
+      for (int co = 0; co < C; ++co) {
+        std::vector<double> row(L, (double)hb[co]);
+        for (int ci = 0; ci < C; ++ci)
+          for (int j = 0; j < K; ++j) {
+            const double wv = hw[((size_t)co * C + ci) * K + j];
+            const int lo = std::max(0, pad - j), hi = std::min(L, L + pad - j);
+            const double* ar = act.data() + (size_t)ci * L + (j - pad);
+            for (int l = lo; l < hi; ++l) row[l] += wv * ar[l];
+          }
+        std::vector<double> s1(nblk, 0.0), s2(nblk, 0.0);
+        for (int l = 0; l < L; ++l) {
+          const double ref = row[l] + hres[((size_t)b * C + co) * pitch + l];
+          const double got = hy[((size_t)b * C + co) * pitch + l];
+          err = std::fmax(err, std::fabs(got - ref));
+          ymax = std::fmax(ymax, std::fabs(ref));
+          s1[l / (3 * BT_)] += got;
+          s2[l / (3 * BT_)] += got * got;
+        }
+        for (int t = 0; t < nblk; ++t) {
+          const float* pp = hpart.data() + (((size_t)b * C + co) * nblk + t) * 2;
+          perr = std::fmax(perr, std::fmax(std::fabs(pp[0] - s1[t]), std::fabs(pp[1] - s2[t])));
+          pmax = std::fmax(pmax, std::fmax(std::fabs(s1[t]), std::fabs(s2[t])));
+        }
+      }
+    }
+    const bool ok = err < 2e-5 * ymax && perr < 1e-4 * pmax;
+    printf("wino %s TN=%d k=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums %.3e of %.3e  -> %s\n", host ? "selftest (host emulation)" : "check", TN, K, C, L,
+           B, (int)adain, err, ymax, perr, pmax, ok ? "OK" : "MISMATCH");
+    return ok ? 0 : 1;
+}
+
+// Host emulation of the two kernels' DATA FLOW (same plane / packed-weight index formulas, same transform constants, fp64
+// accumulation instead of MFMA): `wino_bench selftest` runs it through the same checker without a GPU, so that the packer,
+// the layouts, the transforms and the checker itself are known to be consistent before the first GPU visit.
+static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pitch, int Lt, int cg_tot, int nblk,
+                         const std::vector<float>& hx, const std::vector<float>& hres, const std::vector<float>& hb,
+                         const std::vector<float>& hst, const std::vector<float>& hga, const std::vector<float>& hbe,
+                         const std::vector<float>& hal, const Packed& pk, std::vector<float>& hy, std::vector<float>& hpart) {
+  const int G = (K + 2) / 3, pad = (K - 1) / 2, BT_ = 32 * TN;
+  std::vector<_Float16> vs((size_t)B * 2 * P * cg_tot * Lt * 8, (_Float16)0.0f);
+  auto a_at = [&](int b, int ci, int l) -> float {
+    if (l < 0 || l >= L || ci >= C) return 0.f;
+    float u = hx[((size_t)b * C + ci) * pitch + l];
+    if (adain) {
+      float w = (u - hst[((size_t)b * C + ci) * 2]) * hst[((size_t)b * C + ci) * 2 + 1];
+      w = (1.0f + hga[(size_t)b * C + ci]) * w + hbe[(size_t)b * C + ci];
+      const float al = hal[ci], sn = sinf(al * w);
+      u = w + (1.0f / al) * (sn * sn);
+    }
+    return u * 8.f;
+  };
+  for (int b = 0; b < B; ++b)
+    for (int cg = 0; cg < cg_tot; ++cg)
+      for (int T = 0; T < Lt; ++T)
+        for (int e = 0; e < 8; ++e) {
+          float dd[5];
+          for (int n = 0; n < 5; ++n) dd[n] = a_at(b, cg * 8 + e, 3 * T - pad + n);
+          float v[P];
+          v[0] = (2.f * dd[0] - dd[1]) + (dd[3] - 2.f * dd[2]);
+          v[1] = (dd[3] - dd[2]) - 2.f * dd[1];
+          v[2] = (2.f * dd[1] + dd[3]) - 3.f * dd[2];
+          v[3] = dd[3] - dd[1];
+          v[4] = (2.f * dd[1] - dd[2]) + (dd[4] - 2.f * dd[3]);
+          for (int p = 0; p < P; ++p) {
+            const float uc = v[p] > 65504.f ? 65504.f : (v[p] < -65504.f ? -65504.f : v[p]);
+            const _Float16 h = (_Float16)uc;
+            vs[(((((size_t)b * 2 + 0) * P + p) * cg_tot + cg) * Lt + T) * 8 + e] = h;
+            vs[(((((size_t)b * 2 + 1) * P + p) * cg_tot + cg) * Lt + T) * 8 + e] = (_Float16)(uc - (float)h);
+          }
+        }
+  hy.assign(hx.size(), 0.f);
+  hpart.assign((size_t)B * C * nblk * 2, 0.f);
+  const int ks = pk.ks_eff;
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < C; ++co) {
+      const float osc_r = (1.f / 8.f) * pk.row_scale[co];
+      for (int blk = 0; blk < nblk; ++blk) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int tt = 0; tt < BT_; ++tt) {
+          const int T = blk * BT_ + tt;
+          double Y[P] = {0, 0, 0, 0, 0};
+          for (int i16 = 0; i16 < pk.cin_pad / 16; ++i16)
+            for (int g = 0; g < G; ++g)
+              for (int p = 0; p < P; ++p)
+                for (int kg = 0; kg < 2; ++kg) {
+                  const size_t wb = ((((size_t)i16 * ks + (g * P + p)) * 2 + kg) * pk.co_pad + co) * 16;
+                  const size_t xh = (((((size_t)b * 2 + 0) * P + p) * cg_tot + (i16 * 2 + kg)) * Lt + T + g) * 8;
+                  const size_t xl = (((((size_t)b * 2 + 1) * P + p) * cg_tot + (i16 * 2 + kg)) * Lt + T + g) * 8;
+                  for (int e8 = 0; e8 < 8; ++e8) {
+                    const double wh = (double)(float)pk.q[wb + e8], wl = (double)(float)pk.q[wb + 8 + e8];
+                    const double ah = (double)(float)vs[xh + e8], al = (double)(float)vs[xl + e8];
+                    Y[p] += wh * ah + wh * al + wl * ah;
+                  }
+                }
+          const double o[3] = {(Y[0] + Y[1]) + (Y[2] + Y[3]), (Y[1] - Y[2]) + 2.0 * Y[3], (Y[1] + Y[2]) + (4.0 * Y[3] + Y[4])};
+          for (int i = 0; i < 3; ++i) {
+            const int l = 3 * T + i;
+            if (l >= L) continue;
+            const float t = fmaf((float)o[i], osc_r, hb[co]) + hres[((size_t)b * C + co) * pitch + l];
+            hy[((size_t)b * C + co) * pitch + l] = t;
+            s1 += t;
+            s2 += (double)t * t;
+          }
+        }
+        hpart[(((size_t)b * C + co) * nblk + blk) * 2 + 0] = (float)s1;
+        hpart[(((size_t)b * C + co) * nblk + blk) * 2 + 1] = (float)s2;
+      }
+    }
+}
+
 template <int TN>
-static int run_case(int K, int C, int L, int B, int reps, bool check, bool adain) {
+static int run_case(int K, int C, int L, int B, int reps, int mode, bool adain) {  // mode 0 bench, 1 GPU check, 2 host selftest
+  const bool check = mode != 0;
   const int G = (K + 2) / 3;
   const int pad = (K - 1) / 2;
   const int n_tiles = (L + 2) / 3;
@@ -448,6 +577,11 @@ static int run_case(int K, int C, int L, int B, int reps, bool check, bool adain
   for (auto& v : hal) v = 1.0f + 0.5f * frand();
 
   Packed pk = pack_w3(hw, C, C, K, G);
+  if (mode == 2) {
+    std::vector<float> hy, hpart;
+    host_emulate(TN, K, C, L, B, adain, pitch, Lt, cg_tot, nblk, hx, hres, hb, hst, hga, hbe, hal, pk, hy, hpart);
+    return check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, true);
+  }
   float *x, *res, *y, *bias, *rsc, *part, *st, *ga, *be, *al;
   _Float16* wq;
   h8* vs;
@@ -499,47 +633,7 @@ static int run_case(int K, int C, int L, int B, int reps, bool check, bool adain
     std::vector<float> hy(hx.size()), hpart((size_t)B * C * nblk * 2);
     CK(hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hpart.data(), part, hpart.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<double> act((size_t)C * L);
-    double err = 0.0, ymax = 0.0, perr = 0.0, pmax = 0.0;
-    for (int b = 0; b < B; ++b) {
-      for (int ci = 0; ci < C; ++ci)
-        for (int l = 0; l < L; ++l) {
-          double u = hx[((size_t)b * C + ci) * pitch + l];
-          if (adain) {
-            const double w = (u - hst[((size_t)b * C + ci) * 2]) * hst[((size_t)b * C + ci) * 2 + 1];
-            u = snake_ref((1.0 + hga[(size_t)b * C + ci]) * w + hbe[(size_t)b * C + ci], hal[ci]);
-          }
-          act[(size_t)ci * L + l] = u;
-        }
-      for (int co = 0; co < C; ++co) {
-        std::vector<double> row(L, (double)hb[co]);
-        for (int ci = 0; ci < C; ++ci)
-          for (int j = 0; j < K; ++j) {
-            const double wv = hw[((size_t)co * C + ci) * K + j];
-            const int lo = std::max(0, pad - j), hi = std::min(L, L + pad - j);
-            const double* ar = act.data() + (size_t)ci * L + (j - pad);
-            for (int l = lo; l < hi; ++l) row[l] += wv * ar[l];
-          }
-        std::vector<double> s1(nblk, 0.0), s2(nblk, 0.0);
-        for (int l = 0; l < L; ++l) {
-          const double ref = row[l] + hres[((size_t)b * C + co) * pitch + l];
-          const double got = hy[((size_t)b * C + co) * pitch + l];
-          err = std::fmax(err, std::fabs(got - ref));
-          ymax = std::fmax(ymax, std::fabs(ref));
-          s1[l / (3 * BT_)] += got;
-          s2[l / (3 * BT_)] += got * got;
-        }
-        for (int t = 0; t < nblk; ++t) {
-          const float* pp = hpart.data() + (((size_t)b * C + co) * nblk + t) * 2;
-          perr = std::fmax(perr, std::fmax(std::fabs(pp[0] - s1[t]), std::fabs(pp[1] - s2[t])));
-          pmax = std::fmax(pmax, std::fmax(std::fabs(s1[t]), std::fabs(s2[t])));
-        }
-      }
-    }
-    const bool ok = err < 2e-5 * ymax && perr < 1e-4 * pmax;
-    printf("wino check TN=%d k=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums %.3e of %.3e  -> %s\n", TN, K, C, L,
-           B, (int)adain, err, ymax, perr, pmax, ok ? "OK" : "MISMATCH");
-    return ok ? 0 : 1;
+    return check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, mode == 2);
   }
 
   hipEvent_t e0, e1;
@@ -569,24 +663,25 @@ static int run_case(int K, int C, int L, int B, int reps, bool check, bool adain
 }
 
 template <int TN>
-static int check_all() {
+static int check_all(int mode) {
   int bad = 0;
-  bad |= run_case<TN>(11, 128, 1000, 2, 1, true, false);   // edge tiles along l
-  bad |= run_case<TN>(11, 128, 1152, 1, 1, true, true);    // interior tiles only, AdaIN + Snake prologue
-  bad |= run_case<TN>(7, 128, 777, 2, 1, true, true);
-  bad |= run_case<TN>(7, 256, 389, 1, 1, true, false);     // two co blocks
-  bad |= run_case<TN>(11, 96, 500, 1, 1, true, false);     // C_out < 128: row guard
+  bad |= run_case<TN>(11, 128, 1000, 2, 1, mode, false);   // edge tiles along l
+  bad |= run_case<TN>(11, 128, 1152, 1, 1, mode, true);    // interior tiles only, AdaIN + Snake prologue
+  bad |= run_case<TN>(7, 128, 777, 2, 1, mode, true);
+  bad |= run_case<TN>(7, 256, 389, 1, 1, mode, false);     // two co blocks
+  bad |= run_case<TN>(11, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
   return bad;
 }
 
 int main(int argc, char** argv) {
-  if (argc > 1 && !strcmp(argv[1], "check")) {
-    const int bad = check_all<2>() | check_all<1>();
+  if (argc > 1 && (!strcmp(argv[1], "check") || !strcmp(argv[1], "selftest"))) {
+    const int mode = !strcmp(argv[1], "check") ? 1 : 2;  // selftest: host emulation of the data flow, no GPU needed
+    const int bad = check_all<2>(mode) | check_all<1>(mode);
     printf(bad ? "wino check: FAILED\n" : "wino check: all cases OK\n");
     return bad;
   }
   auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
   const int K = arg(1, 11), C = arg(2, 128), L = arg(3, 48001), B = arg(4, 32), reps = arg(5, 10), tn = arg(6, 2);
   if (K != 7 && K != 11) { fprintf(stderr, "k must be 7 or 11\n"); return 2; }
-  return tn == 1 ? run_case<1>(K, C, L, B, reps, false, true) : run_case<2>(K, C, L, B, reps, false, true);
+  return tn == 1 ? run_case<1>(K, C, L, B, reps, 0, true) : run_case<2>(K, C, L, B, reps, 0, true);
 }
