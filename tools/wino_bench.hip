@@ -478,9 +478,10 @@ static int check_result(int TN, int K, int C, int L, int B, bool adain, int pitc
 static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pitch, int Lt, int cg_tot, int nblk,
                          const std::vector<float>& hx, const std::vector<float>& hres, const std::vector<float>& hb,
                          const std::vector<float>& hst, const std::vector<float>& hga, const std::vector<float>& hbe,
-                         const std::vector<float>& hal, const Packed& pk, std::vector<float>& hy, std::vector<float>& hpart) {
+                         const std::vector<float>& hal, const Packed& pk, std::vector<float>& hy, std::vector<float>& hpart,
+                         std::vector<_Float16>& vs) {
   const int G = (K + 2) / 3, pad = (K - 1) / 2, BT_ = 32 * TN;
-  std::vector<_Float16> vs((size_t)B * 2 * P * cg_tot * Lt * 8, (_Float16)0.0f);
+  vs.assign((size_t)B * 2 * P * cg_tot * Lt * 8, (_Float16)0.0f);
   auto a_at = [&](int b, int ci, int l) -> float {
     if (l < 0 || l >= L || ci >= C) return 0.f;
     float u = hx[((size_t)b * C + ci) * pitch + l];
@@ -551,6 +552,93 @@ static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pit
     }
 }
 
+// Thread-level host twin of conv_w3_kernel (selftest only): the SAME index expressions as the device code -- staging
+// offsets, LDS image, per-lane fragment addresses, weight pointer arithmetic, accumulator-register -> tile mapping, epilogue
+// addresses -- with the MFMA replaced by its documented semantics (A operand: lane (m, kg) holds A[m][8 kg .. 8 kg + 7];
+// B operand: lane (n, kg) holds B[8 kg .. 8 kg + 7][n]; D: lane (n, kg) register r holds D[8 (r / 4) + 4 kg + r % 4][n]).
+template <int G, int TN>
+static void host_twin_conv(const std::vector<_Float16>& vs, const Packed& pk, int cg_tot, int Lt, const std::vector<float>& bias,
+                           const std::vector<float>& hres, int pitch, int C_out, int L_out, int B, int nblk,
+                           std::vector<float>& hy, std::vector<float>& hpart) {
+  constexpr int BT_ = 32 * TN, XW = BT_ + G - 1, ROWS = 2 * P * CG, S = ROWS * XW, NS = (S + NT - 1) / NT, LBUF = NS * NT;
+  constexpr int SPC = G * P;
+  const int64_t pstride = (int64_t)cg_tot * Lt, plane_stride = (int64_t)P * pstride;
+  const int64_t a_step = (int64_t)2 * pk.co_pad * 2;
+  const int nchunk = pk.cin_pad / CI_T;
+  auto slot_of = [&](const std::vector<_Float16>& arr, int64_t h8_index, int e) { return (double)(float)arr[(size_t)h8_index * 8 + e]; };
+  std::vector<int64_t> image(LBUF);  // LDS image: global h8 index staged into each slot
+  std::vector<double> D((size_t)4 * P * TN * 32 * 32);
+  for (int b = 0; b < B; ++b)
+    for (int by = 0; by < (C_out + 127) / 128; ++by)
+      for (int bx = 0; bx < nblk; ++bx) {
+        const int t0 = bx * BT_, m0 = by * 128;
+        const int64_t vsb = (int64_t)b * 2 * plane_stride + t0;
+        std::fill(D.begin(), D.end(), 0.0);
+        for (int c = 0; c < nchunk; ++c) {
+          for (int tid = 0; tid < NT; ++tid)
+            for (int i = 0; i < NS; ++i) {
+              const int slot = tid + i * NT;
+              const int row = slot / XW, col = slot - row * XW;
+              const int pl = row / (P * CG), rem = row % (P * CG), p = rem / CG, g8 = rem % CG;
+              const int64_t soff = slot < S ? (pl * plane_stride + p * pstride + (int64_t)g8 * Lt + col) : 0;
+              image[tid + i * NT] = vsb + (int64_t)c * CG * Lt + soff;
+            }
+          for (int i = 0; i < SPC; ++i) {
+            const int g = i / P, p = i % P;
+            const int64_t step = (int64_t)c * SPC + i;
+            for (int wave = 0; wave < 4; ++wave)
+              for (int j = 0; j < TN; ++j)
+                for (int m = 0; m < 32; ++m)      // A-operand lane l31 = m
+                  for (int n = 0; n < 32; ++n) {  // B-operand lane l31 = n
+                    double sum = 0.0;
+                    for (int kg = 0; kg < 2; ++kg) {
+                      const int64_t xh = image[(p * CG + kg) * XW + g + m + j * 32];
+                      const int64_t xl = image[(p * CG + kg) * XW + g + m + j * 32 + P * CG * XW];
+                      const int co_a = m0 + wave * 32 + n;
+                      const int64_t ap = ((int64_t)kg * pk.co_pad + co_a) * 2 + step * a_step;
+                      for (int e = 0; e < 8; ++e) {
+                        const double bh = slot_of(vs, xh, e), bl = slot_of(vs, xl, e);
+                        const double ah = slot_of(pk.q, ap, e), al = slot_of(pk.q, ap + 1, e);
+                        sum += bh * ah + bl * ah + bh * al;
+                      }
+                    }
+                    D[((((size_t)wave * P + p) * TN + j) * 32 + m) * 32 + n] += sum;
+                  }
+          }
+        }
+        for (int wave = 0; wave < 4; ++wave)
+          for (int lane = 0; lane < 64; lane += 1) {
+            const int kg = lane >> 5, l31 = lane & 31;
+            const int co = m0 + wave * 32 + l31;
+            const bool rok = co < C_out;
+            if (!rok) continue;
+            const float osc_r = (1.f / 8.f) * pk.row_scale[co];
+            double s1 = 0.0, s2 = 0.0;
+            for (int j = 0; j < TN; ++j)
+              for (int q = 0; q < 4; ++q) {
+                const int l0 = 3 * (t0 + 32 * j + 8 * q + 4 * kg);
+                for (int e = 0; e < 4; ++e) {
+                  const int r = 4 * q + e, m = 8 * (r / 4) + 4 * kg + r % 4;
+                  double Y[P];
+                  for (int p = 0; p < P; ++p) Y[p] = D[((((size_t)wave * P + p) * TN + j) * 32 + m) * 32 + l31];
+                  const double o[3] = {(Y[0] + Y[1]) + (Y[2] + Y[3]), (Y[1] - Y[2]) + 2.0 * Y[3], (Y[1] + Y[2]) + (4.0 * Y[3] + Y[4])};
+                  for (int i = 0; i < 3; ++i) {
+                    const int l = l0 + 3 * e + i;
+                    if (l >= L_out) continue;
+                    const float t = fmaf((float)o[i], osc_r, bias[co]) + hres[((size_t)b * C_out + co) * pitch + l];
+                    hy[((size_t)b * C_out + co) * pitch + l] = t;
+                    s1 += t;
+                    s2 += (double)t * t;
+                  }
+                }
+              }
+            float* pp = hpart.data() + (((size_t)b * C_out + co) * nblk + bx) * 2;  // lane + its kg partner
+            pp[0] += (float)s1;
+            pp[1] += (float)s2;
+          }
+      }
+}
+
 template <int TN>
 static int run_case(int K, int C, int L, int B, int reps, int mode, bool adain) {  // mode 0 bench, 1 GPU check, 2 host selftest
   const bool check = mode != 0;
@@ -579,8 +667,20 @@ static int run_case(int K, int C, int L, int B, int reps, int mode, bool adain) 
   Packed pk = pack_w3(hw, C, C, K, G);
   if (mode == 2) {
     std::vector<float> hy, hpart;
-    host_emulate(TN, K, C, L, B, adain, pitch, Lt, cg_tot, nblk, hx, hres, hb, hst, hga, hbe, hal, pk, hy, hpart);
-    return check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, true);
+    std::vector<_Float16> hvs;
+    host_emulate(TN, K, C, L, B, adain, pitch, Lt, cg_tot, nblk, hx, hres, hb, hst, hga, hbe, hal, pk, hy, hpart, hvs);
+    int bad = check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, true);
+    if (L <= 600) {  // thread-level twin of the conv kernel's index arithmetic (slow: small cases only)
+      std::fill(hy.begin(), hy.end(), 0.f);
+      std::fill(hpart.begin(), hpart.end(), 0.f);
+      std::vector<float> hbp(pk.co_pad, 0.f);
+      std::copy(hb.begin(), hb.end(), hbp.begin());
+      if (G == 4) host_twin_conv<4, TN>(hvs, pk, cg_tot, Lt, hbp, hres, pitch, C, L, B, nblk, hy, hpart);
+      else host_twin_conv<3, TN>(hvs, pk, cg_tot, Lt, hbp, hres, pitch, C, L, B, nblk, hy, hpart);
+      printf("  thread-level twin: ");
+      bad |= check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, true);
+    }
+    return bad;
   }
   float *x, *res, *y, *bias, *rsc, *part, *st, *ga, *be, *al;
   _Float16* wq;
