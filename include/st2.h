@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 15
+#define ST2_ABI_VERSION 16
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -452,7 +452,9 @@ int st2_load_weights(st2_engine* e, const char* name, const float* data, const i
 /* Packs everything loaded so far (split-f16 conv layouts, polyphase ConvTranspose / strided-conv forms, concatenated
  * AdaIN fc matrix) and uploads it in one device allocation.  which: bit 0 = decoder, bit 1 = denoiser, bit 2 = prosody
  * predictor (names prefixed "predictor."), bit 3 = text encoder ("text_encoder."), bit 4 = PL-BERT ("bert.", the HF
- * AlbertModel keys) with the `bert_encoder` Linear ("bert_encoder.weight" / ".bias") when it was loaded.
+ * AlbertModel keys) with the `bert_encoder` Linear ("bert_encoder.weight" / ".bias") when it was loaded, bit 5 = the
+ * reference-audio style encoders ("style_encoder." / "predictor_encoder.", whichever were loaded; spectral-norm triples
+ * folded by the caller: X.weight = weight_orig / (u . (W_mat v)), replacing X.weight_orig / weight_u / weight_v).
  * Synchronous; call once after the last st2_load_weights (again after loading new weights). */
 int st2_finalize_weights(st2_engine* e, int32_t which);
 
@@ -572,6 +574,17 @@ int st2_sizeof_front_args(void);
 int64_t st2_front_workspace_bytes(st2_engine* e, const st2_front_args* a);
 int st2_front_forward(st2_engine* e, const st2_front_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* StyleEncoder.forward (models.py:139-164; `compute_style`, Demo/Inference_LibriTTS.ipynb:100-111): mel [B][80][T] (the
+ * normalised log-mel of the reference recording, T >= 80 frames) -> style [B][style_dim].  which = 0: `style_encoder`
+ * (acoustic half of ref_s), 1: `predictor_encoder` (prosodic half); ref_s = cat(which 0, which 1).  Conv2d layers run as
+ * split-f16 Conv1d over the width with their kernel rows stacked along the channels (maps stored (h, c, w)), the
+ * depthwise stride-2 conv and the 2x2 average as st2_dwconv3x3s2 / st2_avgpool2x2.  The mel itself is five kernel-level
+ * calls (st2_stft_frames, st2_conv1d with the windowed-DFT matrix, st2_power_spectrum, st2_conv1d with the filter bank,
+ * st2_log_norm: styletts2_amd/style.py mel_spectrogram_engine).  Same memory / stream contract as st2_decoder_forward. */
+int64_t st2_style_workspace_bytes(st2_engine* e, int32_t which, int32_t B, int32_t n_mels, int32_t T);
+int st2_style_forward(st2_engine* e, int32_t which, const float* mel, int32_t B, int32_t n_mels, int32_t T, float* style,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- measurement hook (bench.py's roofline leg) ------------------------------------------------------------------- *
  * st2_conv_timing(1) clears and starts, (0) stops recording a HIP event pair around every st2_conv1d_xs launch (C_in >=
  * 64, L_out >= 256) on its launch stream, whichever plan issues it.  st2_conv_timing_read (after stopping) waits for the
@@ -592,7 +605,7 @@ enum st2_backend_slot {
   ST2_BE_ADD_CHANVEC, ST2_BE_MEAN_TOKENS_LEN, ST2_BE_AXPBYPCZ, ST2_BE_TIME_FEATURES, ST2_BE_TOKENS_TO_CHANNELS,
   ST2_BE_BROADCAST_COLS, ST2_BE_COPY_NCL, ST2_BE_EXPAND_BY_DURATIONS,
   ST2_BE_LSTM_BIDIR,  /* st2_lstm_bidir's arguments with (void* scratch, int64_t scratch_bytes) inserted before `stream` */
-  ST2_BE_COLNORM_APPLY, ST2_BE_DURATION_HEAD, ST2_BE_MASK_TAIL, ST2_BE_EMBED_TOKENS,
+  ST2_BE_COLNORM_APPLY, ST2_BE_DURATION_HEAD, ST2_BE_MASK_TAIL, ST2_BE_EMBED_TOKENS, ST2_BE_DWCONV3X3S2, ST2_BE_AVGPOOL2X2,
   ST2_BE_DEV_ALLOC,   /* void* (*)(int64_t bytes) */
   ST2_BE_DEV_FREE,    /* void (*)(void*) */
   ST2_BE_UPLOAD,      /* int (*)(void* dst, const void* src, int64_t bytes): synchronous host -> device copy */

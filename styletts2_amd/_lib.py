@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -91,8 +91,8 @@ BACKEND_SLOTS = ["conv1d_f16s", "conv1d_xs", "act_split", "stats_finalize", "con
                  "instnorm_stats", "colnorm_stats", "style_fc", "convt_interleave_stats", "adain_leaky_pool",
                  "har_source", "stft_mag_phase", "istft", "attention_keylen", "add_chanvec", "mean_tokens_len",
                  "axpbypcz", "time_features", "tokens_to_channels", "broadcast_cols", "copy_ncl", "expand_by_durations",
-                 "lstm_bidir", "colnorm_apply", "duration_head", "mask_tail", "embed_tokens", "dev_alloc", "dev_free",
-                 "upload"]  # enum st2_backend_slot
+                 "lstm_bidir", "colnorm_apply", "duration_head", "mask_tail", "embed_tokens", "dwconv3x3s2",
+                 "avgpool2x2", "dev_alloc", "dev_free", "upload"]  # enum st2_backend_slot
 
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -179,6 +179,9 @@ _SIGNATURES = {
     "st2_bert_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "st2_bert_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p, C.c_int64,
                                    C.c_void_p]),
+    "st2_style_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "st2_style_forward": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int32, C.c_int32, C.c_int32, f32p, C.c_void_p, C.c_int64,
+                                    C.c_void_p]),
     "st2_sizeof_front_args": (C.c_int, []),
     "st2_front_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(FrontArgs)]),
     "st2_front_forward": (C.c_int, [C.c_void_p, C.POINTER(FrontArgs), C.c_void_p, C.c_int64, C.c_void_p]),

@@ -57,6 +57,8 @@ struct Backend {
   decltype(&st2_duration_head) duration_head;
   decltype(&st2_mask_tail) mask_tail;
   decltype(&st2_embed_tokens) embed_tokens;
+  decltype(&st2_dwconv3x3s2) dwconv3x3s2;
+  decltype(&st2_avgpool2x2) avgpool2x2;
   void* (*dev_alloc)(int64_t);
   void (*dev_free)(void*);
   int (*upload)(void*, const void*, int64_t);
@@ -94,7 +96,7 @@ const Backend kHipBackend = {st2_conv1d_f16s, st2_conv1d_xs, st2_act_split, st2_
                              st2_istft, st2_attention_keylen, st2_add_chanvec, st2_mean_tokens_len, st2_axpbypcz,
                              st2_time_features, st2_tokens_to_channels, st2_broadcast_cols, st2_copy_ncl,
                              st2_expand_by_durations, hip_lstm, st2_colnorm_apply, st2_duration_head, st2_mask_tail,
-                             st2_embed_tokens, hip_alloc, hip_free, hip_upload};
+                             st2_embed_tokens, st2_dwconv3x3s2, st2_avgpool2x2, hip_alloc, hip_free, hip_upload};
 Backend g_be = kHipBackend;
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -355,6 +357,21 @@ struct PBert {  // PL-BERT: HF AlbertModel, one shared layer (Utils/PLBERT/util.
   bool has_enc = false, ready = false;
 };
 
+struct PStyleBlk {  // ResBlk(normalize=False, downsample='half'), models.py:97-137
+  int c_in = 0, c_out = 0;
+  SplitW w1, w2, wsc;
+  int64_t b1 = -1, b2 = -1, wd = -1, bd = -1;
+  bool has_sc = false;
+};
+struct PStyleEnc {  // StyleEncoder, models.py:139-164 (spectral-norm convs folded by the caller)
+  int64_t w0 = -1, b0 = -1;
+  int c0 = 0, c_last = 0, style_dim = 0;
+  std::vector<PStyleBlk> blocks;
+  SplitW w5, wl;
+  int64_t b5 = -1, bl = -1;
+  bool ready = false;
+};
+
 struct PPredictor {  // ProsodyPredictor.F0Ntrain (models.py:497-510)
   bool ready = false;
   int J = 0;
@@ -377,6 +394,8 @@ struct st2_engine {
   PDuration dur;
   PText text;
   PBert bert;
+  PStyleEnc style[2];  // 0 = style_encoder (acoustic), 1 = predictor_encoder (prosodic)
+  int64_t zeros = -1;  // 4096 zero floats (map borders)
   template <class T>
   T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
   const float* F(int64_t off) const { return P<const float>(off); }
@@ -1609,6 +1628,168 @@ int front_plan(Ctx& c, const st2_engine& e, const st2_front_args& a) {
   return c.rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// style-encoder plan == StyleEncoder.forward (styletts2_amd/style.py): feature maps stored (h, c, w) with one zero row
+// above and below, every 3x3 Conv2d one split-f16 Conv1d over the width with 3 stacked rows as its input channels
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int STYLE_ZEROS = 4096;
+
+// Conv2d weight [Co][Ci][kh][kw] -> Conv1d weight [Co][kh*Ci][kw] on kh stacked image rows (channel index dh*Ci + ci)
+std::vector<float> rows_as_channels(const HostTensor& t) {
+  const int co = (int)t.shape[0], ci = (int)t.shape[1], kh = (int)t.shape[2], kw = (int)t.shape[3];
+  std::vector<float> v((size_t)co * kh * ci * kw);
+  for (int o = 0; o < co; ++o)
+    for (int i = 0; i < ci; ++i)
+      for (int dh = 0; dh < kh; ++dh)
+        for (int x = 0; x < kw; ++x)
+          v[(((size_t)o * kh + dh) * ci + i) * kw + x] = t.data[(((size_t)o * ci + i) * kh + dh) * kw + x];
+  return v;
+}
+
+int pack_style(st2_engine& e, Blob& blob, int which, std::string* err) {
+  Packer pk{e, blob};
+  PStyleEnc s;
+  const std::string R = which == 0 ? "style_encoder." : "predictor_encoder.";
+  auto conv2d = [&](const std::string& name) -> SplitW {  // folded Conv2d -> packed Conv1d over stacked rows
+    const HostTensor* t = pk.get(name);
+    if (!t || t->shape.size() != 4) { pk.ok = false; if (pk.missing.empty()) pk.missing = name + " (4-D expected)"; return SplitW(); }
+    const std::vector<float> v = rows_as_channels(*t);
+    return pack_split(blob, v.data(), (int)t->shape[0], (int)(t->shape[1] * t->shape[2]), (int)t->shape[3]);
+  };
+  const HostTensor* first = pk.get(R + "shared.0.weight");
+  if (!first || first->shape.size() != 4 || first->shape[1] != 1 || first->shape[2] != 3 || first->shape[3] != 3) {
+    *err = "missing or malformed style-encoder parameter " + R + "shared.0.weight (spectral norm folded by the caller)";
+    return 1;
+  }
+  s.c0 = (int)first->shape[0];
+  s.w0 = blob.add_f32(rows_as_channels(*first));  // [C0][3][3]: plain OIK for st2_conv1d_direct
+  s.b0 = pk.vec(R + "shared.0.bias");
+  int i = 1;
+  for (; pk.has(R + "shared." + std::to_string(i) + ".conv1.weight"); ++i) {
+    const std::string Bn = R + "shared." + std::to_string(i);
+    PStyleBlk b;
+    const HostTensor* w1 = pk.get(Bn + ".conv1.weight");
+    const HostTensor* w2 = pk.get(Bn + ".conv2.weight");
+    const HostTensor* wd = pk.get(Bn + ".downsample_res.conv.weight");
+    if (!w1 || !w2 || !wd) break;
+    b.c_in = (int)w1->shape[1];
+    b.c_out = (int)w2->shape[0];
+    b.w1 = conv2d(Bn + ".conv1.weight");  b.b1 = pk.vec(Bn + ".conv1.bias");
+    b.w2 = conv2d(Bn + ".conv2.weight");  b.b2 = pk.vec(Bn + ".conv2.bias");
+    b.wd = blob.add_f32(wd->data);        b.bd = pk.vec(Bn + ".downsample_res.conv.bias");  // [C][1][3][3] == [C][3][3]
+    if (pk.has(Bn + ".conv1x1.weight")) {
+      b.wsc = conv2d(Bn + ".conv1x1.weight");
+      b.has_sc = true;
+    }
+    s.blocks.push_back(b);
+  }
+  // shared.{i} = LeakyReLU, shared.{i+1} = the 5x5 valid conv (models.py:151-153)
+  const std::string last = R + "shared." + std::to_string(i + 1);
+  s.w5 = conv2d(last + ".weight");
+  s.b5 = pk.vec(last + ".bias");
+  s.c_last = s.w5.C_out;
+  s.wl = pk.conv_w(R + "unshared.weight");
+  s.bl = pk.vec(R + "unshared.bias");
+  s.style_dim = s.wl.C_out;
+  if (!pk.ok || s.blocks.empty() || s.c0 > STYLE_ZEROS || s.c_last > STYLE_ZEROS) {
+    *err = "missing style-encoder parameter " + pk.missing;
+    return 1;
+  }
+  s.ready = true;
+  e.style[which] = s;
+  return 0;
+}
+
+int style_plan(Ctx& c, const st2_engine& e, const PStyleEnc& s, const float* mel, int B, int H, int W, float* out) {
+  // [B][h + 2][ch][w] map whose rows 0 and h + 1 are zero (the rows 1 .. h are written by the producing kernel)
+  auto new_map = [&](int h, int ch, int w) -> float* {
+    float* p = c.a.f32((int64_t)B * (h + 2) * ch * w);
+    for (int r : {0, h + 1})
+      RUN(c, g_be.broadcast_cols(e.F(e.zeros), 0, p + (int64_t)r * ch * w, (int64_t)(h + 2) * ch * w, w, B, ch, w, c.stream));
+    return p;
+  };
+  // rows r0 .. r0 + k - 1 of utterance b's padded map stacked along the channels: [h][k * ch][w] (overlapping view)
+  auto rows = [&](float* P, int b, int h, int ch, int w, int k, int r0) {
+    View v;
+    v.p = P + (int64_t)b * (h + 2) * ch * w + (int64_t)r0 * ch * w;
+    v.B = h; v.C = k * ch; v.L = w; v.bs = (int64_t)ch * w; v.cs = w;  // k = 3 from row 0 / k = 1 from row 1: h image rows
+    return v;
+  };
+  auto plain = [&](float* p, int b, int h, int ch, int w) {  // [h][ch][w] of utterance b in an unpadded [B][h][ch][w] buffer
+    View v;
+    v.p = p + (int64_t)b * h * ch * w;
+    v.B = h; v.C = ch; v.L = w; v.bs = (int64_t)ch * w; v.cs = w;
+    return v;
+  };
+  float* m0 = new_map(H, 1, W);
+  RUN(c, g_be.copy_ncl(mel, (int64_t)H * W, W, m0 + W, (int64_t)(H + 2) * W, W, B, H, W, c.stream));
+  int C = s.c0;
+  float* P = new_map(H, C, W);
+  for (int b = 0; b < B; ++b) {
+    const View x = rows(m0, b, H, 1, W, 3, 0);
+    RUN(c, g_be.conv1d_direct(x.p, x.bs, x.cs, e.F(s.w0), e.F(s.b0), P + (int64_t)b * (H + 2) * C * W + (int64_t)C * W,
+                              (int64_t)C * W, W, H, 3, C, W, W, 3, 1, 1, c.stream));
+  }
+  for (const PStyleBlk& blk : s.blocks) {
+    const int Co = blk.c_out, Ho = H / 2, Wo = (W + 1) / 2;
+    // shortcut: 1x1 conv at full resolution, then the 2x2 average (models.py:118-123)
+    float* SC = c.a.f32((int64_t)B * Ho * Co * Wo);
+    if (blk.has_sc) {
+      float* S = c.a.f32((int64_t)B * H * Co * W);
+      for (int b = 0; b < B; ++b) conv(c, e, rows(P, b, H, C, W, 1, 1), blk.wsc, plain(S, b, H, Co, W), ConvOpt());
+      RUN(c, g_be.avgpool2x2(S, (int64_t)H * Co * W, (int64_t)Co * W, W, B, Co, H, W, SC, (int64_t)Ho * Co * Wo, (int64_t)Co * Wo,
+                             Wo, c.stream));
+    } else {
+      RUN(c, g_be.avgpool2x2(P + (int64_t)C * W, (int64_t)(H + 2) * C * W, (int64_t)C * W, W, B, C, H, W, SC,
+                             (int64_t)Ho * Co * Wo, (int64_t)Co * Wo, Wo, c.stream));
+    }
+    // residual: leaky -> conv1 3x3 -> depthwise stride-2 3x3 -> leaky -> conv2 3x3 (models.py:125-135)
+    float* R1 = c.a.f32((int64_t)B * H * C * W);
+    for (int b = 0; b < B; ++b) {
+      ConvOpt o;
+      o.pad_left = 1; o.bias = e.F(blk.b1); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
+      conv(c, e, rows(P, b, H, C, W, 3, 0), blk.w1, plain(R1, b, H, C, W), o);
+    }
+    float* P2 = new_map(Ho, C, Wo);
+    RUN(c, g_be.dwconv3x3s2(R1, (int64_t)H * C * W, (int64_t)C * W, W, e.F(blk.wd), e.F(blk.bd), B, C, H, W, P2 + (int64_t)C * Wo,
+                            (int64_t)(Ho + 2) * C * Wo, (int64_t)C * Wo, Wo, c.stream));
+    float* Pn = new_map(Ho, Co, Wo);
+    for (int b = 0; b < B; ++b) {  // (shortcut + residual) / sqrt(2) in the epilogue
+      ConvOpt o;
+      o.pad_left = 1; o.bias = e.F(blk.b2); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
+      o.res = plain(SC, b, Ho, Co, Wo); o.div = (float)sqrt(2.0);
+      View y = rows(Pn, b, Ho, Co, Wo, 1, 1);
+      conv(c, e, rows(P2, b, Ho, C, Wo, 3, 0), blk.w2, y, o);
+    }
+    P = Pn; H = Ho; W = Wo; C = Co;
+  }
+  // LeakyReLU -> 5x5 valid conv -> global average -> LeakyReLU -> Linear (models.py:151-163)
+  const int Cl = s.c_last, Wf = W - 4;
+  float* Fm = c.a.f32((int64_t)B * Cl * Wf);
+  for (int b = 0; b < B; ++b) {
+    View x;
+    x.p = P + (int64_t)b * (H + 2) * C * W + (int64_t)C * W;
+    x.B = 1; x.C = 5 * C; x.L = W; x.bs = (int64_t)5 * C * W; x.cs = W;
+    View y;
+    y.p = Fm + (int64_t)b * Cl * Wf;
+    y.B = 1; y.C = Cl; y.L = Wf; y.bs = (int64_t)Cl * Wf; y.cs = Wf;
+    ConvOpt o;
+    o.bias = e.F(s.b5); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
+    conv(c, e, x, s.w5, y, o);
+  }
+  float* m = c.a.f32((int64_t)B * Cl);
+  RUN(c, g_be.mean_tokens_len(Fm, (int64_t)Cl * Wf, Wf, m, Cl, B, Cl, Wf, nullptr, c.stream));
+  {
+    View x, y;
+    x.p = m; x.B = B; x.C = Cl; x.L = 1; x.bs = Cl; x.cs = 1;
+    y.p = out; y.B = B; y.C = s.style_dim; y.L = 1; y.bs = s.style_dim; y.cs = 1;
+    ConvOpt o;
+    o.bias = e.F(s.bl); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
+    conv(c, e, x, s.wl, y, o);
+  }
+  return c.rc;
+}
+
 bool check_cfg(const st2_model_config& c) {
   return c.n_upsamples >= 1 && c.n_upsamples <= 4 && c.n_resblock_kernels >= 1 && c.n_resblock_kernels <= 4 &&
          (c.decoder_kind == 0 || c.decoder_kind == 1) && c.dim_in > 0 && c.style_dim > 0 && c.dn_layers >= 0;
@@ -1640,7 +1821,7 @@ extern "C" int st2_debug_set_backend(void* const* table, int32_t entries) {
   SLOT(broadcast_cols, ST2_BE_BROADCAST_COLS); SLOT(copy_ncl, ST2_BE_COPY_NCL);
   SLOT(expand_by_durations, ST2_BE_EXPAND_BY_DURATIONS); SLOT(lstm_bidir, ST2_BE_LSTM_BIDIR);
   SLOT(colnorm_apply, ST2_BE_COLNORM_APPLY); SLOT(duration_head, ST2_BE_DURATION_HEAD); SLOT(mask_tail, ST2_BE_MASK_TAIL);
-  SLOT(embed_tokens, ST2_BE_EMBED_TOKENS);
+  SLOT(embed_tokens, ST2_BE_EMBED_TOKENS); SLOT(dwconv3x3s2, ST2_BE_DWCONV3X3S2); SLOT(avgpool2x2, ST2_BE_AVGPOOL2X2);
   SLOT(dev_alloc, ST2_BE_DEV_ALLOC); SLOT(dev_free, ST2_BE_DEV_FREE); SLOT(upload, ST2_BE_UPLOAD);
 #undef SLOT
   return 0;
@@ -1678,7 +1859,7 @@ extern "C" int st2_load_weights(st2_engine* e, const char* name, const float* da
 }
 
 extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
-  ST2_REQUIRE(e && (which & 31) != 0, "st2_finalize_weights: bad arguments");
+  ST2_REQUIRE(e && (which & 63) != 0, "st2_finalize_weights: bad arguments");
   Blob blob;
   std::string err;
   if (which & 1) ST2_REQUIRE(pack_decoder(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
@@ -1694,6 +1875,17 @@ extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
   else e->text.ready = false;
   if (which & 16) ST2_REQUIRE(pack_bert(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
   else e->bert.ready = false;
+  e->style[0].ready = e->style[1].ready = false;
+  if (which & 32) {
+    int found = 0;
+    for (int k = 0; k < 2; ++k)
+      if (e->host.count(std::string(k == 0 ? "style_encoder." : "predictor_encoder.") + "shared.0.weight")) {
+        ST2_REQUIRE(pack_style(*e, blob, k, &err) == 0, "st2_finalize_weights: %s", err.c_str());
+        ++found;
+      }
+    ST2_REQUIRE(found > 0, "st2_finalize_weights: no style_encoder.* / predictor_encoder.* parameters were loaded");
+    e->zeros = blob.add_f32(std::vector<float>((size_t)STYLE_ZEROS, 0.0f));
+  }
   if (e->wbase) {
     g_be.dev_free(e->wbase);
     e->wbase = nullptr;
@@ -1786,6 +1978,32 @@ extern "C" int st2_bert_forward(st2_engine* e, const int64_t* tokens, const int3
   ST2_REQUIRE(!c.a.overflow, "st2_bert_forward: workspace of %lld B is too small (need %lld B, see st2_bert_workspace_bytes)",
               (long long)workspace_bytes, (long long)c.a.peak);
   return c.rc;
+}
+
+extern "C" int64_t st2_style_workspace_bytes(st2_engine* e, int32_t which, int32_t B, int32_t n_mels, int32_t T) {
+  if (!e || which < 0 || which > 1 || !e->style[which].ready || B <= 0 || n_mels != 80 || T < 80) return -1;
+  Ctx c;
+  c.dry = true;
+  c.a.dry = true;
+  style_plan(c, *e, e->style[which], nullptr, B, n_mels, T, nullptr);
+  return c.a.peak + 256;
+}
+
+extern "C" int st2_style_forward(st2_engine* e, int32_t which, const float* mel, int32_t B, int32_t n_mels, int32_t T,
+                                 float* style, void* workspace, int64_t workspace_bytes, void* stream) {
+  ST2_REQUIRE(e && which >= 0 && which <= 1 && e->style[which].ready, "st2_style_forward: style-encoder weights not finalized");
+  ST2_REQUIRE(mel && style && workspace && B > 0, "st2_style_forward: bad arguments");
+  ST2_REQUIRE(n_mels == 80 && T >= 80, "st2_style_forward: needs an 80-bin mel of >= 80 frames (four halvings, then the 5x5 "
+              "valid conv), got %d x %d", n_mels, T);
+  ST2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "st2_style_forward: workspace must be 256-byte aligned");
+  Ctx c;
+  c.stream = stream;
+  c.a.base = static_cast<char*>(workspace);
+  c.a.cap = workspace_bytes;
+  const int rc = style_plan(c, *e, e->style[which], mel, B, n_mels, T, style);
+  ST2_REQUIRE(!c.a.overflow, "st2_style_forward: workspace of %lld B is too small (need %lld B, see st2_style_workspace_bytes)",
+              (long long)workspace_bytes, (long long)c.a.peak);
+  return rc;
 }
 
 extern "C" int st2_sizeof_front_args(void) { return (int)sizeof(st2_front_args); }

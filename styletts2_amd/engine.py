@@ -178,6 +178,24 @@ class Engine:
                                              t_en.data_ptr(), ws_ptr, nbytes, stream), "st2_text_forward")
         return t_en
 
+    # -- reference-audio style encoders ---------------------------------------------------------------------------------------
+    def style_forward(self, which, mel):
+        """mel [B, 1, 80, T] or [B, 80, T] (normalised log-mel, T >= 80) -> [B, style_dim]: one `st2_style_forward` call;
+        which = 0 `style_encoder`, 1 `predictor_encoder`."""
+        mel = mel.float().reshape(mel.shape[0], mel.shape[-2], mel.shape[-1]).contiguous()
+        B, H, T = mel.shape
+        dev = mel.device
+        nbytes = self.lib.st2_style_workspace_bytes(self.h, which, B, H, T)
+        if nbytes <= 0:
+            raise _lib.St2Error("st2_style_workspace_bytes failed (style-encoder weights not finalized, or not an 80 x >= 80 mel)")
+        out = torch.empty((B, self.style_dims[which]), device=dev, dtype=torch.float32)
+        ws = torch.empty((nbytes + 256,), device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(self.lib.st2_style_forward(self.h, which, mel.data_ptr(), B, H, T, out.data_ptr(), ws_ptr, nbytes, stream),
+                   "st2_style_forward")
+        return out
+
     # -- PL-BERT ---------------------------------------------------------------------------------------------------------
     def bert_forward(self, tokens, lengths=None):
         """tokens int64 [B, N], lengths int32 [B] on the device or None -> last hidden state [B, N, hidden] (a transposed
@@ -326,6 +344,37 @@ def build_text_engine(text_encoder, device):
     eng = Engine(cfg)
     eng.load_module("text_encoder.", text_encoder)
     eng.finalize(8, device)
+    return eng
+
+
+def _style_state(enc):
+    """StyleEncoder parameters as st2_load_weights wants them: every spectral-norm triple folded on the host
+    (X.weight = weight_orig / (u . (W_mat v)), style._SNConv2d.folded_host), plain tensors as they are."""
+    from .style import _SNConv2d
+    out = {}
+    for name, m in enc.named_modules():
+        if isinstance(m, _SNConv2d):
+            out[name + ".weight"] = m.folded_host()
+            if m.bias is not None:
+                out[name + ".bias"] = m.bias.detach().float().cpu()
+    out["unshared.weight"] = enc.unshared.weight.detach().float().cpu()
+    out["unshared.bias"] = enc.unshared.bias.detach().float().cpu()
+    return out
+
+
+def build_style_engine(style_encoder, predictor_encoder, device):
+    """Engine handle holding the two reference-audio style encoders (st2_style_forward; either may be None)."""
+    cfg = _lib.ModelConfig()
+    cfg.decoder_kind, cfg.dim_in, cfg.upsample_initial_channel, cfg.style_dim = 0, 512, 512, 128
+    cfg.n_upsamples, cfg.n_resblock_kernels = 1, 1
+    eng = Engine(cfg)
+    eng.style_dims = [0, 0]
+    for which, (prefix, enc) in enumerate((("style_encoder.", style_encoder), ("predictor_encoder.", predictor_encoder))):
+        if enc is not None:
+            for k, v in _style_state(enc).items():
+                eng.load(prefix + k, v)
+            eng.style_dims[which] = enc.unshared.out_features
+    eng.finalize(32, device)
     return eng
 
 

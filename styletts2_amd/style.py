@@ -19,7 +19,8 @@ Both the encoders and the mel front-end run on the engine's HIP kernels (`forwar
   * mel: `st2_stft_frames` (reflect-padded frame columns) -> windowed DFT as an exact-fp32 MFMA k=1 conv
     [2050][1200] -> `st2_power_spectrum` -> mel filter bank as a k=1 conv [80][1025] -> `st2_log_norm`.
 `forward_torch` / `mel_spectrogram` are the same maths on PyTorch ops (A-B path, `ST2_STYLE=torch`; the CPU metric
-helper of the parity tests).  There is no silent fallback: CPU tensors raise unless ST2_STYLE=torch.
+helper of the parity tests).  `ST2_STYLE=plan` runs the two encoders as C++ launch plans (`st2_style_forward`,
+csrc/st2_engine.hip style_plan: the same kernels issued from C++; validated on the CPU backend, tests/test_engine_cpu.py).  There is no silent fallback: CPU tensors raise unless ST2_STYLE=torch.
 
 The mel front-end restates `torchaudio.transforms.MelSpectrogram(n_mels=80, n_fft=2048, win_length=1200,
 hop_length=300)` with torchaudio's defaults (power 2, periodic Hann window zero-padded to n_fft, centre + reflect
@@ -308,12 +309,28 @@ def mel_spectrogram_engine(wave, n_fft=2048, win_length=1200, hop_length=300, n_
     return ops.log_norm_(mel, 1e-5, MEL_MEAN, MEL_STD)
 
 
+def _style_engine(model, dev):
+    """The st2_engine handle behind ST2_STYLE=plan, packed once per (weights, device)."""
+    from . import engine
+    mods = [model.style_encoder, model.predictor_encoder]
+    stamp = tuple((p.data_ptr(), p._version) for m in mods for p in list(m.parameters()) + list(m.buffers()))
+    cached = getattr(model.style_encoder, "_plan_engine", None)
+    if cached is None or cached[0] != stamp or cached[1].device != dev:
+        cached = (stamp, engine.build_style_engine(model.style_encoder, model.predictor_encoder, dev))
+        model.style_encoder._plan_engine = cached
+    return cached[1]
+
+
 @torch.no_grad()
 def compute_style(model, wave):
     """`compute_style` of Demo/Inference_LibriTTS.ipynb:100-111 minus the file I/O: wave [L] or [B, L] at 24 kHz
     (already trimmed; the notebook trims with librosa.effects.trim(top_db=30) on the host) -> ref_s [B, 256]."""
     if wave.dim() == 1:
         wave = wave.unsqueeze(0)
+    if os.environ.get("ST2_STYLE", "engine") == "plan":  # both encoders as C++ launch plans (st2_style_forward)
+        mel = mel_spectrogram_engine(wave)
+        eng = _style_engine(model, wave.device)
+        return torch.cat([eng.style_forward(0, mel), eng.style_forward(1, mel)], dim=1)
     if os.environ.get("ST2_STYLE", "engine") == "torch":
         mel = mel_spectrogram(wave).unsqueeze(1)                   # [B, 1, 80, T]
     else:

@@ -308,6 +308,18 @@ def embed_tokens(tokens, B, N, table, V, E, add, pos, length, y, y_bs, y_cs, str
     return 0
 
 
+def dwconv3x3s2(x, x_bs, x_hs, x_cs, w, bias, B, Cc, H, W, y, y_bs, y_hs, y_cs, stream):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    R.dwconv3x3s2(_t(x, (B, H, Cc, W), (x_bs, x_hs, x_cs, 1)), _t(w, (Cc, 3, 3), (9, 3, 1)), _t(bias, (Cc,), (1,)),
+                  _t(y, (B, Ho, Cc, Wo), (y_bs, y_hs, y_cs, 1)))
+    return 0
+
+
+def avgpool2x2(x, x_bs, x_hs, x_cs, B, Cc, H, W, y, y_bs, y_hs, y_cs, stream):
+    R.avgpool2x2(_t(x, (B, H, Cc, W), (x_bs, x_hs, x_cs, 1)), _t(y, (B, H // 2, Cc, (W + 1) // 2), (y_bs, y_hs, y_cs, 1)))
+    return 0
+
+
 def dev_alloc(nbytes):
     buf = C.create_string_buffer(int(nbytes) + 512)
     addr = (C.addressof(buf) + 255) & ~255

@@ -9,6 +9,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+echo "== style plan probe"; timeout 200 python tools/probe_style_plan.py > $OUT/style_plan.log 2>&1; tail -4 $OUT/style_plan.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 echo "== bench (default: Python front under a hipGraph)"; timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python -c "import json;r=json.load(open('$OUT/bench.json'));print(r['ms_per_step'], r['value'], r['config']['host_issue_ms_per_step'], r['roofline']['frac'])"
