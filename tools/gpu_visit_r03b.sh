@@ -13,4 +13,9 @@ for k in 11 7; do
     echo "== F(3,3) k=$k TN=$tn"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 $tn | tee -a $OUT/wino_bench.log
   done
 done
+for d in 3 5; do   # dilated convs1 (residue-major output) and the convs2 behind them (residue-major input)
+  echo "== production kernel k=11 dil=$d"; timeout 120 tools/bin/xs_bench_0 11 $d 128 48001 32 0 1 10 | tee -a $OUT/xs_bench.log
+  echo "== F(3,3) k=11 dil=$d"; timeout 120 tools/bin/wino_bench 11 128 48001 32 10 2 $d 1 | tee -a $OUT/wino_bench.log
+  echo "== F(3,3) k=11 dil=1 behind dil=$d"; timeout 120 tools/bin/wino_bench 11 128 48001 32 10 2 1 $d | tee -a $OUT/wino_bench.log
+done
 echo "== C=256, L=8000"; timeout 120 tools/bin/xs_bench_0 11 1 256 8000 32 1 1 10 | tee -a $OUT/xs_bench.log; timeout 120 tools/bin/wino_bench 11 256 8000 32 10 2 | tee -a $OUT/wino_bench.log

@@ -5,8 +5,9 @@
 //
 //   tools/bin/wino_bench selftest        no GPU: host emulation of the kernels' data flow through the same checker
 //   tools/bin/wino_bench check           small shapes (edge tiles included) against a direct fp64 conv on the host
-//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2]   timing of the transform pass and the conv
-//                                          (TN = 32-tile blocks per wave: 2 -> 2 workgroups / CU, 1 -> 3 workgroups / CU)
+//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2] [dil=1] [src_dil=1]   timing of both kernels
+//                                          (TN = 32-tile blocks per wave: 2 -> 2 workgroups / CU, 1 -> 3 workgroups / CU;
+//                                           dil = the conv's dilation, src_dil = dilation of the layer that produced x)
 //
 // Maths (points 0, 1, -1, 2, inf; verified on the CPU by tools/winograd_numerics.py):
 //   y[3T + i] = sum_j w[j] a[3T + i + j - pad],  w zero-padded to 3G taps, group g = taps 3g .. 3g + 2
@@ -59,6 +60,10 @@ struct WArgs {
   const float* res; int64_t res_bs; int res_cs;
   float* part; int part_nt;   // per (b, co, tile block of 96 TN outputs): (sum, sum of squares) of the stored values
   int C_out, L_out;
+  // dilation d > 1: the grid's batch index is the VIRTUAL batch vb = b * d + r, one per residue r of l = d q + r; the kernel
+  // convolves the stride-d subsequence a_r[q] = a[d q + r] (planes and output are per virtual batch: the output tensor is
+  // residue-major [b][r][co][q], which the next activation pass un-permutes) and L_out is the natural length
+  int dil;
 };
 
 template <int N, class F>
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
   const int t0 = blockIdx.x * BT_;        // first tile
   const int m0 = blockIdx.y * 128;
   const int b = blockIdx.z;
+  const int L_eff = d.dil > 1 ? (d.L_out - (b % d.dil) + d.dil - 1) / d.dil : d.L_out;  // outputs of this (virtual) batch item
 
   const int64_t pstride = (int64_t)d.cg_tot * d.Lt;      // slots per (plane, point)
   const int64_t plane_stride = (int64_t)P * pstride;     // slots per plane
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs + (int64_t)coc * d.res_cs : nullptr;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.y) | (uintptr_t)(d.y_bs * 4) | (uintptr_t)(d.y_cs * 4)) & 15) == 0 &&
                       (!d.res || ((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0);
-  const bool full = vec_ok && m0 + 128 <= d.C_out && 3 * (t0 + BT_) <= d.L_out;  // workgroup-uniform
+  const bool full = vec_ok && m0 + 128 <= d.C_out && 3 * (t0 + BT_) <= L_eff;  // workgroup-uniform
   float s1 = 0.f, s2 = 0.f;
   static_for<TN * 4>([&](auto jq_tag) __attribute__((always_inline)) {
     constexpr int j = decltype(jq_tag)::value / 4, q = decltype(jq_tag)::value % 4;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
 #pragma unroll
       for (int e = 0; e < 12; ++e) {
         const int l = l0 + e;
-        const bool ok = rok && l < d.L_out;
+        const bool ok = rok && l < L_eff;
         float t = fmaf(o[e], osc_r, bias_r);
         if (rb) t += ok ? rb[l] : 0.f;
         if (ok) {
@@ -275,6 +281,8 @@ struct AArgs {
   const float* stats; const float* gamma; const float* beta; int64_t gb_bs; const float* alpha;
   float x_scale;
   h8* vs; int cg_tot; int Lt;
+  int dil;      // conv dilation d: grid z = B * d virtual batch items, item (b, r) transforms a_r[q] = a[d q + r]; pad in q units
+  int src_dil;  // > 1: x is the residue-major output of a dilated layer, x[(b * src_dil + l % src_dil)][ci][l / src_dil]
 };
 
 constexpr int AT_TILES = 256;
@@ -286,15 +294,22 @@ __global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
   __shared__ float sa[8 * AT_PITCH];
   const int tile0 = blockIdx.x * AT_TILES;
   const int cg = blockIdx.y;
-  const int b = blockIdx.z;
-  const int p0 = 3 * tile0 - a.pad;  // first input position of the workgroup
+  const int vb = blockIdx.z;
+  const int b = vb / a.dil, r = vb - b * a.dil;
+  const int p0 = 3 * tile0 - a.pad;  // first input position (in q units) of the workgroup
   for (int idx = threadIdx.x; idx < 8 * AT_POS; idx += 256) {
     const int e = idx / AT_POS, i = idx - e * AT_POS;
-    const int l = p0 + i;
+    const int q = p0 + i;
+    const int l = a.dil * q + r;  // natural position
     const int ci = cg * 8 + e;
     float u = 0.f;
-    if (l >= 0 && l < a.L && ci < a.C) {
-      u = a.x[(int64_t)b * a.x_bs + (int64_t)ci * a.x_cs + l];
+    if (q >= 0 && l < a.L && ci < a.C) {
+      if (a.src_dil > 1) {
+        const int rs = l % a.src_dil, qs = l / a.src_dil;
+        u = a.x[((int64_t)b * a.src_dil + rs) * a.x_bs + (int64_t)ci * a.x_cs + qs];
+      } else {
+        u = a.x[(int64_t)b * a.x_bs + (int64_t)ci * a.x_cs + l];
+      }
       if constexpr (PRO == 1) {
         const float* st = a.stats + ((int64_t)b * a.C + ci) * 2;
         const float g = 1.0f + a.gamma[(int64_t)b * a.gb_bs + ci];
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
     }
   }
   const int64_t pstride = (int64_t)a.cg_tot * a.Lt;
-  h8* dst = a.vs + (int64_t)b * 2 * P * pstride + (int64_t)cg * a.Lt + T;
+  h8* dst = a.vs + (int64_t)vb * 2 * P * pstride + (int64_t)cg * a.Lt + T;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     dst[p * pstride] = hi[p];
@@ -424,81 +439,136 @@ static int launch_conv(const WArgs& d, int B) {
   return 0;
 }
 
-static int check_result(int TN, int K, int C, int L, int B, bool adain, int pitch, int nblk, const std::vector<float>& hx,
-                        const std::vector<float>& hres, const std::vector<float>& hw, const std::vector<float>& hb,
-                        const std::vector<float>& hst, const std::vector<float>& hga, const std::vector<float>& hbe,
-                        const std::vector<float>& hal, const std::vector<float>& hy, const std::vector<float>& hpart, bool host) {
-  const int pad = (K - 1) / 2, BT_ = 32 * TN;
-    std::vector<double> act((size_t)C * L);
-    double err = 0.0, ymax = 0.0, perr = 0.0, pmax = 0.0;
-    for (int b = 0; b < B; ++b) {
-      for (int ci = 0; ci < C; ++ci)
-        for (int l = 0; l < L; ++l) {
-          double u = hx[((size_t)b * C + ci) * pitch + l];
-          if (adain) {
-            const double w = (u - hst[((size_t)b * C + ci) * 2]) * hst[((size_t)b * C + ci) * 2 + 1];
-            u = snake_ref((1.0 + hga[(size_t)b * C + ci]) * w + hbe[(size_t)b * C + ci], hal[ci]);
-          }
-          act[(size_t)ci * L + l] = u;
-        }
-      for (int co = 0; co < C; ++co) {
-        std::vector<double> row(L, (double)hb[co]);
-        for (int ci = 0; ci < C; ++ci)
-          for (int j = 0; j < K; ++j) {
-            const double wv = hw[((size_t)co * C + ci) * K + j];
-            const int lo = std::max(0, pad - j), hi = std::min(L, L + pad - j);
-            const double* ar = act.data() + (size_t)ci * L + (j - pad);
-            for (int l = lo; l < hi; ++l) row[l] += wv * ar[l];
-          }
-        std::vector<double> s1(nblk, 0.0), s2(nblk, 0.0);
-        for (int l = 0; l < L; ++l) {
-          const double ref = row[l] + hres[((size_t)b * C + co) * pitch + l];
-          const double got = hy[((size_t)b * C + co) * pitch + l];
-          err = std::fmax(err, std::fabs(got - ref));
-          ymax = std::fmax(ymax, std::fabs(ref));
-          s1[l / (3 * BT_)] += got;
-          s2[l / (3 * BT_)] += got * got;
-        }
-        for (int t = 0; t < nblk; ++t) {
-          const float* pp = hpart.data() + (((size_t)b * C + co) * nblk + t) * 2;
-          perr = std::fmax(perr, std::fmax(std::fabs(pp[0] - s1[t]), std::fabs(pp[1] - s2[t])));
-          pmax = std::fmax(pmax, std::fmax(std::fabs(s1[t]), std::fabs(s2[t])));
-        }
-      }
-    }
-    const bool ok = err < 2e-5 * ymax && perr < 1e-4 * pmax;
-    printf("wino %s TN=%d k=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums %.3e of %.3e  -> %s\n", host ? "selftest (host emulation)" : "check", TN, K, C, L,
-           B, (int)adain, err, ymax, perr, pmax, ok ? "OK" : "MISMATCH");
-    return ok ? 0 : 1;
+struct Case {
+  int TN, K, C, L, B, dil, src_dil;
+  bool adain;
+  // derived
+  int G, padq, Lq, n_tiles, BT_, nblk, Lt, cg_tot, pitch, pitch_q, pitch_s, VB;
+  void derive() {
+    G = (K + 2) / 3; padq = (K - 1) / 2;
+    Lq = (L + dil - 1) / dil;                       // longest stride-d subsequence
+    n_tiles = (Lq + 2) / 3; BT_ = 32 * TN; nblk = (n_tiles + BT_ - 1) / BT_;
+    Lt = nblk * BT_ + 8;                            // every workgroup stages BT_ + G - 1 <= BT_ + 3 tiles
+    cg_tot = (C + 15) / 16 * 16 / 8;
+    pitch = (L + 31) / 32 * 32;                     // natural rows (host reference, residual)
+    pitch_q = (Lq + 31) / 32 * 32;                  // output rows: y[vb = b * dil + r][co][q]
+    pitch_s = ((L + src_dil - 1) / src_dil + 31) / 32 * 32;  // input rows when x is residue-major
+    VB = B * dil;
+  }
+};
+
+struct HostData {
+  std::vector<float> hx, hxsrc, hres, hw, hb, hst, hga, hbe, hal;  // hx natural [B][C][pitch]; hxsrc = what the device reads
+};
+
+static void make_data(const Case& c, HostData& h) {
+  h.hx.assign((size_t)c.B * c.C * c.pitch, 0.f); h.hres.assign((size_t)c.B * c.C * c.pitch, 0.f);
+  h.hw.resize((size_t)c.C * c.C * c.K); h.hb.resize(c.C); h.hst.resize((size_t)c.B * c.C * 2);
+  h.hga.resize((size_t)c.B * c.C); h.hbe.resize((size_t)c.B * c.C); h.hal.resize(c.C);
+  rng_state = 777u + c.K * 131 + c.L + 7 * c.dil + 3 * c.src_dil;
+  for (auto& v : h.hx) v = 1.5f * frand();
+  for (auto& v : h.hres) v = frand();
+  const float wsc = 1.0f / std::sqrt((float)(c.C * c.K));
+  for (auto& v : h.hw) v = 1.7f * wsc * frand();
+  for (auto& v : h.hb) v = 0.3f * frand();
+  for (size_t i = 0; i < h.hst.size(); i += 2) { h.hst[i] = 0.2f * frand(); h.hst[i + 1] = 1.0f + 0.3f * frand(); }
+  for (auto& v : h.hga) v = 0.3f * frand();
+  for (auto& v : h.hbe) v = 0.3f * frand();
+  for (auto& v : h.hal) v = 1.0f + 0.5f * frand();
+  if (c.src_dil > 1) {  // the residue-major layout a dilated layer leaves behind
+    h.hxsrc.assign((size_t)c.B * c.src_dil * c.C * c.pitch_s, 0.f);
+    for (int b = 0; b < c.B; ++b)
+      for (int ci = 0; ci < c.C; ++ci)
+        for (int l = 0; l < c.L; ++l)
+          h.hxsrc[(((size_t)b * c.src_dil + l % c.src_dil) * c.C + ci) * c.pitch_s + l / c.src_dil] =
+              h.hx[((size_t)b * c.C + ci) * c.pitch + l];
+  } else {
+    h.hxsrc = h.hx;
+  }
 }
 
-// Host emulation of the two kernels' DATA FLOW (same plane / packed-weight index formulas, same transform constants, fp64
-// accumulation instead of MFMA): `wino_bench selftest` runs it through the same checker without a GPU, so that the packer,
-// the layouts, the transforms and the checker itself are known to be consistent before the first GPU visit.
-static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pitch, int Lt, int cg_tot, int nblk,
-                         const std::vector<float>& hx, const std::vector<float>& hres, const std::vector<float>& hb,
-                         const std::vector<float>& hst, const std::vector<float>& hga, const std::vector<float>& hbe,
-                         const std::vector<float>& hal, const Packed& pk, std::vector<float>& hy, std::vector<float>& hpart,
-                         std::vector<_Float16>& vs) {
-  const int G = (K + 2) / 3, pad = (K - 1) / 2, BT_ = 32 * TN;
-  vs.assign((size_t)B * 2 * P * cg_tot * Lt * 8, (_Float16)0.0f);
-  auto a_at = [&](int b, int ci, int l) -> float {
-    if (l < 0 || l >= L || ci >= C) return 0.f;
-    float u = hx[((size_t)b * C + ci) * pitch + l];
-    if (adain) {
-      float w = (u - hst[((size_t)b * C + ci) * 2]) * hst[((size_t)b * C + ci) * 2 + 1];
-      w = (1.0f + hga[(size_t)b * C + ci]) * w + hbe[(size_t)b * C + ci];
-      const float al = hal[ci], sn = sinf(al * w);
+// hy [VB][C][pitch_q], hpart [VB][C][nblk][2] (device layouts) against a direct fp64 dilated conv of the natural tensors
+static int check_result(const Case& c, const HostData& h, const std::vector<float>& hy, const std::vector<float>& hpart,
+                        const char* what) {
+  const int C = c.C, L = c.L, K = c.K;
+  std::vector<double> act((size_t)C * L);
+  double err = 0.0, ymax = 0.0, perr = 0.0, pmax = 0.0;
+  for (int b = 0; b < c.B; ++b) {
+    for (int ci = 0; ci < C; ++ci)
+      for (int l = 0; l < L; ++l) {
+        double u = h.hx[((size_t)b * C + ci) * c.pitch + l];
+        if (c.adain) {
+          const double w = (u - h.hst[((size_t)b * C + ci) * 2]) * h.hst[((size_t)b * C + ci) * 2 + 1];
+          u = snake_ref((1.0 + h.hga[(size_t)b * C + ci]) * w + h.hbe[(size_t)b * C + ci], h.hal[ci]);
+        }
+        act[(size_t)ci * L + l] = u;
+      }
+    for (int co = 0; co < C; ++co) {
+      std::vector<double> row(L, (double)h.hb[co]);
+      for (int ci = 0; ci < C; ++ci)
+        for (int j = 0; j < K; ++j) {
+          const double wv = h.hw[((size_t)co * C + ci) * K + j];
+          const int off = (j - c.padq) * c.dil;
+          const int lo = std::max(0, -off), hi = std::min(L, L - off);
+          const double* ar = act.data() + (size_t)ci * L + off;
+          for (int l = lo; l < hi; ++l) row[l] += wv * ar[l];
+        }
+      std::vector<double> s1((size_t)c.dil * c.nblk, 0.0), s2((size_t)c.dil * c.nblk, 0.0);
+      for (int l = 0; l < L; ++l) {
+        const int r = l % c.dil, q = l / c.dil;
+        const double ref = row[l] + (c.dil == 1 ? (double)h.hres[((size_t)b * C + co) * c.pitch + l] : 0.0);
+        const double got = hy[(((size_t)b * c.dil + r) * C + co) * c.pitch_q + q];
+        err = std::fmax(err, std::fabs(got - ref));
+        ymax = std::fmax(ymax, std::fabs(ref));
+        s1[(size_t)r * c.nblk + q / (3 * c.BT_)] += got;
+        s2[(size_t)r * c.nblk + q / (3 * c.BT_)] += got * got;
+      }
+      for (int r = 0; r < c.dil; ++r)
+        for (int t = 0; t < c.nblk; ++t) {
+          const float* pp = hpart.data() + ((((size_t)b * c.dil + r) * C + co) * c.nblk + t) * 2;
+          perr = std::fmax(perr, std::fmax(std::fabs(pp[0] - s1[(size_t)r * c.nblk + t]), std::fabs(pp[1] - s2[(size_t)r * c.nblk + t])));
+          pmax = std::fmax(pmax, std::fmax(std::fabs(s1[(size_t)r * c.nblk + t]), std::fabs(s2[(size_t)r * c.nblk + t])));
+        }
+    }
+  }
+  const bool ok = err < 2e-5 * ymax && perr < 1e-4 * pmax;
+  printf("wino %s TN=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums %.3e of %.3e"
+         "  -> %s\n", what, c.TN, K, c.dil, c.src_dil, C, L, c.B, (int)c.adain, err, ymax, perr, pmax, ok ? "OK" : "MISMATCH");
+  return ok ? 0 : 1;
+}
+
+// Host emulation of the two kernels' DATA FLOW (same plane / packed-weight / permutation index formulas, same transform
+// constants, fp64 accumulation instead of MFMA): `wino_bench selftest` runs it through the same checker without a GPU, so
+// that the packer, the layouts, the transforms and the checker itself are known to be consistent before the first GPU visit.
+static void host_act(const Case& c, const HostData& h, std::vector<_Float16>& vs) {
+  vs.assign((size_t)c.VB * 2 * P * c.cg_tot * c.Lt * 8, (_Float16)0.0f);
+  const int x_cs = c.src_dil > 1 ? c.pitch_s : c.pitch;
+  const int64_t x_bs = (int64_t)c.C * x_cs;
+  auto a_rq = [&](int b, int r, int ci, int q) -> float {  // act_w3_kernel's staging loop
+    const int l = c.dil * q + r;
+    if (!(q >= 0 && l < c.L && ci < c.C)) return 0.f;
+    float u;
+    if (c.src_dil > 1) {
+      const int rs = l % c.src_dil, qs = l / c.src_dil;
+      u = h.hxsrc[((int64_t)b * c.src_dil + rs) * x_bs + (int64_t)ci * x_cs + qs];
+    } else {
+      u = h.hxsrc[(int64_t)b * x_bs + (int64_t)ci * x_cs + l];
+    }
+    if (c.adain) {
+      float w = (u - h.hst[((size_t)b * c.C + ci) * 2]) * h.hst[((size_t)b * c.C + ci) * 2 + 1];
+      w = (1.0f + h.hga[(size_t)b * c.C + ci]) * w + h.hbe[(size_t)b * c.C + ci];
+      const float al = h.hal[ci], sn = sinf(al * w);
       u = w + (1.0f / al) * (sn * sn);
     }
     return u * 8.f;
   };
-  for (int b = 0; b < B; ++b)
-    for (int cg = 0; cg < cg_tot; ++cg)
-      for (int T = 0; T < Lt; ++T)
+  for (int vb = 0; vb < c.VB; ++vb) {
+    const int b = vb / c.dil, r = vb - b * c.dil;
+    for (int cg = 0; cg < c.cg_tot; ++cg)
+      for (int T = 0; T < c.Lt; ++T)
         for (int e = 0; e < 8; ++e) {
           float dd[5];
-          for (int n = 0; n < 5; ++n) dd[n] = a_at(b, cg * 8 + e, 3 * T - pad + n);
+          for (int n = 0; n < 5; ++n) dd[n] = a_rq(b, r, cg * 8 + e, 3 * T - c.padq + n);
           float v[P];
           v[0] = (2.f * dd[0] - dd[1]) + (dd[3] - 2.f * dd[2]);
           v[1] = (dd[3] - dd[2]) - 2.f * dd[1];
@@ -507,29 +577,36 @@ static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pit
           v[4] = (2.f * dd[1] - dd[2]) + (dd[4] - 2.f * dd[3]);
           for (int p = 0; p < P; ++p) {
             const float uc = v[p] > 65504.f ? 65504.f : (v[p] < -65504.f ? -65504.f : v[p]);
-            const _Float16 h = (_Float16)uc;
-            vs[(((((size_t)b * 2 + 0) * P + p) * cg_tot + cg) * Lt + T) * 8 + e] = h;
-            vs[(((((size_t)b * 2 + 1) * P + p) * cg_tot + cg) * Lt + T) * 8 + e] = (_Float16)(uc - (float)h);
+            const _Float16 hh = (_Float16)uc;
+            vs[(((((size_t)vb * 2 + 0) * P + p) * c.cg_tot + cg) * c.Lt + T) * 8 + e] = hh;
+            vs[(((((size_t)vb * 2 + 1) * P + p) * c.cg_tot + cg) * c.Lt + T) * 8 + e] = (_Float16)(uc - (float)hh);
           }
         }
-  hy.assign(hx.size(), 0.f);
-  hpart.assign((size_t)B * C * nblk * 2, 0.f);
+  }
+}
+
+static void host_conv(const Case& c, const HostData& h, const Packed& pk, const std::vector<_Float16>& vs, std::vector<float>& hy,
+                      std::vector<float>& hpart) {
+  hy.assign((size_t)c.VB * c.C * c.pitch_q, 0.f);
+  hpart.assign((size_t)c.VB * c.C * c.nblk * 2, 0.f);
   const int ks = pk.ks_eff;
-  for (int b = 0; b < B; ++b)
-    for (int co = 0; co < C; ++co) {
+  for (int vb = 0; vb < c.VB; ++vb) {
+    const int b = vb / c.dil, r = vb - b * c.dil;
+    const int L_eff = c.dil > 1 ? (c.L - r + c.dil - 1) / c.dil : c.L;
+    for (int co = 0; co < c.C; ++co) {
       const float osc_r = (1.f / 8.f) * pk.row_scale[co];
-      for (int blk = 0; blk < nblk; ++blk) {
+      for (int blk = 0; blk < c.nblk; ++blk) {
         double s1 = 0.0, s2 = 0.0;
-        for (int tt = 0; tt < BT_; ++tt) {
-          const int T = blk * BT_ + tt;
+        for (int tt = 0; tt < c.BT_; ++tt) {
+          const int T = blk * c.BT_ + tt;
           double Y[P] = {0, 0, 0, 0, 0};
           for (int i16 = 0; i16 < pk.cin_pad / 16; ++i16)
-            for (int g = 0; g < G; ++g)
+            for (int g = 0; g < c.G; ++g)
               for (int p = 0; p < P; ++p)
                 for (int kg = 0; kg < 2; ++kg) {
                   const size_t wb = ((((size_t)i16 * ks + (g * P + p)) * 2 + kg) * pk.co_pad + co) * 16;
-                  const size_t xh = (((((size_t)b * 2 + 0) * P + p) * cg_tot + (i16 * 2 + kg)) * Lt + T + g) * 8;
-                  const size_t xl = (((((size_t)b * 2 + 1) * P + p) * cg_tot + (i16 * 2 + kg)) * Lt + T + g) * 8;
+                  const size_t xh = (((((size_t)vb * 2 + 0) * P + p) * c.cg_tot + (i16 * 2 + kg)) * c.Lt + T + g) * 8;
+                  const size_t xl = (((((size_t)vb * 2 + 1) * P + p) * c.cg_tot + (i16 * 2 + kg)) * c.Lt + T + g) * 8;
                   for (int e8 = 0; e8 < 8; ++e8) {
                     const double wh = (double)(float)pk.q[wb + e8], wl = (double)(float)pk.q[wb + 8 + e8];
                     const double ah = (double)(float)vs[xh + e8], al = (double)(float)vs[xl + e8];
@@ -538,18 +615,20 @@ static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pit
                 }
           const double o[3] = {(Y[0] + Y[1]) + (Y[2] + Y[3]), (Y[1] - Y[2]) + 2.0 * Y[3], (Y[1] + Y[2]) + (4.0 * Y[3] + Y[4])};
           for (int i = 0; i < 3; ++i) {
-            const int l = 3 * T + i;
-            if (l >= L) continue;
-            const float t = fmaf((float)o[i], osc_r, hb[co]) + hres[((size_t)b * C + co) * pitch + l];
-            hy[((size_t)b * C + co) * pitch + l] = t;
+            const int q = 3 * T + i;
+            if (q >= L_eff) continue;
+            float t = fmaf((float)o[i], osc_r, h.hb[co]);
+            if (c.dil == 1) t += h.hres[((size_t)b * c.C + co) * c.pitch + q];
+            hy[((size_t)vb * c.C + co) * c.pitch_q + q] = t;
             s1 += t;
             s2 += (double)t * t;
           }
         }
-        hpart[(((size_t)b * C + co) * nblk + blk) * 2 + 0] = (float)s1;
-        hpart[(((size_t)b * C + co) * nblk + blk) * 2 + 1] = (float)s2;
+        hpart[(((size_t)vb * c.C + co) * c.nblk + blk) * 2 + 0] = (float)s1;
+        hpart[(((size_t)vb * c.C + co) * c.nblk + blk) * 2 + 1] = (float)s2;
       }
     }
+  }
 }
 
 // Thread-level host twin of conv_w3_kernel (selftest only): the SAME index expressions as the device code -- staging
@@ -557,35 +636,38 @@ static void host_emulate(int TN, int K, int C, int L, int B, bool adain, int pit
 // addresses -- with the MFMA replaced by its documented semantics (A operand: lane (m, kg) holds A[m][8 kg .. 8 kg + 7];
 // B operand: lane (n, kg) holds B[8 kg .. 8 kg + 7][n]; D: lane (n, kg) register r holds D[8 (r / 4) + 4 kg + r % 4][n]).
 template <int G, int TN>
-static void host_twin_conv(const std::vector<_Float16>& vs, const Packed& pk, int cg_tot, int Lt, const std::vector<float>& bias,
-                           const std::vector<float>& hres, int pitch, int C_out, int L_out, int B, int nblk,
+static void host_twin_conv(const Case& c, const HostData& h, const Packed& pk, const std::vector<_Float16>& vs,
                            std::vector<float>& hy, std::vector<float>& hpart) {
   constexpr int BT_ = 32 * TN, XW = BT_ + G - 1, ROWS = 2 * P * CG, S = ROWS * XW, NS = (S + NT - 1) / NT, LBUF = NS * NT;
   constexpr int SPC = G * P;
+  const int cg_tot = c.cg_tot, Lt = c.Lt, C_out = c.C;
+  hy.assign((size_t)c.VB * c.C * c.pitch_q, 0.f);
+  hpart.assign((size_t)c.VB * c.C * c.nblk * 2, 0.f);
   const int64_t pstride = (int64_t)cg_tot * Lt, plane_stride = (int64_t)P * pstride;
   const int64_t a_step = (int64_t)2 * pk.co_pad * 2;
   const int nchunk = pk.cin_pad / CI_T;
   auto slot_of = [&](const std::vector<_Float16>& arr, int64_t h8_index, int e) { return (double)(float)arr[(size_t)h8_index * 8 + e]; };
   std::vector<int64_t> image(LBUF);  // LDS image: global h8 index staged into each slot
   std::vector<double> D((size_t)4 * P * TN * 32 * 32);
-  for (int b = 0; b < B; ++b)
+  for (int b = 0; b < c.VB; ++b) {  // b = the grid's (virtual) batch index
+    const int L_eff = c.dil > 1 ? (c.L - (b % c.dil) + c.dil - 1) / c.dil : c.L;
     for (int by = 0; by < (C_out + 127) / 128; ++by)
-      for (int bx = 0; bx < nblk; ++bx) {
+      for (int bx = 0; bx < c.nblk; ++bx) {
         const int t0 = bx * BT_, m0 = by * 128;
         const int64_t vsb = (int64_t)b * 2 * plane_stride + t0;
         std::fill(D.begin(), D.end(), 0.0);
-        for (int c = 0; c < nchunk; ++c) {
+        for (int ch = 0; ch < nchunk; ++ch) {
           for (int tid = 0; tid < NT; ++tid)
             for (int i = 0; i < NS; ++i) {
               const int slot = tid + i * NT;
               const int row = slot / XW, col = slot - row * XW;
               const int pl = row / (P * CG), rem = row % (P * CG), p = rem / CG, g8 = rem % CG;
               const int64_t soff = slot < S ? (pl * plane_stride + p * pstride + (int64_t)g8 * Lt + col) : 0;
-              image[tid + i * NT] = vsb + (int64_t)c * CG * Lt + soff;
+              image[tid + i * NT] = vsb + (int64_t)ch * CG * Lt + soff;
             }
           for (int i = 0; i < SPC; ++i) {
             const int g = i / P, p = i % P;
-            const int64_t step = (int64_t)c * SPC + i;
+            const int64_t step = (int64_t)ch * SPC + i;
             for (int wave = 0; wave < 4; ++wave)
               for (int j = 0; j < TN; ++j)
                 for (int m = 0; m < 32; ++m)      // A-operand lane l31 = m
@@ -607,133 +689,115 @@ static void host_twin_conv(const std::vector<_Float16>& vs, const Packed& pk, in
           }
         }
         for (int wave = 0; wave < 4; ++wave)
-          for (int lane = 0; lane < 64; lane += 1) {
+          for (int lane = 0; lane < 64; ++lane) {
             const int kg = lane >> 5, l31 = lane & 31;
             const int co = m0 + wave * 32 + l31;
-            const bool rok = co < C_out;
-            if (!rok) continue;
+            if (co >= C_out) continue;
             const float osc_r = (1.f / 8.f) * pk.row_scale[co];
             double s1 = 0.0, s2 = 0.0;
             for (int j = 0; j < TN; ++j)
               for (int q = 0; q < 4; ++q) {
                 const int l0 = 3 * (t0 + 32 * j + 8 * q + 4 * kg);
                 for (int e = 0; e < 4; ++e) {
-                  const int r = 4 * q + e, m = 8 * (r / 4) + 4 * kg + r % 4;
+                  const int rr = 4 * q + e, m = 8 * (rr / 4) + 4 * kg + rr % 4;
                   double Y[P];
                   for (int p = 0; p < P; ++p) Y[p] = D[((((size_t)wave * P + p) * TN + j) * 32 + m) * 32 + l31];
                   const double o[3] = {(Y[0] + Y[1]) + (Y[2] + Y[3]), (Y[1] - Y[2]) + 2.0 * Y[3], (Y[1] + Y[2]) + (4.0 * Y[3] + Y[4])};
                   for (int i = 0; i < 3; ++i) {
                     const int l = l0 + 3 * e + i;
-                    if (l >= L_out) continue;
-                    const float t = fmaf((float)o[i], osc_r, bias[co]) + hres[((size_t)b * C_out + co) * pitch + l];
-                    hy[((size_t)b * C_out + co) * pitch + l] = t;
+                    if (l >= L_eff) continue;
+                    float t = fmaf((float)o[i], osc_r, h.hb[co]);
+                    if (c.dil == 1) t += h.hres[((size_t)b * C_out + co) * c.pitch + l];
+                    hy[((size_t)b * C_out + co) * c.pitch_q + l] = t;
                     s1 += t;
                     s2 += (double)t * t;
                   }
                 }
               }
-            float* pp = hpart.data() + (((size_t)b * C_out + co) * nblk + bx) * 2;  // lane + its kg partner
+            float* pp = hpart.data() + (((size_t)b * C_out + co) * c.nblk + bx) * 2;  // lane + its kg partner
             pp[0] += (float)s1;
             pp[1] += (float)s2;
           }
       }
+  }
 }
 
+// mode 0 = timing, 1 = GPU check, 2 = host selftest
 template <int TN>
-static int run_case(int K, int C, int L, int B, int reps, int mode, bool adain) {  // mode 0 bench, 1 GPU check, 2 host selftest
-  const bool check = mode != 0;
-  const int G = (K + 2) / 3;
-  const int pad = (K - 1) / 2;
-  const int n_tiles = (L + 2) / 3;
-  const int BT_ = 32 * TN;
-  const int Lt = (n_tiles + BT_ - 1) / BT_ * BT_ + 8;   // every workgroup stages BT_ + G - 1 <= BT_ + 3 tiles
-  const int cg_tot = (C + 15) / 16 * 16 / 8;
-  const int pitch = (L + 31) / 32 * 32;
-  const int nblk = (n_tiles + BT_ - 1) / BT_;
-
-  std::vector<float> hx((size_t)B * C * pitch), hres((size_t)B * C * pitch), hw((size_t)C * C * K), hb(C), hst((size_t)B * C * 2),
-      hga((size_t)B * C), hbe((size_t)B * C), hal(C);
-  rng_state = 777u + K * 131 + L;
-  for (auto& v : hx) v = 1.5f * frand();
-  for (auto& v : hres) v = frand();
-  const float wsc = 1.0f / std::sqrt((float)(C * K));
-  for (auto& v : hw) v = 1.7f * wsc * frand();
-  for (auto& v : hb) v = 0.3f * frand();
-  for (size_t i = 0; i < hst.size(); i += 2) { hst[i] = 0.2f * frand(); hst[i + 1] = 1.0f + 0.3f * frand(); }
-  for (auto& v : hga) v = 0.3f * frand();
-  for (auto& v : hbe) v = 0.3f * frand();
-  for (auto& v : hal) v = 1.0f + 0.5f * frand();
-
-  Packed pk = pack_w3(hw, C, C, K, G);
+static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, int mode, bool adain) {
+  Case c;
+  c.TN = TN; c.K = K; c.C = C; c.L = L; c.B = B; c.dil = dil; c.src_dil = src_dil; c.adain = adain;
+  c.derive();
+  HostData h;
+  make_data(c, h);
+  Packed pk = pack_w3(h.hw, C, C, K, c.G);
   if (mode == 2) {
     std::vector<float> hy, hpart;
     std::vector<_Float16> hvs;
-    host_emulate(TN, K, C, L, B, adain, pitch, Lt, cg_tot, nblk, hx, hres, hb, hst, hga, hbe, hal, pk, hy, hpart, hvs);
-    int bad = check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, true);
+    host_act(c, h, hvs);
+    host_conv(c, h, pk, hvs, hy, hpart);
+    int bad = check_result(c, h, hy, hpart, "selftest (data flow)");
     if (L <= 600) {  // thread-level twin of the conv kernel's index arithmetic (slow: small cases only)
-      std::fill(hy.begin(), hy.end(), 0.f);
-      std::fill(hpart.begin(), hpart.end(), 0.f);
-      std::vector<float> hbp(pk.co_pad, 0.f);
-      std::copy(hb.begin(), hb.end(), hbp.begin());
-      if (G == 4) host_twin_conv<4, TN>(hvs, pk, cg_tot, Lt, hbp, hres, pitch, C, L, B, nblk, hy, hpart);
-      else host_twin_conv<3, TN>(hvs, pk, cg_tot, Lt, hbp, hres, pitch, C, L, B, nblk, hy, hpart);
-      printf("  thread-level twin: ");
-      bad |= check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, true);
+      if (c.G == 4) host_twin_conv<4, TN>(c, h, pk, hvs, hy, hpart);
+      else host_twin_conv<3, TN>(c, h, pk, hvs, hy, hpart);
+      bad |= check_result(c, h, hy, hpart, "selftest (thread-level twin)");
     }
     return bad;
   }
   float *x, *res, *y, *bias, *rsc, *part, *st, *ga, *be, *al;
   _Float16* wq;
   h8* vs;
-  const size_t vs_slots = (size_t)B * 2 * P * cg_tot * Lt;
-  CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&res, hres.size() * 4)); CK(hipMalloc(&y, hx.size() * 4));
+  const size_t vs_slots = (size_t)c.VB * 2 * P * c.cg_tot * c.Lt;
+  const size_t y_elems = (size_t)c.VB * C * c.pitch_q;
+  CK(hipMalloc(&x, h.hxsrc.size() * 4)); CK(hipMalloc(&res, h.hres.size() * 4)); CK(hipMalloc(&y, y_elems * 4));
   CK(hipMalloc(&bias, (size_t)pk.co_pad * 4)); CK(hipMalloc(&rsc, (size_t)pk.co_pad * 4));
-  CK(hipMalloc(&part, (size_t)B * C * nblk * 8)); CK(hipMalloc(&wq, pk.q.size() * 2)); CK(hipMalloc(&vs, vs_slots * 16));
-  CK(hipMalloc(&st, hst.size() * 4)); CK(hipMalloc(&ga, hga.size() * 4)); CK(hipMalloc(&be, hbe.size() * 4));
-  CK(hipMalloc(&al, hal.size() * 4));
-  CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(res, hres.data(), hres.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&part, (size_t)c.VB * C * c.nblk * 8)); CK(hipMalloc(&wq, pk.q.size() * 2)); CK(hipMalloc(&vs, vs_slots * 16));
+  CK(hipMalloc(&st, h.hst.size() * 4)); CK(hipMalloc(&ga, h.hga.size() * 4)); CK(hipMalloc(&be, h.hbe.size() * 4));
+  CK(hipMalloc(&al, h.hal.size() * 4));
+  CK(hipMemcpy(x, h.hxsrc.data(), h.hxsrc.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(res, h.hres.data(), h.hres.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, (size_t)pk.co_pad * 4));
-  CK(hipMemcpy(bias, hb.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias, h.hb.data(), (size_t)C * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(rsc, pk.row_scale.data(), (size_t)pk.co_pad * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(wq, pk.q.data(), pk.q.size() * 2, hipMemcpyHostToDevice));
-  CK(hipMemcpy(st, hst.data(), hst.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(ga, hga.data(), hga.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(be, hbe.data(), hbe.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(al, hal.data(), hal.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(st, h.hst.data(), h.hst.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(ga, h.hga.data(), h.hga.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(be, h.hbe.data(), h.hbe.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(al, h.hal.data(), h.hal.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(vs, 0, vs_slots * 16));
-  CK(hipMemset(y, 0, hx.size() * 4));
+  CK(hipMemset(y, 0, y_elems * 4));
 
   AArgs a;
-  a.x = x; a.x_bs = (int64_t)C * pitch; a.x_cs = pitch; a.C = C; a.L = L; a.pad = pad; a.pro = adain ? 1 : 0;
+  const int x_cs = src_dil > 1 ? c.pitch_s : c.pitch;
+  a.x = x; a.x_bs = (int64_t)C * x_cs; a.x_cs = x_cs; a.C = C; a.L = L; a.pad = c.padq; a.pro = adain ? 1 : 0;
   a.stats = st; a.gamma = ga; a.beta = be; a.gb_bs = C; a.alpha = al; a.x_scale = 8.f;
-  a.vs = vs; a.cg_tot = cg_tot; a.Lt = Lt;
+  a.vs = vs; a.cg_tot = c.cg_tot; a.Lt = c.Lt; a.dil = dil; a.src_dil = src_dil;
   WArgs d;
   memset(&d, 0, sizeof(d));
-  d.vs = vs; d.cg_tot = cg_tot; d.Lt = Lt;
+  d.vs = vs; d.cg_tot = c.cg_tot; d.Lt = c.Lt;
   d.wq = reinterpret_cast<const h8*>(wq); d.co_pad = pk.co_pad; d.cin_pad = pk.cin_pad;
   d.row_scale = rsc; d.bias = bias; d.out_scale = 1.f / 8.f;
-  d.y = y; d.y_bs = (int64_t)C * pitch; d.y_cs = pitch;
-  d.res = res; d.res_bs = (int64_t)C * pitch; d.res_cs = pitch;
-  d.part = part; d.part_nt = nblk;
-  d.C_out = C; d.L_out = L;
+  d.y = y; d.y_bs = (int64_t)C * c.pitch_q; d.y_cs = c.pitch_q;
+  if (dil == 1) { d.res = res; d.res_bs = (int64_t)C * c.pitch; d.res_cs = c.pitch; }  // the residual add sits after convs2
+  d.part = part; d.part_nt = c.nblk;
+  d.C_out = C; d.L_out = L; d.dil = dil;
 
   auto run_act = [&]() -> int {
-    dim3 grid((Lt + AT_TILES - 1) / AT_TILES, cg_tot, B);
+    dim3 grid((c.Lt + AT_TILES - 1) / AT_TILES, c.cg_tot, c.VB);
     if (adain) hipLaunchKernelGGL((act_w3_kernel<1>), grid, dim3(256), 0, 0, a);
     else hipLaunchKernelGGL((act_w3_kernel<0>), grid, dim3(256), 0, 0, a);
     CK(hipGetLastError());
     return 0;
   };
-  auto run_conv = [&]() -> int { return G == 4 ? launch_conv<4, TN>(d, B) : launch_conv<3, TN>(d, B); };
+  auto run_conv = [&]() -> int { return c.G == 4 ? launch_conv<4, TN>(d, c.VB) : launch_conv<3, TN>(d, c.VB); };
   if (run_act() || run_conv()) return 1;
   CK(hipDeviceSynchronize());
 
-  if (check) {
-    std::vector<float> hy(hx.size()), hpart((size_t)B * C * nblk * 2);
+  if (mode == 1) {
+    std::vector<float> hy(y_elems), hpart((size_t)c.VB * C * c.nblk * 2);
     CK(hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hpart.data(), part, hpart.size() * 4, hipMemcpyDeviceToHost));
-    return check_result(TN, K, C, L, B, adain, pitch, nblk, hx, hres, hw, hb, hst, hga, hbe, hal, hy, hpart, mode == 2);
+    return check_result(c, h, hy, hpart, "check");
   }
 
   hipEvent_t e0, e1;
@@ -755,8 +819,8 @@ static int run_case(int K, int C, int L, int B, int reps, int mode, bool adain) 
   ms_act /= reps;
   ms_conv /= reps;
   const double flop = 2.0 * B * C * (double)C * K * L;
-  printf("wino_bench TN=%d k=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + planes written), conv %.4f ms = "
-         "%.1f algorithmic TFLOP/s (%.3f of 833)\n", TN, K, C, L, B, (int)adain, ms_act,
+  printf("wino_bench TN=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + planes "
+         "written), conv %.4f ms = %.1f algorithmic TFLOP/s (%.3f of 833)\n", TN, K, dil, src_dil, C, L, B, (int)adain, ms_act,
          ((double)B * C * L * 4 + (double)vs_slots * 16) / ms_act / 1e9, ms_conv, flop / ms_conv / 1e9,
          flop / ms_conv / 1e9 / (2500.0 / 3));
   return 0;
@@ -765,11 +829,15 @@ static int run_case(int K, int C, int L, int B, int reps, int mode, bool adain) 
 template <int TN>
 static int check_all(int mode) {
   int bad = 0;
-  bad |= run_case<TN>(11, 128, 1000, 2, 1, mode, false);   // edge tiles along l
-  bad |= run_case<TN>(11, 128, 1152, 1, 1, mode, true);    // interior tiles only, AdaIN + Snake prologue
-  bad |= run_case<TN>(7, 128, 777, 2, 1, mode, true);
-  bad |= run_case<TN>(7, 256, 389, 1, 1, mode, false);     // two co blocks
-  bad |= run_case<TN>(11, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
+  bad |= run_case<TN>(11, 1, 1, 128, 1000, 2, 1, mode, false);   // edge tiles along l
+  bad |= run_case<TN>(11, 1, 1, 128, 1152, 1, 1, mode, true);    // interior tiles only, AdaIN + Snake prologue
+  bad |= run_case<TN>(7, 1, 1, 128, 777, 2, 1, mode, true);
+  bad |= run_case<TN>(7, 1, 1, 256, 389, 1, 1, mode, false);     // two co blocks
+  bad |= run_case<TN>(11, 1, 1, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
+  bad |= run_case<TN>(11, 3, 1, 128, 1000, 1, 1, mode, true);    // dilated (convs1): residue-major output, no residual
+  bad |= run_case<TN>(7, 5, 1, 128, 523, 2, 1, mode, false);
+  bad |= run_case<TN>(11, 1, 3, 128, 598, 1, 1, mode, true);     // convs2 behind a dilation-3 layer: residue-major input
+  bad |= run_case<TN>(7, 1, 5, 128, 1001, 1, 1, mode, true);
   return bad;
 }
 
@@ -782,6 +850,7 @@ int main(int argc, char** argv) {
   }
   auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
   const int K = arg(1, 11), C = arg(2, 128), L = arg(3, 48001), B = arg(4, 32), reps = arg(5, 10), tn = arg(6, 2);
+  const int dil = arg(7, 1), src_dil = arg(8, 1);
   if (K != 7 && K != 11) { fprintf(stderr, "k must be 7 or 11\n"); return 2; }
-  return tn == 1 ? run_case<1>(K, C, L, B, reps, 0, true) : run_case<2>(K, C, L, B, reps, 0, true);
+  return tn == 1 ? run_case<1>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<2>(K, dil, src_dil, C, L, B, reps, 0, true);
 }
