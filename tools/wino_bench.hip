@@ -722,6 +722,68 @@ static void host_twin_conv(const Case& c, const HostData& h, const Packed& pk, c
   }
 }
 
+// Thread-level host twin of act_w3_kernel: the same staging loop (idx -> (e, i) -> q -> l, source permutation) into an
+// `sa` image and the same per-thread reads / destination index; compared with host_act on hi + lo (selftest only).
+static int host_twin_act(const Case& c, const HostData& h, const std::vector<_Float16>& vs_ref) {
+  const int x_cs = c.src_dil > 1 ? c.pitch_s : c.pitch;
+  const int64_t x_bs = (int64_t)c.C * x_cs;
+  const int64_t pstride = (int64_t)c.cg_tot * c.Lt;
+  std::vector<float> sa((size_t)8 * AT_PITCH);
+  double worst = 0.0, scale = 0.0;
+  for (int vb = 0; vb < c.VB; ++vb)
+    for (int cg = 0; cg < c.cg_tot; ++cg)
+      for (int bx = 0; bx < (c.Lt + AT_TILES - 1) / AT_TILES; ++bx) {
+        const int tile0 = bx * AT_TILES;
+        const int b = vb / c.dil, r = vb - b * c.dil;
+        const int p0 = 3 * tile0 - c.padq;
+        for (int tid = 0; tid < 256; ++tid)
+          for (int idx = tid; idx < 8 * AT_POS; idx += 256) {
+            const int e = idx / AT_POS, i = idx - e * AT_POS;
+            const int q = p0 + i;
+            const int l = c.dil * q + r;
+            const int ci = cg * 8 + e;
+            float u = 0.f;
+            if (q >= 0 && l < c.L && ci < c.C) {
+              if (c.src_dil > 1) {
+                const int rs = l % c.src_dil, qs = l / c.src_dil;
+                u = h.hxsrc[((int64_t)b * c.src_dil + rs) * x_bs + (int64_t)ci * x_cs + qs];
+              } else {
+                u = h.hxsrc[(int64_t)b * x_bs + (int64_t)ci * x_cs + l];
+              }
+              if (c.adain) {
+                float w = (u - h.hst[((size_t)b * c.C + ci) * 2]) * h.hst[((size_t)b * c.C + ci) * 2 + 1];
+                w = (1.0f + h.hga[(size_t)b * c.C + ci]) * w + h.hbe[(size_t)b * c.C + ci];
+                const float al = h.hal[ci], sn = sinf(al * w);
+                u = w + (1.0f / al) * (sn * sn);
+              }
+              u *= 8.f;
+            }
+            sa[(size_t)e * AT_PITCH + i] = u;
+          }
+        for (int tid = 0; tid < 256; ++tid) {
+          const int T = tile0 + tid;
+          if (T >= c.Lt) continue;
+          for (int e = 0; e < 8; ++e) {
+            const float* sp = sa.data() + (size_t)e * AT_PITCH + 3 * tid;
+            const float d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3], d4 = sp[4];
+            const float v[P] = {(2.f * d0 - d1) + (d3 - 2.f * d2), (d3 - d2) - 2.f * d1, (2.f * d1 + d3) - 3.f * d2, d3 - d1,
+                                (2.f * d1 - d2) + (d4 - 2.f * d3)};
+            for (int p = 0; p < P; ++p) {
+              const int64_t dst = (int64_t)vb * 2 * P * pstride + (int64_t)cg * c.Lt + T;  // h8 index of the hi slot of point 0
+              const double ref = (double)(float)vs_ref[(size_t)(dst + p * pstride) * 8 + e] +
+                                 (double)(float)vs_ref[(size_t)(dst + (P + p) * pstride) * 8 + e];
+              worst = std::fmax(worst, std::fabs(ref - (double)v[p]));
+              scale = std::fmax(scale, std::fabs((double)v[p]));
+            }
+          }
+        }
+      }
+  const bool ok = worst < 1e-5 * scale;  // hi + lo carries ~22 bits of v
+  printf("wino selftest (transform-pass twin) k=%d dil=%d src_dil=%d C=%d L=%d: max |hi + lo - v| = %.3e of %.3e -> %s\n", c.K, c.dil,
+         c.src_dil, c.C, c.L, worst, scale, ok ? "OK" : "MISMATCH");
+  return ok ? 0 : 1;
+}
+
 // mode 0 = timing, 1 = GPU check, 2 = host selftest
 template <int TN>
 static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, int mode, bool adain) {
@@ -737,6 +799,7 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
     host_act(c, h, hvs);
     host_conv(c, h, pk, hvs, hy, hpart);
     int bad = check_result(c, h, hy, hpart, "selftest (data flow)");
+    if (TN == 2) bad |= host_twin_act(c, h, hvs);
     if (L <= 600) {  // thread-level twin of the conv kernel's index arithmetic (slow: small cases only)
       if (c.G == 4) host_twin_conv<4, TN>(c, h, pk, hvs, hy, hpart);
       else host_twin_conv<3, TN>(c, h, pk, hvs, hy, hpart);
