@@ -295,7 +295,8 @@ def mask_tail(x, x_bs, x_cs, B, Cc, L, length, stream):
 
 def embed_tokens(tokens, B, N, table, V, E, add, pos, length, y, y_bs, y_cs, stream):
     tok = _t(tokens, (B, N), (N, 1), torch.int64)
-    emb = _t(table, (V, E), (E, 1))[tok]                                     # [B, N, E]
+    valid = (tok >= 0) & (tok < V)                                           # st2.h: ids outside [0, V) contribute 0
+    emb = _t(table, (V, E), (E, 1))[tok.clamp(0, V - 1)] * valid.unsqueeze(-1)  # [B, N, E]
     if add:
         emb = emb + _t(add, (E,), (1,))
     if pos:
