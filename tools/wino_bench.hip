@@ -1,25 +1,27 @@
-// EXPERIMENT (not part of the library): Toom-Cook F(3, 3) form of the split-f16 MFMA conv for the vocoder's long
-// undilated filters (k = 11 -> four 3-tap groups, k = 7 -> three), DESIGN.md section 7 item 0.  Stand-alone binary: plain
+// EXPERIMENT (not part of the library): Toom-Cook F(M, R) forms -- F(3, 3) and F(4, 4) -- of the split-f16 MFMA conv for the
+// vocoder's long filters (k = 11 / 7 as ceil(k / R) R-tap groups accumulated in the transform domain), DESIGN.md section 7
+// item 0.  The tile step M equals the group width R, so ONE transformed copy of the input serves all groups.  Stand-alone binary: plain
 // hipMalloc buffers, its own CPU fp64 check, HIP events.  Written at the end of round 2 without GPU minutes left -- the
 // first thing to run in round 3:
 //
 //   tools/bin/wino_bench selftest        no GPU: host emulation of the kernels' data flow through the same checker
 //   tools/bin/wino_bench check           small shapes (edge tiles included) against a direct fp64 conv on the host
-//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2] [dil=1] [src_dil=1]   timing of both kernels
-//                                          (TN = 32-tile blocks per wave: 2 -> 2 workgroups / CU, 1 -> 3 workgroups / CU;
-//                                           dil = the conv's dilation, src_dil = dilation of the layer that produced x)
+//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2] [dil=1] [src_dil=1] [scheme=33] [occ=2]   timing
+//                                          (TN = 32-tile blocks per wave; dil = the conv's dilation, src_dil = dilation of the
+//                                           layer that produced x; scheme 33 = F(3,3) (TN 1 or 2), 44 = F(4,4) (TN 1, occ = 2 or 3 workgroups / CU))
 //
-// Maths (points 0, 1, -1, 2, inf; verified on the CPU by tools/winograd_numerics.py):
-//   y[3T + i] = sum_j w[j] a[3T + i + j - pad],  w zero-padded to 3G taps, group g = taps 3g .. 3g + 2
-//   V_p[ci][T'] = sum_n BT[p][n] a[ci][3T' - pad + n]                (input transform, fp32, then hi / lo f16 split)
-//   U_{g,p}[co][ci] = sum_r Gm[p][r] w[co][ci][3g + r]               (weight transform, fp64 at pack time)
-//   Y_p[co][T]  = sum_{g, ci} U_{g,p}[co][ci] V_p[ci][T + g]         (5 independent G-tap convs over the TILE index: MFMA)
-//   y[co][3T + i] = sum_p AT[i][p] Y_p[co][T]                        (inverse transform on the fp32 accumulators)
-// i.e. 5 G / 3 MFMA-multiplies per output instead of 3 G - 1 (k = 11: 6.67 vs 11, k = 7: 5 vs 7).
+// Maths (P = M + R - 1 points: 0, +-1, 2, inf for F(3,3); 0, +-1, +-2, 1/2, inf for F(4,4); matrices built by toom() below,
+// rounding studied on the CPU by tools/winograd_numerics.py):
+//   y[M T + i] = sum_j w[j] a[M T + i + j - pad],  w zero-padded to R G taps, group g = taps R g .. R g + R - 1
+//   V_p[ci][T'] = sum_n BT[p][n] a[ci][M T' - pad + n]               (input transform, fp32, then hi / lo f16 split)
+//   U_{g,p}[co][ci] = sum_r Gm[p][r] w[co][ci][R g + r]              (weight transform, fp64 at pack time)
+//   Y_p[co][T]  = sum_{g, ci} U_{g,p}[co][ci] V_p[ci][T + g]         (P independent G-tap convs over the TILE index: MFMA)
+//   y[co][M T + i] = sum_p AT[i][p] Y_p[co][T]                       (inverse transform on the fp32 accumulators)
+// i.e. P G / M MFMA-multiplies per output: k = 11: 6.67 (F(3,3)) / 5.25 (F(4,4)) vs 11; k = 7: 5 / 3.5 vs 7.
 //
-// Kernel structure = csrc/st2_conv1d_xs_impl.h with "taps" t = g * 5 + p: the packed-weight layout (st2.h) is reused with
-// ks_eff = 5 G, the chunk image in LDS has one row set per point, the accumulators are acc[p][j] (transposed tile: lane =
-// output row, registers = runs of 4 consecutive TILES = 12 consecutive outputs -> three 16-byte stores).
+// Kernel structure = csrc/st2_conv1d_xs_impl.h with "taps" t = g * P + p: the packed-weight layout (st2.h) is reused with
+// ks_eff = P G, the chunk image in LDS has one row set per point, the accumulators are acc[p][j] (transposed tile: lane =
+// output row, registers = runs of 4 consecutive TILES = 4 M consecutive outputs -> M 16-byte stores).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -44,7 +46,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     }                                                                          \
   } while (0)
 
-constexpr int P = 5;        // Winograd points
+template <int M_, int R_>
+struct Scheme {
+  static constexpr int M = M_, R = R_, P = M_ + R_ - 1;  // outputs per tile (= tile step), taps per group, points
+};
+typedef Scheme<3, 3> S33;
+typedef Scheme<4, 4> S44;
+struct Toom {  // transform matrices in fp32, sized for the largest scheme (kernel arguments: scalar loads)
+  float BT[7][7];  // V_p = sum_n BT[p][n] d[n]
+  float AT[4][7];  // y_i = sum_p AT[i][p] Y_p
+};
 constexpr int NT = 256;     // threads per workgroup
 constexpr int CI_T = 16;    // input channels per chunk (one MFMA k-step per (g, p))
 constexpr int CG = CI_T / 8;
@@ -60,6 +71,7 @@ struct WArgs {
   const float* res; int64_t res_bs; int res_cs;
   float* part; int part_nt;   // per (b, co, tile block of 96 TN outputs): (sum, sum of squares) of the stored values
   int C_out, L_out;
+  Toom tm;
   // dilation d > 1: the grid's batch index is the VIRTUAL batch vb = b * d + r, one per residue r of l = d q + r; the kernel
   // convolves the stride-d subsequence a_r[q] = a[d q + r] (planes and output are per virtual batch: the output tensor is
   // residue-major [b][r][co][q], which the next activation pass un-permutes) and L_out is the natural length
@@ -77,13 +89,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------------------------------------------------
 // conv over tiles: workgroup = 4 waves along co (128 output rows) x 32 TN tiles (= 96 TN outputs)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int G, int TN>
-__global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArgs d) {  // TN = 1: <= 168 VGPRs, 3 workgroups / CU
+// OCC = workgroups per CU the register budget is held to (3: <= 168 VGPRs; F(4,4) then parks the staged activations of the
+// next chunk in scratch -- 3 x 16 B per lane per chunk of ~2000 MFMA cycles)
+template <class S, int G, int TN, int OCC>
+__global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
+  constexpr int P = S::P, M = S::M;
   constexpr int BT_ = 32 * TN;            // tiles per workgroup
   constexpr int XW = BT_ + G - 1;         // staged tile slots per image row
   constexpr int ROWS = 2 * P * CG;        // image rows per chunk: (plane, point, channel group)
-  constexpr int S = ROWS * XW;
-  constexpr int NS = (S + NT - 1) / NT;
+  constexpr int SLOTS = ROWS * XW;
+  constexpr int NS = (SLOTS + NT - 1) / NT;
   constexpr int LBUF = NS * NT;
   constexpr int SPC = G * P;              // k-steps per chunk
   constexpr int NSET = 3;
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
     const int row = slot / XW;
     const int col = slot - row * XW;
     const int pl = row / (P * CG), rem = row % (P * CG), p = rem / CG, g8 = rem % CG;
-    soff[i] = slot < S ? (int)(pl * plane_stride + p * pstride + (int64_t)g8 * d.Lt + col) : 0;
+    soff[i] = slot < SLOTS ? (int)(pl * plane_stride + p * pstride + (int64_t)g8 * d.Lt + col) : 0;
   }
   h8 xr[NS];
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
 
   // ---- epilogue: inverse transform, scale, bias, residual, store, statistics ------------------------------------------
   // lane (l31, kg) owns output row co and, in acc[p][j][4 q + e], tile T = t0 + 32 j + 8 q + 4 kg + e: the four tiles of a
-  // (j, q) are 12 consecutive outputs starting at 3 (t0 + 32 j + 8 q + 4 kg)
+  // (j, q) are 4 M consecutive outputs starting at M (t0 + 32 j + 8 q + 4 kg)
   const int co = m0 + wave * 32 + l31;
   const bool rok = co < d.C_out;
   const int coc = rok ? co : d.C_out - 1;
@@ -210,28 +225,29 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs + (int64_t)coc * d.res_cs : nullptr;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.y) | (uintptr_t)(d.y_bs * 4) | (uintptr_t)(d.y_cs * 4)) & 15) == 0 &&
                       (!d.res || ((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0);
-  const bool full = vec_ok && m0 + 128 <= d.C_out && 3 * (t0 + BT_) <= L_eff;  // workgroup-uniform
+  const bool full = vec_ok && m0 + 128 <= d.C_out && M * (t0 + BT_) <= L_eff;  // workgroup-uniform
   float s1 = 0.f, s2 = 0.f;
   static_for<TN * 4>([&](auto jq_tag) __attribute__((always_inline)) {
     constexpr int j = decltype(jq_tag)::value / 4, q = decltype(jq_tag)::value % 4;
-    const int l0 = 3 * (t0 + 32 * j + 8 * q + 4 * kg);
-    float o[12];
+    const int l0 = M * (t0 + 32 * j + 8 * q + 4 * kg);
+    float o[4 * M];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float Y0 = acc[0][j][4 * q + e], Y1 = acc[1][j][4 * q + e], Y2 = acc[2][j][4 * q + e],
-                  Y3 = acc[3][j][4 * q + e], Y4 = acc[4][j][4 * q + e];
-      o[3 * e + 0] = (Y0 + Y1) + (Y2 + Y3);
-      o[3 * e + 1] = (Y1 - Y2) + 2.f * Y3;
-      o[3 * e + 2] = (Y1 + Y2) + (4.f * Y3 + Y4);
-    }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        float t = d.tm.AT[i][0] * acc[0][j][4 * q + e];
+#pragma unroll
+        for (int p = 1; p < P; ++p) t = fmaf(d.tm.AT[i][p], acc[p][j][4 * q + e], t);
+        o[M * e + i] = t;
+      }
     if (full) {
-      f32x4 rv[3];
+      f32x4 rv[M];
       if (rb) {
 #pragma unroll
-        for (int v = 0; v < 3; ++v) rv[v] = *reinterpret_cast<const f32x4*>(rb + l0 + 4 * v);
+        for (int v = 0; v < M; ++v) rv[v] = *reinterpret_cast<const f32x4*>(rb + l0 + 4 * v);
       }
 #pragma unroll
-      for (int v = 0; v < 3; ++v) {
+      for (int v = 0; v < M; ++v) {
         f32x4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(NT, TN >= 2 ? 2 : 3) void conv_w3_kernel(const WArg
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 12; ++e) {
+      for (int e = 0; e < 4 * M; ++e) {
         const int l = l0 + e;
         const bool ok = rok && l < L_eff;
         float t = fmaf(o[e], osc_r, bias_r);
@@ -283,20 +299,25 @@ struct AArgs {
   h8* vs; int cg_tot; int Lt;
   int dil;      // conv dilation d: grid z = B * d virtual batch items, item (b, r) transforms a_r[q] = a[d q + r]; pad in q units
   int src_dil;  // > 1: x is the residue-major output of a dilated layer, x[(b * src_dil + l % src_dil)][ci][l / src_dil]
+  Toom tm;
 };
 
 constexpr int AT_TILES = 256;
-constexpr int AT_POS = 3 * AT_TILES + 2;   // input positions per workgroup
-constexpr int AT_PITCH = AT_POS + 1;       // odd pitch: the 8 channel rows start in different banks
+template <class S>
+struct ActGeom {
+  static constexpr int POS = S::M * AT_TILES + S::R - 1;  // input positions per workgroup
+  static constexpr int PITCH = POS | 1;                   // odd pitch: the 8 channel rows start in different banks
+};
 
-template <int PRO>
+template <class S, int PRO>
 __global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
+  constexpr int P = S::P, M = S::M, AT_POS = ActGeom<S>::POS, AT_PITCH = ActGeom<S>::PITCH;
   __shared__ float sa[8 * AT_PITCH];
   const int tile0 = blockIdx.x * AT_TILES;
   const int cg = blockIdx.y;
   const int vb = blockIdx.z;
   const int b = vb / a.dil, r = vb - b * a.dil;
-  const int p0 = 3 * tile0 - a.pad;  // first input position (in q units) of the workgroup
+  const int p0 = M * tile0 - a.pad;  // first input position (in q units) of the workgroup
   for (int idx = threadIdx.x; idx < 8 * AT_POS; idx += 256) {
     const int e = idx / AT_POS, i = idx - e * AT_POS;
     const int q = p0 + i;
@@ -329,17 +350,16 @@ __global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
   h8 hi[P], lo[P];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float* s = sa + e * AT_PITCH + 3 * threadIdx.x;
-    const float d0 = s[0], d1 = s[1], d2 = s[2], d3 = s[3], d4 = s[4];
-    float v[P];
-    v[0] = (2.f * d0 - d1) + (d3 - 2.f * d2);
-    v[1] = (d3 - d2) - 2.f * d1;
-    v[2] = (2.f * d1 + d3) - 3.f * d2;
-    v[3] = d3 - d1;
-    v[4] = (2.f * d1 - d2) + (d4 - 2.f * d3);
+    const float* s = sa + e * AT_PITCH + M * threadIdx.x;
+    float dd[P];
+#pragma unroll
+    for (int n = 0; n < P; ++n) dd[n] = s[n];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float uc = st2_clamp_f16(v[p]);
+      float v = a.tm.BT[p][0] * dd[0];
+#pragma unroll
+      for (int n = 1; n < P; ++n) v = fmaf(a.tm.BT[p][n], dd[n], v);
+      const float uc = st2_clamp_f16(v);
       const _Float16 h = (_Float16)uc;
       hi[p][e] = h;
       lo[p][e] = (_Float16)(uc - (float)h);
@@ -363,16 +383,90 @@ static float frand() {  // uniform in [-1, 1)
   return ((int)((rng_state >> 8) & 0xffff) - 32768) * (1.f / 32768.f);
 }
 
+// Toom-Cook F(M, R) with P - 1 finite points + infinity:  y = AT [(Gm g) * (BT d)]  (Vandermonde construction, fp64)
+struct ToomD {
+  int M, R, P;
+  double AT[4][7], Gm[7][4], BT[7][7];
+};
+static ToomD toom(int M, int R) {
+  ToomD t;
+  memset(&t, 0, sizeof(t));
+  t.M = M; t.R = R; t.P = M + R - 1;
+  const int n = t.P;
+  static const double pts33[] = {0, 1, -1, 2}, pts44[] = {0, 1, -1, 2, -2, 0.5};
+  const double* pts = (M == 3) ? pts33 : pts44;
+  for (int k = 0; k < n - 1; ++k) {
+    double den = 1.0;
+    for (int j = 0; j < n - 1; ++j)
+      if (j != k) den *= pts[k] - pts[j];
+    for (int i = 0; i < M; ++i) t.AT[i][k] = std::pow(pts[k], i);
+    for (int r = 0; r < R; ++r) t.Gm[k][r] = std::pow(pts[k], r) / den;
+    // BT row k: coefficients of prod_{j != k} (x - p_j), ascending powers
+    double poly[8] = {1.0, 0, 0, 0, 0, 0, 0, 0};
+    int deg = 0;
+    for (int j = 0; j < n - 1; ++j) {
+      if (j == k) continue;
+      for (int z = deg + 1; z >= 1; --z) poly[z] = poly[z - 1] - pts[j] * poly[z];
+      poly[0] = -pts[j] * poly[0];
+      ++deg;
+    }
+    for (int z = 0; z <= deg; ++z) t.BT[k][z] = poly[z];
+  }
+  t.AT[M - 1][n - 1] = 1.0;
+  t.Gm[n - 1][R - 1] = 1.0;
+  {  // last BT row: prod_j (x - p_j)
+    double poly[8] = {1.0, 0, 0, 0, 0, 0, 0, 0};
+    int deg = 0;
+    for (int j = 0; j < n - 1; ++j) {
+      for (int z = deg + 1; z >= 1; --z) poly[z] = poly[z - 1] - pts[j] * poly[z];
+      poly[0] = -pts[j] * poly[0];
+      ++deg;
+    }
+    for (int z = 0; z <= deg; ++z) t.BT[n - 1][z] = poly[z];
+  }
+  return t;
+}
+static int toom_selfcheck(const ToomD& t) {  // AT [(Gm g) * (BT d)] == correlation of d with g
+  double worst = 0.0;
+  for (int trial = 0; trial < 20; ++trial) {
+    double dd[7], g[4];
+    for (int i = 0; i < t.P; ++i) dd[i] = frand();
+    for (int i = 0; i < t.R; ++i) g[i] = frand();
+    for (int i = 0; i < t.M; ++i) {
+      double ref = 0.0, got = 0.0;
+      for (int j = 0; j < t.R; ++j) ref += g[j] * dd[i + j];
+      for (int p = 0; p < t.P; ++p) {
+        double u = 0.0, v = 0.0;
+        for (int r = 0; r < t.R; ++r) u += t.Gm[p][r] * g[r];
+        for (int n = 0; n < t.P; ++n) v += t.BT[p][n] * dd[n];
+        got += t.AT[i][p] * u * v;
+      }
+      worst = std::fmax(worst, std::fabs(got - ref));
+    }
+  }
+  printf("toom F(%d,%d): max |transform-domain - direct| = %.2e\n", t.M, t.R, worst);
+  return worst < 1e-12 ? 0 : 1;
+}
+static Toom toom_f32(const ToomD& t) {
+  Toom f;
+  memset(&f, 0, sizeof(f));
+  for (int p = 0; p < t.P; ++p)
+    for (int n = 0; n < t.P; ++n) f.BT[p][n] = (float)t.BT[p][n];
+  for (int i = 0; i < t.M; ++i)
+    for (int p = 0; p < t.P; ++p) f.AT[i][p] = (float)t.AT[i][p];
+  return f;
+}
+
 struct Packed {
   std::vector<_Float16> q;
   std::vector<float> row_scale;
   int co_pad, cin_pad, ks_eff;
 };
 
-// U_{g,p} = sum_r Gm[p][r] w[3g + r] in fp64, then csrc/st2_engine.hip pack_split with ks = 5 G (per-row power-of-two scale,
+// U_{g,p} = sum_r Gm[p][r] w[R g + r] in fp64, then csrc/st2_engine.hip pack_split with ks = P G (per-row power-of-two scale,
 // hi / lo f16, [(i16 * ks + t) * 2 + kg][co_pad][16])
-static Packed pack_w3(const std::vector<float>& w, int C_out, int C_in, int K, int G) {
-  static const double Gm[5][3] = {{0.5, 0, 0}, {-0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0, 0, 1}};
+static Packed pack_w3(const ToomD& tm, const std::vector<float>& w, int C_out, int C_in, int K, int G) {
+  const int P = tm.P, R = tm.R;
   Packed r;
   r.ks_eff = P * G;
   r.cin_pad = (C_in + 15) / 16 * 16;
@@ -386,9 +480,9 @@ static Packed pack_w3(const std::vector<float>& w, int C_out, int C_in, int K, i
       for (int g = 0; g < G; ++g)
         for (int p = 0; p < P; ++p) {
           double s = 0.0;
-          for (int rr = 0; rr < 3; ++rr) {
-            const int j = 3 * g + rr;
-            if (j < K) s += Gm[p][rr] * (double)w[((size_t)co * C_in + ci) * K + j];
+          for (int rr = 0; rr < R; ++rr) {
+            const int j = R * g + rr;
+            if (j < K) s += tm.Gm[p][rr] * (double)w[((size_t)co * C_in + ci) * K + j];
           }
           const float v = (float)s;
           u[(size_t)ci * r.ks_eff + g * P + p] = v;
@@ -420,34 +514,34 @@ static double snake_ref(double v, double al) {
   return v + s * s / al;
 }
 
-template <int G, int TN>
-static int launch_conv(const WArgs& d, int B) {
+template <class S, int G, int TN, int OCC>
+static int launch_conv(const WArgs& d, int B, int nblk) {
   constexpr int BT_ = 32 * TN;
   constexpr int XW = BT_ + G - 1;
-  constexpr int NS = (2 * P * CG * XW + NT - 1) / NT;
+  constexpr int NS = (2 * S::P * CG * XW + NT - 1) / NT;
   const size_t smem = (size_t)2 * NS * NT * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w3_kernel<G, TN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w3_kernel<S, G, TN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            160 * 1024));
     attr_done = true;
   }
-  const int n_tiles = (d.L_out + 2) / 3;
-  dim3 grid((n_tiles + BT_ - 1) / BT_, (d.C_out + 127) / 128, B);
-  hipLaunchKernelGGL((conv_w3_kernel<G, TN>), grid, dim3(NT), smem, 0, d);
+  dim3 grid(nblk, (d.C_out + 127) / 128, B);
+  hipLaunchKernelGGL((conv_w3_kernel<S, G, TN, OCC>), grid, dim3(NT), smem, 0, d);
   CK(hipGetLastError());
   return 0;
 }
 
 struct Case {
-  int TN, K, C, L, B, dil, src_dil;
+  int M, R, P, TN, K, C, L, B, dil, src_dil;
   bool adain;
   // derived
   int G, padq, Lq, n_tiles, BT_, nblk, Lt, cg_tot, pitch, pitch_q, pitch_s, VB;
   void derive() {
-    G = (K + 2) / 3; padq = (K - 1) / 2;
+    P = M + R - 1;
+    G = (K + R - 1) / R; padq = (K - 1) / 2;
     Lq = (L + dil - 1) / dil;                       // longest stride-d subsequence
-    n_tiles = (Lq + 2) / 3; BT_ = 32 * TN; nblk = (n_tiles + BT_ - 1) / BT_;
+    n_tiles = (Lq + M - 1) / M; BT_ = 32 * TN; nblk = (n_tiles + BT_ - 1) / BT_;
     Lt = nblk * BT_ + 8;                            // every workgroup stages BT_ + G - 1 <= BT_ + 3 tiles
     cg_tot = (C + 15) / 16 * 16 / 8;
     pitch = (L + 31) / 32 * 32;                     // natural rows (host reference, residual)
@@ -520,8 +614,8 @@ static int check_result(const Case& c, const HostData& h, const std::vector<floa
         const double got = hy[(((size_t)b * c.dil + r) * C + co) * c.pitch_q + q];
         err = std::fmax(err, std::fabs(got - ref));
         ymax = std::fmax(ymax, std::fabs(ref));
-        s1[(size_t)r * c.nblk + q / (3 * c.BT_)] += got;
-        s2[(size_t)r * c.nblk + q / (3 * c.BT_)] += got * got;
+        s1[(size_t)r * c.nblk + q / (c.M * c.BT_)] += got;
+        s2[(size_t)r * c.nblk + q / (c.M * c.BT_)] += got * got;
       }
       for (int r = 0; r < c.dil; ++r)
         for (int t = 0; t < c.nblk; ++t) {
@@ -532,49 +626,55 @@ static int check_result(const Case& c, const HostData& h, const std::vector<floa
     }
   }
   const bool ok = err < 2e-5 * ymax && perr < 1e-4 * pmax;
-  printf("wino %s TN=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums %.3e of %.3e"
-         "  -> %s\n", what, c.TN, K, c.dil, c.src_dil, C, L, c.B, (int)c.adain, err, ymax, perr, pmax, ok ? "OK" : "MISMATCH");
+  printf("wino %s F(%d,%d) TN=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: max |y - ref| = %.3e of %.3e, partial sums "
+         "%.3e of %.3e  -> %s\n", what, c.M, c.R, c.TN, K, c.dil, c.src_dil, C, L, c.B, (int)c.adain, err, ymax, perr, pmax,
+         ok ? "OK" : "MISMATCH");
   return ok ? 0 : 1;
+}
+
+// the activation arithmetic of act_w3_kernel's staging loop on the host (sinf instead of the device's polynomial)
+static float host_a_rq(const Case& c, const HostData& h, int b, int r, int ci, int q) {
+  const int x_cs = c.src_dil > 1 ? c.pitch_s : c.pitch;
+  const int64_t x_bs = (int64_t)c.C * x_cs;
+  const int l = c.dil * q + r;
+  if (!(q >= 0 && l < c.L && ci < c.C)) return 0.f;
+  float u;
+  if (c.src_dil > 1) {
+    const int rs = l % c.src_dil, qs = l / c.src_dil;
+    u = h.hxsrc[((int64_t)b * c.src_dil + rs) * x_bs + (int64_t)ci * x_cs + qs];
+  } else {
+    u = h.hxsrc[(int64_t)b * x_bs + (int64_t)ci * x_cs + l];
+  }
+  if (c.adain) {
+    float w = (u - h.hst[((size_t)b * c.C + ci) * 2]) * h.hst[((size_t)b * c.C + ci) * 2 + 1];
+    w = (1.0f + h.hga[(size_t)b * c.C + ci]) * w + h.hbe[(size_t)b * c.C + ci];
+    const float al = h.hal[ci], sn = sinf(al * w);
+    u = w + (1.0f / al) * (sn * sn);
+  }
+  return u * 8.f;
+}
+static void host_transform(const Case& c, const Toom& tm, const float* dd, float* v) {  // the device's fmaf order
+  for (int p = 0; p < c.P; ++p) {
+    float t = tm.BT[p][0] * dd[0];
+    for (int n = 1; n < c.P; ++n) t = fmaf(tm.BT[p][n], dd[n], t);
+    v[p] = t;
+  }
 }
 
 // Host emulation of the two kernels' DATA FLOW (same plane / packed-weight / permutation index formulas, same transform
 // constants, fp64 accumulation instead of MFMA): `wino_bench selftest` runs it through the same checker without a GPU, so
 // that the packer, the layouts, the transforms and the checker itself are known to be consistent before the first GPU visit.
-static void host_act(const Case& c, const HostData& h, std::vector<_Float16>& vs) {
+static void host_act(const Case& c, const HostData& h, const Toom& tm, std::vector<_Float16>& vs) {
+  const int P = c.P;
   vs.assign((size_t)c.VB * 2 * P * c.cg_tot * c.Lt * 8, (_Float16)0.0f);
-  const int x_cs = c.src_dil > 1 ? c.pitch_s : c.pitch;
-  const int64_t x_bs = (int64_t)c.C * x_cs;
-  auto a_rq = [&](int b, int r, int ci, int q) -> float {  // act_w3_kernel's staging loop
-    const int l = c.dil * q + r;
-    if (!(q >= 0 && l < c.L && ci < c.C)) return 0.f;
-    float u;
-    if (c.src_dil > 1) {
-      const int rs = l % c.src_dil, qs = l / c.src_dil;
-      u = h.hxsrc[((int64_t)b * c.src_dil + rs) * x_bs + (int64_t)ci * x_cs + qs];
-    } else {
-      u = h.hxsrc[(int64_t)b * x_bs + (int64_t)ci * x_cs + l];
-    }
-    if (c.adain) {
-      float w = (u - h.hst[((size_t)b * c.C + ci) * 2]) * h.hst[((size_t)b * c.C + ci) * 2 + 1];
-      w = (1.0f + h.hga[(size_t)b * c.C + ci]) * w + h.hbe[(size_t)b * c.C + ci];
-      const float al = h.hal[ci], sn = sinf(al * w);
-      u = w + (1.0f / al) * (sn * sn);
-    }
-    return u * 8.f;
-  };
   for (int vb = 0; vb < c.VB; ++vb) {
     const int b = vb / c.dil, r = vb - b * c.dil;
     for (int cg = 0; cg < c.cg_tot; ++cg)
       for (int T = 0; T < c.Lt; ++T)
         for (int e = 0; e < 8; ++e) {
-          float dd[5];
-          for (int n = 0; n < 5; ++n) dd[n] = a_rq(b, r, cg * 8 + e, 3 * T - c.padq + n);
-          float v[P];
-          v[0] = (2.f * dd[0] - dd[1]) + (dd[3] - 2.f * dd[2]);
-          v[1] = (dd[3] - dd[2]) - 2.f * dd[1];
-          v[2] = (2.f * dd[1] + dd[3]) - 3.f * dd[2];
-          v[3] = dd[3] - dd[1];
-          v[4] = (2.f * dd[1] - dd[2]) + (dd[4] - 2.f * dd[3]);
+          float dd[7], v[7];
+          for (int n = 0; n < P; ++n) dd[n] = host_a_rq(c, h, b, r, cg * 8 + e, c.M * T - c.padq + n);
+          host_transform(c, tm, dd, v);
           for (int p = 0; p < P; ++p) {
             const float uc = v[p] > 65504.f ? 65504.f : (v[p] < -65504.f ? -65504.f : v[p]);
             const _Float16 hh = (_Float16)uc;
@@ -585,8 +685,16 @@ static void host_act(const Case& c, const HostData& h, std::vector<_Float16>& vs
   }
 }
 
-static void host_conv(const Case& c, const HostData& h, const Packed& pk, const std::vector<_Float16>& vs, std::vector<float>& hy,
-                      std::vector<float>& hpart) {
+// inverse transform + epilogue arithmetic shared by the host emulations (the device's fmaf order on fp32 inputs)
+static float host_out(const Case& c, const Toom& tm, const double* Y, int i) {
+  float t = tm.AT[i][0] * (float)Y[0];
+  for (int p = 1; p < c.P; ++p) t = fmaf(tm.AT[i][p], (float)Y[p], t);
+  return t;
+}
+
+static void host_conv(const Case& c, const HostData& h, const Toom& tm, const Packed& pk, const std::vector<_Float16>& vs,
+                      std::vector<float>& hy, std::vector<float>& hpart) {
+  const int P = c.P;
   hy.assign((size_t)c.VB * c.C * c.pitch_q, 0.f);
   hpart.assign((size_t)c.VB * c.C * c.nblk * 2, 0.f);
   const int ks = pk.ks_eff;
@@ -599,7 +707,7 @@ static void host_conv(const Case& c, const HostData& h, const Packed& pk, const 
         double s1 = 0.0, s2 = 0.0;
         for (int tt = 0; tt < c.BT_; ++tt) {
           const int T = blk * c.BT_ + tt;
-          double Y[P] = {0, 0, 0, 0, 0};
+          double Y[7] = {0, 0, 0, 0, 0, 0, 0};
           for (int i16 = 0; i16 < pk.cin_pad / 16; ++i16)
             for (int g = 0; g < c.G; ++g)
               for (int p = 0; p < P; ++p)
@@ -613,11 +721,10 @@ static void host_conv(const Case& c, const HostData& h, const Packed& pk, const 
                     Y[p] += wh * ah + wh * al + wl * ah;
                   }
                 }
-          const double o[3] = {(Y[0] + Y[1]) + (Y[2] + Y[3]), (Y[1] - Y[2]) + 2.0 * Y[3], (Y[1] + Y[2]) + (4.0 * Y[3] + Y[4])};
-          for (int i = 0; i < 3; ++i) {
-            const int q = 3 * T + i;
+          for (int i = 0; i < c.M; ++i) {
+            const int q = c.M * T + i;
             if (q >= L_eff) continue;
-            float t = fmaf((float)o[i], osc_r, h.hb[co]);
+            float t = fmaf(host_out(c, tm, Y, i), osc_r, h.hb[co]);
             if (c.dil == 1) t += h.hres[((size_t)b * c.C + co) * c.pitch + q];
             hy[((size_t)vb * c.C + co) * c.pitch_q + q] = t;
             s1 += t;
@@ -635,10 +742,11 @@ static void host_conv(const Case& c, const HostData& h, const Packed& pk, const 
 // offsets, LDS image, per-lane fragment addresses, weight pointer arithmetic, accumulator-register -> tile mapping, epilogue
 // addresses -- with the MFMA replaced by its documented semantics (A operand: lane (m, kg) holds A[m][8 kg .. 8 kg + 7];
 // B operand: lane (n, kg) holds B[8 kg .. 8 kg + 7][n]; D: lane (n, kg) register r holds D[8 (r / 4) + 4 kg + r % 4][n]).
-template <int G, int TN>
-static void host_twin_conv(const Case& c, const HostData& h, const Packed& pk, const std::vector<_Float16>& vs,
+template <class S, int G, int TN>
+static void host_twin_conv(const Case& c, const HostData& h, const Toom& tm, const Packed& pk, const std::vector<_Float16>& vs,
                            std::vector<float>& hy, std::vector<float>& hpart) {
-  constexpr int BT_ = 32 * TN, XW = BT_ + G - 1, ROWS = 2 * P * CG, S = ROWS * XW, NS = (S + NT - 1) / NT, LBUF = NS * NT;
+  constexpr int P = S::P, M = S::M;
+  constexpr int BT_ = 32 * TN, XW = BT_ + G - 1, ROWS = 2 * P * CG, SS = ROWS * XW, NS = (SS + NT - 1) / NT, LBUF = NS * NT;
   constexpr int SPC = G * P;
   const int cg_tot = c.cg_tot, Lt = c.Lt, C_out = c.C;
   hy.assign((size_t)c.VB * c.C * c.pitch_q, 0.f);
@@ -662,7 +770,7 @@ static void host_twin_conv(const Case& c, const HostData& h, const Packed& pk, c
               const int slot = tid + i * NT;
               const int row = slot / XW, col = slot - row * XW;
               const int pl = row / (P * CG), rem = row % (P * CG), p = rem / CG, g8 = rem % CG;
-              const int64_t soff = slot < S ? (pl * plane_stride + p * pstride + (int64_t)g8 * Lt + col) : 0;
+              const int64_t soff = slot < SS ? (pl * plane_stride + p * pstride + (int64_t)g8 * Lt + col) : 0;
               image[tid + i * NT] = vsb + (int64_t)ch * CG * Lt + soff;
             }
           for (int i = 0; i < SPC; ++i) {
@@ -697,16 +805,15 @@ static void host_twin_conv(const Case& c, const HostData& h, const Packed& pk, c
             double s1 = 0.0, s2 = 0.0;
             for (int j = 0; j < TN; ++j)
               for (int q = 0; q < 4; ++q) {
-                const int l0 = 3 * (t0 + 32 * j + 8 * q + 4 * kg);
+                const int l0 = M * (t0 + 32 * j + 8 * q + 4 * kg);
                 for (int e = 0; e < 4; ++e) {
                   const int rr = 4 * q + e, m = 8 * (rr / 4) + 4 * kg + rr % 4;
-                  double Y[P];
+                  double Y[7];
                   for (int p = 0; p < P; ++p) Y[p] = D[((((size_t)wave * P + p) * TN + j) * 32 + m) * 32 + l31];
-                  const double o[3] = {(Y[0] + Y[1]) + (Y[2] + Y[3]), (Y[1] - Y[2]) + 2.0 * Y[3], (Y[1] + Y[2]) + (4.0 * Y[3] + Y[4])};
-                  for (int i = 0; i < 3; ++i) {
-                    const int l = l0 + 3 * e + i;
+                  for (int i = 0; i < M; ++i) {
+                    const int l = l0 + M * e + i;
                     if (l >= L_eff) continue;
-                    float t = fmaf((float)o[i], osc_r, h.hb[co]);
+                    float t = fmaf(host_out(c, tm, Y, i), osc_r, h.hb[co]);
                     if (c.dil == 1) t += h.hres[((size_t)b * C_out + co) * c.pitch + l];
                     hy[((size_t)b * C_out + co) * c.pitch_q + l] = t;
                     s1 += t;
@@ -724,9 +831,9 @@ static void host_twin_conv(const Case& c, const HostData& h, const Packed& pk, c
 
 // Thread-level host twin of act_w3_kernel: the same staging loop (idx -> (e, i) -> q -> l, source permutation) into an
 // `sa` image and the same per-thread reads / destination index; compared with host_act on hi + lo (selftest only).
-static int host_twin_act(const Case& c, const HostData& h, const std::vector<_Float16>& vs_ref) {
-  const int x_cs = c.src_dil > 1 ? c.pitch_s : c.pitch;
-  const int64_t x_bs = (int64_t)c.C * x_cs;
+template <class S>
+static int host_twin_act(const Case& c, const HostData& h, const Toom& tm, const std::vector<_Float16>& vs_ref) {
+  constexpr int P = S::P, M = S::M, AT_POS = ActGeom<S>::POS, AT_PITCH = ActGeom<S>::PITCH;
   const int64_t pstride = (int64_t)c.cg_tot * c.Lt;
   std::vector<float> sa((size_t)8 * AT_PITCH);
   double worst = 0.0, scale = 0.0;
@@ -735,39 +842,19 @@ static int host_twin_act(const Case& c, const HostData& h, const std::vector<_Fl
       for (int bx = 0; bx < (c.Lt + AT_TILES - 1) / AT_TILES; ++bx) {
         const int tile0 = bx * AT_TILES;
         const int b = vb / c.dil, r = vb - b * c.dil;
-        const int p0 = 3 * tile0 - c.padq;
+        const int p0 = M * tile0 - c.padq;
         for (int tid = 0; tid < 256; ++tid)
           for (int idx = tid; idx < 8 * AT_POS; idx += 256) {
             const int e = idx / AT_POS, i = idx - e * AT_POS;
-            const int q = p0 + i;
-            const int l = c.dil * q + r;
-            const int ci = cg * 8 + e;
-            float u = 0.f;
-            if (q >= 0 && l < c.L && ci < c.C) {
-              if (c.src_dil > 1) {
-                const int rs = l % c.src_dil, qs = l / c.src_dil;
-                u = h.hxsrc[((int64_t)b * c.src_dil + rs) * x_bs + (int64_t)ci * x_cs + qs];
-              } else {
-                u = h.hxsrc[(int64_t)b * x_bs + (int64_t)ci * x_cs + l];
-              }
-              if (c.adain) {
-                float w = (u - h.hst[((size_t)b * c.C + ci) * 2]) * h.hst[((size_t)b * c.C + ci) * 2 + 1];
-                w = (1.0f + h.hga[(size_t)b * c.C + ci]) * w + h.hbe[(size_t)b * c.C + ci];
-                const float al = h.hal[ci], sn = sinf(al * w);
-                u = w + (1.0f / al) * (sn * sn);
-              }
-              u *= 8.f;
-            }
-            sa[(size_t)e * AT_PITCH + i] = u;
+            sa[(size_t)e * AT_PITCH + i] = host_a_rq(c, h, b, r, cg * 8 + e, p0 + i);
           }
         for (int tid = 0; tid < 256; ++tid) {
           const int T = tile0 + tid;
           if (T >= c.Lt) continue;
           for (int e = 0; e < 8; ++e) {
-            const float* sp = sa.data() + (size_t)e * AT_PITCH + 3 * tid;
-            const float d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3], d4 = sp[4];
-            const float v[P] = {(2.f * d0 - d1) + (d3 - 2.f * d2), (d3 - d2) - 2.f * d1, (2.f * d1 + d3) - 3.f * d2, d3 - d1,
-                                (2.f * d1 - d2) + (d4 - 2.f * d3)};
+            const float* sp = sa.data() + (size_t)e * AT_PITCH + M * tid;
+            float v[7];
+            host_transform(c, tm, sp, v);
             for (int p = 0; p < P; ++p) {
               const int64_t dst = (int64_t)vb * 2 * P * pstride + (int64_t)cg * c.Lt + T;  // h8 index of the hi slot of point 0
               const double ref = (double)(float)vs_ref[(size_t)(dst + p * pstride) * 8 + e] +
@@ -779,30 +866,39 @@ static int host_twin_act(const Case& c, const HostData& h, const std::vector<_Fl
         }
       }
   const bool ok = worst < 1e-5 * scale;  // hi + lo carries ~22 bits of v
-  printf("wino selftest (transform-pass twin) k=%d dil=%d src_dil=%d C=%d L=%d: max |hi + lo - v| = %.3e of %.3e -> %s\n", c.K, c.dil,
-         c.src_dil, c.C, c.L, worst, scale, ok ? "OK" : "MISMATCH");
+  printf("wino selftest (transform-pass twin) F(%d,%d) k=%d dil=%d src_dil=%d C=%d L=%d: max |hi + lo - v| = %.3e of %.3e -> %s\n",
+         c.M, c.R, c.K, c.dil, c.src_dil, c.C, c.L, worst, scale, ok ? "OK" : "MISMATCH");
   return ok ? 0 : 1;
 }
 
+template <class S, int TN, class F>
+static auto by_groups(int G, F&& f) {  // G = ceil(k / R): 4 or 3 for F(3,3), 3 or 2 for F(4,4)
+  if (G == 4) return f(std::integral_constant<int, 4>{});
+  if (G == 3) return f(std::integral_constant<int, 3>{});
+  return f(std::integral_constant<int, 2>{});
+}
+
 // mode 0 = timing, 1 = GPU check, 2 = host selftest
-template <int TN>
+template <class S, int TN, int OCC>
 static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, int mode, bool adain) {
   Case c;
+  c.M = S::M; c.R = S::R;
   c.TN = TN; c.K = K; c.C = C; c.L = L; c.B = B; c.dil = dil; c.src_dil = src_dil; c.adain = adain;
   c.derive();
+  const ToomD td = toom(S::M, S::R);
+  const Toom tm = toom_f32(td);
   HostData h;
   make_data(c, h);
-  Packed pk = pack_w3(h.hw, C, C, K, c.G);
+  Packed pk = pack_w3(td, h.hw, C, C, K, c.G);
   if (mode == 2) {
     std::vector<float> hy, hpart;
     std::vector<_Float16> hvs;
-    host_act(c, h, hvs);
-    host_conv(c, h, pk, hvs, hy, hpart);
+    host_act(c, h, tm, hvs);
+    host_conv(c, h, tm, pk, hvs, hy, hpart);
     int bad = check_result(c, h, hy, hpart, "selftest (data flow)");
-    if (TN == 2) bad |= host_twin_act(c, h, hvs);
+    if (TN == 1 || S::M == 3) bad |= host_twin_act<S>(c, h, tm, hvs);
     if (L <= 600) {  // thread-level twin of the conv kernel's index arithmetic (slow: small cases only)
-      if (c.G == 4) host_twin_conv<4, TN>(c, h, pk, hvs, hy, hpart);
-      else host_twin_conv<3, TN>(c, h, pk, hvs, hy, hpart);
+      by_groups<S, TN>(c.G, [&](auto g_tag) { host_twin_conv<S, decltype(g_tag)::value, TN>(c, h, tm, pk, hvs, hy, hpart); return 0; });
       bad |= check_result(c, h, hy, hpart, "selftest (thread-level twin)");
     }
     return bad;
@@ -810,7 +906,7 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
   float *x, *res, *y, *bias, *rsc, *part, *st, *ga, *be, *al;
   _Float16* wq;
   h8* vs;
-  const size_t vs_slots = (size_t)c.VB * 2 * P * c.cg_tot * c.Lt;
+  const size_t vs_slots = (size_t)c.VB * 2 * S::P * c.cg_tot * c.Lt;
   const size_t y_elems = (size_t)c.VB * C * c.pitch_q;
   CK(hipMalloc(&x, h.hxsrc.size() * 4)); CK(hipMalloc(&res, h.hres.size() * 4)); CK(hipMalloc(&y, y_elems * 4));
   CK(hipMalloc(&bias, (size_t)pk.co_pad * 4)); CK(hipMalloc(&rsc, (size_t)pk.co_pad * 4));
@@ -834,7 +930,7 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
   const int x_cs = src_dil > 1 ? c.pitch_s : c.pitch;
   a.x = x; a.x_bs = (int64_t)C * x_cs; a.x_cs = x_cs; a.C = C; a.L = L; a.pad = c.padq; a.pro = adain ? 1 : 0;
   a.stats = st; a.gamma = ga; a.beta = be; a.gb_bs = C; a.alpha = al; a.x_scale = 8.f;
-  a.vs = vs; a.cg_tot = c.cg_tot; a.Lt = c.Lt; a.dil = dil; a.src_dil = src_dil;
+  a.vs = vs; a.cg_tot = c.cg_tot; a.Lt = c.Lt; a.dil = dil; a.src_dil = src_dil; a.tm = tm;
   WArgs d;
   memset(&d, 0, sizeof(d));
   d.vs = vs; d.cg_tot = c.cg_tot; d.Lt = c.Lt;
@@ -843,16 +939,18 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
   d.y = y; d.y_bs = (int64_t)C * c.pitch_q; d.y_cs = c.pitch_q;
   if (dil == 1) { d.res = res; d.res_bs = (int64_t)C * c.pitch; d.res_cs = c.pitch; }  // the residual add sits after convs2
   d.part = part; d.part_nt = c.nblk;
-  d.C_out = C; d.L_out = L; d.dil = dil;
+  d.C_out = C; d.L_out = L; d.dil = dil; d.tm = tm;
 
   auto run_act = [&]() -> int {
     dim3 grid((c.Lt + AT_TILES - 1) / AT_TILES, c.cg_tot, c.VB);
-    if (adain) hipLaunchKernelGGL((act_w3_kernel<1>), grid, dim3(256), 0, 0, a);
-    else hipLaunchKernelGGL((act_w3_kernel<0>), grid, dim3(256), 0, 0, a);
+    if (adain) hipLaunchKernelGGL((act_w3_kernel<S, 1>), grid, dim3(256), 0, 0, a);
+    else hipLaunchKernelGGL((act_w3_kernel<S, 0>), grid, dim3(256), 0, 0, a);
     CK(hipGetLastError());
     return 0;
   };
-  auto run_conv = [&]() -> int { return c.G == 4 ? launch_conv<4, TN>(d, c.VB) : launch_conv<3, TN>(d, c.VB); };
+  auto run_conv = [&]() -> int {
+    return by_groups<S, TN>(c.G, [&](auto g_tag) { return launch_conv<S, decltype(g_tag)::value, TN, OCC>(d, c.VB, c.nblk); });
+  };
   if (run_act() || run_conv()) return 1;
   CK(hipDeviceSynchronize());
 
@@ -882,38 +980,43 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
   ms_act /= reps;
   ms_conv /= reps;
   const double flop = 2.0 * B * C * (double)C * K * L;
-  printf("wino_bench TN=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + planes "
-         "written), conv %.4f ms = %.1f algorithmic TFLOP/s (%.3f of 833)\n", TN, K, dil, src_dil, C, L, B, (int)adain, ms_act,
-         ((double)B * C * L * 4 + (double)vs_slots * 16) / ms_act / 1e9, ms_conv, flop / ms_conv / 1e9,
+  printf("wino_bench F(%d,%d) TN=%d occ=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + "
+         "planes written), conv %.4f ms = %.1f algorithmic TFLOP/s (%.3f of 833)\n", S::M, S::R, TN, OCC, K, dil, src_dil, C, L,
+         B, (int)adain, ms_act, ((double)B * C * L * 4 + (double)vs_slots * 16) / ms_act / 1e9, ms_conv, flop / ms_conv / 1e9,
          flop / ms_conv / 1e9 / (2500.0 / 3));
   return 0;
 }
 
-template <int TN>
+template <class S, int TN, int OCC>
 static int check_all(int mode) {
   int bad = 0;
-  bad |= run_case<TN>(11, 1, 1, 128, 1000, 2, 1, mode, false);   // edge tiles along l
-  bad |= run_case<TN>(11, 1, 1, 128, 1152, 1, 1, mode, true);    // interior tiles only, AdaIN + Snake prologue
-  bad |= run_case<TN>(7, 1, 1, 128, 777, 2, 1, mode, true);
-  bad |= run_case<TN>(7, 1, 1, 256, 389, 1, 1, mode, false);     // two co blocks
-  bad |= run_case<TN>(11, 1, 1, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
-  bad |= run_case<TN>(11, 3, 1, 128, 1000, 1, 1, mode, true);    // dilated (convs1): residue-major output, no residual
-  bad |= run_case<TN>(7, 5, 1, 128, 523, 2, 1, mode, false);
-  bad |= run_case<TN>(11, 1, 3, 128, 598, 1, 1, mode, true);     // convs2 behind a dilation-3 layer: residue-major input
-  bad |= run_case<TN>(7, 1, 5, 128, 1001, 1, 1, mode, true);
+  bad |= run_case<S, TN, OCC>(11, 1, 1, 128, 1000, 2, 1, mode, false);   // edge tiles along l
+  bad |= run_case<S, TN, OCC>(11, 1, 1, 128, 1152, 1, 1, mode, true);    // AdaIN + Snake prologue
+  bad |= run_case<S, TN, OCC>(7, 1, 1, 128, 777, 2, 1, mode, true);
+  bad |= run_case<S, TN, OCC>(7, 1, 1, 256, 389, 1, 1, mode, false);     // two co blocks
+  bad |= run_case<S, TN, OCC>(11, 1, 1, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
+  bad |= run_case<S, TN, OCC>(11, 3, 1, 128, 1000, 1, 1, mode, true);    // dilated (convs1): residue-major output, no residual
+  bad |= run_case<S, TN, OCC>(7, 5, 1, 128, 523, 2, 1, mode, false);
+  bad |= run_case<S, TN, OCC>(11, 1, 3, 128, 598, 1, 1, mode, true);     // convs2 behind a dilation-3 layer: residue-major input
+  bad |= run_case<S, TN, OCC>(7, 1, 5, 128, 1001, 1, 1, mode, true);
   return bad;
 }
 
 int main(int argc, char** argv) {
   if (argc > 1 && (!strcmp(argv[1], "check") || !strcmp(argv[1], "selftest"))) {
     const int mode = !strcmp(argv[1], "check") ? 1 : 2;  // selftest: host emulation of the data flow, no GPU needed
-    const int bad = check_all<2>(mode) | check_all<1>(mode);
+    int bad = toom_selfcheck(toom(3, 3)) | toom_selfcheck(toom(4, 4));
+    bad |= check_all<S33, 2, 2>(mode) | check_all<S33, 1, 3>(mode) | check_all<S44, 1, 2>(mode);
+    if (mode == 1) bad |= check_all<S44, 1, 3>(mode);  // same data flow, other register budget: GPU only
     printf(bad ? "wino check: FAILED\n" : "wino check: all cases OK\n");
     return bad;
   }
   auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
   const int K = arg(1, 11), C = arg(2, 128), L = arg(3, 48001), B = arg(4, 32), reps = arg(5, 10), tn = arg(6, 2);
-  const int dil = arg(7, 1), src_dil = arg(8, 1);
+  const int dil = arg(7, 1), src_dil = arg(8, 1), scheme = arg(9, 33);
   if (K != 7 && K != 11) { fprintf(stderr, "k must be 7 or 11\n"); return 2; }
-  return tn == 1 ? run_case<1>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<2>(K, dil, src_dil, C, L, B, reps, 0, true);
+  const int occ = arg(10, 2);
+  if (scheme == 44)
+    return occ == 3 ? run_case<S44, 1, 3>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S44, 1, 2>(K, dil, src_dil, C, L, B, reps, 0, true);
+  return tn == 1 ? run_case<S33, 1, 3>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S33, 2, 2>(K, dil, src_dil, C, L, B, reps, 0, true);
 }
