@@ -1691,8 +1691,12 @@ int pack_style(st2_engine& e, Blob& blob, int which, std::string* err) {
   s.wl = pk.conv_w(R + "unshared.weight");
   s.bl = pk.vec(R + "unshared.bias");
   s.style_dim = s.wl.C_out;
-  if (!pk.ok || s.blocks.empty() || s.c0 > STYLE_ZEROS || s.c_last > STYLE_ZEROS) {
+  if (!pk.ok || s.c0 > STYLE_ZEROS || s.c_last > STYLE_ZEROS) {
     *err = "missing style-encoder parameter " + pk.missing;
+    return 1;
+  }
+  if (s.blocks.size() != 4 || s.w5.ks != 5 || s.w5.C_in != 5 * s.blocks.back().c_out) {  // 80 mel bins -> 5 rows -> 5x5 valid conv
+    *err = "style encoder " + R + ": expected four down-sampling ResBlks and a 5x5 valid conv (models.py:139-164)";
     return 1;
   }
   s.ready = true;
