@@ -13,8 +13,11 @@ for k in 11 7; do
     echo "== F(3,3) k=$k TN=$tn"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 $tn | tee -a $OUT/wino_bench.log
   done
   for occ in 2 3; do
-    echo "== F(4,4) k=$k occ=$occ"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 1 1 1 44 $occ | tee -a $OUT/wino_bench.log
+    for wm in 4 2; do   # wm = 2: waves pair up on the same output rows (weight fragments shared through the vector L1)
+      echo "== F(4,4) k=$k occ=$occ WM=$wm"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 1 1 1 44 $occ $wm | tee -a $OUT/wino_bench.log
+    done
   done
+  echo "== F(3,3) k=$k TN=1 WM=2"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 1 1 1 33 3 2 | tee -a $OUT/wino_bench.log
 done
 for d in 3 5; do   # dilated convs1 (residue-major output) and the convs2 behind them (residue-major input)
   echo "== production kernel k=11 dil=$d"; timeout 120 tools/bin/xs_bench_0 11 $d 128 48001 32 0 1 10 | tee -a $OUT/xs_bench.log

@@ -6,9 +6,10 @@
 //
 //   tools/bin/wino_bench selftest        no GPU: host emulation of the kernels' data flow through the same checker
 //   tools/bin/wino_bench check           small shapes (edge tiles included) against a direct fp64 conv on the host
-//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2] [dil=1] [src_dil=1] [scheme=33] [occ=2]   timing
+//   tools/bin/wino_bench [k=11] [C=128] [L=48001] [B=32] [reps=10] [TN=2] [dil=1] [src_dil=1] [scheme=33] [occ=2] [WM=4]   timing
 //                                          (TN = 32-tile blocks per wave; dil = the conv's dilation, src_dil = dilation of the
-//                                           layer that produced x; scheme 33 = F(3,3) (TN 1 or 2), 44 = F(4,4) (TN 1, occ = 2 or 3 workgroups / CU))
+//                                           layer that produced x; scheme 33 = F(3,3) (TN 1 or 2), 44 = F(4,4) (TN 1, occ = 2 or 3 workgroups / CU);
+//                                           WM = waves along co: 4 -> 128 co x 32 TN tiles, 2 -> 64 co x 64 TN tiles per workgroup)
 //
 // Maths (P = M + R - 1 points: 0, +-1, 2, inf for F(3,3); 0, +-1, +-2, 1/2, inf for F(4,4); matrices built by toom() below,
 // rounding studied on the CPU by tools/winograd_numerics.py):
@@ -87,14 +88,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// conv over tiles: workgroup = 4 waves along co (128 output rows) x 32 TN tiles (= 96 TN outputs)
+// conv over tiles: workgroup = 4 waves as WM (co blocks of 32) x WN = 4 / WM (blocks of 32 TN tiles); waves that share their
+// output rows (WN > 1) read the same weight fragments in step, i.e. mostly from the CU's vector L1 instead of L2
 // ---------------------------------------------------------------------------------------------------------------------
 // OCC = workgroups per CU the register budget is held to (3: <= 168 VGPRs; F(4,4) then parks the staged activations of the
 // next chunk in scratch -- 3 x 16 B per lane per chunk of ~2000 MFMA cycles)
-template <class S, int G, int TN, int OCC>
+template <class S, int G, int TN, int OCC, int WM>
 __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
-  constexpr int P = S::P, M = S::M;
-  constexpr int BT_ = 32 * TN;            // tiles per workgroup
+  constexpr int P = S::P, M = S::M, WN = 4 / WM, BM = 32 * WM;
+  constexpr int BT_ = 32 * TN * WN;       // tiles per workgroup
   constexpr int XW = BT_ + G - 1;         // staged tile slots per image row
   constexpr int ROWS = 2 * P * CG;        // image rows per chunk: (plane, point, channel group)
   constexpr int SLOTS = ROWS * XW;
@@ -108,11 +110,12 @@ __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;  // = co block of 32 within the workgroup
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
   const int kg = lane >> 5;
   const int l31 = lane & 31;
   const int t0 = blockIdx.x * BT_;        // first tile
-  const int m0 = blockIdx.y * 128;
+  const int m0 = blockIdx.y * BM;
   const int b = blockIdx.z;
   const int L_eff = d.dil > 1 ? (d.L_out - (b % d.dil) + d.dil - 1) / d.dil : d.L_out;  // outputs of this (virtual) batch item
 
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
 
-  const int co_a = m0 + wave * 32 + l31;  // < co_pad by construction of the packing
+  const int co_a = m0 + wm * 32 + l31;  // < co_pad by construction of the packing
   const h8* ap = d.wq + ((int64_t)kg * d.co_pad + co_a) * 2;
   const int64_t a_step = (int64_t)2 * d.co_pad * 2;
   const int nchunk = d.cin_pad / CI_T;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunk;
-    const h8* xbuf = lds + (size_t)buf * LBUF + l31;
+    const h8* xbuf = lds + (size_t)buf * LBUF + wn * (32 * TN) + l31;
     static_for<SPC>([&](auto i_tag) __attribute__((always_inline)) {
       constexpr int i = decltype(i_tag)::value;
       constexpr int g = i / P, p = i % P;
@@ -214,9 +217,10 @@ __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
   __builtin_amdgcn_s_setprio(0);
 
   // ---- epilogue: inverse transform, scale, bias, residual, store, statistics ------------------------------------------
-  // lane (l31, kg) owns output row co and, in acc[p][j][4 q + e], tile T = t0 + 32 j + 8 q + 4 kg + e: the four tiles of a
-  // (j, q) are 4 M consecutive outputs starting at M (t0 + 32 j + 8 q + 4 kg)
-  const int co = m0 + wave * 32 + l31;
+  // lane (l31, kg) owns output row co and, in acc[p][j][4 q + e], tile T = tw + 32 j + 8 q + 4 kg + e: the four tiles of a
+  // (j, q) are 4 M consecutive outputs starting at M (tw + 32 j + 8 q + 4 kg)
+  const int tw = t0 + wn * (32 * TN);  // this wave's first tile
+  const int co = m0 + wm * 32 + l31;
   const bool rok = co < d.C_out;
   const int coc = rok ? co : d.C_out - 1;
   const float osc_r = d.out_scale * d.row_scale[co];
@@ -225,11 +229,11 @@ __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
   const float* rb = d.res ? d.res + (int64_t)b * d.res_bs + (int64_t)coc * d.res_cs : nullptr;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.y) | (uintptr_t)(d.y_bs * 4) | (uintptr_t)(d.y_cs * 4)) & 15) == 0 &&
                       (!d.res || ((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0);
-  const bool full = vec_ok && m0 + 128 <= d.C_out && M * (t0 + BT_) <= L_eff;  // workgroup-uniform
+  const bool full = vec_ok && m0 + BM <= d.C_out && M * (t0 + BT_) <= L_eff;  // workgroup-uniform
   float s1 = 0.f, s2 = 0.f;
   static_for<TN * 4>([&](auto jq_tag) __attribute__((always_inline)) {
     constexpr int j = decltype(jq_tag)::value / 4, q = decltype(jq_tag)::value % 4;
-    const int l0 = M * (t0 + 32 * j + 8 * q + 4 * kg);
+    const int l0 = M * (tw + 32 * j + 8 * q + 4 * kg);
     float o[4 * M];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -278,8 +282,9 @@ __global__ __launch_bounds__(NT, OCC) void conv_w3_kernel(const WArgs d) {
   if (d.part) {
     const float a1 = s1 + __shfl_xor(s1, 32, 64);
     const float a2 = s2 + __shfl_xor(s2, 32, 64);
-    if (kg == 0 && rok && (int)blockIdx.x < d.part_nt) {
-      float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + co) * d.part_nt + blockIdx.x;
+    const int pblk = blockIdx.x * WN + wn;  // one partial per wave block of 32 TN tiles
+    if (kg == 0 && rok && pblk < d.part_nt) {
+      float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + co) * d.part_nt + pblk;
       *pp = make_float2(a1, a2);
     }
   }
@@ -514,26 +519,27 @@ static double snake_ref(double v, double al) {
   return v + s * s / al;
 }
 
-template <class S, int G, int TN, int OCC>
-static int launch_conv(const WArgs& d, int B, int nblk) {
-  constexpr int BT_ = 32 * TN;
+template <class S, int G, int TN, int OCC, int WM>
+static int launch_conv(const WArgs& d, int B, int nblk) {  // nblk = wave blocks of 32 TN tiles (a multiple of WN)
+  constexpr int WN = 4 / WM;
+  constexpr int BT_ = 32 * TN * WN;
   constexpr int XW = BT_ + G - 1;
   constexpr int NS = (2 * S::P * CG * XW + NT - 1) / NT;
   const size_t smem = (size_t)2 * NS * NT * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w3_kernel<S, G, TN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w3_kernel<S, G, TN, OCC, WM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            160 * 1024));
     attr_done = true;
   }
-  dim3 grid(nblk, (d.C_out + 127) / 128, B);
-  hipLaunchKernelGGL((conv_w3_kernel<S, G, TN, OCC>), grid, dim3(NT), smem, 0, d);
+  dim3 grid(nblk / WN, (d.C_out + 32 * WM - 1) / (32 * WM), B);
+  hipLaunchKernelGGL((conv_w3_kernel<S, G, TN, OCC, WM>), grid, dim3(NT), smem, 0, d);
   CK(hipGetLastError());
   return 0;
 }
 
 struct Case {
-  int M, R, P, TN, K, C, L, B, dil, src_dil;
+  int M, R, P, TN, WM, K, C, L, B, dil, src_dil;
   bool adain;
   // derived
   int G, padq, Lq, n_tiles, BT_, nblk, Lt, cg_tot, pitch, pitch_q, pitch_s, VB;
@@ -541,8 +547,10 @@ struct Case {
     P = M + R - 1;
     G = (K + R - 1) / R; padq = (K - 1) / 2;
     Lq = (L + dil - 1) / dil;                       // longest stride-d subsequence
-    n_tiles = (Lq + M - 1) / M; BT_ = 32 * TN; nblk = (n_tiles + BT_ - 1) / BT_;
-    Lt = nblk * BT_ + 8;                            // every workgroup stages BT_ + G - 1 <= BT_ + 3 tiles
+    n_tiles = (Lq + M - 1) / M; BT_ = 32 * TN;      // BT_ = tiles per WAVE block (statistics granule)
+    const int WN = 4 / WM;
+    nblk = (n_tiles + BT_ * WN - 1) / (BT_ * WN) * WN;  // wave blocks, padded to whole workgroups
+    Lt = nblk * BT_ + 8;                            // every workgroup stages WN BT_ + G - 1 <= WN BT_ + 3 tiles
     cg_tot = (C + 15) / 16 * 16 / 8;
     pitch = (L + 31) / 32 * 32;                     // natural rows (host reference, residual)
     pitch_q = (Lq + 31) / 32 * 32;                  // output rows: y[vb = b * dil + r][co][q]
@@ -742,11 +750,12 @@ static void host_conv(const Case& c, const HostData& h, const Toom& tm, const Pa
 // offsets, LDS image, per-lane fragment addresses, weight pointer arithmetic, accumulator-register -> tile mapping, epilogue
 // addresses -- with the MFMA replaced by its documented semantics (A operand: lane (m, kg) holds A[m][8 kg .. 8 kg + 7];
 // B operand: lane (n, kg) holds B[8 kg .. 8 kg + 7][n]; D: lane (n, kg) register r holds D[8 (r / 4) + 4 kg + r % 4][n]).
-template <class S, int G, int TN>
+template <class S, int G, int TN, int WM>
 static void host_twin_conv(const Case& c, const HostData& h, const Toom& tm, const Packed& pk, const std::vector<_Float16>& vs,
                            std::vector<float>& hy, std::vector<float>& hpart) {
   constexpr int P = S::P, M = S::M;
-  constexpr int BT_ = 32 * TN, XW = BT_ + G - 1, ROWS = 2 * P * CG, SS = ROWS * XW, NS = (SS + NT - 1) / NT, LBUF = NS * NT;
+  constexpr int WN = 4 / WM, BM = 32 * WM;
+  constexpr int BT_ = 32 * TN * WN, XW = BT_ + G - 1, ROWS = 2 * P * CG, SS = ROWS * XW, NS = (SS + NT - 1) / NT, LBUF = NS * NT;
   constexpr int SPC = G * P;
   const int cg_tot = c.cg_tot, Lt = c.Lt, C_out = c.C;
   hy.assign((size_t)c.VB * c.C * c.pitch_q, 0.f);
@@ -759,9 +768,9 @@ static void host_twin_conv(const Case& c, const HostData& h, const Toom& tm, con
   std::vector<double> D((size_t)4 * P * TN * 32 * 32);
   for (int b = 0; b < c.VB; ++b) {  // b = the grid's (virtual) batch index
     const int L_eff = c.dil > 1 ? (c.L - (b % c.dil) + c.dil - 1) / c.dil : c.L;
-    for (int by = 0; by < (C_out + 127) / 128; ++by)
-      for (int bx = 0; bx < c.nblk; ++bx) {
-        const int t0 = bx * BT_, m0 = by * 128;
+    for (int by = 0; by < (C_out + BM - 1) / BM; ++by)
+      for (int bx = 0; bx < c.nblk / WN; ++bx) {
+        const int t0 = bx * BT_, m0 = by * BM;
         const int64_t vsb = (int64_t)b * 2 * plane_stride + t0;
         std::fill(D.begin(), D.end(), 0.0);
         for (int ch = 0; ch < nchunk; ++ch) {
@@ -781,10 +790,11 @@ static void host_twin_conv(const Case& c, const HostData& h, const Toom& tm, con
                 for (int m = 0; m < 32; ++m)      // A-operand lane l31 = m
                   for (int n = 0; n < 32; ++n) {  // B-operand lane l31 = n
                     double sum = 0.0;
+                    const int wm = wave / WN, wn = wave % WN;
                     for (int kg = 0; kg < 2; ++kg) {
-                      const int64_t xh = image[(p * CG + kg) * XW + g + m + j * 32];
-                      const int64_t xl = image[(p * CG + kg) * XW + g + m + j * 32 + P * CG * XW];
-                      const int co_a = m0 + wave * 32 + n;
+                      const int64_t xh = image[(p * CG + kg) * XW + g + wn * (32 * TN) + m + j * 32];
+                      const int64_t xl = image[(p * CG + kg) * XW + g + wn * (32 * TN) + m + j * 32 + P * CG * XW];
+                      const int co_a = m0 + wm * 32 + n;
                       const int64_t ap = ((int64_t)kg * pk.co_pad + co_a) * 2 + step * a_step;
                       for (int e = 0; e < 8; ++e) {
                         const double bh = slot_of(vs, xh, e), bl = slot_of(vs, xl, e);
@@ -799,13 +809,15 @@ static void host_twin_conv(const Case& c, const HostData& h, const Toom& tm, con
         for (int wave = 0; wave < 4; ++wave)
           for (int lane = 0; lane < 64; ++lane) {
             const int kg = lane >> 5, l31 = lane & 31;
-            const int co = m0 + wave * 32 + l31;
+            const int wm = wave / WN, wn = wave % WN;
+            const int tw = t0 + wn * (32 * TN);
+            const int co = m0 + wm * 32 + l31;
             if (co >= C_out) continue;
             const float osc_r = (1.f / 8.f) * pk.row_scale[co];
             double s1 = 0.0, s2 = 0.0;
             for (int j = 0; j < TN; ++j)
               for (int q = 0; q < 4; ++q) {
-                const int l0 = M * (t0 + 32 * j + 8 * q + 4 * kg);
+                const int l0 = M * (tw + 32 * j + 8 * q + 4 * kg);
                 for (int e = 0; e < 4; ++e) {
                   const int rr = 4 * q + e, m = 8 * (rr / 4) + 4 * kg + rr % 4;
                   double Y[7];
@@ -821,7 +833,7 @@ static void host_twin_conv(const Case& c, const HostData& h, const Toom& tm, con
                   }
                 }
               }
-            float* pp = hpart.data() + (((size_t)b * C_out + co) * c.nblk + bx) * 2;  // lane + its kg partner
+            float* pp = hpart.data() + (((size_t)b * C_out + co) * c.nblk + bx * WN + wn) * 2;  // lane + its kg partner
             pp[0] += (float)s1;
             pp[1] += (float)s2;
           }
@@ -879,11 +891,11 @@ static auto by_groups(int G, F&& f) {  // G = ceil(k / R): 4 or 3 for F(3,3), 3 
 }
 
 // mode 0 = timing, 1 = GPU check, 2 = host selftest
-template <class S, int TN, int OCC>
+template <class S, int TN, int OCC, int WM>
 static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, int mode, bool adain) {
   Case c;
   c.M = S::M; c.R = S::R;
-  c.TN = TN; c.K = K; c.C = C; c.L = L; c.B = B; c.dil = dil; c.src_dil = src_dil; c.adain = adain;
+  c.TN = TN; c.WM = WM; c.K = K; c.C = C; c.L = L; c.B = B; c.dil = dil; c.src_dil = src_dil; c.adain = adain;
   c.derive();
   const ToomD td = toom(S::M, S::R);
   const Toom tm = toom_f32(td);
@@ -898,7 +910,7 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
     int bad = check_result(c, h, hy, hpart, "selftest (data flow)");
     if (TN == 1 || S::M == 3) bad |= host_twin_act<S>(c, h, tm, hvs);
     if (L <= 600) {  // thread-level twin of the conv kernel's index arithmetic (slow: small cases only)
-      by_groups<S, TN>(c.G, [&](auto g_tag) { host_twin_conv<S, decltype(g_tag)::value, TN>(c, h, tm, pk, hvs, hy, hpart); return 0; });
+      by_groups<S, TN>(c.G, [&](auto g_tag) { host_twin_conv<S, decltype(g_tag)::value, TN, WM>(c, h, tm, pk, hvs, hy, hpart); return 0; });
       bad |= check_result(c, h, hy, hpart, "selftest (thread-level twin)");
     }
     return bad;
@@ -949,7 +961,7 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
     return 0;
   };
   auto run_conv = [&]() -> int {
-    return by_groups<S, TN>(c.G, [&](auto g_tag) { return launch_conv<S, decltype(g_tag)::value, TN, OCC>(d, c.VB, c.nblk); });
+    return by_groups<S, TN>(c.G, [&](auto g_tag) { return launch_conv<S, decltype(g_tag)::value, TN, OCC, WM>(d, c.VB, c.nblk); });
   };
   if (run_act() || run_conv()) return 1;
   CK(hipDeviceSynchronize());
@@ -980,25 +992,25 @@ static int run_case(int K, int dil, int src_dil, int C, int L, int B, int reps, 
   ms_act /= reps;
   ms_conv /= reps;
   const double flop = 2.0 * B * C * (double)C * K * L;
-  printf("wino_bench F(%d,%d) TN=%d occ=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + "
-         "planes written), conv %.4f ms = %.1f algorithmic TFLOP/s (%.3f of 833)\n", S::M, S::R, TN, OCC, K, dil, src_dil, C, L,
+  printf("wino_bench F(%d,%d) TN=%d occ=%d WM=%d k=%d dil=%d src_dil=%d C=%d L=%d B=%d adain=%d: transform pass %.4f ms (%.2f TB/s of x read + "
+         "planes written), conv %.4f ms = %.1f algorithmic TFLOP/s (%.3f of 833)\n", S::M, S::R, TN, OCC, WM, K, dil, src_dil, C, L,
          B, (int)adain, ms_act, ((double)B * C * L * 4 + (double)vs_slots * 16) / ms_act / 1e9, ms_conv, flop / ms_conv / 1e9,
          flop / ms_conv / 1e9 / (2500.0 / 3));
   return 0;
 }
 
-template <class S, int TN, int OCC>
+template <class S, int TN, int OCC, int WM>
 static int check_all(int mode) {
   int bad = 0;
-  bad |= run_case<S, TN, OCC>(11, 1, 1, 128, 1000, 2, 1, mode, false);   // edge tiles along l
-  bad |= run_case<S, TN, OCC>(11, 1, 1, 128, 1152, 1, 1, mode, true);    // AdaIN + Snake prologue
-  bad |= run_case<S, TN, OCC>(7, 1, 1, 128, 777, 2, 1, mode, true);
-  bad |= run_case<S, TN, OCC>(7, 1, 1, 256, 389, 1, 1, mode, false);     // two co blocks
-  bad |= run_case<S, TN, OCC>(11, 1, 1, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
-  bad |= run_case<S, TN, OCC>(11, 3, 1, 128, 1000, 1, 1, mode, true);    // dilated (convs1): residue-major output, no residual
-  bad |= run_case<S, TN, OCC>(7, 5, 1, 128, 523, 2, 1, mode, false);
-  bad |= run_case<S, TN, OCC>(11, 1, 3, 128, 598, 1, 1, mode, true);     // convs2 behind a dilation-3 layer: residue-major input
-  bad |= run_case<S, TN, OCC>(7, 1, 5, 128, 1001, 1, 1, mode, true);
+  bad |= run_case<S, TN, OCC, WM>(11, 1, 1, 128, 1000, 2, 1, mode, false);   // edge tiles along l
+  bad |= run_case<S, TN, OCC, WM>(11, 1, 1, 128, 1152, 1, 1, mode, true);    // AdaIN + Snake prologue
+  bad |= run_case<S, TN, OCC, WM>(7, 1, 1, 128, 777, 2, 1, mode, true);
+  bad |= run_case<S, TN, OCC, WM>(7, 1, 1, 256, 389, 1, 1, mode, false);     // two co blocks
+  bad |= run_case<S, TN, OCC, WM>(11, 1, 1, 96, 500, 1, 1, mode, false);     // C_out < 128: row guard
+  bad |= run_case<S, TN, OCC, WM>(11, 3, 1, 128, 1000, 1, 1, mode, true);    // dilated (convs1): residue-major output, no residual
+  bad |= run_case<S, TN, OCC, WM>(7, 5, 1, 128, 523, 2, 1, mode, false);
+  bad |= run_case<S, TN, OCC, WM>(11, 1, 3, 128, 598, 1, 1, mode, true);     // convs2 behind a dilation-3 layer: residue-major input
+  bad |= run_case<S, TN, OCC, WM>(7, 1, 5, 128, 1001, 1, 1, mode, true);
   return bad;
 }
 
@@ -1006,8 +1018,8 @@ int main(int argc, char** argv) {
   if (argc > 1 && (!strcmp(argv[1], "check") || !strcmp(argv[1], "selftest"))) {
     const int mode = !strcmp(argv[1], "check") ? 1 : 2;  // selftest: host emulation of the data flow, no GPU needed
     int bad = toom_selfcheck(toom(3, 3)) | toom_selfcheck(toom(4, 4));
-    bad |= check_all<S33, 2, 2>(mode) | check_all<S33, 1, 3>(mode) | check_all<S44, 1, 2>(mode);
-    if (mode == 1) bad |= check_all<S44, 1, 3>(mode);  // same data flow, other register budget: GPU only
+    bad |= check_all<S33, 2, 2, 4>(mode) | check_all<S33, 1, 3, 4>(mode) | check_all<S44, 1, 2, 4>(mode) | check_all<S44, 1, 2, 2>(mode);
+    if (mode == 1) bad |= check_all<S44, 1, 3, 4>(mode) | check_all<S44, 1, 3, 2>(mode) | check_all<S33, 1, 3, 2>(mode);  // other budgets / shapes: GPU only
     printf(bad ? "wino check: FAILED\n" : "wino check: all cases OK\n");
     return bad;
   }
@@ -1015,8 +1027,11 @@ int main(int argc, char** argv) {
   const int K = arg(1, 11), C = arg(2, 128), L = arg(3, 48001), B = arg(4, 32), reps = arg(5, 10), tn = arg(6, 2);
   const int dil = arg(7, 1), src_dil = arg(8, 1), scheme = arg(9, 33);
   if (K != 7 && K != 11) { fprintf(stderr, "k must be 7 or 11\n"); return 2; }
-  const int occ = arg(10, 2);
-  if (scheme == 44)
-    return occ == 3 ? run_case<S44, 1, 3>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S44, 1, 2>(K, dil, src_dil, C, L, B, reps, 0, true);
-  return tn == 1 ? run_case<S33, 1, 3>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S33, 2, 2>(K, dil, src_dil, C, L, B, reps, 0, true);
+  const int occ = arg(10, 2), wm = arg(11, 4);
+  if (scheme == 44) {
+    if (wm == 2) return occ == 3 ? run_case<S44, 1, 3, 2>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S44, 1, 2, 2>(K, dil, src_dil, C, L, B, reps, 0, true);
+    return occ == 3 ? run_case<S44, 1, 3, 4>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S44, 1, 2, 4>(K, dil, src_dil, C, L, B, reps, 0, true);
+  }
+  if (tn == 1) return wm == 2 ? run_case<S33, 1, 3, 2>(K, dil, src_dil, C, L, B, reps, 0, true) : run_case<S33, 1, 3, 4>(K, dil, src_dil, C, L, B, reps, 0, true);
+  return run_case<S33, 2, 2, 4>(K, dil, src_dil, C, L, B, reps, 0, true);
 }
