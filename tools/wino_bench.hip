@@ -1015,6 +1015,14 @@ static int check_all(int mode) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 2 && !strcmp(argv[1], "selftest") && !strcmp(argv[2], "quick")) {  // a few seconds: one small case per scheme
+    int bad = toom_selfcheck(toom(3, 3)) | toom_selfcheck(toom(4, 4));
+    bad |= run_case<S33, 2, 2, 4>(11, 1, 1, 96, 200, 1, 1, 2, true);
+    bad |= run_case<S44, 1, 2, 2>(7, 3, 1, 64, 230, 1, 1, 2, false);
+    bad |= run_case<S44, 1, 2, 4>(11, 1, 5, 32, 150, 1, 1, 2, true);
+    printf(bad ? "wino check: FAILED\n" : "wino check: all cases OK\n");
+    return bad;
+  }
   if (argc > 1 && (!strcmp(argv[1], "check") || !strcmp(argv[1], "selftest"))) {
     const int mode = !strcmp(argv[1], "check") ? 1 : 2;  // selftest: host emulation of the data flow, no GPU needed
     int bad = toom_selfcheck(toom(3, 3)) | toom_selfcheck(toom(4, 4));
