@@ -31,9 +31,10 @@ struct Scheme {
 };
 typedef Scheme<3, 3> S33;
 typedef Scheme<4, 4> S44;
+typedef Scheme<6, 6> S66;
 struct Toom {  // transform matrices in fp32, sized for the largest scheme (kernel arguments: scalar loads)
-  float BT[7][7];  // V_p = sum_n BT[p][n] d[n]
-  float AT[4][7];  // y_i = sum_p AT[i][p] Y_p
+  float BT[11][11];  // V_p = sum_n BT[p][n] d[n]
+  float AT[6][11];   // y_i = sum_p AT[i][p] Y_p
 };
 constexpr int NT = 256;     // threads per workgroup
 constexpr int CI_T = 16;    // input channels per chunk (one MFMA k-step per (g, p))
@@ -295,16 +296,16 @@ struct AArgs {
   Toom tm;
 };
 
-constexpr int AT_TILES = 256;
 template <class S>
 struct ActGeom {
-  static constexpr int POS = S::M * AT_TILES + S::R - 1;  // input positions per workgroup
+  static constexpr int TILES = S::M <= 4 ? 256 : 128;     // tiles per workgroup (the activated positions must fit in LDS)
+  static constexpr int POS = S::M * TILES + S::R - 1;     // input positions per workgroup
   static constexpr int PITCH = POS | 1;                   // odd pitch: the 8 channel rows start in different banks
 };
 
 template <class S, int PRO>
 __global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
-  constexpr int P = S::P, M = S::M, AT_POS = ActGeom<S>::POS, AT_PITCH = ActGeom<S>::PITCH;
+  constexpr int P = S::P, M = S::M, AT_TILES = ActGeom<S>::TILES, AT_POS = ActGeom<S>::POS, AT_PITCH = ActGeom<S>::PITCH;
   __shared__ float sa[8 * AT_PITCH];
   const int tile0 = blockIdx.x * AT_TILES;
   const int cg = blockIdx.y;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void act_w3_kernel(const AArgs a) {
   }
   __syncthreads();
   const int T = tile0 + threadIdx.x;
-  if (T >= a.Lt) return;
+  if ((int)threadIdx.x >= AT_TILES || T >= a.Lt) return;
   h8 hi[P], lo[P];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, visit b: the Toom-Cook F(3,3) / F(4,4) conv experiment (tools/wino_bench.hip) -- correctness
+# Round 3, visit b: the Toom-Cook F(3,3) / F(4,4) / F(6,6) conv experiment (tools/wino_bench.hip) -- correctness
 # against the host fp64 conv first, then timing next to the production kernel on the same box.
 #   bash tools/build_xs_bench.sh 0 && gpurun --timeout 600 -- 'bash tools/gpu_visit_r03b.sh r03b'
 set -u
@@ -16,6 +16,9 @@ for k in 11 7; do
     for wm in 4 2; do   # wm = 2: waves pair up on the same output rows (weight fragments shared through the vector L1)
       echo "== F(4,4) k=$k occ=$occ WM=$wm"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 1 1 1 44 $occ $wm | tee -a $OUT/wino_bench.log
     done
+  done
+  for wm in 4 2; do
+    echo "== F(6,6) k=$k WM=$wm"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 1 1 1 66 2 $wm | tee -a $OUT/wino_bench.log
   done
   echo "== F(3,3) k=$k TN=1 WM=2"; timeout 120 tools/bin/wino_bench $k 128 48001 32 10 1 1 1 33 3 2 | tee -a $OUT/wino_bench.log
 done

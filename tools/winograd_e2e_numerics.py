@@ -1,4 +1,4 @@
-"""CPU numerics study, part 3 (no GPU): what does the Toom-Cook F(4,4) / F(3,3) form of the k >= 7, C >= 128 convs do to the
+"""CPU numerics study, part 3 (no GPU): what does the Toom-Cook F(3,3) / F(4,4) / F(6,6) forms of the k >= 7, C >= 128 convs do to the
 END-TO-END waveform of the iSTFTNet generator?  The oracle's generator (oracle/st2_oracle.py) is run three times on the same
 synthetic weights and inputs with `F.conv1d` intercepted for the qualifying resblock convs:
   exact     the oracle as it is (fp32 ATen conv)
@@ -41,7 +41,7 @@ def row_scale(w2d):
 
 
 def toom(M, R):
-    pts = {3: [0, 1, -1, 2], 4: [0, 1, -1, 2, -2, 0.5]}[M]
+    pts = {3: [0, 1, -1, 2], 4: [0, 1, -1, 2, -2, 0.5], 6: [0, 1, -1, 2, -2, 0.5, -0.5, 3, -3, 1.0 / 3]}[M]
     n = M + R - 1
     AT, G, BT = np.zeros((M, n)), np.zeros((n, R)), np.zeros((n, n))
     for k, p in enumerate(pts):
@@ -136,7 +136,7 @@ def main():
     B, T = 1, 24
     asr, F0, N, s, noise = synth.decoder_inputs(B, T, 5)
     waves = {}
-    for mode in ("exact", "direct", "F(3,3)", "F(4,4)"):
+    for mode in ("exact", "direct", "F(3,3)", "F(4,4)", "F(6,6)"):
         f = PatchedF(mode)
         O.F = f
         try:
@@ -146,7 +146,7 @@ def main():
             O.F = TF
         print("%-7s intercepted convs %3d   waveform abs-max %.3f rms %.4f" % (mode, f.hits, float(waves[mode].abs().max()), rms(waves[mode])))
     ref = waves["exact"]
-    for mode in ("direct", "F(3,3)", "F(4,4)"):
+    for mode in ("direct", "F(3,3)", "F(4,4)", "F(6,6)"):
         print("%-7s vs exact: waveform RMS error %.3e (bar 1e-4)   max |diff| %.3e" % (mode, rms(waves[mode] - ref),
                                                                                  float((waves[mode] - ref).abs().max())))
 

@@ -92,7 +92,7 @@ for name, pts, m in (("F(2,3)", [0, 1, -1], 2), ("F(3,3)", [0, 1, -1, 2], 3), ("
         ng * n / m, K, np.abs(BT).max(), np.abs(G).max(), np.abs(AT).max()))
 
 
-# ---- part 2: tile step = group width (F(3,3), F(4,4), F(5,5)) for k = 11 and k = 7 --------------------------------------
+# ---- part 2: tile step = group width (F(3,3), F(4,4), F(5,5); F(6,6) end to end: tools/winograd_e2e_numerics.py) for k = 11 and k = 7 --------------------------------------
 def split(a):
     hi = a.astype(np.float16); lo = (a - hi.astype(np.float64)).astype(np.float16)
     return hi.astype(np.float64), lo.astype(np.float64)
