@@ -28,7 +28,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 
@@ -267,7 +266,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-stream", action="store_true", help="issue every step on one stream (no front/decoder overlap)")
+    ap.add_argument("--schedule", choices=["auto", "single", "two-stream", "partitioned"], default="auto",
+                    help="how consecutive steps share the GPU: `single` = everything on one stream; `two-stream` = front "
+                         "of step k+1 on a second (high-priority) stream under the decoder of step k, placement left to "
+                         "the hardware scheduler; `partitioned` = the same pipeline on two streams with complementary CU "
+                         "masks (--front-cus); `auto` (default) = time --calib-steps steps of each during the warm-up "
+                         "and run the timed region on the fastest (boxes differ in how they co-schedule two queues)")
+    ap.add_argument("--single-stream", action="store_true", help="same as --schedule single")
+    ap.add_argument("--front-cus", type=int, default=32, help="CUs given to the front stream by --schedule partitioned")
+    ap.add_argument("--calib-steps", type=int, default=3)
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
     ap.add_argument("--eager-front", action="store_true",
                     help="issue the device-only front of a step / sentence (text encoder, PL-BERT, sampler, duration "
@@ -295,9 +302,8 @@ def main():
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": dt}), flush=True)
         return
 
-    from _util import manifest
+    from benchdata import manifest, synth  # workload definitions: model manifests, seeded synthetic weights
     from styletts2_amd import _lib, models, ops, pipeline
-    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -329,14 +335,29 @@ def main():
     frames = N_PHONEMES * FRAMES_PER_PHONEME
     ref_s = ref_s.to(dev) if cfg["multispeaker"] else None
 
-    # Two HIP streams: the front of step k+1 (text encoder, PL-BERT, diffusion sampler, duration / prosody predictors:
-    # latency-bound small kernels) is issued on `front` and overlaps the decoder + vocoder of step k on the main
-    # stream.  Every step is still one complete pass tokens -> waveform over the batch; --single-stream turns it off.
-    # the front stream gets the higher priority: its small kernels then take CU slots as the decoder's workgroups
-    # retire instead of queueing behind them (--front-priority 0 = equal priorities)
-    front = None if (a.single_stream or longform) else torch.cuda.Stream(dev, priority=a.front_priority)
-    if front is not None:
-        front.wait_stream(torch.cuda.current_stream(dev))
+    # Schedules (see --schedule).  Every step is one complete pass tokens -> waveform over the batch in all of them; they
+    # differ only in which HIP stream the front of a step (text encoder, PL-BERT, diffusion sampler, duration / prosody
+    # predictors: latency-bound small kernels) is issued on, i.e. in whether it may overlap the previous step's decoder.
+    if a.single_stream:
+        a.schedule = "single"
+    if longform and a.schedule in ("auto", "partitioned"):
+        a.schedule = "two-stream"  # synthesize_long owns its side stream
+    sched = {}  # name -> (main stream or None = torch's current, front stream or None)
+    if not longform:
+        sched["single"] = (None, None)
+        sched["two-stream"] = (None, torch.cuda.Stream(dev, priority=a.front_priority))
+        try:
+            ps = pipeline.PartitionedStreams(dev, a.front_cus)
+            sched["partitioned"] = (ps.main, ps.front)
+        except Exception as e:  # CU masks refused by this driver: the schedule is simply not a candidate
+            log("partitioned streams unavailable: %s" % e)
+            if a.schedule == "partitioned":
+                raise
+        for m, f in sched.values():
+            for st in (m, f):
+                if st is not None:
+                    st.wait_stream(torch.cuda.current_stream(dev))
+    active = {"name": a.schedule if a.schedule != "auto" else "two-stream"}
 
     first_chunk_ms = []
     # The device-only front of a step / sentence (text encoder, PL-BERT, diffusion sampler, style mixing, duration
@@ -357,16 +378,18 @@ def main():
                     w[-1].item()  # the first sentence's waveform has left the GPU queue: a streaming consumer has it
                     first_chunk_ms.append((time.perf_counter() - t_start) * 1e3)
             waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
-                                                durations=durs, overlap=not a.single_stream, bucket=16,
+                                                durations=durs, overlap=a.schedule != "single", bucket=16,
                                                 on_chunk=on_chunk, front=lf_front)
             return waves
     else:
         audio_s = B * AUDIO_S_PER_UTT
 
         def step():
-            return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
-                                      embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
-                                      front_stream=front, front=lf_front)
+            main_s, front_s = sched[active["name"]]
+            with torch.cuda.stream(main_s if main_s is not None else torch.cuda.current_stream(dev)):
+                return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
+                                          embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
+                                          front_stream=front_s, front=lf_front)
 
     if lf_front is not None:  # set-up, not a warm-up step: the hipGraph of the front is recorded here (one eager pass + the
         out = step()          # capture), so that --warmup 0 does not put a capture inside the timed region
@@ -376,6 +399,34 @@ def main():
         out = step()
         torch.cuda.synchronize()
         log("warm-up step %d done" % i)
+
+    def time_steps(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    # Calibration (untimed, part of the warm-up): ms/step of every schedule on THIS box.  Boxes of the same SKU differ in
+    # how their command processor co-schedules two queues, so the schedule is chosen by measurement,
+    # the way a serving process would at start-up; all candidates are reported in `config.schedules_ms_per_step`.
+    calib = {}
+    if not longform and a.calib_steps > 0:
+        for name in sched:
+            active["name"] = name
+            step()  # first use of these streams: allocator warm-up
+            calib[name] = time_steps(a.calib_steps)
+            log("calibration: %-11s %.2f ms/step" % (name, calib[name]))
+        if world > 1:  # every rank runs the same schedule: rank 0's choice (no collective in steady state either way)
+            order = sorted(calib)
+            tt = torch.tensor([calib[n] for n in order], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            calib = dict(zip(order, tt.tolist()))
+        active["name"] = min(calib, key=calib.get) if a.schedule == "auto" else a.schedule
+        log("schedule: %s" % active["name"])
+    elif not longform:
+        active["name"] = a.schedule if a.schedule != "auto" else "two-stream"
     first_chunk_ms.clear()
     # roofline leg: per-launch HIP events around every split-f16 conv launch, by shape class
     lib = _lib.load()
@@ -418,8 +469,9 @@ def main():
             by_class.setdefault((int(ks), int(ci), int(co), int(L), int(b)), []).append(ms)
         roof = roofline(by_class)
         roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
-        streams = "1" if (a.single_stream or (front is None and not longform)) else \
-            "2 (front of step k+1 overlaps decoder of step k)"
+        name = active["name"]
+        streams = {"single": "1", "two-stream": "2 (front of step k+1 overlaps decoder of step k)",
+                   "partitioned": "2 on complementary CU masks (front %d CUs, decoder the rest)" % a.front_cus}[name]
         res = {
             "metric": "audio-seconds/sec (RTF^-1) end-to-end, 10 s utterance batch",
             "value": world * audio_s * a.steps / dt,
@@ -432,7 +484,8 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "phonemes": N_PHONEMES,
                        "diffusion_steps": steps_d, "decoder": man["config"]["decoder"]["type"],
                        "audio_s_per_step_per_gpu": audio_s, "parallelism": "utterance-sharded x%d" % world,
-                       "streams": streams, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
+                       "streams": streams, "schedule": name, "schedule_requested": a.schedule,
+                       "schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()}, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
                        "plan": os.environ.get("ST2_PLAN", "engine"), "graphed_front": not a.eager_front,
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,

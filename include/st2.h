@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 16
+#define ST2_ABI_VERSION 17
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -592,6 +592,16 @@ int st2_style_forward(st2_engine* e, int32_t which, const float* mel, int32_t B,
  * (rows may be NULL to count), < 0 on error.  Not thread safe; not legal under stream capture. */
 int st2_conv_timing(int enable);
 int st2_conv_timing_read(double* rows, int32_t cap_rows);
+
+/* ---- CU-partitioned streams (ABI v17) ---------------------------------------------------------------------------- *
+ * A HIP stream whose kernels may only be placed on the compute units whose bit is set in `mask` (n_words x 32 bits, bit i
+ * = CU i in the driver's numbering, which deals consecutive bits out round-robin over the 8 XCDs and their shader
+ * engines: the low 64 bits are 8 CUs of every XCD).  The two-stage pipeline (front of batch k+1 under the decoder of
+ * batch k) uses a pair of complementary masks so that the latency-bound front kernels -- among them the spin-waiting
+ * cooperative BiLSTM groups -- own their CUs instead of competing with 12 000-workgroup convs for slots.
+ * st2_stream_destroy waits for the stream's work.  The handle is a hipStream_t. */
+int st2_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** stream);
+int st2_stream_destroy(void* stream);
 
 /* ---- testing hook ---------------------------------------------------------------------------------------------- *
  * Replaces the kernel / memory entry points the launch plans call by the caller's (an array of ST2_BACKEND_ENTRIES

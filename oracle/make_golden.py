@@ -16,6 +16,7 @@ import torch
 from oracle import ref_harness as RH
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+MANIFESTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchdata", "manifests")
 HOT_MODULES = ["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert", "style_encoder",
                "predictor_encoder"]
 HIFIGAN_OVERRIDE = {"multispeaker": True,
@@ -42,7 +43,7 @@ CONFIGS = (("ljspeech", "config.yml", None), ("libritts", "config_libritts.yml",
 
 
 def manifests():
-    os.makedirs(GOLDEN, exist_ok=True)
+    os.makedirs(MANIFESTS, exist_ok=True)
     for tag, cfgname, ov in CONFIGS:
         model, args, cfg = RH.build_reference_model(cfgname, seed=0,
                                                     overrides=istftnet_decoder_override() if ov else None,
@@ -54,7 +55,7 @@ def manifests():
                                        "std": float(v.float().std()) if v.numel() > 1 else 0.0,
                                        "mean": float(v.float().mean())}
                                    for k, v in sd.items()}
-        path = os.path.join(GOLDEN, "manifest_%s.json" % tag)
+        path = os.path.join(MANIFESTS, "manifest_%s.json" % tag)
         with open(path, "w") as f:
             json.dump(man, f, indent=0, sort_keys=True)
         print(path, {k: len(v) for k, v in man["modules"].items()})

@@ -1,7 +1,8 @@
 """In-tree build of libst2_hip.so (hipcc, gfx950 only).
 
 `python -m styletts2_amd._build` or `__graft_entry__.build()`.  Objects are cached under
-styletts2_amd/csrc/build/ and rebuilt when a source or header is newer.
+styletts2_amd/csrc/build/ next to the compiler-written dependency file of each translation unit (`-MD -MF`): an object is
+rebuilt when its source, ANY header it actually included, or the flag set changed -- no hand-kept header list to go stale.
 """
 import os
 import subprocess
@@ -32,29 +33,57 @@ def _newer(src_list, target):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in src_list)
+    return any((not os.path.exists(s)) or os.path.getmtime(s) > t for s in src_list)
+
+
+def _depfile_inputs(depfile):
+    """Prerequisites listed in a make-style depfile written by `hipcc -MD -MF` (None if it is missing or unreadable:
+    the object is then rebuilt)."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    deps = text.split(":", 1)[1].split()
+    return [d for d in deps if not d.startswith("/opt/rocm") and not d.startswith("/usr/")] or None
+
+
+def _stale(src, obj, flags):
+    """True when `obj` must be rebuilt: missing, built with other flags, or older than the source / any included header."""
+    stamp = obj + ".flags"
+    try:
+        if open(stamp).read() != " ".join(flags):
+            return True
+    except OSError:
+        return True
+    deps = _depfile_inputs(obj[:-2] + ".d")
+    return deps is None or _newer([src] + deps, obj)
 
 
 def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in ("st2_common.h", "st2_act.h", "st2_conv1d_xs_impl.h",
-                                                "st2_conv1d_f16s_impl.h")] + [os.path.join(INCLUDE, "st2.h")]
     objs = []
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer([src] + headers, obj):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if force or _stale(src, obj, FLAGS):
+            cmd = [hipcc] + FLAGS + ["-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
             if verbose:
                 print("[st2 build]", " ".join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+            if os.path.exists(obj + ".flags"):
+                os.remove(obj + ".flags")
+            procs.append((s, obj, subprocess.Popen(cmd)))
+    for s, obj, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % s)
+        with open(obj + ".flags", "w") as f:
+            f.write(" ".join(FLAGS))
     if force or procs or _newer(objs, LIB_PATH):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:

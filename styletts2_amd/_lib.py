@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -203,6 +203,8 @@ _SIGNATURES = {
                                   C.c_void_p]),
     "st2_conv_timing": (C.c_int, [C.c_int]),
     "st2_conv_timing_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
+    "st2_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "st2_stream_destroy": (C.c_int, [C.c_void_p]),
     "st2_debug_set_backend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
     "st2_stft_frames": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p,
                                   C.c_int64, C.c_int32, C.c_void_p]),

@@ -68,3 +68,37 @@ extern "C" int st2_status(int clear) {
     v |= clear ? __atomic_exchange_n(g_status_host + i, 0, __ATOMIC_SEQ_CST) : __atomic_load_n(g_status_host + i, __ATOMIC_SEQ_CST);
   return v;
 }
+
+// ---- CU-partitioned streams (st2.h, ABI v17) -----------------------------------------------------------------------
+extern "C" int st2_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** stream) {
+  if (!mask || n_words <= 0 || !stream) {
+    st2_set_error("st2_stream_create_cu_mask: bad arguments");
+    return 1;
+  }
+  bool any = false;
+  for (int i = 0; i < n_words; ++i) any |= mask[i] != 0;
+  if (!any) {
+    st2_set_error("st2_stream_create_cu_mask: empty CU mask");
+    return 1;
+  }
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask);
+  if (e != hipSuccess) {
+    st2_set_error("st2_stream_create_cu_mask: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return 1;
+  }
+  *stream = s;
+  return 0;
+}
+
+extern "C" int st2_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) {
+    st2_set_error("st2_stream_destroy: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return 1;
+  }
+  return 0;
+}

@@ -17,6 +17,51 @@ import torch
 from . import ops
 
 
+class PartitionedStreams:
+    """A pair of HIP streams on complementary compute-unit masks (st2_stream_create_cu_mask, include/st2.h): `front`
+    owns `front_cus` of the device's CUs (dealt out evenly over the 8 XCDs by the driver's bit numbering), `main` the
+    rest.  The two-stage pipeline of `inference(front_stream=...)` then no longer depends on the hardware scheduler
+    interleaving two queues: the front's latency-bound kernels (64-workgroup cooperative BiLSTM groups that spin on each
+    other, 100-token transformer layers) cannot be starved of CU slots by the decoder's 12 000-workgroup convs, and the
+    decoder cannot be stalled behind them.  Use as
+
+        ps = PartitionedStreams(dev, front_cus=32)
+        with torch.cuda.stream(ps.main):
+            wave = inference(..., front_stream=ps.front)
+    """
+
+    def __init__(self, dev, front_cus, total_cus=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = torch.device(dev)
+        if total_cus is None:
+            total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if not 0 < front_cus < total_cus:
+            raise ValueError("front_cus must be in (0, %d)" % total_cus)
+        words = (total_cus + 31) // 32
+        self.front_cus, self.total_cus = front_cus, total_cus
+        self._handles = []
+        with torch.cuda.device(dev):
+            streams = []
+            for lo, hi in ((0, front_cus), (front_cus, total_cus)):
+                mask = (C.c_uint32 * words)()
+                for b in range(lo, hi):
+                    mask[b // 32] |= 1 << (b % 32)
+                h = C.c_void_p()
+                _lib.check(lib.st2_stream_create_cu_mask(mask, words, C.byref(h)), "st2_stream_create_cu_mask")
+                self._handles.append(h)
+                streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+        self.front, self.main = streams
+
+    def close(self):
+        from . import _lib
+        lib = _lib.load()
+        for h in self._handles:
+            lib.st2_stream_destroy(h)
+        self._handles = []
+
+
 def _pad_mask(lengths, N):
     """utils.length_to_mask (reference utils.py:42-46: True where position >= length) at a fixed width N: a bucketed
     batch may be wider than its longest utterance."""

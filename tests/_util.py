@@ -13,8 +13,8 @@ MEL_L1_TOL = 1e-3
 
 
 def manifest(tag):
-    with open(os.path.join(GOLDEN, "manifest_%s.json" % tag)) as f:
-        return json.load(f)
+    from benchdata import manifest as _m  # benchdata/manifests/manifest_<tag>.json
+    return _m(tag)
 
 
 def decoder_kwargs(dc, hidden=512, style_dim=128, n_mels=80):
