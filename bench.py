@@ -109,8 +109,11 @@ def cpu_baseline(man, sds, cfg):
     """The reference path on the host cores, on a bounded sample of the same workload: ONE 10 s utterance (100 phonemes,
     the config's diffusion steps and decoder), 1 warm-up + best of 3, at 8 / 16 / 32 / 64 threads (oneDNN / MKL stop
     scaling far below the GPU box's core count), best reported with its thread count.  kind = "reference": the
-    UNMODIFIED reference modules (oracle/ref_harness.py; only where /root/reference exists, i.e. the build container);
-    kind = "port": the oracle, a CPU restatement of the same path (oracle/st2_oracle.py)."""
+    UNMODIFIED reference modules through oracle/ref_harness.py -- from /root/reference where that exists (build
+    container), else from oracle/_ref (the same modules compiled to bytecode by oracle/make_ref.py, which is what
+    travels to the GPU box); the oracle port (oracle/st2_oracle.py, the CPU restatement the parity tests check against)
+    is timed beside it at the reference's best thread count and reported as `port`.  kind = "port" only when neither
+    form of the reference is present."""
     from oracle import st2_oracle as O
     steps = cfg["steps"]
     tokens, lengths, noise, durations, ref_s = synthetic_inputs(1, 0)
@@ -123,12 +126,12 @@ def cpu_baseline(man, sds, cfg):
         O.inference(sds, man["config"], man["plbert"], tokens, lengths, noise, step_noise, sine_noise,
                     diffusion_steps=steps, ref_s=rs, durations=durations)
 
-    kind, fn = "port", run_port
+    kind, fn, origin = "port", run_port, None
     try:
         from oracle import ref_harness as RH
         if RH.reference_available():
             fn = _reference_runner(RH, man, sds, cfg, tokens, lengths, noise, rs, durations)
-            kind = "reference"
+            kind, origin = "reference", "%s (%s)" % (RH.REFERENCE_ROOT, RH.reference_kind())
     except Exception as e:  # the reference needs its import stubs; fall back to the port and say so
         log("reference harness unavailable (%s): timing the oracle port" % e)
     ncpu = os.cpu_count() or 1
@@ -138,16 +141,23 @@ def cpu_baseline(man, sds, cfg):
     t_start = time.time()
     for th in sweep:
         results[th] = _time_best(fn, th)
-        if time.time() - t_start > 60.0:  # keep the whole leg bounded
+        if time.time() - t_start > 45.0:  # keep the whole leg bounded
             break
     best_th = min(results, key=results.get)
     best = results[best_th]
-    return {"value": AUDIO_S_PER_UTT / best, "unit": "audio-s/s", "cores": best_th, "kind": kind,
-            "host_cores": ncpu, "threads_tried": {str(k): round(v, 3) for k, v in results.items()},
-            "sample": "1 utterance x 10 s (100 phonemes, %d diffusion steps, %s decoder%s), best of 3 after 1 warm-up "
-                      "at the best of %s threads, %.2f s wall" % (steps, man["config"]["decoder"]["type"],
-                                                                   ", ref_s features" if rs is not None else "",
-                                                                   sorted(results), best)}
+    out = {"value": AUDIO_S_PER_UTT / best, "unit": "audio-s/s", "cores": best_th, "kind": kind,
+           "host_cores": ncpu, "threads_tried": {str(k): round(v, 3) for k, v in results.items()},
+           "sample": "1 utterance x 10 s (100 phonemes, %d diffusion steps, %s decoder%s), best of 3 after 1 warm-up "
+                     "at the best of %s threads, %.2f s wall" % (steps, man["config"]["decoder"]["type"],
+                                                                  ", ref_s features" if rs is not None else "",
+                                                                  sorted(results), best)}
+    if kind == "reference":
+        out["reference_modules"] = origin
+        tp = _time_best(run_port, best_th)
+        out["port"] = {"value": AUDIO_S_PER_UTT / tp, "unit": "audio-s/s", "cores": best_th, "wall_s": round(tp, 3),
+                       "what": "oracle/st2_oracle.py (the CPU restatement the parity tests check against) on the same "
+                               "utterance and thread count"}
+    return out
 
 
 def _reference_runner(RH, man, sds, cfg, tokens, lengths, noise, ref_s, durations):
@@ -273,7 +283,7 @@ def main():
                          "masks (--front-cus); `auto` (default) = time --calib-steps steps of each during the warm-up "
                          "and run the timed region on the fastest (boxes differ in how they co-schedule two queues)")
     ap.add_argument("--single-stream", action="store_true", help="same as --schedule single")
-    ap.add_argument("--front-cus", type=int, default=32, help="CUs given to the front stream by --schedule partitioned")
+    ap.add_argument("--front-cus", type=int, default=64, help="CUs given to the front stream by --schedule partitioned")
     ap.add_argument("--calib-steps", type=int, default=3)
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
     ap.add_argument("--eager-front", action="store_true",
@@ -343,16 +353,21 @@ def main():
     if longform and a.schedule in ("auto", "partitioned"):
         a.schedule = "two-stream"  # synthesize_long owns its side stream
     sched = {}  # name -> (main stream or None = torch's current, front stream or None)
+    ps = None
     if not longform:
-        sched["single"] = (None, None)
-        sched["two-stream"] = (None, torch.cuda.Stream(dev, priority=a.front_priority))
-        try:
-            ps = pipeline.PartitionedStreams(dev, a.front_cus)
-            sched["partitioned"] = (ps.main, ps.front)
-        except Exception as e:  # CU masks refused by this driver: the schedule is simply not a candidate
-            log("partitioned streams unavailable: %s" % e)
-            if a.schedule == "partitioned":
-                raise
+        want = ("single", "two-stream", "partitioned") if a.schedule == "auto" else (a.schedule,)
+        if "single" in want:
+            sched["single"] = (None, None)
+        if "two-stream" in want:
+            sched["two-stream"] = (None, torch.cuda.Stream(dev, priority=a.front_priority))
+        if "partitioned" in want:
+            try:
+                ps = pipeline.PartitionedStreams(dev, a.front_cus)
+                sched["partitioned"] = (ps.main, ps.front)
+            except Exception as e:  # CU masks refused by this driver: the schedule is simply not a candidate
+                log("partitioned streams unavailable: %s" % e)
+                if a.schedule == "partitioned":
+                    raise
         for m, f in sched.values():
             for st in (m, f):
                 if st is not None:
@@ -499,6 +514,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(man, sds, cfg)
         print(json.dumps(res), flush=True)
+    if ps is not None:  # the CU-masked streams are this process's: destroyed before the runtime's own exit handlers run
+        torch.cuda.synchronize()
+        ps.close()
 
 
 if __name__ == "__main__":

@@ -4,8 +4,10 @@ Imports the *unmodified* reference modules from /root/reference so that
 (a) golden fixtures can be generated (oracle/make_golden.py) and
 (b) the CPU restatement in oracle/st2_oracle.py can be pinned against them.
 
-/root/reference only exists in the build container, never on the GPU box, so
-nothing under tests/ -m gpu, bench.py or smoke() may import this file.
+/root/reference only exists in the build container, never on the GPU box.  What travels there is oracle/_ref/ (built
+by oracle/make_ref.py from the reference where it lies: its modules as CPython bytecode, git-ignored): bench.py's
+`cpu_baseline` leg loads the reference through this file from there (`"kind": "reference"`).  The `-m gpu` tests and
+smoke() do not use it; the product never imports it.
 
 The three sys.modules stubs follow SURVEY.md App. A.5: the reference imports
 `einops_exts`, `munch` and `torchaudio`, none of which is installed here and
@@ -15,11 +17,30 @@ import os
 import sys
 import types
 
-REFERENCE_ROOT = os.environ.get("ST2_REFERENCE_ROOT", "/root/reference")
+_BUILT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")  # oracle/make_ref.py: bytecode of the reference
+
+
+def _default_root():
+    """ST2_REFERENCE_ROOT if set; the reference checkout where it exists (build container); else oracle/_ref -- the
+    reference's own modules compiled to bytecode by oracle/make_ref.py, which is what travels to the GPU box."""
+    env = os.environ.get("ST2_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isfile("/root/reference/models.py"):
+        return "/root/reference"
+    return _BUILT
+
+
+REFERENCE_ROOT = _default_root()
 
 
 def reference_available() -> bool:
-    return os.path.isfile(os.path.join(REFERENCE_ROOT, "models.py"))
+    return any(os.path.isfile(os.path.join(REFERENCE_ROOT, n)) for n in ("models.py", "models.pyc"))
+
+
+def reference_kind() -> str:
+    """"source" (a checkout) or "bytecode" (oracle/_ref): the same modules either way."""
+    return "source" if os.path.isfile(os.path.join(REFERENCE_ROOT, "models.py")) else "bytecode"
 
 
 def _install_stubs():
@@ -104,16 +125,23 @@ def load_reference():
     return types.SimpleNamespace(**_loaded)
 
 
+def _yaml(rel):
+    path = os.path.join(REFERENCE_ROOT, rel)
+    if os.path.isfile(path):
+        import yaml
+        with open(path) as f:
+            return yaml.safe_load(f)
+    import json
+    with open(os.path.join(REFERENCE_ROOT, "configs.json")) as f:  # oracle/_ref: the parsed ymls (make_ref.py)
+        return json.load(f)[rel]
+
+
 def load_config(name="config.yml"):
-    import yaml
-    with open(os.path.join(REFERENCE_ROOT, "Configs", name)) as f:
-        return yaml.safe_load(f)
+    return _yaml("Configs/" + name)
 
 
 def plbert_config():
-    import yaml
-    with open(os.path.join(REFERENCE_ROOT, "Utils", "PLBERT", "config.yml")) as f:
-        return yaml.safe_load(f)["model_params"]
+    return _yaml("Utils/PLBERT/config.yml")["model_params"]
 
 
 def recursive_munch(d):

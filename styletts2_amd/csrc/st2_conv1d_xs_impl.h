@@ -287,6 +287,7 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
               d.xs_lp, d.L_out, BN, KS, d.dil, d.xs_halo);
   if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_xs: part_nt=%d < %d tiles", d.part_nt,
                           st2_cdiv(d.L_out, 128));
+  if constexpr (TN < 4) ST2_REQUIRE(!d.part, "st2_conv1d_xs: the narrow token tiles do not produce partial sums");
   static bool attr_done = false;
   if (!attr_done) {
     if constexpr (OCC == 3)

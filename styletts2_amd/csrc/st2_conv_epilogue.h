@@ -43,7 +43,8 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
   // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
   const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
   const bool want_part = d.part != nullptr;
-  constexpr int NPT = TN / 4;               // 128-column partial-sum tiles per wave tile
+  constexpr int NPT = TN >= 4 ? TN / 4 : 1;  // 128-column partial-sum tiles per wave tile (TN < 4: narrow token-GEMM
+  constexpr int JB = TN >= 4 ? 4 : TN;       // tiles, launched without partial sums); column blocks per residual batch
   const int ptile = (n0 + wn * (32 * TN)) / 128;  // first 128-column tile index of this wave's partial sums
   const int co = m0 + wm * 32 + l31;       // this lane's output row (< wq_co_pad by construction of the packing)
   const int lw = n0 + wn * (32 * TN) + 4 * kg;  // first position of this lane's (j = 0, q = 0) quad
@@ -80,7 +81,7 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
     const int ro = coc * d.res_cs;   // + (l >> res_shift)
     const int r2o = coc * d.res2_cs + lw;
     float s1 = 0.f, s2 = 0.f;
-    float s1d[NPT], s2d[NPT];  // finished 128-column sums
+    float s1d[NPT] = {}, s2d[NPT] = {};  // finished 128-column sums
     auto finish = [&](float v) __attribute__((always_inline)) -> float {
       if (use_div) v = v / d.div;
       if constexpr (ACT == -1) {  // generic build: one body for every activation (run-time switch, wave-uniform)
@@ -111,17 +112,17 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
       // cost one HBM round trip each, 8 in series per tile: measured 27 000 cycles of epilogue against a 101 000-cycle
       // k loop (per-workgroup s_memtime stamps, tools/xs_bench.hip), i.e. a fifth of every workgroup slot's time.
 #pragma unroll
-      for (int jh = 0; jh < TN; jh += 4) {
-        f32x4 rv[4][4];
+      for (int jh = 0; jh < TN; jh += JB) {
+        f32x4 rv[JB][4];
         if (use_res) {
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
+          for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               rv[jj][q] = *reinterpret_cast<const f32x4*>(rb + ro + lw + (jh + jj) * 32 + 8 * q);
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < JB; ++jj) {
           const int j = jh + jj;
           f32x4 r2v[4];
           if (use_res2) {
