@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--eager-front", action="store_true",
                     help="issue the device-only front of a step / sentence (text encoder, PL-BERT, sampler, duration "
                          "encoder) kernel by kernel from Python instead of replaying it from one hipGraph")
+    ap.add_argument("--lstm", choices=["coop", "single"], default="coop",
+                    help="diagnostic: `single` replaces the cooperative BiLSTM (spin-waiting 8-CU groups) by the single-CU "
+                         "kernel the library falls back to; never the measured configuration")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
@@ -313,7 +316,8 @@ def main():
         return
 
     from benchdata import manifest, synth  # workload definitions: model manifests, seeded synthetic weights
-    from styletts2_amd import _lib, models, ops, pipeline
+    from styletts2_amd import _hooks, _lib, models, ops, pipeline
+    _hooks.lstm = a.lstm
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -501,7 +505,7 @@ def main():
                        "audio_s_per_step_per_gpu": audio_s, "parallelism": "utterance-sharded x%d" % world,
                        "streams": streams, "schedule": name, "schedule_requested": a.schedule,
                        "schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()}, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
-                       "plan": os.environ.get("ST2_PLAN", "engine"), "graphed_front": not a.eager_front,
+                       "plan": _hooks.plan, "lstm": a.lstm, "graphed_front": not a.eager_front,
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,
         }

@@ -520,3 +520,50 @@ def long_form(sds, cfg, plbert_params, sentences, noises, step_noises, sine_nois
         w = w.reshape(-1)
         waves.append(w[:-trim] if trim else w)
     return waves, s_prev
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-audio style path: StyleEncoder (models.py:139-164) over ResBlk (:97-137), LearnedDownSample (:27-42),
+# DownSample (:63-77), all under old-style torch.nn.utils.spectral_norm (state_dict: weight_orig / weight_u / weight_v)
+# ------------------------------------------------------------------------------------------------
+def sn_weight(sd, prefix):
+    """Eval-mode spectral norm: no power iteration, W = weight_orig / sigma with sigma = u . (W_mat v)
+    (torch/nn/utils/spectral_norm.py compute_weight, do_power_iteration=False)."""
+    w = sd[prefix + ".weight_orig"].float()
+    u, v = sd[prefix + ".weight_u"].float(), sd[prefix + ".weight_v"].float()
+    return w / torch.dot(u, torch.mv(w.reshape(w.shape[0], -1), v))
+
+
+def _style_resblk(sd, p, x):
+    """ResBlk(normalize=False, downsample='half'), models.py:97-137."""
+    sc = x
+    if (p + ".conv1x1.weight_orig") in sd:                                  # learned_sc: dim_in != dim_out
+        sc = F.conv2d(sc, sn_weight(sd, p + ".conv1x1"))
+    if sc.shape[-1] % 2 != 0:                                               # DownSample('half'), models.py:72-75
+        sc = torch.cat([sc, sc[..., -1].unsqueeze(-1)], dim=-1)
+    sc = F.avg_pool2d(sc, 2)
+    r = F.conv2d(F.leaky_relu(x, 0.2), sn_weight(sd, p + ".conv1"), sd[p + ".conv1.bias"], 1, 1)
+    c = r.shape[1]                                                          # LearnedDownSample('half'): depthwise 3x3 / 2
+    r = F.conv2d(r, sn_weight(sd, p + ".downsample_res.conv"), sd[p + ".downsample_res.conv.bias"], 2, 1, 1, c)
+    r = F.conv2d(F.leaky_relu(r, 0.2), sn_weight(sd, p + ".conv2"), sd[p + ".conv2.bias"], 1, 1)
+    return (sc + r) / math.sqrt(2)
+
+
+def style_encoder(sd, mel):
+    """StyleEncoder.forward (models.py:139-164): mel [B, 1, 80, T] -> style [B, style_dim]; `sd` is the module's own
+    state_dict (keys `shared.N...`, `unshared...`)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    h = F.conv2d(mel.float(), sn_weight(sd, "shared.0"), sd["shared.0.bias"], 1, 1)
+    for i in range(1, 5):
+        h = _style_resblk(sd, "shared.%d" % i, h)
+    h = F.conv2d(F.leaky_relu(h, 0.2), sn_weight(sd, "shared.6"), sd["shared.6.bias"])   # 5x5, valid
+    h = F.leaky_relu(F.adaptive_avg_pool2d(h, 1), 0.2).reshape(h.shape[0], -1)
+    return F.linear(h, sd["unshared.weight"], sd["unshared.bias"])
+
+
+def compute_style(sd_style, sd_pred, wave):
+    """`compute_style` of Demo/Inference_LibriTTS.ipynb:100-111 minus the file I/O: wave [B, L] at 24 kHz -> ref_s
+    [B, 256] = cat(style_encoder(mel), predictor_encoder(mel)); the mel is oracle/mel_ref.py (fp64) rounded to fp32."""
+    from oracle import mel_ref
+    mel = mel_ref.mel_spectrogram_t(wave).unsqueeze(1)
+    return torch.cat([style_encoder(sd_style, mel), style_encoder(sd_pred, mel)], dim=1)

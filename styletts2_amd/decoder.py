@@ -13,7 +13,6 @@ hands the following MFMA conv pre-split operands, and the InstanceNorm statistic
 producing conv's epilogue (`want_stats`), so no tensor is read just to be reduced.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -72,11 +71,9 @@ class _PackedResBlock1:
 
 
 def run_resblock1(pk: _PackedResBlock1, bank: StyleBank, h, x, x_stats=None, mrf_acc=None, mrf_last=False,
-                  n_mrf=3, out=None, mrf_acc_fn=None):
+                  n_mrf=3, out=None):
     """AdaINResBlock1.forward (Modules/istftnet.py:66-75).  `mrf_acc`/`mrf_last` fold the multi-receptive-field
-    sum `xs += resblock(x)` and the final `/ num_kernels` (istftnet.py:369-375) into the last conv's epilogue.
-    `mrf_acc_fn` (multi-stream MRF): called right before the last conv, returns the accumulator of the previous
-    resblock after making this stream wait for it."""
+    sum `xs += resblock(x)` and the final `/ num_kernels` (istftnet.py:369-375) into the last conv's epilogue."""
     p = pk.p
     C, ks = p.channels, p.ks
     nsteps = len(p.dilation)
@@ -91,8 +88,6 @@ def run_resblock1(pk: _PackedResBlock1, bank: StyleBank, h, x, x_stats=None, mrf
         kw = dict(dil=1, pad_left=(ks - 1) // 2, bias=pk.c2[i].bias, pro=ops.PRO_ADAIN_SNAKE, stats=st2, gamma=g2,
                   beta=b2, alpha=pk.a2[i], res=x)
         if last:
-            if mrf_acc_fn is not None:
-                mrf_acc = mrf_acc_fn()
             x = ops.conv1d(xt, pk.c2[i].wt, C, ks, res2=mrf_acc, div=float(n_mrf) if mrf_last else 1.0, out=out, **kw)
         else:
             x, st = ops.conv1d(xt, pk.c2[i].wt, C, ks, want_stats=True, **kw)
@@ -175,7 +170,6 @@ class Generator(nn.Module):
                 self.resblocks.append(AdaINResBlock1Params(self.channels[i], k, tuple(d), style_dim))
         self.conv_post = WNConv1d(self.channels[-1], (self.n_fft + 2) if kind == "istftnet" else 1, 7)
         self.upsample_scale = int(math.prod(self.rates)) * (self.hop if kind == "istftnet" else 1)
-        self._mrf_side = {}  # side streams of the multi-stream MRF, per (device, main stream)
 
     # -- plan helpers ----------------------------------------------------------------------
     def register(self, bank: StyleBank):
@@ -208,48 +202,16 @@ class Generator(nn.Module):
         return pk
 
     def _mrf(self, pk, bank, h, x, st, i):
-        """Multi-receptive-field fusion: num_kernels AdaINResBlock1 chains on the same input, summed and divided.
-
-        The chains only meet in the running sum, which the LAST conv of each chain adds in its epilogue.  On a HIP
-        device they are therefore issued on separate streams (the last, slowest chain on the current one): a chain
-        alternates an HBM-bound activation pass with an MFMA-bound conv, so kernels of different chains use
-        complementary resources, and launch tails overlap.  The summation order -- ((r0 + r1) + r2) / n -- and every
-        result are those of the single-stream order (ST2_MRF_STREAMS=0)."""
+        """Multi-receptive-field fusion: num_kernels AdaINResBlock1 chains on the same input, summed and divided.  The
+        chains only meet in the running sum, which the LAST conv of each chain adds in its epilogue; the summation order
+        is ((r0 + r1) + r2) / n.  (Issuing the chains on separate streams was measured in round 1 and is neutral: a
+        12 000-workgroup conv leaves no CU slots to co-run in -- DESIGN.md section 3.)"""
         n = self.num_kernels
         blocks = pk.resblocks[i * n:(i + 1) * n]
-        if not x.is_cuda or n < 2 or os.environ.get("ST2_MRF_STREAMS", "0") != "1":
-            acc = None
-            for j in range(n):
-                acc = run_resblock1(blocks[j], bank, h, x, x_stats=st, mrf_acc=acc, mrf_last=(j == n - 1), n_mrf=n)
-            return acc
-        main = torch.cuda.current_stream(x.device)
-        key = (x.device, main.cuda_stream)
-        side = self._mrf_side.get(key)
-        if side is None:
-            side = self._mrf_side[key] = [torch.cuda.Stream(x.device) for _ in range(n - 1)]
-        fork = torch.cuda.Event()
-        fork.record(main)
-        accs, done = [None] * n, [None] * n
-
-        def chain(j):
-            def wait_prev():
-                if j == 0:
-                    return None
-                torch.cuda.current_stream(x.device).wait_event(done[j - 1])
-                return accs[j - 1]
-            accs[j] = run_resblock1(blocks[j], bank, h, x, x_stats=st, mrf_last=(j == n - 1), n_mrf=n,
-                                    mrf_acc_fn=wait_prev)
-            done[j] = torch.cuda.Event()
-            done[j].record(torch.cuda.current_stream(x.device))
-
-        for j in range(n - 1):
-            with torch.cuda.stream(side[j]):
-                side[j].wait_event(fork)
-                chain(j)
-        chain(n - 1)  # waits (transitively) for every side chain before its last conv: the streams are joined
-        for j in range(n - 1):  # allocated on side[j], read by the next chain's last conv on another stream
-            accs[j].record_stream(main if j + 1 == n - 1 else side[j + 1])
-        return accs[n - 1]
+        acc = None
+        for j in range(n):
+            acc = run_resblock1(blocks[j], bank, h, x, x_stats=st, mrf_acc=acc, mrf_last=(j == n - 1), n_mrf=n)
+        return acc
 
     def run(self, pk, bank, h, x, f0_curve, noise=None, har=None, taps=None):
         B = x.shape[0]

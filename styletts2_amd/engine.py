@@ -4,26 +4,23 @@ st2_decoder_forward / st2_sampler_run / st2_prosody_forward).
 The launch plans of `Decoder.forward` (Modules/istftnet.py:499-528, Modules/hifigan.py:446-475) and
 `DiffusionSampler.forward` (Modules/diffusion/sampler.py:573-586) live in C++ (csrc/st2_engine.hip); a module forward is
 ONE ctypes call here: PyTorch supplies the device buffers (inputs, output, one workspace) and the stream, nothing else.
-The per-kernel Python plans (decoder.py, diffusion.py) remain as the tap-point / A-B path: `ST2_PLAN=python` selects
-them, and CPU tensors always take them (the CPU plan tests substitute per-kernel contracts for the HIP wrappers).
+The per-kernel Python plans (decoder.py, diffusion.py, text.py, style.py) remain as the tap-point path of the parity
+tests (`_hooks.override(plan="python")`, tests only -- no environment switch), and CPU tensors always take them (the CPU
+plan tests substitute per-kernel contracts for the HIP wrappers; the real wrappers raise on a CPU tensor).
 """
 import ctypes as C
 import math
-import os
 
 import torch
 
-from . import _lib
+from . import _hooks, _lib
 from . import weights as W
 
 
 def plan_mode():
-    """"engine" (default): module forwards are single C-ABI calls into the C++ plans; "python": the per-kernel Python
-    plans.  Read from ST2_PLAN at call time."""
-    mode = os.environ.get("ST2_PLAN", "engine")
-    if mode not in ("engine", "python"):
-        raise ValueError("ST2_PLAN must be engine or python, got %r" % mode)
-    return mode
+    """"engine": module forwards are single C-ABI calls into the C++ plans (the product path); "python": the
+    per-kernel Python plans, selectable from tests only (_hooks.py)."""
+    return _hooks.plan
 
 
 def _folded_state(module):

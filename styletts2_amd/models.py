@@ -15,7 +15,7 @@ from .decoder import Decoder
 from .diffusion import (GraphedSampler, ADPM2Sampler, AudioDiffusionConditional, DiffusionSampler, KarrasSchedule,  # noqa: F401
                         StyleTransformer1d, Transformer1d)
 from .style import StyleEncoder
-from .text import ProsodyPredictor, TextEncoder, build_plbert
+from .text import EngineLinear, ProsodyPredictor, TextEncoder, build_plbert
 from .utils import Munch, recursive_munch  # noqa: F401
 from .weights import strip_module_prefix
 
@@ -65,7 +65,7 @@ def build_model(args, text_aligner=None, pitch_extractor=None, bert=None):
                                           embedding_mask_proba=args.diffusion.embedding_mask_proba)
     return Munch(
         bert=bert,
-        bert_encoder=nn.Linear(bert.config.hidden_size, args.hidden_dim),
+        bert_encoder=EngineLinear(bert.config.hidden_size, args.hidden_dim),
         predictor=predictor,
         decoder=decoder,
         text_encoder=text_encoder,

@@ -6,11 +6,10 @@ tensors.  PyTorch is plumbing here (allocation, streams); all arithmetic happens
 There is no CPU path: a tensor that is not on a HIP device raises.
 """
 import ctypes as C
-import os
 
 import torch
 
-from . import _lib
+from . import _hooks, _lib
 from .weights import F16S_X_SCALE, SplitConvWeight
 from ._lib import (ACT_EXP_SIN, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY, ACT_NONE, ACT_TANH, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE,  # noqa: F401
                    PRO_COLNORM, PRO_LEAKY, PRO_NONE, PRO_SNAKE, ConvDesc)
@@ -94,13 +93,10 @@ def prefer_fused(pro, C_in, ks):
 
 
 def conv_path():
-    """How convs with a prologue over split-f16 weights are issued: "xs" (default) = st2_act_split + st2_conv1d_xs
-    (activation in an HBM-bound pass of its own, pure MFMA conv, InstanceNorm partial sums from the conv epilogue);
-    "fused" = st2_conv1d_f16s with the prologue inside the MFMA kernel.  Read from ST2_CONV_PATH at call time."""
-    mode = os.environ.get("ST2_CONV_PATH", "xs")
-    if mode not in ("xs", "fused"):
-        raise ValueError("ST2_CONV_PATH must be xs or fused, got %r" % mode)
-    return mode
+    """How convs with a prologue over split-f16 weights are issued: "xs" = st2_act_split + st2_conv1d_xs (activation in an
+    HBM-bound pass of its own, pure MFMA conv, InstanceNorm partial sums from the conv epilogue) unless `prefer_fused`
+    routes the layer to st2_conv1d_f16s; "fused" (contract tests only, _hooks.py) = st2_conv1d_f16s everywhere."""
+    return _hooks.conv_path
 
 
 class XsTensor:
@@ -519,13 +515,10 @@ _coop_refused = False      # the device could not hold a cooperative launch co-r
 
 
 def lstm_mode():
-    """"coop" (default): W_hh register-resident over 8 CUs per group, one hidden-state exchange per step
-    (st2_lstm_bidir_coop); "single": one CU per (utterance, direction) streaming W_hh from L2 (st2_lstm_bidir).
-    Read from ST2_LSTM at call time."""
-    mode = os.environ.get("ST2_LSTM", "coop")
-    if mode not in ("coop", "single"):
-        raise ValueError("ST2_LSTM must be coop or single, got %r" % mode)
-    return mode
+    """"coop": W_hh register-resident over 8 CUs per group, one hidden-state exchange per step (st2_lstm_bidir_coop);
+    "single" (tests only, _hooks.py): one CU per (utterance, direction) streaming W_hh from L2 (st2_lstm_bidir) -- the
+    kernel the library itself falls back to when a device cannot hold a cooperative launch co-resident."""
+    return _hooks.lstm
 
 
 def lstm_bidir(G, whh_t, lengths=None, out=None):

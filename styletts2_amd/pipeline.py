@@ -10,11 +10,16 @@ Differences from the notebooks, all host-side:
   * optional `durations=` forces the per-phoneme durations (throughput runs use 4 frames / phoneme so that
     every utterance is exactly 10 s) and removes the only data-dependent host sync.
 """
-import os
-
 import torch
 
-from . import ops
+from . import _hooks, ops
+
+
+def _engine_path(dev, taps=None):
+    """The product path: every stage one C-ABI call into its C++ launch plan (csrc/st2_engine.hip).  The per-kernel Python
+    plans run only where a plan has to be stepped through: tap points (`taps`), the tests' `_hooks.override(plan="python")`
+    and the CPU plan tests (host tensors; the real kernel wrappers raise on those)."""
+    return dev.type == "cuda" and taps is None and _hooks.plan == "engine"
 
 
 class PartitionedStreams:
@@ -99,8 +104,9 @@ def predict_durations(model, d, lj_tail=False, input_lengths=None):
 
 @torch.no_grad()
 def _front_engine(model, dev):
-    """The st2_engine handle behind ST2_FRONT=engine, packed once per (weights, device): rebuilt when a front module's
-    parameters were reloaded (in-place version counters) or moved (storage addresses)."""
+    """The st2_engine handle of the front (text encoder, PL-BERT + bert_encoder, style denoiser, prosody predictor), packed
+    once per (weights, device): rebuilt when a front module's parameters were reloaded (in-place version counters) or
+    moved (storage addresses)."""
     from . import engine
     mods = [model.text_encoder, model.bert, model.bert_encoder, model.diffusion.diffusion.net, model.predictor]
     stamp = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
@@ -119,7 +125,7 @@ def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_n
     the host), so the whole function is legal under stream capture (`GraphedFront`)."""
     dev = tokens.device
     B, N = tokens.shape
-    if os.environ.get("ST2_FRONT", "python") == "engine":  # the same stages as ONE C-ABI call (csrc/st2_engine.hip front_plan)
+    if _engine_path(dev, taps):  # ONE C-ABI call: st2_front_forward (csrc/st2_engine.hip front_plan)
         from .diffusion import GraphedSampler
         smp = sampler.sampler if isinstance(sampler, GraphedSampler) else sampler
         if lengths_dev is None and lengths_host is not None and not bool((lengths_host == N).all()):
@@ -194,7 +200,7 @@ class GraphedFront:
         return refs
 
     def _engine_mode(self):
-        return os.environ.get("ST2_FRONT", "python") == "engine"
+        return _hooks.plan == "engine"
 
     def _stale(self, g, dev):
         if g["engine"] is not None or self._engine_mode():  # recorded over / now running on the C++ front: same handle?
@@ -327,6 +333,10 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
         sel = (lambda v: v) if len(idx) == B else (lambda v: v[torch.as_tensor(idx, device=dev)])
         dur = sel(durations)
         # hifigan: one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
+        if _engine_path(dev, taps):  # alignment expansion + F0Ntrain as ONE C-ABI call (st2_prosody_forward)
+            asr, F0_pred, N_pred = _front_engine(model, dev).prosody_forward(sel(d_cm), sel(t_en), dur, sel(s), T,
+                                                                             shift=hifigan)
+            return dict(asr=asr, F0=F0_pred, N=N_pred, ref=sel(ref), en=None)
         en = expand_by_durations(sel(d_cm), dur, T, shift=hifigan)                    # [b, 640, T]
         asr = expand_by_durations(sel(t_en), dur, T, shift=hifigan)                   # [b, 512, T]
         F0_pred, N_pred = model.predictor.F0Ntrain(en, sel(s))

@@ -9,7 +9,8 @@ LearnedDownSample :27-42, all under old-style `torch.nn.utils.spectral_norm`: `w
 rescale (no power iteration), folded once per load exactly as the reference computes it: sigma = u . (W_mat v),
 W = weight_orig / sigma.
 
-Both the encoders and the mel front-end run on the engine's HIP kernels (`forward` / `mel_spectrogram_engine`):
+Both the encoders and the mel front-end run on the engine's HIP kernels (`forward` = one `st2_style_forward` call into the
+C++ launch plan, csrc/st2_engine.hip style_plan; `mel_spectrogram_engine` = five kernel-level calls):
   * feature maps are stored (h, c, w) with one zero row above and below, so three consecutive rows ARE the 3C-channel
     input of a Conv1d over the width: every 3x3 Conv2d is one split-f16 MFMA `st2_conv1d` per utterance (batch = image
     rows, LeakyReLU as the conv prologue, residual add and 1/sqrt(2) in the epilogue), the 5x5 valid conv the same with
@@ -18,25 +19,26 @@ Both the encoders and the mel front-end run on the engine's HIP kernels (`forwar
     LeakyReLU prologue;
   * mel: `st2_stft_frames` (reflect-padded frame columns) -> windowed DFT as an exact-fp32 MFMA k=1 conv
     [2050][1200] -> `st2_power_spectrum` -> mel filter bank as a k=1 conv [80][1025] -> `st2_log_norm`.
-`forward_torch` / `mel_spectrogram` are the same maths on PyTorch ops (A-B path, `ST2_STYLE=torch`; the CPU metric
-helper of the parity tests).  `ST2_STYLE=plan` runs the two encoders as C++ launch plans (`st2_style_forward`,
-csrc/st2_engine.hip style_plan: the same kernels issued from C++; validated on the CPU backend, tests/test_engine_cpu.py).  There is no silent fallback: CPU tensors raise unless ST2_STYLE=torch.
+There is no PyTorch forward behind any of this: the nn.Modules below are parameter holders with the reference's keys, a
+CPU tensor raises in the kernel wrappers.  The per-kernel Python plan (`StyleEncoder._forward_kernels`) is the tests' tap
+path (`_hooks.override(plan="python")`) and what the CPU plan tests step through; the C++ plan is bitwise equal to it on
+the GPU (profiles/r03a_style_plan.log).
 
-The mel front-end restates `torchaudio.transforms.MelSpectrogram(n_mels=80, n_fft=2048, win_length=1200,
+The mel front-end implements `torchaudio.transforms.MelSpectrogram(n_mels=80, n_fft=2048, win_length=1200,
 hop_length=300)` with torchaudio's defaults (power 2, periodic Hann window zero-padded to n_fft, centre + reflect
 padding, HTK mel scale, no filter normalisation) INCLUDING the quirk that the reference never passes `sample_rate`
 (meldataset.py:58-59): torchaudio's default 16 000 applies, i.e. the filter bank spans 0-8 kHz of the bin grid.
-torchaudio is not installed in the build container, so this front-end is "parity unpinned" (no golden vector);
-the encoders themselves are pinned against the reference modules (tests/golden/style_vectors.npz).
+torchaudio is not installed in the build container; the front-end is pinned to oracle/mel_ref.py, an independent fp64
+numpy evaluation of torchaudio's documented formulae (fixtures tests/golden/mel_vectors.npz), and the encoders to the
+reference modules themselves (tests/golden/style_vectors.npz).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _hooks, ops
 from . import weights as W
 
 MEL_MEAN, MEL_STD = -4.0, 4.0  # meldataset.py:60
@@ -55,22 +57,13 @@ class _SNConv2d(nn.Module):
         self.register_buffer("weight_v", F.normalize(torch.randn(c_in // groups * kh * kw), dim=0))
         self.bias = nn.Parameter(torch.zeros(c_out)) if bias else None
 
-    def folded(self):
-        """Eval-mode spectral norm: weight_orig / (u . (W_mat v)); no power iteration (spectral_norm.py compute_weight
-        with do_power_iteration=False)."""
-        w = self.weight_orig.detach()
-        sigma = torch.dot(self.weight_u, torch.mv(w.reshape(w.shape[0], -1), self.weight_v))
-        return w / sigma
-
     def folded_host(self):
-        """The same fold on the host in fp32 (what the packed engine weights are built from: identical bits whatever
-        device the module lives on)."""
+        """Eval-mode spectral norm: weight_orig / (u . (W_mat v)); no power iteration (spectral_norm.py compute_weight
+        with do_power_iteration=False) -- on the host in fp32 (what the packed engine weights are built from: identical
+        bits whatever device the module lives on)."""
         w = self.weight_orig.detach().float().cpu()
         sigma = torch.dot(self.weight_u.float().cpu(), torch.mv(w.reshape(w.shape[0], -1), self.weight_v.float().cpu()))
         return w / sigma
-
-    def forward(self, x):
-        return F.conv2d(x, self.folded(), self.bias, self.stride, self.padding, 1, self.groups)
 
 
 class _LearnedDownSample(nn.Module):
@@ -79,9 +72,6 @@ class _LearnedDownSample(nn.Module):
     def __init__(self, dim_in):
         super().__init__()
         self.conv = _SNConv2d(dim_in, dim_in, 3, stride=2, padding=1, groups=dim_in)
-
-    def forward(self, x):
-        return self.conv(x)
 
 
 class _ResBlk(nn.Module):
@@ -96,19 +86,6 @@ class _ResBlk(nn.Module):
         if self.learned_sc:
             self.conv1x1 = _SNConv2d(dim_in, dim_out, 1, 1, 0, bias=False)
 
-    @staticmethod
-    def _avg_half(x):  # DownSample('half'), models.py:72-75: replicate the last column when the width is odd
-        if x.shape[-1] % 2 != 0:
-            x = torch.cat([x, x[..., -1].unsqueeze(-1)], dim=-1)
-        return F.avg_pool2d(x, 2)
-
-    def forward(self, x):
-        sc = self.conv1x1(x) if self.learned_sc else x
-        sc = self._avg_half(sc)
-        r = self.conv1(F.leaky_relu(x, 0.2))
-        r = self.downsample_res(r)
-        r = self.conv2(F.leaky_relu(r, 0.2))
-        return (sc + r) / math.sqrt(2)
 
 
 class StyleEncoder(nn.Module):
@@ -182,10 +159,17 @@ class StyleEncoder(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        """mel [B, 1, 80, T] -> style [B, style_dim] on the HIP kernels (module docstring); ST2_STYLE=torch selects the
-        PyTorch-op path."""
-        if os.environ.get("ST2_STYLE", "engine") == "torch":
-            return self.forward_torch(x)
+        """mel [B, 1, 80, T] -> style [B, style_dim]: one `st2_style_forward` call into the C++ launch plan."""
+        if x.device.type == "cuda" and _hooks.plan == "engine":
+            from . import engine
+            from .text import _cached_engine
+            eng = _cached_engine(self, "_engine", [self], lambda: engine.build_style_engine(self, None, x.device))
+            return eng.style_forward(0, x)
+        return self._forward_kernels(x)
+
+    @torch.no_grad()
+    def _forward_kernels(self, x):
+        """The same plan kernel by kernel from Python (tests' tap path; module docstring)."""
         x = x.float()
         dev = x.device
         pk = self._pk if (self._pk is not None and self._pk.device == dev) else self._prepare(dev)
@@ -238,11 +222,6 @@ class StyleEncoder(nn.Module):
         s = ops.conv1d(m.reshape(B, Cl, 1), pk.wl, self.unshared.out_features, 1, bias=pk.bl, pro=ops.PRO_LEAKY, slope=0.2)
         return s.reshape(B, -1)
 
-    @torch.no_grad()
-    def forward_torch(self, x):
-        h = self.shared(x.float())
-        return self.unshared(h.view(h.size(0), -1))
-
 
 # ---- mel front-end -------------------------------------------------------------------------------------------------
 def _hz_to_mel(f):
@@ -260,19 +239,6 @@ def mel_filterbank(n_freqs=1025, n_mels=80, sample_rate=16000, f_min=0.0, f_max=
     down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
     return torch.clamp(torch.min(down, up), min=0.0)
-
-
-def mel_spectrogram(wave, n_fft=2048, win_length=1200, hop_length=300, n_mels=80):
-    """wave [..., L] (24 kHz) -> normalised log-mel [..., 80, 1 + L // 300]: (log(1e-5 + mel) + 4) / 4
-    (meldataset.py:58-66; Demo/Inference_LibriTTS.ipynb `preprocess`)."""
-    wave = wave.float()
-    window = torch.hann_window(win_length, periodic=True, device=wave.device)
-    spec = torch.stft(wave, n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True,
-                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
-    power = spec.real ** 2 + spec.imag ** 2                        # [..., 1025, frames]
-    fb = mel_filterbank(n_fft // 2 + 1, n_mels).to(wave.device)
-    mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
-    return (torch.log(1e-5 + mel) - MEL_MEAN) / MEL_STD
 
 
 _MEL_PACK = {}
@@ -299,7 +265,8 @@ def _mel_pack(device, n_fft, win_length, n_mels):
 
 @torch.no_grad()
 def mel_spectrogram_engine(wave, n_fft=2048, win_length=1200, hop_length=300, n_mels=80):
-    """`mel_spectrogram` on the HIP kernels: wave [B, L] -> [B, 80, 1 + L // 300] (module docstring)."""
+    """wave [B, L] (24 kHz) -> normalised log-mel [B, 80, 1 + L // 300]: (log(1e-5 + mel) + 4) / 4 (meldataset.py:58-66;
+    Demo/Inference_LibriTTS.ipynb `preprocess`) on the HIP kernels (module docstring)."""
     wave = wave.float().contiguous()
     dft_w, fb_w = _mel_pack(wave.device, n_fft, win_length, n_mels)
     K = n_fft // 2 + 1
@@ -310,7 +277,7 @@ def mel_spectrogram_engine(wave, n_fft=2048, win_length=1200, hop_length=300, n_
 
 
 def _style_engine(model, dev):
-    """The st2_engine handle behind ST2_STYLE=plan, packed once per (weights, device)."""
+    """The st2_engine handle holding BOTH style encoders, packed once per (weights, device)."""
     from . import engine
     mods = [model.style_encoder, model.predictor_encoder]
     stamp = tuple((p.data_ptr(), p._version) for m in mods for p in list(m.parameters()) + list(m.buffers()))
@@ -327,12 +294,9 @@ def compute_style(model, wave):
     (already trimmed; the notebook trims with librosa.effects.trim(top_db=30) on the host) -> ref_s [B, 256]."""
     if wave.dim() == 1:
         wave = wave.unsqueeze(0)
-    if os.environ.get("ST2_STYLE", "engine") == "plan":  # both encoders as C++ launch plans (st2_style_forward)
-        mel = mel_spectrogram_engine(wave)
+    mel = mel_spectrogram_engine(wave)
+    if wave.device.type == "cuda" and _hooks.plan == "engine":  # both encoders as C++ launch plans (st2_style_forward)
         eng = _style_engine(model, wave.device)
         return torch.cat([eng.style_forward(0, mel), eng.style_forward(1, mel)], dim=1)
-    if os.environ.get("ST2_STYLE", "engine") == "torch":
-        mel = mel_spectrogram(wave).unsqueeze(1)                   # [B, 1, 80, T]
-    else:
-        mel = mel_spectrogram_engine(wave).unsqueeze(1)
+    mel = mel.unsqueeze(1)                                         # [B, 1, 80, T]
     return torch.cat([model.style_encoder(mel), model.predictor_encoder(mel)], dim=1)

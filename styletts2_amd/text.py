@@ -1,21 +1,43 @@
 """Text side of the path: TextEncoder (models.py:284-345), PL-BERT wrapper (Utils/PLBERT/util.py:6-12) and the
 ProsodyPredictor with its DurationEncoder (models.py:440-582).
 
-Every conv, every BiLSTM and the whole ALBERT encoder run on the HIP kernels: TextEncoder k=5 convs, F0/N AdainResBlk1d
-stacks and every Linear (token-merged k=1 convs) on the split-f16 MFMA convs, LayerNorm / AdaLayerNorm + LeakyReLU +
-masking on `st2_colnorm_stats` / `st2_colnorm_apply`, LSTM input projections as k=1 convs and the recurrences on
-`st2_lstm_bidir_coop`, PL-BERT attention on `st2_attention_keylen` (ST2_BERT=hf selects the HF forward for A-B runs).
-What is left to PyTorch-ROCm is glue: embedding gathers, the style concatenation of the duration encoder and
-`bert_encoder`'s nn.Linear.  State_dict layouts are the reference's, key for key.
+A module forward on a HIP tensor is ONE C-ABI call into the module's C++ launch plan (`st2_text_forward`,
+`st2_bert_forward`, `st2_duration_forward`; csrc/st2_engine.hip) -- in `pipeline.inference` the whole front is one call
+(`st2_front_forward`) and these module-level forms serve callers that follow the notebooks step by step.  Every conv,
+every BiLSTM and the whole ALBERT encoder run on the HIP kernels: TextEncoder k=5 convs, F0/N AdainResBlk1d stacks and
+every Linear (token-merged k=1 convs) on the split-f16 MFMA convs, LayerNorm / AdaLayerNorm + LeakyReLU + masking on
+`st2_colnorm_stats` / `st2_colnorm_apply`, LSTM input projections as k=1 convs and the recurrences on
+`st2_lstm_bidir_coop`, PL-BERT attention on `st2_attention_keylen`.  There is no PyTorch / HF forward behind any of them.
+The per-kernel Python plans below (the bodies after the `_engine_path` test) are the tap-point path of the parity tests
+(`_hooks.override(plan="python")`) and what the CPU plan tests step through; they issue the same kernels, with a few
+PyTorch glue ops (embedding gathers, the style concatenation) where the C++ plans have kernels of their own.
+State_dict layouts are the reference's, key for key.
 """
+import weakref
+
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from . import ops
+from . import _hooks, ops
 from . import weights as W
 from .decoder import StyleBank, _PackedAdainResBlk, _PackedConv, run_adain_resblk
 from .layers import AdainResBlk1dParams, PlainConv1d, PlainLinear, WNConv1d
+
+
+def _engine_path(dev):
+    """HIP tensor and the product's plan selector: the module forward is one call into its C++ launch plan."""
+    return dev.type == "cuda" and _hooks.plan == "engine"
+
+
+def _cached_engine(owner, attr, modules, build):
+    """st2_engine handle packed once per (weights, device) and kept on `owner`: rebuilt when a parameter was reloaded
+    (in-place version counter) or moved (storage address)."""
+    stamp = tuple((p.data_ptr(), p._version) for m in modules for p in list(m.parameters()) + list(m.buffers()))
+    c = owner.__dict__.get(attr)
+    if c is None or c[0] != stamp:
+        c = (stamp, build())
+        owner.__dict__[attr] = c
+    return c[1]
 
 
 def _device_lengths(lengths, n, device):
@@ -137,6 +159,12 @@ class TextEncoder(_PackedCache, nn.Module):
 
     @torch.no_grad()
     def forward(self, x, input_lengths, m):
+        """tokens [B, N], input_lengths [B], m = length_to_mask(input_lengths) -> t_en [B, C, N] (models.py:302-331; the
+        mask is a function of the lengths in every reference call site, so the C++ plan takes the lengths)."""
+        if _engine_path(x.device):
+            from . import engine
+            eng = _cached_engine(self, "_engine", [self], lambda: engine.build_text_engine(self, x.device))
+            return eng.text_forward(x, _device_lengths(input_lengths, x.shape[1], x.device))
         pk = self._packed(x.device)
         h = self.embedding(x).transpose(1, 2).contiguous()  # [B, C, N]
         mk = m.to(x.device).unsqueeze(1)
@@ -160,10 +188,8 @@ class _AdaLayerNorm(nn.Module):
         self.channels, self.eps = channels, eps
         self.fc = PlainLinear(style_dim, channels * 2)
 
-    def forward(self, x, s):  # x [B, N, C]
-        h = F.linear(s, self.fc.weight, self.fc.bias)
-        gamma, beta = torch.chunk(h.unsqueeze(1), 2, dim=-1)
-        return (1 + gamma) * F.layer_norm(x, (self.channels,), eps=self.eps) + beta
+    def forward(self, x, s):
+        raise NotImplementedError("AdaLayerNorm runs inside DurationEncoder.forward (st2_colnorm_stats / st2_colnorm_apply)")
 
 
 class DurationEncoder(nn.Module):
@@ -179,17 +205,24 @@ class DurationEncoder(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, style, text_lengths, m):
-        """x [B, d_model, N], style [B, sty] -> [B, N, d_model + sty]."""
-        mk = m.to(x.device).unsqueeze(1)  # [B, 1, N]
+        """x [B, d_model, N], style [B, sty] -> [B, N, d_model + sty] (models.py:536-569)."""
         B, _, N = x.shape
         lens = _device_lengths(text_lengths, N, x.device)
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        if _engine_path(x.device) and owner is not None and owner.text_encoder is self:
+            d_cm, _ = owner._pred_engine(x.device).duration_forward(x, style, lens, want_durations=False)
+            return d_cm.transpose(1, 2)
+        mk = m.to(x.device).unsqueeze(1)  # [B, 1, N]
         # channel-major throughout: [x | style] rows, the LSTMs and the AdaLayerNorm all work on [B, C, N]
         sty = style.float().unsqueeze(-1).expand(-1, -1, N)
         h = torch.cat([x.float(), sty], dim=1)
         h.masked_fill_(mk, 0.0)
         for block in self.lstms:
             if isinstance(block, _AdaLayerNorm):
-                gb = F.linear(style, block.fc.weight, block.fc.bias)  # [B, 2C]: gamma | beta (models.py:430-435)
+                # [B, 2C]: gamma | beta (models.py:430-435) on st2_style_fc
+                gb = ops.style_fc(style.float().contiguous(), block.fc.weight.detach().float().t().contiguous(),
+                                  block.fc.bias.detach().float().contiguous())
                 C = block.channels
                 nh = torch.empty((B, C + self.sty_dim, N), device=h.device, dtype=torch.float32)
                 ops.colnorm_apply(h, ops.colnorm_stats(h, eps=block.eps), gb[:, :C], gb[:, C:], gamma_plus_one=True,
@@ -203,12 +236,35 @@ class DurationEncoder(nn.Module):
         return h.transpose(1, 2)
 
 
+class EngineLinear(_PackedCache, nn.Linear):
+    """nn.Linear parameter holder (same state_dict keys) whose forward is a k=1 split-f16 MFMA conv over the merged
+    leading dimensions (`bert_encoder`, models.py:689; `duration_proj.linear_layer`, models.py:34-44)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__(in_features, out_features)
+        self._pk = None
+
+    def _prepare(self, device):
+        pk = type("PackedLinear", (), {})()
+        pk.w = W.pack_linear_auto(self.weight.detach().float().cpu()).to(device)
+        pk.b = self.bias.detach().float().contiguous().to(device)
+        return pk
+
+    @torch.no_grad()
+    def forward(self, x):
+        pk = self._packed(x.device)
+        lead = x.shape[:-1]
+        xc = x.reshape(1, -1, self.in_features).transpose(1, 2).contiguous().float()  # [1, in, M] channel-major tokens
+        y = ops.conv1d(xc, pk.w, self.out_features, 1, bias=pk.b)                      # [1, out, M]
+        return y.transpose(1, 2).reshape(*lead, self.out_features)
+
+
 class _LinearNorm(nn.Module):
     """models.py:34-44 (`linear_layer` key)."""
 
     def __init__(self, in_dim, out_dim):
         super().__init__()
-        self.linear_layer = nn.Linear(in_dim, out_dim)
+        self.linear_layer = EngineLinear(in_dim, out_dim)
 
     def forward(self, x):
         return self.linear_layer(x)
@@ -231,6 +287,12 @@ class ProsodyPredictor(_PackedCache, nn.Module):
         self.F0_proj = PlainConv1d(d_hid // 2, 1, 1)
         self.N_proj = PlainConv1d(d_hid // 2, 1, 1)
         self._pk = None
+        self.text_encoder.__dict__["_owner"] = weakref.ref(self)  # its C++ plan lives in this module's engine handle
+
+    def _pred_engine(self, device):
+        """The st2_engine handle holding the whole predictor (st2_duration_forward, st2_prosody_forward)."""
+        from . import engine
+        return _cached_engine(self, "_engine", [self], lambda: engine.build_predictor_engine(self, device))
 
     def _prepare(self, device):
         pk = type("PackedPredictor", (), {})()
@@ -267,14 +329,12 @@ def build_plbert(plbert_params):
     state_dict are the reference's key for key -- whose forward runs on the engine's HIP kernels and returns
     `last_hidden_state`.  `transformers` is imported lazily so that the rest of the engine imports without it.
 
-    Engine forward (ST2_BERT=hf keeps the HF / hipBLASLt forward for A-B runs): tokens are channel-major and
-    token-merged ([768, B*N] storage), every Linear is one k=1 split-f16 MFMA conv over B*N columns (q|k|v fused into
+    Forward: one `st2_bert_forward` call (C++ plan); the per-kernel plan `forward_engine` below is the tests' tap path.
+    In both, tokens are channel-major and token-merged ([768, B*N] storage), every Linear is one k=1 split-f16 MFMA conv over B*N columns (q|k|v fused into
     one 768->2304 conv), attention is `st2_attention_keylen` (12 heads x 64, key padding from the attention mask),
     the post-LN residual blocks are `st2_colnorm_stats` + `st2_colnorm_apply` (eps 1e-12), the FFN activation
     (gelu_new) sits in the conv epilogue; the embedding LayerNorm is the prologue of the 128->768 mapping conv.
     The 12 layers share one weight set (ALBERT), packed once per load."""
-    import os
-
     from transformers import AlbertConfig, AlbertModel
 
     class CustomAlbert(AlbertModel):
@@ -326,8 +386,18 @@ def build_plbert(plbert_params):
 
         @torch.no_grad()
         def forward(self, input_ids=None, attention_mask=None, **kwargs):
-            if os.environ.get("ST2_BERT", "engine") == "hf" or kwargs:  # explicit A-B switch / unsupported HF options
-                return super().forward(input_ids, attention_mask=attention_mask, **kwargs).last_hidden_state
+            """`bert(tokens, attention_mask=(~text_mask).int())` (Demo/Inference_LJSpeech.ipynb:284) -> last hidden state
+            [B, N, hidden].  Only this call form exists: there is no HF forward behind it, other HF options raise."""
+            if kwargs:
+                raise TypeError("PL-BERT on the MI355X engine takes (input_ids, attention_mask) only; got %s"
+                                % sorted(kwargs))
+            if _engine_path(input_ids.device):
+                from . import engine
+                eng = _cached_engine(self, "_engine", [self], lambda: engine.build_bert_engine(self, input_ids.device))
+                lens = None
+                if attention_mask is not None:  # right-padded batch (length_to_mask): valid keys are a prefix
+                    lens = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32).contiguous()
+                return eng.bert_forward(input_ids, lens)
             return self.forward_engine(input_ids, attention_mask)  # no CPU fallback: non-HIP tensors raise in ops
 
         @torch.no_grad()

@@ -3,9 +3,9 @@
 Done once per load_state_dict(); the reference instead re-evaluates weight-norm on every forward
 (torch.nn.utils.weight_norm hook).
 """
-import os
-
 import torch
+
+from . import _hooks
 
 
 def fold_weight_norm(g, v):
@@ -95,12 +95,9 @@ def pack_conv_f16s(w):
 
 
 def conv_precision():
-    """Which kernel the decoder / vocoder / prosody convolutions are packed for: "f16s" (default; split-f16 MFMA,
-    st2_conv1d_f16s) or "f32" (exact-fp32 MFMA, st2_conv1d).  Read from ST2_CONV_PRECISION at pack time."""
-    mode = os.environ.get("ST2_CONV_PRECISION", "f16s")
-    if mode not in ("f16s", "f32"):
-        raise ValueError("ST2_CONV_PRECISION must be f16s or f32, got %r" % mode)
-    return mode
+    """Which kernel the convolutions are packed for: "f16s" (split-f16 MFMA, st2_conv1d_xs / st2_conv1d_f16s) or, from
+    tests only (_hooks.py), "f32" (the exact-fp32 MFMA build of the same contract, st2_conv1d)."""
+    return _hooks.conv_precision
 
 
 def pack_conv_auto(w):

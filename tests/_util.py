@@ -43,7 +43,7 @@ def mel_l1(wave_a, wave_b):
     """The second parity metric of BASELINE.json's north_star: L1 distance between the reference's normalised log-mel
     spectrograms ((log(1e-5 + mel) + 4) / 4 of MelSpectrogram(n_mels=80, n_fft=2048, win_length=1200, hop_length=300),
     meldataset.py:58-66) of two waveforms [..., L], evaluated on the CPU."""
-    from styletts2_amd.style import mel_spectrogram
-    a = mel_spectrogram(wave_a.detach().cpu().float().reshape(-1, wave_a.shape[-1]))
-    b = mel_spectrogram(wave_b.detach().cpu().float().reshape(-1, wave_b.shape[-1]))
+    from oracle.mel_ref import mel_spectrogram_t  # fp64 evaluation of torchaudio's documented algorithm: not product code
+    a = mel_spectrogram_t(wave_a.detach().cpu().float().reshape(-1, wave_a.shape[-1]))
+    b = mel_spectrogram_t(wave_b.detach().cpu().float().reshape(-1, wave_b.shape[-1]))
     return (a - b).abs().mean().item()

@@ -80,7 +80,7 @@ def test_utils():
 
 
 def test_plbert_has_no_cpu_fallback():
-    """The engine PL-BERT must not silently run the HF forward on CPU tensors (ST2_BERT=hf is the explicit switch)."""
+    """The engine PL-BERT must not silently run the HF forward on CPU tensors (there is none behind it) nor accept HF-only options."""
     import torch
     from _util import manifest
     from styletts2_amd import models
@@ -89,6 +89,8 @@ def test_plbert_has_no_cpu_fallback():
     ids = torch.zeros(1, 5, dtype=torch.long)
     with pytest.raises(St2Error):
         bert(ids, attention_mask=torch.ones(1, 5, dtype=torch.int32))
+    with pytest.raises(TypeError):
+        bert(ids, attention_mask=None, output_hidden_states=True)
 
 
 def test_xs_conv_hot_builds_do_not_spill(tmp_path):

@@ -69,7 +69,6 @@ def test_c_host_matches_python_binding_bitwise(tmp_path, tag, B, T):
     assert r.returncode == 0, r.stderr + r.stdout
     wave_c = torch.from_numpy(np.fromfile(out, dtype="<f4").copy()).reshape(B, 1, 600 * T)
     dec = dec.to("cuda")
-    os.environ.pop("ST2_PLAN", None)
     wave_py = dec(asr.cuda(), F0.cuda(), N.cuda(), s.cuda(), noise=noise.cuda()).cpu()
     assert bool(torch.isfinite(wave_c).all())
     assert torch.equal(wave_c, wave_py)
@@ -101,7 +100,7 @@ def test_c_tts_host_builds_against_the_header(tmp_path):
 def test_c_tts_host_matches_python_bitwise(tmp_path, tag, N):
     """Phoneme ids -> waveform by tools/st2_c_tts.c (plain C: st2_front_forward, one read-back of the durations,
     st2_prosody_forward, st2_decoder_forward) == the same three calls through the Python binding == pipeline.inference
-    with the C++ front (ST2_FRONT=engine), on the same weights, tokens and noise."""
+    (whose stages are those three calls), on the same weights, tokens and noise."""
     from styletts2_amd import engine, models, pipeline
     import synth
     exe = _build_tts(tmp_path)
@@ -162,13 +161,9 @@ def test_c_tts_host_matches_python_bitwise(tmp_path, tag, N):
     wave_py = eng.decoder_forward(asr, F0, Nn, fr["ref"], noise=sine).cpu()
     assert torch.equal(wave_c, wave_py)
     # ... and the product pipeline with the C++ front
-    os.environ["ST2_FRONT"] = "engine"
-    try:
-        wave_pl = pipeline.inference(model, sampler, d(tokens), None, d(noise), diffusion_steps=steps, ref_s=d(ref_s),
-                                     step_noise=d(step_noise), sine_noise=sine, lj_tail=not multi)
-    finally:
-        os.environ.pop("ST2_FRONT", None)
+    wave_pl = pipeline.inference(model, sampler, d(tokens), None, d(noise), diffusion_steps=steps, ref_s=d(ref_s),
+                                 step_noise=d(step_noise), sine_noise=sine, lj_tail=not multi)
     wave_pl = wave_pl[0] if isinstance(wave_pl, list) else wave_pl
     diff = float((wave_pl.cpu().reshape(-1) - wave_c.reshape(-1)).abs().max())
-    print("pipeline (ST2_FRONT=engine) vs C host: max |diff| = %.3e" % diff)
+    print("pipeline.inference vs C host: max |diff| = %.3e" % diff)
     assert diff == 0.0

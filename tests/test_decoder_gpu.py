@@ -98,21 +98,3 @@ def test_decoder_is_deterministic_and_rejects_training_mode():
     dec.train()
     with pytest.raises(RuntimeError):
         dec(asr.to(DEV), F0.to(DEV), N.to(DEV), s.to(DEV))
-
-
-@pytest.mark.parametrize("tag", ["ljspeech", "libritts"])
-def test_multi_stream_mrf_is_bitwise_the_single_stream_result(tag, monkeypatch):
-    """ST2_MRF_STREAMS=1: Generator._mrf issues the three AdaINResBlock1 chains of a stage on separate HIP streams
-    (joined through the running sum's events); the waveform must be bitwise that of the single-stream order, run
-    after run."""
-    dc, dec, sd, (asr, F0, N, s, noise) = _setup(tag, 2, 10)
-    dec = dec.to(DEV)
-    args = (asr.to(DEV), F0.to(DEV), N.to(DEV), s.to(DEV))
-    monkeypatch.setenv("ST2_MRF_STREAMS", "0")
-    ref = dec(*args, noise=noise.to(DEV))
-    torch.cuda.synchronize()
-    monkeypatch.setenv("ST2_MRF_STREAMS", "1")
-    for _ in range(3):
-        out = dec(*args, noise=noise.to(DEV))
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref)

@@ -1,5 +1,5 @@
 """Module-level C ABI on the GPU: `st2_decoder_forward` / `st2_sampler_run` -- the C++ launch
-plans of csrc/st2_engine.hip -- against the per-kernel Python plans (decoder.py / diffusion.py, ST2_PLAN=python).  Both
+plans of csrc/st2_engine.hip -- against the per-kernel Python plans (decoder.py / diffusion.py, _hooks.override(plan="python")).  Both
 issue the same kernels with the same arguments, so their results must be BITWISE equal; the Python plans are in turn
 held to the oracle by test_decoder_gpu.py / test_sampler_gpu.py.  Also: a whole decoder call captured in a hipGraph
 (the entry point allocates nothing and never synchronises), replayed on new inputs."""
@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from _util import decoder_kwargs, manifest
-from styletts2_amd import engine, models
+from styletts2_amd import _hooks, engine, models
 import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.decoder import Decoder
 
@@ -17,19 +17,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-class _plan:
-    def __init__(self, mode):
-        self.mode = mode
-
-    def __enter__(self):
-        self.old = os.environ.get("ST2_PLAN")
-        os.environ["ST2_PLAN"] = self.mode
-
-    def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("ST2_PLAN", None)
-        else:
-            os.environ["ST2_PLAN"] = self.old
+def _plan(mode):
+    return _hooks.override(plan=mode)
 
 
 def _decoder(tag, wseed=1):
@@ -268,11 +257,8 @@ def test_front_plan_engine_matches_python_front(tag, ragged, carry):
     lens_dev = lengths.to(torch.int32).to(DEV) if ragged else None
     outs = {}
     for mode in ("python", "engine"):
-        os.environ["ST2_FRONT"] = mode
-        try:
+        with _hooks.override(plan=mode):
             outs[mode] = pipeline._front_core(model, sampler, tokens, lengths, lens_dev, noise, step_noise, ref_s, s_prev, **kw)
-        finally:
-            os.environ.pop("ST2_FRONT", None)
     torch.cuda.synchronize()
     p, e = outs["python"], outs["engine"]
     for k in ("t_en", "d", "s", "ref"):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ops_ref as R
-from styletts2_amd import ops, weights
+from styletts2_amd import _hooks, ops, weights
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -101,7 +101,7 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
     the prologue fused (st2_conv1d_f16s), `xs` = activation pass + pure split-f16 MFMA conv (st2_act_split +
     st2_conv1d_xs).  The split contract carries the operand split (hi + lo of v * scale), so the bar is the same
     fp32 round-off class for all three."""
-    monkeypatch.setenv("ST2_CONV_PATH", "xs" if kernel == "xs" else "fused")
+    monkeypatch.setattr(_hooks, "conv_path", "xs" if kernel == "xs" else "fused")
     x, w, kw = make_conv_case(seed=1234, **case)
     wt = weights.pack_conv(w) if kernel == "f32" else weights.pack_conv_f16s(w)
     C_out, ks = w.shape[0], w.shape[2]
@@ -135,7 +135,7 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
 def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
     """want_stats: InstanceNorm statistics of the conv OUTPUT from the epilogue's per-tile partial sums
     (st2_conv1d_xs part + st2_stats_finalize) against the fp64 reduction of the stored tensor."""
-    monkeypatch.setenv("ST2_CONV_PATH", "xs")
+    monkeypatch.setattr(_hooks, "conv_path", "xs")
     x, w, kw = make_conv_case(seed=99, B=B, C_in=C_in, C_out=C_out, L=L, ks=ks, dil=dil, pro=R.PRO_ADAIN_SNAKE, res=res)
     wt = weights.pack_conv_f16s(w)
     kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
@@ -425,7 +425,7 @@ def test_token_glue():
 
 def _conv_vs_fp64(x, w, pro, path, monkeypatch, **extra):
     """One conv (C_in x ks x C_out from w) on the engine vs an fp64 evaluation of the un-split operands."""
-    monkeypatch.setenv("ST2_CONV_PATH", "xs" if path == "xs" else "fused")
+    monkeypatch.setattr(_hooks, "conv_path", "xs" if path == "xs" else "fused")
     C_out, C_in, ks = w.shape
     kw = dict(pad_left=(ks - 1) // 2, pro=pro, **extra)
     if pro == R.PRO_LEAKY:
@@ -587,7 +587,7 @@ def test_lstm_coop_timeout_is_reported_not_silent(monkeypatch):
     budget forced to 1 the hand-off fails, ST2_STATUS_LSTM_TIMEOUT is raised and ops.check_status() throws."""
     from styletts2_amd import _lib
     from styletts2_amd.text import EngineLSTM
-    monkeypatch.setenv("ST2_LSTM", "coop")
+    monkeypatch.setattr(_hooks, "lstm", "coop")
     ops.status(clear=True)
     lib = _lib.load()
     torch.manual_seed(3)
@@ -639,7 +639,7 @@ def test_lstm_bidir_matches_torch_lstm(B, N, ragged, mode, monkeypatch):
     both recurrence kernels: `coop` = st2_lstm_bidir_coop (register-resident W_hh over 8 CUs per group; utterance
     blocks of 1 / 4 / 8, partial blocks, ragged lengths inside a block), `single` = st2_lstm_bidir."""
     from styletts2_amd.text import EngineLSTM
-    monkeypatch.setenv("ST2_LSTM", mode)
+    monkeypatch.setattr(_hooks, "lstm", mode)
     torch.manual_seed(N)
     lstm = EngineLSTM(640, 256)
     ref_lstm = torch.nn.LSTM(640, 256, 1, batch_first=True, bidirectional=True)

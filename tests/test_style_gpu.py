@@ -1,6 +1,7 @@
 """Reference-audio style path on the GPU: the HIP kernels of csrc/st2_style.hip against their
-contracts, StyleEncoder on the engine against the golden vectors produced by the unmodified reference module
-(oracle/golden_style.py -> tests/golden/style_vectors.npz), the mel front-end against torch.stft on the CPU."""
+contracts, StyleEncoder on the engine (C++ plan and per-kernel plan) against the golden vectors produced by the
+unmodified reference module (oracle/golden_style.py -> tests/golden/style_vectors.npz) and the oracle, the mel front-end
+against oracle/mel_ref.py's committed fixtures (tests/golden/mel_vectors.npz)."""
 import os
 
 import numpy as np
@@ -8,8 +9,10 @@ import pytest
 import torch
 
 from _util import GOLDEN, manifest
+from oracle import golden_mel, mel_ref
 from oracle import ops_ref as R
-from styletts2_amd import models, ops, style
+from oracle import st2_oracle as O
+from styletts2_amd import _hooks, models, ops, style
 import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.gpu
@@ -42,8 +45,14 @@ def test_style_kernels_match_contracts():
         assert (outp.cpu() - refp).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("plan", ["engine", "python"])
 @pytest.mark.parametrize("tag", ["small", "libritts"])
-def test_style_encoder_engine_matches_reference_vectors(tag):
+def test_style_encoder_engine_matches_reference_vectors(tag, plan):
+    with _hooks.override(plan=plan):
+        _style_encoder_case(tag)
+
+
+def _style_encoder_case(tag):
     c = CASES[tag]
     gold = np.load(os.path.join(GOLDEN, "style_vectors.npz"))["style_" + tag]
     enc = style.StyleEncoder(dim_in=c["dim_in"], style_dim=c["style_dim"], max_conv_dim=c["max_conv_dim"]).eval()
@@ -57,39 +66,37 @@ def test_style_encoder_engine_matches_reference_vectors(tag):
     assert out.shape == gold.shape
     err = np.abs(out - gold).max()
     assert err < 1e-5 * max(1.0, np.abs(gold).max()), err
-    # a 10 s reference recording's map (801 frames): the xs conv path (rows >= 256 columns) against the PyTorch ops
+    # a 10 s reference recording's map (801 frames): the xs conv path (rows >= 256 columns) against the oracle
     xl = torch.randn(1, 1, 80, 801, generator=g) * 0.8 - 0.2
-    ref = enc.cpu().forward_torch(xl)
+    ref = O.style_encoder(enc.cpu().state_dict(), xl)
     got = enc.to(DEV)(xl.to(DEV)).cpu()
     assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
-def test_mel_frontend_engine_matches_torch_stft():
-    g = torch.Generator().manual_seed(5)
-    t = torch.arange(48000) / 24000.0
-    wave = torch.randn(2, 48000, generator=g) * 0.05 + 0.4 * torch.sin(2 * torch.pi * 220.0 * t) * torch.exp(-t)
-    ref = style.mel_spectrogram(wave)
-    out = style.mel_spectrogram_engine(wave.to(DEV)).cpu()
-    assert out.shape == ref.shape == (2, 80, 161)
-    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
-    full = style.mel_spectrogram_engine((wave * 2.4).clamp(-1, 1).to(DEV)).cpu()   # full-scale input: |X|^2 ~ 1e5
-    assert (full - style.mel_spectrogram((wave * 2.4).clamp(-1, 1))).abs().max().item() < 2e-4
+def test_mel_frontend_engine_matches_oracle_fixtures():
+    """mel_spectrogram_engine against the committed outputs of oracle/mel_ref.py (fp64 evaluation of torchaudio's
+    documented MelSpectrogram algorithm incl. the sample_rate = 16000 quirk) on the fixture generator's seeded waveforms:
+    speech-like dynamics, full-scale input (|X|^2 ~ 1e5) and a length that is not a multiple of the hop."""
+    gold = np.load(os.path.join(GOLDEN, "mel_vectors.npz"))
+    for name, wave in golden_mel.waves().items():
+        out = style.mel_spectrogram_engine(wave.to(DEV)).cpu().numpy()
+        assert out.shape == gold[name].shape
+        err = np.abs(out - gold[name]).max()
+        assert err < 2e-4, (name, err)
 
 
-def test_compute_style_engine_vs_torch_path():
+def test_compute_style_engine_vs_oracle():
     man = manifest("libritts")
     args = models.recursive_munch(man["config"])
     model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))
     synth.init_spectral_norm_(model.style_encoder, 3)
     synth.init_spectral_norm_(model.predictor_encoder, 4)
     wave = torch.randn(2, 24000 * 3, generator=torch.Generator().manual_seed(0)) * 0.1
-    os.environ["ST2_STYLE"] = "torch"
-    try:
-        ref = style.compute_style(model, wave)
-    finally:
-        del os.environ["ST2_STYLE"]
+    ref = O.compute_style(model.style_encoder.state_dict(), model.predictor_encoder.state_dict(), wave)
     model.style_encoder.to(DEV)
     model.predictor_encoder.to(DEV)
-    out = style.compute_style(model, wave.to(DEV))
+    out = style.compute_style(model, wave.to(DEV))          # mel kernels + both encoders as C++ plans
     assert out.shape == (2, 256)
     assert (out.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    with _hooks.override(plan="python"):                    # per-kernel plan: bitwise the C++ plan
+        assert torch.equal(style.compute_style(model, wave.to(DEV)), out)

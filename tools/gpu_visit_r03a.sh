@@ -30,7 +30,7 @@ for cus in 16 64; do
 done
 for s in two-stream partitioned single; do
   echo "== kernel trace, schedule $s"
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_$s -o t -- python $R/bench.py --steps 3 --warmup 1 --calib-steps 0 --schedule $s --no-cpu-baseline > $R/$OUT/prof_$s.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_$s -o t -- python $R/bench.py --steps 3 --warmup 1 --calib-steps 0 --schedule $s --no-cpu-baseline > $R/$OUT/prof_$s.log 2>&1)
   f=$(find $OUT/prof_$s -name "*kernel_trace.csv" | head -1)
   [ -n "$f" ] && python tools/trace_overlap.py $f > $OUT/overlap_$s.json && python -c "
 import json;r=json.load(open('$OUT/overlap_$s.json'));print({k:r[k] for k in ('span_ms','gpu_busy_ms','two_or_more_queues_active_ms','overlap_share_of_busiest_queue')}); print(r['queues']); print({k:v for k,v in r['families'].items() if 'lstm' in k or '<11' in k})"

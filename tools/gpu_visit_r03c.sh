@@ -17,7 +17,7 @@ for shape in "2048 1024" "1024 2048" "1024 1024" "512 1024" "1024 512" "2304 768
 done
 for s in two-stream single; do
   echo "== kernel trace, schedule $s"
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_$s -o t -- python $R/bench.py --steps 3 --warmup 1 --calib-steps 0 --schedule $s --no-cpu-baseline > $R/$OUT/prof_$s.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_$s -o t -- python $R/bench.py --steps 3 --warmup 1 --calib-steps 0 --schedule $s --no-cpu-baseline > $R/$OUT/prof_$s.log 2>&1)
   tail -2 $OUT/prof_$s.log | cut -c1-300
   f=$(find $OUT/prof_$s -name "*kernel_trace.csv" | head -1)
   [ -n "$f" ] && python tools/trace_overlap.py $f > $OUT/overlap_$s.json && python -c "
@@ -27,7 +27,7 @@ import json;r=json.load(open('$OUT/overlap_$s.json'));print({k:r[k] for k in ('s
   rm -rf $OUT/prof_$s
 done
 echo "== rocprofv3 over the default command (auto schedule, masked streams closed at exit)"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_auto -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/prof_auto.log 2>&1); echo rc=$?
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_auto -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/prof_auto.log 2>&1); echo rc=$?
 tail -2 $OUT/prof_auto.log | cut -c1-400
 find $OUT/prof_auto -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_auto.csv
 rm -rf $OUT/prof_auto

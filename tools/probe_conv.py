@@ -9,7 +9,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from styletts2_amd import _lib, ops, weights
+from styletts2_amd import _hooks, _lib, ops, weights
 
 dev = "cuda"
 B = int(os.environ.get("PROBE_B", "8"))
@@ -48,7 +48,7 @@ for (Cc, L, ks, dil) in cases:
     flop = 2.0 * B * Cc * Cc * ks * L
     pad = (ks - 1) * dil // 2
     akw = dict(pro=ops.PRO_ADAIN_SNAKE, stats=st, gamma=h[:, :Cc], beta=h[:, Cc:], alpha=alpha)
-    os.environ["ST2_CONV_PATH"] = "fused"
+    _hooks.conv_path = "fused"
     r = dict(C=Cc, L=L, ks=ks, dil=dil)
     r["fused_pro0"] = timed(lambda: ops.conv1d(x, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out))
     r["fused_pro3"] = timed(lambda: ops.conv1d(x, wt, Cc, ks, dil=dil, pad_left=pad, bias=bias, out=out, res=x, **akw))

@@ -5,7 +5,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from styletts2_amd import _lib, ops
+from styletts2_amd import _hooks, _lib, ops
 
 dev = "cuda"
 B, H = int(os.environ.get("PROBE_B", "32")), 256
@@ -14,7 +14,7 @@ for N in (100, 400):
     G = torch.randn(B, 8 * H, N, device=dev)
     outs = {}
     for mode in ("single", "coop_fence", "coop_sc1", "coop"):  # coop = tagged 8-byte granules (the default hand-off)
-        os.environ["ST2_LSTM"] = "single" if mode == "single" else "coop"
+        _hooks.lstm = "single" if mode == "single" else "coop"
         _lib.load().st2_lstm_coop_set_exchange({"coop_fence": 0, "coop_sc1": 1}.get(mode, 2))
         for _ in range(2):
             y = ops.lstm_bidir(G, whh)
