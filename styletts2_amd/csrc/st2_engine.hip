@@ -79,13 +79,14 @@ int hip_upload(void* d, const void* s, int64_t n) {
 
 int hip_lstm(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths, int32_t B, int32_t H,
              int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* scratch, int64_t scratch_bytes, void* stream) {
-  static bool coop_refused = false;
-  if (scratch && scratch_bytes > 0 && !coop_refused) {
+  // No sticky "refused" state: whether a cooperative launch fits depends on the device AND the batch (a refusal at B = 48
+  // says nothing about the latency-critical B = 1 long-form launches, nor about another device of the process).  The
+  // refusal itself is a host-side occupancy comparison -- nothing was launched -- so asking every time costs nothing.
+  if (scratch && scratch_bytes > 0) {
     if (st2_lstm_bidir_coop(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream) == 0)
       return 0;
     const char* msg = st2_last_error();
     if (!msg || !strstr(msg, "co-resident")) return 1;
-    coop_refused = true;  // nothing was launched: the single-CU kernel, now and from here on
   }
   return st2_lstm_bidir(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, stream);
 }
@@ -239,7 +240,7 @@ SplitW pack_split(Blob& blob, const float* w, int C_out, int C_in, int ks) {
     if (amax > 0.f) {
       int e = 0;
       (void)frexpf(amax, &e);
-      scale = ldexpf(1.0f, 14 - e);
+      scale = ldexpf(1.0f, std::min(14 - e, 126));  // clamp: rows with amax < 2^-112 must not get scale = inf (weights.py)
     }
     rs[co] = 1.0f / scale;
     for (int ci = 0; ci < C_in; ++ci)
@@ -421,32 +422,67 @@ struct Packer {
     return &it->second;
   }
   bool has(const std::string& name) const { return e.host.find(name) != e.host.end(); }
-  int64_t vec(const std::string& name) {  // flat fp32 copy
+  // A checkpoint whose layout differs from st2_model_config must fail HERE, with a message -- never index a host tensor
+  // past its end.  `want` lists the expected dimensions, -1 = any; trailing dimensions of size 1 may be absent
+  // (nn.Linear weights stand in for k = 1 convs, [C][1][1] gains for [C] vectors).
+  void fail(const std::string& why) {
+    if (ok) missing = why;
+    ok = false;
+  }
+  static std::string shape_str(const std::vector<int64_t>& s) {
+    std::string r = "[";
+    for (size_t i = 0; i < s.size(); ++i) r += (i ? ", " : "") + std::to_string(s[i]);
+    return r + "]";
+  }
+  const HostTensor* get(const std::string& name, std::initializer_list<int64_t> want) {
     const HostTensor* t = get(name);
-    return t ? blob.add_f32(t->data) : -1;
+    if (!t) return nullptr;
+    std::vector<int64_t> w(want);
+    bool good = t->shape.size() <= w.size();
+    for (size_t i = 0; good && i < w.size(); ++i) {
+      const int64_t have = i < t->shape.size() ? t->shape[i] : 1;
+      good = w[i] < 0 ? have > 0 : have == w[i];
+    }
+    if (!good) {
+      fail(name + " has shape " + shape_str(t->shape) + ", the model configuration needs " + shape_str(w));
+      return nullptr;
+    }
+    return t;
+  }
+  int64_t vec(const std::string& name, int64_t numel = -1) {  // flat fp32 copy (numel >= 0: exact element count)
+    const HostTensor* t = get(name);
+    if (!t) return -1;
+    if (numel >= 0 && t->numel() != numel) {
+      fail(name + " has " + std::to_string(t->numel()) + " elements, the model configuration needs " + std::to_string(numel));
+      return -1;
+    }
+    return blob.add_f32(t->data);
   }
   // nn.Linear weight [out][in] -> [in][out] (the st2_style_fc layout)
-  int64_t lin_t(const std::string& name) {
-    const HostTensor* t = get(name);
-    if (!t || t->shape.size() != 2) { ok = false; if (missing.empty()) missing = name + " (2-D expected)"; return -1; }
+  int64_t lin_t(const std::string& name, int64_t out = -1, int64_t in = -1) {
+    const HostTensor* t = get(name, {out, in});
+    if (!t) return -1;
+    if (t->shape.size() != 2) { fail(name + " (2-D expected)"); return -1; }
     const int64_t O = t->shape[0], I = t->shape[1];
     std::vector<float> v((size_t)(O * I));
     for (int64_t o = 0; o < O; ++o)
       for (int64_t i = 0; i < I; ++i) v[(size_t)(i * O + o)] = t->data[(size_t)(o * I + i)];
     return blob.add_f32(v);
   }
-  SplitW conv_w(const std::string& name) {  // [C_out][C_in][ks] (or nn.Linear [out][in] as ks = 1)
-    const HostTensor* t = get(name);
+  // [C_out][C_in][ks] (or nn.Linear [out][in] as ks = 1); co / ci / ks >= 0 pin the expected geometry
+  SplitW conv_w(const std::string& name, int co = -1, int ci = -1, int ks = -1) {
+    const HostTensor* t = get(name, {co, ci, ks});
     if (!t) return SplitW();
-    const int C_out = (int)t->shape[0], C_in = (int)t->shape[1], ks = t->shape.size() > 2 ? (int)t->shape[2] : 1;
-    return pack_split(blob, t->data.data(), C_out, C_in, ks);
+    if (t->shape.size() < 2) { fail(name + " has shape " + shape_str(t->shape) + ", a conv / linear weight is at least 2-D"); return SplitW(); }
+    const int C_out = (int)t->shape[0], C_in = (int)t->shape[1], k = t->shape.size() > 2 ? (int)t->shape[2] : 1;
+    return pack_split(blob, t->data.data(), C_out, C_in, k);
   }
-  PConv conv(const std::string& prefix, bool bias = true) {
+  PConv conv(const std::string& prefix, bool bias = true, int co = -1, int ci = -1, int ks = -1) {
     PConv c;
-    c.w = conv_w(prefix + ".weight");
+    c.w = conv_w(prefix + ".weight", co, ci, ks);
     c.c_out = c.w.C_out;
     c.ks = c.w.ks;
-    if (bias && has(prefix + ".bias")) c.bias = vec(prefix + ".bias");
+    if (bias && has(prefix + ".bias")) c.bias = vec(prefix + ".bias", c.w.C_out > 0 ? c.w.C_out : -1);
     return c;
   }
 };
@@ -454,8 +490,10 @@ struct Packer {
 struct Bank {  // decoder.StyleBank: every AdaIN fc of the module in one [style][J] matrix
   std::vector<const HostTensor*> ws, bs;
   std::vector<int> chans;
+  std::vector<std::string> names;
   int J = 0;
   int add(Packer& pk, const std::string& prefix, int channels) {
+    names.push_back(prefix + ".fc.weight");
     ws.push_back(pk.get(prefix + ".fc.weight"));
     bs.push_back(pk.get(prefix + ".fc.bias"));
     chans.push_back(channels);
@@ -469,6 +507,11 @@ struct Bank {  // decoder.StyleBank: every AdaIN fc of the module in one [style]
     for (size_t m = 0; m < ws.size(); ++m) {
       const int n = 2 * chans[m];
       if (!ws[m] || !bs[m]) return;
+      if (ws[m]->numel() != (int64_t)n * style_dim || bs[m]->numel() != n) {  // AdaIN fc: Linear(style_dim, 2 * channels)
+        pk.fail("AdaIN fc " + names[m] + " has shape " + Packer::shape_str(ws[m]->shape) + " / bias " + Packer::shape_str(bs[m]->shape) +
+                ", the model configuration needs [" + std::to_string(n) + ", " + std::to_string(style_dim) + "]");
+        return;
+      }
       for (int j = 0; j < n; ++j) {
         for (int k = 0; k < style_dim; ++k) wt[(size_t)k * J + off + j] = ws[m]->data[(size_t)j * style_dim + k];
         b[(size_t)off + j] = bs[m]->data[(size_t)j];
@@ -487,10 +530,10 @@ PResBlock1 pack_resblock1(Packer& pk, const std::string& prefix, int channels, i
   for (int i = 0; i < 3; ++i) {
     const std::string si = std::to_string(i);
     r.dil[i] = dil[i];
-    r.c1[i] = pk.conv(prefix + ".convs1." + si);
-    r.c2[i] = pk.conv(prefix + ".convs2." + si);
-    r.a1[i] = pk.vec(prefix + ".alpha1." + si);
-    r.a2[i] = pk.vec(prefix + ".alpha2." + si);
+    r.c1[i] = pk.conv(prefix + ".convs1." + si, true, channels, channels, ks);
+    r.c2[i] = pk.conv(prefix + ".convs2." + si, true, channels, channels, ks);
+    r.a1[i] = pk.vec(prefix + ".alpha1." + si, channels);
+    r.a2[i] = pk.vec(prefix + ".alpha2." + si, channels);
   }
   return r;
 }
@@ -498,12 +541,12 @@ PResBlock1 pack_resblock1(Packer& pk, const std::string& prefix, int channels, i
 PAdainResBlk pack_adain_resblk(Packer& pk, const std::string& prefix, int dim_in, int dim_out, bool upsample) {
   PAdainResBlk r;
   r.dim_in = dim_in; r.dim_out = dim_out; r.upsample = upsample; r.learned_sc = dim_in != dim_out;
-  r.conv1 = pk.conv(prefix + ".conv1");
-  r.conv2 = pk.conv(prefix + ".conv2");
-  if (r.learned_sc) r.sc = pk.conv(prefix + ".conv1x1", false);
+  r.conv1 = pk.conv(prefix + ".conv1", true, dim_out, dim_in, 3);
+  r.conv2 = pk.conv(prefix + ".conv2", true, dim_out, dim_out, 3);
+  if (r.learned_sc) r.sc = pk.conv(prefix + ".conv1x1", false, dim_out, dim_in, 1);
   if (upsample) {
-    r.pool_w = pk.vec(prefix + ".pool.weight");  // [C][1][3] folded
-    r.pool_b = pk.vec(prefix + ".pool.bias");
+    r.pool_w = pk.vec(prefix + ".pool.weight", (int64_t)dim_in * 3);  // [C][1][3] folded
+    r.pool_b = pk.vec(prefix + ".pool.bias", dim_in);
   }
   return r;
 }
@@ -532,17 +575,17 @@ int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
     d.decode[i].n1 = bank.add(pk, p + ".norm1", 1024 + 2 + 64);
     d.decode[i].n2 = bank.add(pk, p + ".norm2", up ? 512 : 1024);
   }
-  d.f0_w = pk.vec(D + "F0_conv.weight"); d.f0_b = pk.vec(D + "F0_conv.bias");
-  d.n_w = pk.vec(D + "N_conv.weight");   d.n_b = pk.vec(D + "N_conv.bias");
-  d.asr_res = pk.conv(D + "asr_res.0");
+  d.f0_w = pk.vec(D + "F0_conv.weight", 3); d.f0_b = pk.vec(D + "F0_conv.bias", 1);  // Conv1d(1, 1, 3, stride 2)
+  d.n_w = pk.vec(D + "N_conv.weight", 3);   d.n_b = pk.vec(D + "N_conv.bias", 1);
+  d.asr_res = pk.conv(D + "asr_res.0", true, 64, Cin, 1);
 
   PGenerator& g = d.gen;
   const std::string G = D + "generator.";
   const int nu = cfg.n_upsamples, nk = cfg.n_resblock_kernels;
   const bool ist = cfg.decoder_kind == 0;
   const int c0 = cfg.upsample_initial_channel;
-  g.lin_w = pk.vec(G + "m_source.l_linear.weight");
-  g.lin_b = pk.vec(G + "m_source.l_linear.bias");
+  g.lin_w = pk.vec(G + "m_source.l_linear.weight", 9);  // Linear(harmonic_num + 1 = 9, 1), Modules/istftnet.py:283
+  g.lin_b = pk.vec(G + "m_source.l_linear.bias", 1);
   static const int dil135[3] = {1, 3, 5};
   for (int i = 0; i < nu; ++i) g.channels.push_back(c0 >> (i + 1));
   // noise_res first, then resblocks (Generator.register)
@@ -570,8 +613,9 @@ int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
   // noise convs: kernel = 2*stride -> polyphase k = 2 conv; the last one is k = 1
   for (int i = 0; i < nu; ++i) {
     const int stride_f0 = i + 1 < nu ? prod_from(cfg.upsample_rates, i + 1, nu) : 1;
-    const HostTensor* w = pk.get(G + "noise_convs." + std::to_string(i) + ".weight");
+    const HostTensor* w = pk.get(G + "noise_convs." + std::to_string(i) + ".weight", {g.channels[i], -1, -1});
     g.noise_stride.push_back(stride_f0);
+    if (w && w->shape.size() != 3) { pk.fail(G + "noise_convs." + std::to_string(i) + ".weight must be 3-D"); w = nullptr; }
     if (w) {
       const int C_out = (int)w->shape[0], C_in = (int)w->shape[1], K = (int)w->shape[2];
       if (stride_f0 > 1) {
@@ -584,11 +628,12 @@ int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
     } else {
       g.noise_wt.push_back(SplitW());
     }
-    g.noise_b.push_back(pk.vec(G + "noise_convs." + std::to_string(i) + ".bias"));
+    g.noise_b.push_back(pk.vec(G + "noise_convs." + std::to_string(i) + ".bias", g.channels[i]));
   }
   for (int i = 0; i < nu; ++i) {
-    const HostTensor* w = pk.get(G + "ups." + std::to_string(i) + ".weight");  // [C_in][C_out][K]
     const int u = cfg.upsample_rates[i];
+    const HostTensor* w = pk.get(G + "ups." + std::to_string(i) + ".weight", {c0 >> i, c0 >> (i + 1), -1});  // [C_in][C_out][K]
+    if (w && w->shape.size() != 3) { pk.fail(G + "ups." + std::to_string(i) + ".weight must be 3-D"); w = nullptr; }
     if (w) {
       const int C_in = (int)w->shape[0], C_out = (int)w->shape[1], K = (int)w->shape[2];
       if (K != 2 * u) { *err = "ups kernel must be 2*stride"; return 1; }
@@ -597,13 +642,13 @@ int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
     } else {
       g.ups_wt.push_back(SplitW());
     }
-    g.ups_b.push_back(pk.vec(G + "ups." + std::to_string(i) + ".bias"));
+    g.ups_b.push_back(pk.vec(G + "ups." + std::to_string(i) + ".bias", c0 >> (i + 1)));
   }
-  g.post = pk.conv(G + "conv_post");
+  g.post = pk.conv(G + "conv_post", true, ist ? cfg.gen_istft_n_fft + 2 : 1, g.channels.back(), 7);
   if (!ist)
-    for (int i = 0; i <= nu; ++i) g.alphas.push_back(pk.vec(G + "alphas." + std::to_string(i)));
+    for (int i = 0; i <= nu; ++i) g.alphas.push_back(pk.vec(G + "alphas." + std::to_string(i), c0 >> i));
   if (!pk.ok) {
-    *err = "decoder weight missing: " + pk.missing;
+    *err = "decoder weights (missing or malformed): " + pk.missing;
     return 1;
   }
   d.ready = true;
@@ -630,8 +675,8 @@ int pack_denoiser(st2_engine& e, Blob& blob, std::string* err) {
     int off = 0;
     for (int i = 0; i < cfg.dn_layers; ++i)
       for (const char* nm : {".attention.norm", ".attention.norm_context"}) {
-        const HostTensor* w = pk.get(N + "blocks." + std::to_string(i) + nm + ".fc.weight");
-        const HostTensor* bb = pk.get(N + "blocks." + std::to_string(i) + nm + ".fc.bias");
+        const HostTensor* w = pk.get(N + "blocks." + std::to_string(i) + nm + ".fc.weight", {2 * F, Fc});
+        const HostTensor* bb = pk.get(N + "blocks." + std::to_string(i) + nm + ".fc.bias", {2 * F});
         if (w && bb)
           for (int j = 0; j < 2 * F; ++j) {
             for (int k = 0; k < Fc; ++k) wt[(size_t)k * J + off + j] = w->data[(size_t)j * Fc + k];
@@ -646,19 +691,20 @@ int pack_denoiser(st2_engine& e, Blob& blob, std::string* err) {
     const std::string B = N + "blocks." + std::to_string(i);
     PBlock b;
     if (!cfg.multispeaker) {
-      b.n_w = pk.vec(B + ".attention.norm.weight");          b.n_b = pk.vec(B + ".attention.norm.bias");
-      b.nc_w = pk.vec(B + ".attention.norm_context.weight"); b.nc_b = pk.vec(B + ".attention.norm_context.bias");
+      b.n_w = pk.vec(B + ".attention.norm.weight", F);          b.n_b = pk.vec(B + ".attention.norm.bias", F);
+      b.nc_w = pk.vec(B + ".attention.norm_context.weight", F); b.nc_b = pk.vec(B + ".attention.norm_context.bias", F);
     }
-    b.q = pk.conv_w(B + ".attention.to_q.weight");
-    b.kv = pk.conv_w(B + ".attention.to_kv.weight");
-    b.o = pk.conv_w(B + ".attention.attention.to_out.weight"); b.o_b = pk.vec(B + ".attention.attention.to_out.bias");
-    b.f1 = pk.conv_w(B + ".feed_forward.0.weight");            b.f1_b = pk.vec(B + ".feed_forward.0.bias");
+    const int HD = cfg.dn_heads * cfg.dn_head_features, FM = F * cfg.dn_multiplier;
+    b.q = pk.conv_w(B + ".attention.to_q.weight", HD, F, 1);
+    b.kv = pk.conv_w(B + ".attention.to_kv.weight", 2 * HD, F, 1);
+    b.o = pk.conv_w(B + ".attention.attention.to_out.weight", F, HD, 1); b.o_b = pk.vec(B + ".attention.attention.to_out.bias", F);
+    b.f1 = pk.conv_w(B + ".feed_forward.0.weight", FM, F, 1);            b.f1_b = pk.vec(B + ".feed_forward.0.bias", FM);
     b.f1_out = b.f1.C_out;
-    b.f2 = pk.conv_w(B + ".feed_forward.2.weight");            b.f2_b = pk.vec(B + ".feed_forward.2.bias");
+    b.f2 = pk.conv_w(B + ".feed_forward.2.weight", F, FM, 1);            b.f2_b = pk.vec(B + ".feed_forward.2.bias", F);
     d.blocks.push_back(b);
   }
   {  // to_out.1: Conv1d(F, channels, 1) applied to the token mean -> [F][channels] for st2_style_fc
-    const HostTensor* w = pk.get(N + "to_out.1.weight");
+    const HostTensor* w = pk.get(N + "to_out.1.weight", {cfg.dn_channels, F, 1});
     if (w) {
       const int O = (int)w->shape[0], I = (int)w->shape[1];
       std::vector<float> v((size_t)O * I);
@@ -666,11 +712,11 @@ int pack_denoiser(st2_engine& e, Blob& blob, std::string* err) {
         for (int i = 0; i < I; ++i) v[(size_t)i * O + o] = w->data[(size_t)o * I + i];
       d.out_t = blob.add_f32(v);
     }
-    d.out_b = pk.vec(N + "to_out.1.bias");
+    d.out_b = pk.vec(N + "to_out.1.bias", cfg.dn_channels);
   }
-  d.fixed = pk.vec(N + "fixed_embedding.embedding.weight");
+  d.fixed = pk.vec(N + "fixed_embedding.embedding.weight", (int64_t)cfg.dn_max_length * cfg.dn_embedding);
   if (!pk.ok) {
-    *err = "denoiser weight missing: " + pk.missing;
+    *err = "denoiser weights (missing or malformed): " + pk.missing;
     return 1;
   }
   d.ready = true;
@@ -1243,7 +1289,14 @@ PLstm pack_lstm(Packer& pk, const std::string& prefix) {
   const HostTensor* bir = pk.get(prefix + ".bias_ih_l0_reverse");
   const HostTensor* bhr = pk.get(prefix + ".bias_hh_l0_reverse");
   if (!wf || !wr || !hf || !hr || !bif || !bhf || !bir || !bhr) return l;
+  if (wf->shape.size() != 2 || wf->shape[0] % 4 != 0) { pk.fail(prefix + ".weight_ih_l0 must be [4H, I]"); return l; }
   const int G4 = (int)wf->shape[0], I = (int)wf->shape[1], H = G4 / 4;
+  for (const HostTensor* t : {wr})
+    if (t->shape != wf->shape) { pk.fail(prefix + ": the two directions' input weights differ in shape"); return l; }
+  for (const HostTensor* t : {hf, hr})
+    if (t->shape.size() != 2 || t->shape[0] != G4 || t->shape[1] != H) { pk.fail(prefix + ".weight_hh_l0* must be [4H, H]"); return l; }
+  for (const HostTensor* t : {bif, bhf, bir, bhr})
+    if (t->numel() != G4) { pk.fail(prefix + ".bias_* must have 4H elements"); return l; }
   l.H = H;
   std::vector<float> w((size_t)2 * G4 * I);  // cat([W_ih, W_ih_reverse]) as a k = 1 conv weight [8H][I][1]
   std::copy(wf->data.begin(), wf->data.end(), w.begin());
@@ -1285,9 +1338,10 @@ int pack_predictor(st2_engine& e, Blob& blob, std::string* err) {
       r.n2 = bank.add(pk, pre + ".norm2", dout[i]);
     }
   }
-  p.f0p_w = pk.vec(P + "F0_proj.weight"); p.f0p_b = pk.vec(P + "F0_proj.bias");
-  p.np_w = pk.vec(P + "N_proj.weight");   p.np_b = pk.vec(P + "N_proj.bias");
-  if (!pk.ok) { *err = "missing predictor parameter " + pk.missing; return 1; }
+  p.f0p_w = pk.vec(P + "F0_proj.weight", dh / 2); p.f0p_b = pk.vec(P + "F0_proj.bias", 1);  // Conv1d(d_hid / 2, 1, 1)
+  p.np_w = pk.vec(P + "N_proj.weight", dh / 2);   p.np_b = pk.vec(P + "N_proj.bias", 1);
+  if (pk.ok && p.shared.H * 2 != dh) pk.fail(P + "shared: hidden size does not match st2_model_config.pred_hidden");
+  if (!pk.ok) { *err = "predictor parameter missing or malformed: " + pk.missing; return 1; }
   p.J = bank.J;
   bank.pack(pk, cfg.style_dim, &p.bank_wt, &p.bank_b);
   p.ready = true;
@@ -1344,15 +1398,16 @@ int pack_duration(st2_engine& e, Blob& blob, std::string* err) {
   const std::string T = "predictor.text_encoder.lstms.";
   for (int i = 0; pk.has(T + std::to_string(2 * i) + ".weight_ih_l0"); ++i) {
     d.lstms.push_back(pack_lstm(pk, T + std::to_string(2 * i)));
-    d.ada_wt.push_back(pk.lin_t(T + std::to_string(2 * i + 1) + ".fc.weight"));
-    d.ada_b.push_back(pk.vec(T + std::to_string(2 * i + 1) + ".fc.bias"));
+    const int dm = 2 * d.lstms.back().H;  // AdaLayerNorm(style_dim, d_model): fc = Linear(style_dim, 2 * d_model)
+    d.ada_wt.push_back(pk.lin_t(T + std::to_string(2 * i + 1) + ".fc.weight", 2 * dm, e.cfg.style_dim));
+    d.ada_b.push_back(pk.vec(T + std::to_string(2 * i + 1) + ".fc.bias", 2 * dm));
   }
   if (d.lstms.empty()) { *err = "missing predictor parameter predictor.text_encoder.lstms.0.weight_ih_l0"; return 1; }
   d.dur_lstm = pack_lstm(pk, "predictor.lstm");
-  const HostTensor* pw = pk.get("predictor.duration_proj.linear_layer.weight");
+  const HostTensor* pw = pk.get("predictor.duration_proj.linear_layer.weight", {-1, 2 * d.dur_lstm.H});
   d.proj_w = pk.vec("predictor.duration_proj.linear_layer.weight");
-  d.proj_b = pk.vec("predictor.duration_proj.linear_layer.bias");
-  if (!pk.ok || !pw) { *err = "missing predictor parameter " + pk.missing; return 1; }
+  if (pw) d.proj_b = pk.vec("predictor.duration_proj.linear_layer.bias", pw->shape[0]);
+  if (!pk.ok || !pw) { *err = "predictor parameter missing or malformed: " + pk.missing; return 1; }
   d.max_dur = (int)pw->shape[0];
   d.ready = true;
   e.dur = d;
@@ -1422,12 +1477,12 @@ int pack_text(st2_engine& e, Blob& blob, std::string* err) {
   t.emb = blob.add_f32(emb->data);
   for (int i = 0; pk.has(T + "cnn." + std::to_string(i) + ".0.weight"); ++i) {
     const std::string p = T + "cnn." + std::to_string(i);
-    t.convs.push_back(pk.conv(p + ".0"));
-    t.ln_g.push_back(pk.vec(p + ".1.gamma"));
-    t.ln_b.push_back(pk.vec(p + ".1.beta"));
+    t.convs.push_back(pk.conv(p + ".0", true, t.C, t.C, -1));
+    t.ln_g.push_back(pk.vec(p + ".1.gamma", t.C));
+    t.ln_b.push_back(pk.vec(p + ".1.beta", t.C));
   }
   t.lstm = pack_lstm(pk, T + "lstm");
-  if (!pk.ok || t.convs.empty()) { *err = "missing text-encoder parameter " + pk.missing; return 1; }
+  if (!pk.ok || t.convs.empty()) { *err = "text-encoder parameter missing or malformed: " + pk.missing; return 1; }
   t.ready = true;
   e.text = t;
   return 0;
@@ -1474,21 +1529,22 @@ int pack_bert(st2_engine& e, Blob& blob, std::string* err) {
   const HostTensor* kb = pk.get(L + "attention.key.bias");
   const HostTensor* vb = pk.get(L + "attention.value.bias");
   if (!pk.ok || w->shape.size() != 2 || p->shape.size() != 2 || tt->shape.size() != 2 || q->shape.size() != 2) {
-    *err = "missing PL-BERT parameter " + pk.missing;
+    *err = "PL-BERT parameter missing or malformed: " + pk.missing;
     return 1;
   }
   b.V = (int)w->shape[0]; b.E = (int)w->shape[1]; b.P = (int)p->shape[0]; b.H = (int)q->shape[0];
   if (p->shape[1] != b.E || tt->shape[1] != b.E || q->shape[1] != b.H || k->numel() != q->numel() ||
-      v->numel() != q->numel() || b.H % 64 != 0 || e.cfg.bert_layers <= 0) {
+      v->numel() != q->numel() || qb->numel() != b.H || kb->numel() != b.H || vb->numel() != b.H || b.H % 64 != 0 ||
+      e.cfg.bert_layers <= 0) {
     *err = "PL-BERT: inconsistent shapes (64-wide heads, one shared layer) or cfg.bert_layers == 0";
     return 1;
   }
   b.word = blob.add_f32(w->data);
   b.pos = blob.add_f32(p->data);
   b.tok0 = blob.add_f32(std::vector<float>(tt->data.begin(), tt->data.begin() + b.E));  // token_type_ids == 0 everywhere
-  b.eln_w = pk.vec(R + "embeddings.LayerNorm.weight"); b.eln_b = pk.vec(R + "embeddings.LayerNorm.bias");
-  b.map = pk.conv_w(R + "encoder.embedding_hidden_mapping_in.weight");
-  b.map_b = pk.vec(R + "encoder.embedding_hidden_mapping_in.bias");
+  b.eln_w = pk.vec(R + "embeddings.LayerNorm.weight", b.E); b.eln_b = pk.vec(R + "embeddings.LayerNorm.bias", b.E);
+  b.map = pk.conv_w(R + "encoder.embedding_hidden_mapping_in.weight", b.H, b.E, 1);
+  b.map_b = pk.vec(R + "encoder.embedding_hidden_mapping_in.bias", b.H);
   {  // q | k | v as one 3H-row Linear
     const size_t HH = (size_t)b.H * b.H;
     std::vector<float> cat(3 * HH), bias((size_t)3 * b.H);
@@ -1501,18 +1557,19 @@ int pack_bert(st2_engine& e, Blob& blob, std::string* err) {
     b.qkv = pack_split(blob, cat.data(), 3 * b.H, b.H, 1);
     b.qkv_b = blob.add_f32(bias);
   }
-  b.dense = pk.conv_w(L + "attention.dense.weight");      b.dense_b = pk.vec(L + "attention.dense.bias");
-  b.aln_w = pk.vec(L + "attention.LayerNorm.weight");     b.aln_b = pk.vec(L + "attention.LayerNorm.bias");
-  b.ffn = pk.conv_w(L + "ffn.weight");                    b.ffn_b = pk.vec(L + "ffn.bias");
-  b.out = pk.conv_w(L + "ffn_output.weight");             b.out_b = pk.vec(L + "ffn_output.bias");
-  b.fln_w = pk.vec(L + "full_layer_layer_norm.weight");   b.fln_b = pk.vec(L + "full_layer_layer_norm.bias");
+  b.dense = pk.conv_w(L + "attention.dense.weight", b.H, b.H, 1); b.dense_b = pk.vec(L + "attention.dense.bias", b.H);
+  b.aln_w = pk.vec(L + "attention.LayerNorm.weight", b.H);        b.aln_b = pk.vec(L + "attention.LayerNorm.bias", b.H);
+  b.ffn = pk.conv_w(L + "ffn.weight", -1, b.H, 1);
   b.I = b.ffn.C_out;
+  b.ffn_b = pk.vec(L + "ffn.bias", b.I > 0 ? b.I : -1);
+  b.out = pk.conv_w(L + "ffn_output.weight", b.H, b.I > 0 ? b.I : -1, 1); b.out_b = pk.vec(L + "ffn_output.bias", b.H);
+  b.fln_w = pk.vec(L + "full_layer_layer_norm.weight", b.H);      b.fln_b = pk.vec(L + "full_layer_layer_norm.bias", b.H);
   if (pk.has("bert_encoder.weight")) {
-    b.enc = pk.conv_w("bert_encoder.weight");
-    b.enc_b = pk.vec("bert_encoder.bias");
+    b.enc = pk.conv_w("bert_encoder.weight", -1, b.H, 1);
+    b.enc_b = pk.vec("bert_encoder.bias", b.enc.C_out > 0 ? b.enc.C_out : -1);
     b.has_enc = true;
   }
-  if (!pk.ok) { *err = "missing PL-BERT parameter " + pk.missing; return 1; }
+  if (!pk.ok) { *err = "PL-BERT parameter missing or malformed: " + pk.missing; return 1; }
   b.ready = true;
   e.bert = b;
   return 0;
@@ -1672,6 +1729,11 @@ int pack_style(st2_engine& e, Blob& blob, int which, std::string* err) {
     const HostTensor* w2 = pk.get(Bn + ".conv2.weight");
     const HostTensor* wd = pk.get(Bn + ".downsample_res.conv.weight");
     if (!w1 || !w2 || !wd) break;
+    if (w1->shape.size() != 4 || w2->shape.size() != 4 || w1->shape[0] != w1->shape[1] || w2->shape[1] != w1->shape[0] ||
+        wd->numel() != w1->shape[0] * 9) {
+      *err = "malformed style-encoder block " + Bn + " (ResBlk: conv1 [C, C, 3, 3], conv2 [C', C, 3, 3], depthwise [C, 1, 3, 3])";
+      return 1;
+    }
     b.c_in = (int)w1->shape[1];
     b.c_out = (int)w2->shape[0];
     b.w1 = conv2d(Bn + ".conv1.weight");  b.b1 = pk.vec(Bn + ".conv1.bias");
@@ -1692,7 +1754,7 @@ int pack_style(st2_engine& e, Blob& blob, int which, std::string* err) {
   s.bl = pk.vec(R + "unshared.bias");
   s.style_dim = s.wl.C_out;
   if (!pk.ok || s.c0 > STYLE_ZEROS || s.c_last > STYLE_ZEROS) {
-    *err = "missing style-encoder parameter " + pk.missing;
+    *err = "style-encoder parameter missing or malformed: " + pk.missing;
     return 1;
   }
   if (s.blocks.size() != 4 || s.w5.ks != 5 || s.w5.C_in != 5 * s.blocks.back().c_out) {  // 80 mel bins -> 5 rows -> 5x5 valid conv
@@ -1862,46 +1924,86 @@ extern "C" int st2_load_weights(st2_engine* e, const char* name, const float* da
   return 0;
 }
 
+// Everything st2_finalize_weights produces: committed to the engine only after the new blob is on the device.
+struct PackedSet {
+  PDecoder dec;
+  PDenoiser dn;
+  PPredictor pred;
+  PDuration dur;
+  PText text;
+  PBert bert;
+  PStyleEnc style[2];
+  int64_t zeros = -1;
+};
+
+namespace {
+PackedSet packed_of(const st2_engine& e) {
+  PackedSet p;
+  p.dec = e.dec; p.dn = e.dn; p.pred = e.pred; p.dur = e.dur; p.text = e.text; p.bert = e.bert;
+  p.style[0] = e.style[0]; p.style[1] = e.style[1]; p.zeros = e.zeros;
+  return p;
+}
+void commit_packed(st2_engine& e, const PackedSet& p) {
+  e.dec = p.dec; e.dn = p.dn; e.pred = p.pred; e.dur = p.dur; e.text = p.text; e.bert = p.bert;
+  e.style[0] = p.style[0]; e.style[1] = p.style[1]; e.zeros = p.zeros;
+}
+}  // namespace
+
+// Transactional: the pack_* functions write offsets into the NEW host blob, so nothing they produce may become visible
+// before that blob is on the device.  The engine's previous state (structs, ready flags, device blob) is saved first and
+// restored on ANY failure -- a failed call leaves the engine exactly as it was, still usable with its old weights; the old
+// device blob is freed only after the new allocation and upload have succeeded.
 extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
   ST2_REQUIRE(e && (which & 63) != 0, "st2_finalize_weights: bad arguments");
+  const PackedSet saved = packed_of(*e);
   Blob blob;
   std::string err;
-  if (which & 1) ST2_REQUIRE(pack_decoder(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-  else e->dec.ready = false;
-  if (which & 2) ST2_REQUIRE(pack_denoiser(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-  else e->dn.ready = false;
-  if (which & 4) ST2_REQUIRE(pack_predictor(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-  else e->pred.ready = false;
-  e->dur.ready = false;
-  if ((which & 4) && e->host.count("predictor.text_encoder.lstms.0.weight_ih_l0"))
-    ST2_REQUIRE(pack_duration(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-  if (which & 8) ST2_REQUIRE(pack_text(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-  else e->text.ready = false;
-  if (which & 16) ST2_REQUIRE(pack_bert(*e, blob, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-  else e->bert.ready = false;
-  e->style[0].ready = e->style[1].ready = false;
-  if (which & 32) {
-    int found = 0;
-    for (int k = 0; k < 2; ++k)
-      if (e->host.count(std::string(k == 0 ? "style_encoder." : "predictor_encoder.") + "shared.0.weight")) {
-        ST2_REQUIRE(pack_style(*e, blob, k, &err) == 0, "st2_finalize_weights: %s", err.c_str());
-        ++found;
-      }
-    ST2_REQUIRE(found > 0, "st2_finalize_weights: no style_encoder.* / predictor_encoder.* parameters were loaded");
-    e->zeros = blob.add_f32(std::vector<float>((size_t)STYLE_ZEROS, 0.0f));
-  }
-  if (e->wbase) {
-    g_be.dev_free(e->wbase);
-    e->wbase = nullptr;
+  auto pack_all = [&]() -> int {
+    if (which & 1) { if (pack_decoder(*e, blob, &err)) return 1; }
+    else e->dec.ready = false;
+    if (which & 2) { if (pack_denoiser(*e, blob, &err)) return 1; }
+    else e->dn.ready = false;
+    if (which & 4) { if (pack_predictor(*e, blob, &err)) return 1; }
+    else e->pred.ready = false;
+    e->dur.ready = false;
+    if ((which & 4) && e->host.count("predictor.text_encoder.lstms.0.weight_ih_l0"))
+      if (pack_duration(*e, blob, &err)) return 1;
+    if (which & 8) { if (pack_text(*e, blob, &err)) return 1; }
+    else e->text.ready = false;
+    if (which & 16) { if (pack_bert(*e, blob, &err)) return 1; }
+    else e->bert.ready = false;
+    e->style[0].ready = e->style[1].ready = false;
+    if (which & 32) {
+      int found = 0;
+      for (int k = 0; k < 2; ++k)
+        if (e->host.count(std::string(k == 0 ? "style_encoder." : "predictor_encoder.") + "shared.0.weight")) {
+          if (pack_style(*e, blob, k, &err)) return 1;
+          ++found;
+        }
+      if (!found) { err = "no style_encoder.* / predictor_encoder.* parameters were loaded"; return 1; }
+      e->zeros = blob.add_f32(std::vector<float>((size_t)STYLE_ZEROS, 0.0f));
+    }
+    return 0;
+  };
+  if (pack_all() != 0) {
+    commit_packed(*e, saved);  // roll back: old structs and flags, old device blob untouched
+    st2_set_error("st2_finalize_weights: %s", err.c_str());
+    return 1;
   }
   const int64_t bytes = (int64_t)blob.host.size();
   void* p = g_be.dev_alloc(bytes);
-  ST2_REQUIRE(p, "st2_finalize_weights: device allocation of %lld B failed", (long long)bytes);
+  if (!p) {
+    commit_packed(*e, saved);
+    st2_set_error("st2_finalize_weights: device allocation of %lld B failed", (long long)bytes);
+    return 1;
+  }
   if (g_be.upload(p, blob.host.data(), bytes) != 0) {
     g_be.dev_free(p);
+    commit_packed(*e, saved);
     st2_set_error("st2_finalize_weights: upload failed");
     return 1;
   }
+  if (e->wbase) g_be.dev_free(e->wbase);  // only now: the new blob is complete on the device
   e->wbase = static_cast<char*>(p);
   e->wbytes = bytes;
   return 0;

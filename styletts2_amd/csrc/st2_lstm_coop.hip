@@ -23,6 +23,7 @@
 // starts at t = length - 1); arithmetic per gate row is a fixed-order fp32 sum (k ascending inside a 32-slice, the
 // 8 slices ascending), bitwise reproducible.
 #include "st2_common.h"
+#include <atomic>
 
 namespace {
 
@@ -263,18 +264,28 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
   const size_t need = scratch_need(groups, U);
   ST2_REQUIRE(scratch_bytes >= need, "st2_lstm_bidir_coop: scratch of %zu B, need %zu B", scratch_bytes, need);
   // Every workgroup of the launch must be resident at once (the groups spin on each other): ask the runtime how many
-  // the device holds instead of assuming a CU count.  One query per (U, XCH) per process.
-  static int capacity = -1;
-  if (capacity < 0) {
-    int dev = 0, per_cu = 0;
+  // the device holds instead of assuming a CU count.  One query per (U, XCH) and DEVICE (a process may drive several
+  // devices of different size); the cache entries are atomics, a racing first query just computes the same value twice.
+  constexpr int MAX_DEV = 64;
+  static std::atomic<int> capacity_of[MAX_DEV];  // 0 = not queried yet (zero-initialised)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    st2_set_error("st2_lstm_bidir_coop: hipGetDevice failed");
+    return 1;
+  }
+  int capacity = dev >= 0 && dev < MAX_DEV ? capacity_of[dev].load(std::memory_order_relaxed) : 0;
+  if (capacity <= 0) {
+    int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_coop_kernel<U, XCH>, 256, 0) != hipSuccess) {
       (void)hipGetLastError();
       st2_set_error("st2_lstm_bidir_coop: occupancy query failed");
       return 1;
     }
     capacity = per_cu * prop.multiProcessorCount;
+    if (dev >= 0 && dev < MAX_DEV && capacity > 0) capacity_of[dev].store(capacity, std::memory_order_relaxed);
   }
   ST2_REQUIRE(groups * NSL <= capacity, "st2_lstm_bidir_coop: %d workgroups cannot be co-resident on this device "
               "(capacity %d): use st2_lstm_bidir", groups * NSL, capacity);

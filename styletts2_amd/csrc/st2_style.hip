@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void avgpool2x2_kernel(const float* __restrict
 extern "C" int st2_stft_frames(const float* wave, int64_t w_bs, int32_t B, int32_t L, int32_t n_win, int32_t hop,
                                int32_t shift, float* frames, int64_t f_bs, int32_t f_cs, void* stream) {
   ST2_REQUIRE(wave && frames && B > 0 && L > 1 && n_win > 0 && hop > 0, "st2_stft_frames: bad arguments");
-  ST2_REQUIRE(shift >= 0 && shift < L && n_win - shift <= L, "st2_stft_frames: reflection reaches past the signal "
-              "(L=%d, n_win=%d, shift=%d)", L, n_win, shift);
+  // The last frame starts at (L / hop) * hop and reads positions up to i = (L / hop) * hop + n_win - 1 - shift; a single
+  // reflection maps i > L - 1 to 2 (L - 1) - i, which must not go negative (and the left one, shift - j, not past L - 1).
+  ST2_REQUIRE(shift >= 0 && shift < L && (int64_t)(L / hop) * hop + n_win - 1 - shift <= 2 * (int64_t)(L - 1),
+              "st2_stft_frames: reflection reaches past the signal (L=%d, n_win=%d, hop=%d, shift=%d)", L, n_win, hop, shift);
   const int M = L / hop + 1;
   dim3 grid(st2_cdiv(M, 256), n_win, B);
   hipLaunchKernelGGL(stft_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, wave, w_bs, L, n_win, hop, shift, M,

@@ -511,7 +511,6 @@ def colnorm_apply(x, stats, gamma, beta, *, gamma_plus_one=False, act=ACT_NONE, 
 
 
 _last_lstm_scratch = None  # scratch of the most recent cooperative launch (tests read its status word)
-_coop_refused = False      # the device could not hold a cooperative launch co-resident: stay on the single-CU kernel
 
 
 def lstm_mode():
@@ -526,7 +525,7 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
     The cooperative kernel is used when the library accepts the launch (its workgroups must all be co-resident: the
     library checks the device's occupancy and refuses otherwise -- then, and for B > 48, the single-CU kernel runs).
     A cooperative group that times out raises STATUS_LSTM_TIMEOUT, surfaced by `check_status()`."""
-    global _last_lstm_scratch, _coop_refused
+    global _last_lstm_scratch
     lib = _lib.load()
     _chk(G, "G", 3)
     _chk(whh_t, "whh_t", 3)
@@ -538,7 +537,7 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
     if out is None:
         out = torch.empty((B, 2 * H, N), device=G.device, dtype=torch.float32)
     lp = 0 if lengths is None else lengths.data_ptr()
-    nbytes = lib.st2_lstm_coop_scratch_bytes(B) if (lstm_mode() == "coop" and not _coop_refused) else 0
+    nbytes = lib.st2_lstm_coop_scratch_bytes(B) if lstm_mode() == "coop" else 0
     if nbytes > 0:
         scratch = torch.empty((nbytes,), device=G.device, dtype=torch.uint8)
         rc = lib.st2_lstm_bidir_coop(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
@@ -550,7 +549,8 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
         msg = (lib.st2_last_error() or b"").decode()
         if "co-resident" not in msg:
             raise _lib.St2Error("st2_lstm_bidir_coop failed: %s" % msg)
-        _coop_refused = True  # nothing was launched: fall through to the single-CU kernel, now and from here on
+        # refused (host-side occupancy check, nothing was launched): the single-CU kernel for THIS call only -- the
+        # answer depends on the device and the batch, so it is asked again next time
     _lib.check(lib.st2_lstm_bidir(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
                                   out.data_ptr(), out.stride(0), out.stride(1), _stream()), "st2_lstm_bidir")
     return out

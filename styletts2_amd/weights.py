@@ -76,9 +76,12 @@ def pack_conv_f16s(w):
     cin_pad = -(-C_in // f16s_chunk(ks)) * f16s_chunk(ks)
     co_pad = -(-C_out // f16s_co_block(C_out)) * f16s_co_block(C_out)
     amax = w.abs().reshape(C_out, -1).amax(dim=1)
-    # exponent e of amax = m * 2^e, m in [0.5, 1)  ->  scale 2^(14 - e) puts amax in [2^13, 2^14); all-zero rows: 1
+    # exponent e of amax = m * 2^e, m in [0.5, 1)  ->  scale 2^(14 - e) puts amax in [2^13, 2^14); all-zero rows: 1.
+    # The exponent is clamped at 126: a row whose amax is below 2^-112 (pruned / denormal weights) would otherwise get
+    # scale = inf and poison the conv with inf * 0; such a row keeps its (negligible) values at scale 2^126 and a finite
+    # 1 / scale.  Same rule in csrc/st2_engine.hip pack_split (the two packers are bit-identical).
     _, e = torch.frexp(amax)
-    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), 14 - e), torch.ones_like(amax))
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), torch.clamp(14 - e, max=126)), torch.ones_like(amax))
     ws = torch.zeros((co_pad, cin_pad, ks), dtype=torch.float32)
     ws[:C_out, :C_in] = w * scale.view(-1, 1, 1)
     hi = ws.half()
