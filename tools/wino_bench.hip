@@ -32,7 +32,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../styletts2_amd/csrc/st2_wino_impl.h"
+#include "wino_impl.h"
 
 #define CK(x)                                                                  \
   do {                                                                         \
