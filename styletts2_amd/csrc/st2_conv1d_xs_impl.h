@@ -266,6 +266,11 @@ __global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc
   conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
 }
 
+template <int KS, int CI_T, int WM, int WN, int TN>
+__global__ __launch_bounds__(NT, 4) void conv1d_xs_kernel_o4(const st2_conv_desc d) {  // <= 128 VGPRs: narrow tiles only
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
+}
+
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
 int launch(const st2_conv_desc& d, hipStream_t s) {
   constexpr int BM = 32 * WM;
@@ -290,7 +295,10 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   if constexpr (TN < 4) ST2_REQUIRE(!d.part, "st2_conv1d_xs: the narrow token tiles do not produce partial sums");
   static bool attr_done = false;
   if (!attr_done) {
-    if constexpr (OCC == 3)
+    if constexpr (OCC == 4)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else if constexpr (OCC == 3)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     else
@@ -299,7 +307,9 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
     attr_done = true;
   }
   dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
-  if constexpr (OCC == 3)
+  if constexpr (OCC == 4)
+    hipLaunchKernelGGL((conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
+  else if constexpr (OCC == 3)
     hipLaunchKernelGGL((conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
   else
     hipLaunchKernelGGL((conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>), grid, dim3(NT), smem, s, d);
@@ -321,6 +331,16 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
     // (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs
     if constexpr (KS >= 7) {
       if ((int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024) return launch<KS, CI_T, 4, 1, 8, 2>(d, s);
+    }
+    if constexpr (KS == 1) {
+      // Token GEMMs (the denoiser's / PL-BERT's Linears over the B*N merged tokens: C_out 512..1024 x 3 200 columns): at
+      // 128 x 128 they are < 256 workgroups -- fewer than CUs, one per CU, nothing to hide the staging latency of a
+      // 768-cycle chunk behind.  128 (co) x 64 (l) tiles double the workgroup count and 64-channel chunks double the
+      // work between barriers: 1024 x 1024: 35.8 -> 28.9 us, 512 x 1024: 32.7 -> 17.7, 1024 x 2048: 63.6 -> 50.4, 768 x 768:
+      // 27.9 -> 22.4 (tools/gemm_bench.hip, profiles/r03c_gemm_bench.log); launches that already have >= 256 tiles
+      // (C_out >= 2048) are fastest as they are.  Same products in the same order: results are bitwise unchanged.
+      if ((int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B < 256 && d.wq_cin_pad % 64 == 0 && !d.part)
+        return launch<1, 64, 4, 1, 2, 3>(d, s);
     }
     return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
   }

@@ -1,3 +1,4 @@
+// (k3_bench: the same harness on the k = 3 resblock / decoder-front convs -- built from this file with -DK3_BENCH)
 // Micro-benchmark of the k = 1 ("token GEMM") launches of the split-f16 conv kernel: the denoiser's / PL-BERT's Linears run
 // as Conv1d(k = 1) over the B*N merged tokens (M = C_out in 512..2304, K = C_in in 512..2048, N = 3200 tokens at B = 32) and
 // are the third-largest kernel of a bench step (200 launches, 9.5 ms at 0.17-0.28 of the roof: 200 workgroups of 128 x 128
@@ -54,6 +55,22 @@ struct Variant {
 int main(int argc, char** argv) {
   auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
   const int Co = arg(1, 2048), Ci = arg(2, 1024), L = arg(3, 3200), B = arg(4, 1), reps = arg(5, 20);
+#ifdef K3_BENCH
+  const Variant vars[] = {
+      {"128x128 c32 occ3 (library)", &launch<3, 32, 4, 1, 4, 3>, 128, 32},
+      {"128x128 c32 occ2", &launch<3, 32, 4, 1, 4, 2>, 128, 32},
+      {"128x64  c32 occ3", &launch<3, 32, 4, 1, 2, 3>, 128, 32},
+      {"128x64  c32 occ4", &launch<3, 32, 4, 1, 2, 4>, 128, 32},
+      {"64x128  c32 occ3", &launch<3, 32, 2, 2, 2, 3>, 64, 32},
+      {"64x128  c32 occ4", &launch<3, 32, 2, 2, 2, 4>, 64, 32},
+      {"64x64   c32 occ4", &launch<3, 32, 2, 2, 1, 4>, 64, 32},
+      {"128x256 c32 occ2", &launch<3, 32, 4, 1, 8, 2>, 128, 32},
+      {"128x128 c16 occ3", &launch<3, 16, 4, 1, 4, 3>, 128, 16},
+      {"128x64  c16 occ4", &launch<3, 16, 4, 1, 2, 4>, 128, 16},
+  };
+  const int KSZ = 3;
+#else
+  const int KSZ = 1;
   const Variant vars[] = {
       {"128x128 c32 occ3 (library)", &launch<1, 32, 4, 1, 4, 3>, 128, 32},
       {"128x128 c32 occ2", &launch<1, 32, 4, 1, 4, 2>, 128, 32},
@@ -66,6 +83,7 @@ int main(int argc, char** argv) {
       {"64x64   c64 occ3", &launch<1, 64, 2, 2, 1, 3>, 64, 64},
       {"128x32  c64 occ3", &launch<1, 64, 4, 1, 1, 3>, 128, 64},
   };
+#endif
   const int halo = 32;
   const int Lp = halo + (L + 1 + 511) / 512 * 512 + 96;
   const int C_pad = (Ci + 63) / 64 * 64;
@@ -73,7 +91,7 @@ int main(int argc, char** argv) {
   const int co_pad = (Co + 127) / 128 * 128;
   const int pitch = (L + 31) / 32 * 32;
   const int64_t plane = (int64_t)cg * Lp * 8;
-  const int64_t wq_halves = (int64_t)(C_pad / 16) * 2 * co_pad * 16;
+  const int64_t wq_halves = (int64_t)(C_pad / 16) * KSZ * 2 * co_pad * 16;
   const int64_t y_elems = (int64_t)B * Co * pitch;
   _Float16 *xs, *wq;
   float *y, *bias, *rsc;
@@ -90,24 +108,30 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill_f32, dim3((co_pad + 255) / 256), dim3(256), 0, 0, bias, (int64_t)co_pad, 9u);
   hipLaunchKernelGGL(fill_f32, dim3((co_pad + 255) / 256), dim3(256), 0, 0, rsc, (int64_t)co_pad, 11u);
   CK(hipDeviceSynchronize());
-  const double flop = 2.0 * B * Co * (double)Ci * L;
+  const double flop = 2.0 * B * Co * (double)Ci * L * KSZ;
+  const int use_res = arg(6, 0), use_part = arg(7, 0);
+  float *res = nullptr, *part = nullptr;
+  if (use_res) { CK(hipMalloc(&res, y_elems * 4)); hipLaunchKernelGGL(fill_f32, dim3((y_elems + 255) / 256), dim3(256), 0, 0, res, y_elems, 7u); }
+  if (use_part) CK(hipMalloc(&part, (int64_t)B * Co * ((L + 127) / 128) * 2 * 4));
   std::vector<float> ref;
   for (const Variant& v : vars) {
     st2_conv_desc d;
     memset(&d, 0, sizeof(d));
-    d.B = B; d.C_in = Ci; d.C_out = Co; d.L_in = L; d.L_out = L; d.ks = 1; d.dil = 1; d.pad_left = 0;
+    d.B = B; d.C_in = Ci; d.C_out = Co; d.L_in = L; d.L_out = L; d.ks = KSZ; d.dil = 1; d.pad_left = (KSZ - 1) / 2;
     d.wq = wq; d.wq_co_pad = co_pad; d.wq_cin_pad = (Ci + v.ci_t - 1) / v.ci_t * v.ci_t;
     d.x_scale = 8.f; d.out_scale = 1.f / 8.f; d.w_row_scale = rsc;
     d.bias = bias;
     d.y = y; d.y_bs = (int64_t)Co * pitch; d.y_cs = pitch;
     d.div = 1.0f;
     d.xs = xs; d.xs_cg = cg; d.xs_lp = Lp; d.xs_halo = halo;
+    if (use_res) { d.res = res; d.res_bs = (int64_t)Co * pitch; d.res_cs = pitch; }
+    if (use_part && v.co_blk >= 0) { d.part = part; d.part_nt = (L + 127) / 128; }
     CK(hipMemset(y, 0, y_elems * 4));
     bool bad = false;
     for (int i = 0; i < 2 && !bad; ++i) bad = v.fn(d, 0) != 0;
     if (bad) { printf("%-28s refused\n", v.name); continue; }
     CK(hipDeviceSynchronize());
-    std::vector<float> h((size_t)Co * pitch);
+    std::vector<float> h((size_t)Co * pitch);  // first batch item
     CK(hipMemcpy(h.data(), y, h.size() * 4, hipMemcpyDeviceToHost));
     double md = 0;
     if (ref.empty()) ref = h;
@@ -122,7 +146,7 @@ int main(int argc, char** argv) {
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-    printf("gemm_bench M=%d K=%d N=%d B=%d  %-28s %8.1f us  %6.1f TFLOP/s (%.3f of 833)  max|dy vs library| %.2e\n", Co, Ci, L, B,
+    printf("%s M=%d K=%d N=%d B=%d res=%d part=%d  %-28s %8.1f us  %6.1f TFLOP/s (%.3f of 833)  max|dy vs library| %.2e\n", KSZ == 3 ? "k3_bench" : "gemm_bench", Co, Ci, L, B, use_res, use_part,
            v.name, ms * 1e3, flop / ms / 1e9, flop / ms / 1e9 / (2500.0 / 3), md);
   }
   return 0;
