@@ -158,6 +158,10 @@ int st2_sizeof_conv_desc(void);
  *                   split( x_scale * pro(x)[b][cg*8 + e][pos - halo] ),  zero for pos - halo outside [0, L) and for
  *                   channels >= C.  Same prologue arithmetic (op for op) as st2_conv1d_f16s.  cg in [0, xs_cg),
  *                   pos in [0, Lp); xs_cg*8 >= C rounded up to st2_conv1d_f16s_chunk(ks) of the consuming conv.
+ *                   gb_seg > 0 (ST2_PRO_COLNORM only): the gamma / beta row of position l is l / gb_seg instead of the
+ *                   batch index b -- the token-merged view [1][C][B*N] of B utterances of N tokens whose LayerNorm
+ *                   affine is per utterance (the multispeaker denoiser's AdaLayerNorm, Modules/diffusion/modules.py:
+ *                   104-118), so that their q / kv projections run as ONE GEMM over B*N columns.
  *   st2_conv1d_xs:  same GEMM, weights (d.wq ...) and epilogue as st2_conv1d_f16s on those planes: chunks are staged
  *                   global -> LDS as plain 16-byte copies, no per-element arithmetic in the MFMA kernel.  Requires
  *                   pad_left <= xs_halo and Lp large enough for the last tile (checked).  If d.part != NULL the
@@ -167,7 +171,7 @@ int st2_sizeof_conv_desc(void);
  * Replaces the same reference call sites as st2_conv1d_f16s + st2_instnorm_stats. */
 int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L,
                   int32_t pro, float slope, const float* stats, const float* gamma, const float* beta, int64_t gb_bs,
-                  int32_t gamma_plus_one, const float* alpha, float x_scale,
+                  int32_t gb_seg, int32_t gamma_plus_one, const float* alpha, float x_scale,
                   void* xs, int32_t xs_cg, int32_t Lp, int32_t halo, void* stream);
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, void* stream);

@@ -21,15 +21,18 @@ def _snake(u, alpha):
 
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False):
+           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False,
+           gb_seg=0):
     y = _conv1d(x, wt, C_out, ks, dil=dil, pad_left=pad_left, L_out=L_out, bias=bias, out=out, pro=pro, slope=slope,
                 stats=stats, gamma=gamma, beta=beta, gamma_plus_one=gamma_plus_one, alpha=alpha, res=res,
-                res_shift=res_shift, res2=res2, div=div, act=act, act_split=act_split, act_slope=act_slope)
+                res_shift=res_shift, res2=res2, div=div, act=act, act_split=act_split, act_slope=act_slope,
+                gb_seg=gb_seg)
     return (y, instnorm_stats(y)) if want_stats else y
 
 
-def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None):
-    """pro(x): the prologue of the conv contract = what st2_act_split materialises (before the x8 scale + hi/lo split)."""
+def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None, gb_seg=0):
+    """pro(x): the prologue of the conv contract = what st2_act_split materialises (before the x8 scale + hi/lo split).
+    gb_seg > 0 (PRO_COLNORM, x [1, C, L]): gamma / beta [G, C], row l // gb_seg applies at column l."""
     u = x
     if pro == PRO_LEAKY:
         u = F.leaky_relu(x, slope)
@@ -41,21 +44,25 @@ def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, g
         u = _snake(x, alpha)
     elif pro == PRO_COLNORM:
         n = (x - stats[:, :, 0].unsqueeze(1)) * stats[:, :, 1].unsqueeze(1)
-        g = gamma.unsqueeze(-1)
+        if gb_seg:
+            rows = torch.arange(x.shape[-1]) // gb_seg
+            g, bt = gamma[rows].t().unsqueeze(0), beta[rows].t().unsqueeze(0)   # [1, C, L]
+        else:
+            g, bt = gamma.unsqueeze(-1), beta.unsqueeze(-1)
         if gamma_plus_one:
             g = 1.0 + g
-        u = n * g + beta.unsqueeze(-1)
+        u = n * g + bt
     return u
 
 
 def _conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
             pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-            res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0):
+            res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, gb_seg=0):
     B, C_in, L_in = x.shape
     if L_out is None:
         L_out = L_in
     u = activate(x, pro=pro, slope=slope, stats=stats, gamma=gamma, beta=beta, gamma_plus_one=gamma_plus_one,
-                 alpha=alpha)
+                 alpha=alpha, gb_seg=gb_seg)
     if hasattr(wt, "wq"):  # split-f16 packing (st2_conv1d_f16s): operands are hi + lo of v * scale; lo*lo dropped
         w = wt.dense()
         xs = 8.0 if pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_COLNORM) else 1.0  # ops.x_scale_for(pro)

@@ -19,7 +19,7 @@ struct ActArgs {
   const float* x; int64_t x_bs; int x_cs;
   int C, L;
   float slope;
-  const float* stats; const float* gamma; const float* beta; int64_t gb_bs; int gamma_plus_one;
+  const float* stats; const float* gamma; const float* beta; int64_t gb_bs; int gb_seg; int gamma_plus_one;
   const float* alpha;
   float x_scale;
   st2_h8* xs; int xs_cg, Lp, halo;
@@ -73,9 +73,12 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
       const float al = a.alpha[cc];
       u = snake(u, al, 1.0f / al);
     } else if constexpr (PRO == ST2_PRO_COLNORM) {
-      const float g0 = a.gamma[(int64_t)b * a.gb_bs + cc];
+      // affine row: the batch item (wave-uniform, scalar loads) or -- token-merged view of several utterances -- the
+      // utterance this position belongs to (per lane; the rows are a few KB and L2 / L1 resident)
+      const int64_t row = a.gb_seg > 0 ? (int64_t)(lc / a.gb_seg) : (int64_t)b;
+      const float g0 = a.gamma[row * a.gb_bs + cc];
       const float g = a.gamma_plus_one ? 1.0f + g0 : g0;
-      const float bt = a.beta[(int64_t)b * a.gb_bs + cc];
+      const float bt = a.beta[row * a.gb_bs + cc];
       const float w = (u - cmean) * crstd;
       u = w * g + bt;
     }
@@ -128,7 +131,7 @@ void launch_act(const ActArgs& a, int B, hipStream_t s) {
 
 extern "C" int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t C, int32_t L, int32_t pro,
                              float slope, const float* stats, const float* gamma, const float* beta, int64_t gb_bs,
-                             int32_t gamma_plus_one, const float* alpha, float x_scale, void* xs, int32_t xs_cg,
+                             int32_t gb_seg, int32_t gamma_plus_one, const float* alpha, float x_scale, void* xs, int32_t xs_cg,
                              int32_t Lp, int32_t halo, void* stream) {
   ST2_REQUIRE(x && xs && B > 0 && C > 0 && L > 0, "st2_act_split: bad arguments");
   ST2_REQUIRE(B <= 65535 && xs_cg <= 65535, "st2_act_split: grid too large");
@@ -140,9 +143,10 @@ extern "C" int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t
     ST2_REQUIRE(stats && gamma && beta, "st2_act_split: prologue %d needs stats/gamma/beta", pro);
   if (pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE) ST2_REQUIRE(alpha, "st2_act_split: snake needs alpha");
   ST2_REQUIRE(x_scale > 0.f, "st2_act_split: x_scale must be set");
+  ST2_REQUIRE(gb_seg >= 0 && (gb_seg == 0 || pro == ST2_PRO_COLNORM), "st2_act_split: gb_seg=%d is for ST2_PRO_COLNORM", gb_seg);
   ActArgs a;
   a.x = x; a.x_bs = x_bs; a.x_cs = x_cs; a.C = C; a.L = L; a.slope = slope;
-  a.stats = stats; a.gamma = gamma; a.beta = beta; a.gb_bs = gb_bs; a.gamma_plus_one = gamma_plus_one;
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.gb_bs = gb_bs; a.gb_seg = gb_seg; a.gamma_plus_one = gamma_plus_one;
   a.alpha = alpha; a.x_scale = x_scale;
   a.xs = reinterpret_cast<st2_h8*>(xs); a.xs_cg = xs_cg; a.Lp = Lp; a.halo = halo;
   a.status = st2_status_device_ptr();

@@ -736,6 +736,7 @@ struct ConvOpt {
   const float* gamma = nullptr;
   const float* beta = nullptr;
   int64_t gb_bs = 0;
+  int gb_seg = 0;  // > 0: affine row = column / gb_seg (token-merged view, per-utterance AdaLayerNorm; xs path only)
   int gamma_plus_one = 0;
   const float* alpha = nullptr;
   View res; int res_shift = 0;
@@ -778,7 +779,7 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     const int cg = (x.C + 31) / 32 * 32 / 8;
     const int Lp = xs_row_slots(x.L);
     void* xs = c.a.alloc((int64_t)x.B * 2 * cg * Lp * 16);
-    RUN(c, g_be.act_split(x.p, x.bs, x.cs, x.B, x.C, x.L, o.pro, o.slope, o.stats, o.gamma, o.beta, o.gb_bs,
+    RUN(c, g_be.act_split(x.p, x.bs, x.cs, x.B, x.C, x.L, o.pro, o.slope, o.stats, o.gamma, o.beta, o.gb_bs, o.gb_seg,
                           o.gamma_plus_one, o.alpha, d.x_scale, xs, cg, Lp, XS_HALO, c.stream));
     d.xs = xs; d.xs_cg = cg; d.xs_lp = Lp; d.xs_halo = XS_HALO;
     float* part = nullptr;
@@ -791,6 +792,10 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     RUN(c, g_be.conv1d_xs(&d, c.stream));
     if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
   } else {
+    if (o.gb_seg > 0) {
+      if (c.rc == 0) { st2_set_error("engine: a per-segment affine (gb_seg) needs the act_split + xs path"); c.rc = 1; }
+      return;
+    }
     d.x = x.p; d.x_bs = x.bs; d.x_cs = x.cs;
     d.pro = o.pro; d.slope = o.slope;
     d.stats = o.stats; d.gamma = o.gamma; d.beta = o.beta; d.gb_bs = o.gb_bs; d.gamma_plus_one = o.gamma_plus_one;
@@ -1157,9 +1162,14 @@ void dn_run(Sess& s, View base, const float* x, const float* m, float* out) {
       o1.gamma = e.F(b.n_w);  o1.beta = e.F(b.n_b);
       o2.gamma = e.F(b.nc_w); o2.beta = e.F(b.nc_b);
     }
-    // the multispeaker net's AdaLayerNorm affine is per utterance: its q / kv convs run on the [B][F][N] view of the
-    // same (token-merged) storage; everything else -- o, f1, f2: three quarters of the FLOPs -- runs merged in both nets
-    View Xv = cfg.multispeaker ? X : dn_cv(s, X), qv = cfg.multispeaker ? qkv : dn_cv(s, qkv);
+    // The multispeaker net's AdaLayerNorm affine is per utterance.  Its q / kv convs still run as ONE GEMM over the B*N
+    // merged columns: st2_act_split picks the affine row of a column from its utterance (gb_seg = N).  That needs the xs
+    // pair (>= XS_MIN_L columns); smaller calls (one sentence of the long-form loop) keep the [B][F][N] view.  Measured
+    // at B = 32, N = 100: 2 x 99 us (fused kernel on 32 rows of 100 columns, 0.04-0.08 of the roof) -> ~65 us per layer.
+    const bool seg = cfg.multispeaker && s.merged && B > 1 && (int64_t)B * N >= XS_MIN_L;
+    if (seg) o1.gb_seg = o2.gb_seg = N;
+    const bool per_utt = cfg.multispeaker && !seg;
+    View Xv = per_utt ? X : dn_cv(s, X), qv = per_utt ? qkv : dn_cv(s, qkv);
     conv(c, e, Xv, b.q, qv.rows(0, mid), o1);
     conv(c, e, Xv, b.kv, qv.rows(mid, 3 * mid), o2);
     View att = dn_alloc(s, mid);

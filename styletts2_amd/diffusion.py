@@ -490,18 +490,22 @@ class _Transformer(nn.Module):
         nblk = len(pk.blocks)
         for i, b in enumerate(pk.blocks):
             st = ops.colnorm_stats(X)
-            stv = st if self.multispeaker else st.view(1, B * N, 2)
+            # The multispeaker net's AdaLayerNorm affine is per utterance.  With the token-merged storage its q / kv convs
+            # still run as ONE GEMM over the B*N columns: st2_act_split takes the affine row of a column from its
+            # utterance (gb_seg = N).  Needs the xs pair (>= XS_MIN_L columns); smaller calls keep the [B, F, N] view.
+            seg = self.multispeaker and s.merged and B > 1 and B * N >= ops.XS_MIN_L
+            stv = st if (self.multispeaker and not seg) else st.view(1, B * N, 2)
             qkv = A(3 * mid)
             if self.multispeaker:
                 o = 4 * Fz * i
                 g1, b1 = s.ada[:, o:o + Fz], s.ada[:, o + Fz:o + 2 * Fz]
                 g2, b2 = s.ada[:, o + 2 * Fz:o + 3 * Fz], s.ada[:, o + 3 * Fz:o + 4 * Fz]
-                kw1 = dict(gamma=g1, beta=b1, gamma_plus_one=True)
-                kw2 = dict(gamma=g2, beta=b2, gamma_plus_one=True)
+                kw1 = dict(gamma=g1, beta=b1, gamma_plus_one=True, gb_seg=N if seg else 0)
+                kw2 = dict(gamma=g2, beta=b2, gamma_plus_one=True, gb_seg=N if seg else 0)
             else:
                 kw1 = dict(gamma=b.n_w, beta=b.n_b)
                 kw2 = dict(gamma=b.nc_w, beta=b.nc_b)
-            Vq = (lambda t: t) if self.multispeaker else V  # per-utterance affine: [B, F, N] view of the merged storage
+            Vq = (lambda t: t) if (self.multispeaker and not seg) else V
             ops.conv1d(Vq(X), b.q, mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=Vq(qkv)[:, :mid], **kw1)
             ops.conv1d(Vq(X), b.kv, 2 * mid, 1, pro=ops.PRO_COLNORM, stats=stv, out=Vq(qkv)[:, mid:], **kw2)
             att = ops.attention(qkv[:, :mid], qkv[:, mid:2 * mid], qkv[:, 2 * mid:], self.heads,

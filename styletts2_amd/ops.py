@@ -122,9 +122,10 @@ def xs_row_slots(L):
 
 
 def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-              c_pad=32):
+              c_pad=32, gb_seg=0):
     """`st2_act_split`: x [B, C, L] fp32 -> XsTensor holding split_f16(x_scale * pro(x)) with the conv's zero padding
-    (x_scale = x_scale_for(pro))."""
+    (x_scale = x_scale_for(pro)).  `gb_seg` > 0 (PRO_COLNORM on a token-merged view [1, C, G * gb_seg]): gamma / beta
+    are [G, C] and row l // gb_seg applies at position l (per-utterance AdaLayerNorm affine, include/st2.h)."""
     lib = _lib.load()
     _chk(x, "x", 3)
     B, Cc, L = x.shape
@@ -141,12 +142,16 @@ def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, g
         assert gamma.shape[1] == Cc and beta.shape[1] == Cc
         gbs = gamma.stride(0) if gamma.shape[0] > 1 else 0
         bbs = beta.stride(0) if beta.shape[0] > 1 else 0
-        assert gamma.shape[0] in (1, B) and beta.shape[0] == gamma.shape[0] and gbs == bbs
+        if gb_seg:
+            assert pro == PRO_COLNORM and B == 1 and gamma.shape[0] * gb_seg >= L and beta.shape[0] == gamma.shape[0]
+            assert gbs == bbs
+        else:
+            assert gamma.shape[0] in (1, B) and beta.shape[0] == gamma.shape[0] and gbs == bbs
     if pro in (PRO_ADAIN_SNAKE, PRO_SNAKE):
         _chk(alpha, "alpha", 1)
         assert alpha.numel() == Cc and alpha.is_contiguous()
     _lib.check(lib.st2_act_split(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, pro, slope, _ptr(stats),
-                                 _ptr(gamma), _ptr(beta), gbs, 1 if gamma_plus_one else 0, _ptr(alpha),
+                                 _ptr(gamma), _ptr(beta), gbs, int(gb_seg), 1 if gamma_plus_one else 0, _ptr(alpha),
                                  x_scale_for(pro), data.data_ptr(), cg, Lp, XS_HALO, _stream()), "st2_act_split")
     return XsTensor(data, Cc, L, XS_HALO, x_scale_for(pro))
 
@@ -219,7 +224,8 @@ def _launch_conv(fn, fname, d):
 
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False):
+           res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False,
+           gb_seg=0):
     """Fused Conv1d, see `st2_conv1d` / `st2_conv1d_f16s` / `st2_conv1d_xs` in include/st2.h.  wt is either the
     packed K-major fp32 weight [C_in*ks, w_ld] of weights.pack_conv() (exact-fp32 MFMA kernel) or a
     weights.SplitConvWeight from weights.pack_conv_f16s() (split-f16 MFMA kernels, fp32-class accuracy at 5.3x the
@@ -232,10 +238,13 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     if (split and pad_left <= XS_HALO and L_in >= XS_MIN_L and (pro != PRO_NONE or C_in >= XS_MIN_C_PLAIN)
             and conv_path() == "xs" and not prefer_fused(pro, C_in, ks)):
         xs = activate(x, pro=pro, slope=slope, stats=stats, gamma=gamma, beta=beta,
-                                    gamma_plus_one=gamma_plus_one, alpha=alpha)
+                      gamma_plus_one=gamma_plus_one, alpha=alpha, gb_seg=gb_seg)
         return conv1d_xs(xs, wt, C_out, ks, dil=dil, pad_left=pad_left, L_out=L_out, bias=bias, out=out, res=res,
                          res_shift=res_shift, res2=res2, div=div, act=act, act_split=act_split, act_slope=act_slope,
                          want_stats=want_stats)
+    if gb_seg:
+        raise _lib.St2Error("gb_seg (per-segment affine of a token-merged view) exists on the st2_act_split + "
+                            "st2_conv1d_xs path only; this call routes to the fused kernel")
     if split:
         if (wt.C_in, wt.C_out, wt.ks) != (C_in, C_out, ks) or not wt.wq.is_cuda or not wt.wq.is_contiguous():
             raise _lib.St2Error("split weight is for (C_in=%d, C_out=%d, ks=%d) on %s, call has (%d, %d, %d)" % (

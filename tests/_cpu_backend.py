@@ -58,8 +58,14 @@ def _epilogue_kwargs(d):
     return kw
 
 
-def _prologue_kwargs(pro, slope, stats, gamma, beta, gb_bs, gamma_plus_one, alpha, B, Cc, L):
+def _prologue_kwargs(pro, slope, stats, gamma, beta, gb_bs, gamma_plus_one, alpha, B, Cc, L, gb_seg=0):
     kw = dict(pro=pro, slope=slope, gamma_plus_one=bool(gamma_plus_one))
+    if gb_seg:  # token-merged view: one affine row per segment of gb_seg columns
+        assert pro == R.PRO_COLNORM and B == 1
+        G = -(-L // gb_seg)
+        kw.update(stats=_t(stats, (B, L, 2), (L * 2, 2, 1)), gamma=_t(gamma, (G, Cc), (gb_bs, 1)),
+                  beta=_t(beta, (G, Cc), (gb_bs, 1)), gb_seg=gb_seg)
+        return kw
     if pro in (R.PRO_ADAIN_LEAKY, R.PRO_ADAIN_SNAKE):
         kw.update(stats=_t(stats, (B, Cc, 2), (Cc * 2, 2, 1)), gamma=_gb(gamma, gb_bs, B, Cc), beta=_gb(beta, gb_bs, B, Cc))
     if pro == R.PRO_COLNORM:
@@ -97,11 +103,11 @@ def _emit_part(d, y):
         part[..., 1] = (yd * yd).sum(-1).float()
 
 
-def act_split(x, x_bs, x_cs, B, Cc, L, pro, slope, stats, gamma, beta, gb_bs, gamma_plus_one, alpha, x_scale, xs, xs_cg,
-              Lp, halo, stream):
+def act_split(x, x_bs, x_cs, B, Cc, L, pro, slope, stats, gamma, beta, gb_bs, gb_seg, gamma_plus_one, alpha, x_scale, xs,
+              xs_cg, Lp, halo, stream):
     assert x_scale == _x_scale(pro)
     xv = _ncl(x, x_bs, x_cs, B, Cc, L)
-    kw = _prologue_kwargs(pro, slope, stats, gamma, beta, gb_bs, gamma_plus_one, alpha, B, Cc, L)
+    kw = _prologue_kwargs(pro, slope, stats, gamma, beta, gb_bs, gamma_plus_one, alpha, B, Cc, L, gb_seg)
     u = R.activate(xv, **kw) * x_scale
     hi = u.half()
     lo = (u - hi.float()).half()

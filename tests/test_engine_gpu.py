@@ -66,7 +66,10 @@ def _diffusion(tag, seed=2):
 
 @pytest.mark.parametrize("tag,B,N,steps,scale,ragged", [("ljspeech", 2, 37, 5, 1.0, False), ("ljspeech", 3, 100, 5, 1.5, False),
                                                         ("libritts", 2, 64, 10, 1.0, False), ("libritts", 1, 130, 5, 2.0, False),
-                                                        ("ljspeech", 3, 48, 5, 1.0, True), ("libritts", 2, 80, 5, 1.5, True)])
+                                                        ("ljspeech", 3, 48, 5, 1.0, True), ("libritts", 2, 80, 5, 1.5, True),
+                                                        # B * N >= 256: the multispeaker q / kv convs as one token-merged
+                                                        # GEMM with per-utterance affine rows (st2_act_split gb_seg)
+                                                        ("libritts", 4, 80, 4, 1.5, False), ("libritts", 3, 96, 4, 1.0, True)])
 def test_sampler_engine_equals_python_plan_bitwise(tag, B, N, steps, scale, ragged):
     man, diff = _diffusion(tag)
     sampler = models.DiffusionSampler(diff.diffusion, sampler=models.ADPM2Sampler(),

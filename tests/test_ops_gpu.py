@@ -172,6 +172,41 @@ def test_activate_planes_match_contract(pro):
     assert bool(torch.isfinite(d).all())
 
 
+def test_activate_segment_affine_matches_contract():
+    """st2_act_split with gb_seg: the token-merged view [1, C, G * N] of G utterances whose LayerNorm affine is per
+    utterance -- row l // N of gamma / beta applies at column l -- and the k = 1 conv over it equals the per-utterance
+    fused conv on the [G, C, N] view of the same storage."""
+    G, C, N, C_out = 5, 96, 61, 40
+    gen_ = torch.Generator().manual_seed(11)
+    store = torch.randn(C, G, N, generator=gen_)                       # token-merged channel-major storage
+    xb = store.permute(1, 0, 2)                                         # [G, C, N] view
+    xm = store.reshape(1, C, G * N)                                     # [1, C, G*N] view
+    gamma, beta = torch.randn(G, C, generator=gen_) * 0.3, torch.randn(G, C, generator=gen_) * 0.3
+    st = R.colnorm_stats(xb)                                            # [G, N, 2]
+    stm = st.reshape(1, G * N, 2)
+    ref = R.activate(xm, pro=R.PRO_COLNORM, stats=stm, gamma=gamma, beta=beta, gamma_plus_one=True, gb_seg=N)
+    per = torch.cat([R.activate(xb[i:i + 1], pro=R.PRO_COLNORM, stats=st[i:i + 1], gamma=gamma[i:i + 1],
+                                beta=beta[i:i + 1], gamma_plus_one=True) for i in range(G)], dim=2)
+    assert torch.equal(ref, per)                                        # the contract itself: segment rows == per-utterance
+    xs = ops.activate(g(store).reshape(1, C, G * N), pro=R.PRO_COLNORM, stats=g(stm), gamma=g(gamma), beta=g(beta),
+                      gamma_plus_one=True, gb_seg=N)
+    torch.cuda.synchronize()
+    d = xs.data.cpu().float()
+    val = (d[:, 0] + d[:, 1]).permute(0, 1, 3, 2).reshape(1, -1, d.shape[3]) / xs.x_scale
+    got = val[:, :C, xs.halo:xs.halo + G * N]
+    assert (got - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    w = torch.randn(C_out, C, 1, generator=gen_) * 0.1
+    wt = weights.pack_conv_f16s(w).to(DEV)
+    y_m = ops.conv1d(g(store).reshape(1, C, G * N), wt, C_out, 1, pro=R.PRO_COLNORM, stats=g(stm), gamma=g(gamma),
+                     beta=g(beta), gamma_plus_one=True, gb_seg=N)       # G * N >= 256: act_split + xs conv
+    y_b = ops.conv1d(g(store).permute(1, 0, 2), wt, C_out, 1, pro=R.PRO_COLNORM, stats=g(st), gamma=g(gamma),
+                     beta=g(beta), gamma_plus_one=True)                 # N < 256: fused kernel per utterance
+    ref_y = R.conv1d(xm, weights.pack_conv_f16s(w), C_out, 1, pro=R.PRO_COLNORM, stats=stm, gamma=gamma, beta=beta,
+                     gamma_plus_one=True, gb_seg=N)
+    assert rel_err(y_m, ref_y) < 3e-6
+    assert rel_err(y_b.permute(1, 0, 2).reshape(1, C_out, G * N), ref_y) < 3e-6
+
+
 def test_conv1d_writes_into_channel_slice():
     """Producers write straight into the [x | asr_res | F0 | N] concat buffer (Modules/istftnet.py:522)."""
     x, w, kw = make_conv_case(seed=7, B=2, C_in=16, C_out=24, L=70, ks=3, dil=1, pro=R.PRO_NONE)

@@ -27,7 +27,8 @@ def _diffusion(tag, seed=2):
 
 @pytest.mark.parametrize("tag,B,N,steps,scale", [("ljspeech", 2, 37, 5, 1.0), ("ljspeech", 3, 100, 5, 1.5),
                                                  ("libritts", 2, 64, 10, 1.0), ("libritts", 1, 130, 5, 2.0),
-                                                 ("ljspeech", 1, 512, 3, 1.0)])
+                                                 ("ljspeech", 1, 512, 3, 1.0),
+                                                 ("libritts", 4, 80, 4, 1.5)])  # B * N >= 256: merged q / kv GEMMs
 def test_sampler_matches_oracle_per_step(tag, B, N, steps, scale):
     man, diff = _diffusion(tag)
     sd = O.sub(diff.state_dict(), "unet")

@@ -17,7 +17,7 @@
 #include <stdint.h>
 #include <type_traits>
 
-#include "st2_act.h"
+#include "../styletts2_amd/csrc/st2_act.h"
 
 namespace st2w {
 
