@@ -317,173 +317,6 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Token GEMM build of the same contract (KS == 1, dil == 1): the denoiser's / PL-BERT's Linears over the B*N merged tokens.
-// Same operands, same MFMA sequence per accumulator (results are bitwise those of conv1d_xs_body<1, ...>), different
-// pipelining: with K <= 2048 and <= 3 200 columns a launch has 100 .. 450 tiles for 256 CUs -- one or two workgroups per CU,
-// i.e. one or two waves per SIMD -- so nothing but the wave's own prefetch distance hides memory latency.  The conv body
-// stages ONE chunk ahead (its chunks are 11 taps long); here a chunk is 2 .. 4 k-steps (~0.4 .. 0.8 k cycles), so the
-// activation stream runs PF chunks ahead in PF named register sets (the chunk loop is unrolled PF times: set indices are
-// compile-time constants, no register moves on in-flight loads) and the weight fragments NSETG - 1 k-steps ahead.
-// Requires nchunk % PF == 0 (the host falls back to the conv body otherwise).
-template <int CI_T, int WM, int WN, int TN, int PF, int NSETG>
-__device__ __forceinline__ void gemm_xs_body(const st2_conv_desc& d) {
-  constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * TN * WN;
-  constexpr int CG = CI_T / 8;
-  constexpr int ROWS = 2 * CG;
-  constexpr int S16 = CI_T / 16;
-  constexpr int XW = BN;
-  constexpr int S = ROWS * XW;
-  static_assert(S % NT == 0, "whole slots per thread");
-  static_assert(PF % 2 == 0, "LDS buffer index must be a compile-time function of the unrolled position");
-  constexpr int NS = S / NT;
-  static_assert(WM * WN == 4, "4 waves");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  h8* lds = reinterpret_cast<h8*>(smem_raw);  // [2][S]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int kg = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN;
-  const int wn = wave % WN;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
-  const int b = blockIdx.z;
-
-  const int Lp = d.xs_lp;
-  const int64_t gplane = (int64_t)d.xs_cg * Lp;
-  const h8* xsb = reinterpret_cast<const h8*>(d.xs) + (int64_t)b * 2 * gplane + (n0 - d.pad_left + d.xs_halo);
-  int soff[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int slot = tid + i * NT;
-    const int row = slot / XW;
-    const int col = slot - row * XW;
-    soff[i] = (int)((row / CG) * gplane + (int64_t)(row % CG) * Lp + col);
-  }
-  const int nchunk = d.wq_cin_pad / CI_T;
-  h8 xq[PF][NS];
-  auto load_set = [&](auto u_tag, int c) __attribute__((always_inline)) {
-    constexpr int U = decltype(u_tag)::value;
-    const h8* src = xsb + (int64_t)c * CG * Lp;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) xq[U][i] = src[soff[i]];
-  };
-  auto store_set = [&](auto u_tag, int buf) __attribute__((always_inline)) {
-    constexpr int U = decltype(u_tag)::value;
-    h8* dst = lds + (size_t)buf * S;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) dst[tid + i * NT] = xq[U][i];
-  };
-
-  f32x16 acc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  const int co_a = m0 + wm * 32 + l31;
-  const h8* ap = reinterpret_cast<const h8*>(d.wq) + ((int64_t)kg * d.wq_co_pad + co_a) * 2;
-  const int64_t a_step = (int64_t)2 * d.wq_co_pad * 2;
-  const int nsteps = nchunk * S16;
-  constexpr int SPG = PF * S16;                 // k-steps per unrolled group
-  static_assert(SPG % NSETG == 0, "the weight-set index must repeat with the unrolled group");
-  h8 a_hi[NSETG], a_lo[NSETG];
-  // weight fragments of k-steps 0 .. NSETG - 2 first (their loads return before the activation loads issued next)
-  int issued = 0;  // k-steps whose weights have been requested
-#pragma unroll
-  for (int k = 0; k < NSETG - 1; ++k) {
-    if (k > 0 && k < nsteps) ap += a_step;
-    a_hi[k] = ap[0];
-    a_lo[k] = ap[1];
-  }
-  issued = NSETG - 1 < nsteps ? NSETG - 1 : nsteps;
-  static_for<PF>([&](auto u) __attribute__((always_inline)) { load_set(u, min((int)decltype(u)::value, nchunk - 1)); });
-  store_set(std::integral_constant<int, 0>{}, 0);
-  __syncthreads();
-
-  __builtin_amdgcn_s_setprio(1);
-  for (int c0 = 0; c0 < nchunk; c0 += PF) {
-    static_for<PF>([&](auto u_tag) __attribute__((always_inline)) {
-      constexpr int U = decltype(u_tag)::value;
-      const int c = c0 + U;
-      constexpr int buf = U & 1;  // c0 is a multiple of the even PF
-      const h8* xbuf = lds + (size_t)buf * S + kg * XW + wn * (32 * TN) + l31;
-#pragma unroll
-      for (int sidx = 0; sidx < S16; ++sidx) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int i = U * S16 + sidx;                 // k-step within the unrolled group (compile-time)
-        const int cur = i % NSETG, pre = (i + NSETG - 1) % NSETG;
-        // weights of k-step (global) + NSETG - 1: unconditional load, pointer advanced by a scalar select
-        if (issued < nsteps) ap += a_step;
-        issued += 1;
-        a_hi[pre] = ap[0];
-        a_lo[pre] = ap[1];
-        // set U held chunk c (now in LDS): free -> request chunk c + PF, AFTER this step's weight prefetch
-        if (sidx == 0) load_set(u_tag, min(c + PF, nchunk - 1));
-        __builtin_amdgcn_sched_barrier(0x786);
-        const h8 ah = a_hi[cur], al = a_lo[cur];
-        const h8* xp = xbuf + (2 * sidx) * XW;
-        h8 bh[TN], bl[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh[j] = xp[j * 32];
-          bl[j] = xp[CG * XW + j * 32];
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al, acc[j], 0, 0, 0);
-      }
-      // chunk c + 1 (set (U + 1) % PF, requested PF - 1 chunks ago) -> the other LDS buffer
-      store_set(std::integral_constant<int, (U + 1) % PF>{}, buf ^ 1);
-      __syncthreads();
-    });
-  }
-  __builtin_amdgcn_s_setprio(0);
-  st2_conv_epilogue<TN, WM, WN>(d, acc, b, m0, n0, wm, wn, l31, kg);
-}
-
-template <int CI_T, int WM, int WN, int TN, int PF, int NSETG, int OCC>
-__global__ __launch_bounds__(NT, OCC) void gemm_xs_kernel(const st2_conv_desc d) {
-  gemm_xs_body<CI_T, WM, WN, TN, PF, NSETG>(d);
-}
-
-template <int CI_T, int WM, int WN, int TN, int PF, int NSETG, int OCC>
-int launch_gemm(const st2_conv_desc& d, hipStream_t s) {
-  constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * TN * WN;
-  ST2_REQUIRE(d.ks == 1 && d.dil == 1, "st2_conv1d_xs (token GEMM build): ks = %d, dil = %d", d.ks, d.dil);
-  ST2_REQUIRE(d.wq_cin_pad % (CI_T * PF) == 0, "st2_conv1d_xs (token GEMM build): %d input channels are not a multiple of "
-              "%d", d.wq_cin_pad, CI_T * PF);
-  ST2_REQUIRE(d.wq_co_pad % BM == 0 && d.wq_co_pad >= d.C_out, "st2_conv1d_xs: wq_co_pad=%d must be a multiple of %d "
-              "covering C_out=%d", d.wq_co_pad, BM, d.C_out);
-  ST2_REQUIRE(d.xs_cg * 8 >= d.wq_cin_pad, "st2_conv1d_xs: xs has %d channel groups, kernel needs %d", d.xs_cg,
-              d.wq_cin_pad / 8);
-  const int n_tiles = st2_cdiv(d.L_out, BN);
-  ST2_REQUIRE((int64_t)(n_tiles - 1) * BN - d.pad_left + d.xs_halo + BN <= d.xs_lp,
-              "st2_conv1d_xs: xs rows of %d slots are too short for L_out=%d (tile %d)", d.xs_lp, d.L_out, BN);
-  if constexpr (TN < 4) ST2_REQUIRE(!d.part, "st2_conv1d_xs: the narrow token tiles do not produce partial sums");
-  const size_t smem = (size_t)2 * (2 * CI_T / 8) * BN * 16;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<CI_T, WM, WN, TN, PF, NSETG, OCC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
-  hipLaunchKernelGGL((gemm_xs_kernel<CI_T, WM, WN, TN, PF, NSETG, OCC>), grid, dim3(NT), smem, s, d);
-  ST2_CHECK_LAUNCH("st2_conv1d_xs");
-  return 0;
-}
-
 }  // namespace
 
 namespace st2xs {

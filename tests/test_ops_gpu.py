@@ -176,7 +176,7 @@ def test_activate_segment_affine_matches_contract():
     """st2_act_split with gb_seg: the token-merged view [1, C, G * N] of G utterances whose LayerNorm affine is per
     utterance -- row l // N of gamma / beta applies at column l -- and the k = 1 conv over it equals the per-utterance
     fused conv on the [G, C, N] view of the same storage."""
-    G, C, N, C_out = 5, 96, 61, 40
+    G, C, N, C_out = 5, 160, 61, 40  # C > 128: a k = 1 conv with a prologue takes the act_split + xs pair (ops.prefer_fused)
     gen_ = torch.Generator().manual_seed(11)
     store = torch.randn(C, G, N, generator=gen_)                       # token-merged channel-major storage
     xb = store.permute(1, 0, 2)                                         # [G, C, N] view

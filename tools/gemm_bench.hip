@@ -82,14 +82,6 @@ int main(int argc, char** argv) {
       {"64x64   c32 occ3", &launch<1, 32, 2, 2, 1, 3>, 64, 32},
       {"64x64   c64 occ3", &launch<1, 64, 2, 2, 1, 3>, 64, 64},
       {"128x32  c64 occ3", &launch<1, 64, 4, 1, 1, 3>, 128, 64},
-      {"G 128x64  c64 pf4 ns8 occ2", &launch_gemm<64, 4, 1, 2, 4, 8, 2>, 128, 64},
-      {"G 128x64  c64 pf2 ns4 occ3", &launch_gemm<64, 4, 1, 2, 2, 4, 3>, 128, 64},
-      {"G 128x64  c64 pf4 ns4 occ3", &launch_gemm<64, 4, 1, 2, 4, 4, 3>, 128, 64},
-      {"G 128x64  c32 pf4 ns8 occ3", &launch_gemm<32, 4, 1, 2, 4, 8, 3>, 128, 32},
-      {"G 128x128 c32 pf4 ns8 occ2", &launch_gemm<32, 4, 1, 4, 4, 8, 2>, 128, 32},
-      {"G 128x128 c32 pf2 ns4 occ3", &launch_gemm<32, 4, 1, 4, 2, 4, 3>, 128, 32},
-      {"G 128x128 c64 pf2 ns8 occ2", &launch_gemm<64, 4, 1, 4, 2, 8, 2>, 128, 64},
-      {"G 64x128  c64 pf4 ns8 occ3", &launch_gemm<64, 2, 2, 2, 4, 8, 3>, 64, 64},
   };
 #endif
   const int halo = 32;
