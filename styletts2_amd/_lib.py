@@ -148,6 +148,7 @@ _SIGNATURES = {
     "st2_lstm_coop_scratch_bytes": (C.c_int64, [C.c_int32]),
     "st2_lstm_coop_set_exchange": (C.c_int, [C.c_int]),
     "st2_lstm_coop_set_spin_limit": (C.c_int, [C.c_int]),
+    "st2_lstm_coop_set_block": (C.c_int, [C.c_int]),
     "st2_lstm_bidir_coop": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "st2_add_chanvec": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, f32p, C.c_int64, C.c_int32,

@@ -323,7 +323,11 @@ int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, cons
   }
 }
 
-int block_size(int B) { return B > 48 ? 0 : (B > 4 ? 8 : (B > 1 ? 4 : 1)); }
+int g_block = 0;  // st2_lstm_coop_set_block(): 0 = by batch size, else 1 / 4 / 8 (measurement hook)
+int block_size(int B) {
+  if (g_block == 1 || g_block == 4 || g_block == 8) return (2 * st2_cdiv(B, g_block) * NSL <= 256) ? g_block : 0;
+  return B > 48 ? 0 : (B > 4 ? 8 : (B > 1 ? 4 : 1));
+}
 
 }  // namespace
 
@@ -333,6 +337,11 @@ extern "C" int st2_lstm_coop_set_exchange(int mode) {
     return 1;
   }
   g_xch = mode;
+  return 0;
+}
+
+extern "C" int st2_lstm_coop_set_block(int utterances) {
+  g_block = utterances;
   return 0;
 }
 

@@ -136,7 +136,8 @@ def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_n
         o = _front_engine(model, dev).front_forward(tokens, noise, step_noise, table, sigma0, lengths=lengths_dev, ref_s=ref_s,
                                                     s_prev=s_prev, embedding_scale=embedding_scale, alpha=alpha, beta=beta,
                                                     t=t, predict=predict, tail=5 if lj_tail else 0)
-        return dict(t_en=o["t_en"], d=o["d_cm"].transpose(1, 2), s=o["s"], ref=o["ref"], durations=o["durations"])
+        return dict(t_en=o["t_en"], d=o["d_cm"].transpose(1, 2), s=o["s"], ref=o["ref"], durations=o["durations"],
+                    s_mixed=o["s_pred"])  # [B, 2 sty] = (ref | s), written by the plan: no torch.cat on the product path
     if lengths_dev is not None:  # mask built on the device; the modules take the device copy (text.py _device_lengths)
         text_mask = torch.arange(N, device=dev).unsqueeze(0) >= lengths_dev.reshape(-1, 1)
         len_arg = lengths_dev
@@ -324,7 +325,8 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     durations = durations.to(dev)
     if taps is not None:
         taps["durations"] = durations
-    out = dict(ref=ref, s_pred=torch.cat([ref, s], dim=-1), durations=durations)
+    s_mixed = f.get("s_mixed")
+    out = dict(ref=ref, s_pred=s_mixed if s_mixed is not None else torch.cat([ref, s], dim=-1), durations=durations)
     d_cm = d.transpose(-1, -2).contiguous()
 
     def expand(idx):

@@ -30,6 +30,21 @@ for N in (100, 400):
                                                                       ops.lstm_coop_status() if mode != "single" else 0),
               flush=True)
     _lib.load().st2_lstm_coop_set_exchange(2)
+    for blk in (4, 8):  # utterances per cooperative group: 4 -> twice the groups (128 workgroups at B = 32), half the mat-vec
+        _lib.load().st2_lstm_coop_set_block(blk)
+        _hooks.lstm = "coop"
+        for _ in range(2):
+            y = ops.lstm_bidir(G, whh)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            y = ops.lstm_bidir(G, whh)
+        e1.record()
+        torch.cuda.synchronize()
+        print("lstm coop block=%d B=%d N=%d: %.3f ms (%.2f us/step) max |y - single| = %.3g" % (
+            blk, B, N, e0.elapsed_time(e1) / 5, e0.elapsed_time(e1) / 5 / N * 1e3, (y - outs["single"]).abs().max().item()),
+            flush=True)
+    _lib.load().st2_lstm_coop_set_block(0)
     print("   max |coop - single| = %.3g, |coop_fence - single| = %.3g" % (
         (outs["coop"] - outs["single"]).abs().max().item(), (outs["coop_fence"] - outs["single"]).abs().max().item()),
         flush=True)
