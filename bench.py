@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--lstm", choices=["coop", "single"], default="coop",
                     help="diagnostic: `single` replaces the cooperative BiLSTM (spin-waiting 8-CU groups) by the single-CU "
                          "kernel the library falls back to; never the measured configuration")
+    ap.add_argument("--lstm-block", type=int, default=0, choices=[0, 1, 2, 4, 8],
+                    help="diagnostic: utterances per cooperative BiLSTM group (0 = the library's rule)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
@@ -318,6 +320,7 @@ def main():
     from benchdata import manifest, synth  # workload definitions: model manifests, seeded synthetic weights
     from styletts2_amd import _hooks, _lib, models, ops, pipeline
     _hooks.lstm = a.lstm
+    _lib.load().st2_lstm_coop_set_block(a.lstm_block)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

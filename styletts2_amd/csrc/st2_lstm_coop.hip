@@ -323,10 +323,17 @@ int launch_coop(const float* G, int64_t g_bs, int g_cs, const float* whh_t, cons
   }
 }
 
-int g_block = 0;  // st2_lstm_coop_set_block(): 0 = by batch size, else 1 / 4 / 8 (measurement hook)
+int g_block = 0;  // st2_lstm_coop_set_block(): 0 = by batch size, else 1 / 2 / 4 / 8 (measurement hook)
+constexpr int MAX_COOP_WG = 256;  // workgroups of one cooperative launch (the occupancy query at launch has the last word)
+// Utterances per cooperative group.  A group's step = its mat-vec (U x 128 fmas per thread) + one cross-CU exchange, so
+// fewer utterances per group means a shorter step as long as the groups still fit the chip side by side: at B = 32 blocks
+// of 4 (128 workgroups) run 2.9 us / step against 4.35 us for blocks of 8 (64 workgroups) -- profiles/r03h_probe_lstm.log.
 int block_size(int B) {
-  if (g_block == 1 || g_block == 4 || g_block == 8) return (2 * st2_cdiv(B, g_block) * NSL <= 256) ? g_block : 0;
-  return B > 48 ? 0 : (B > 4 ? 8 : (B > 1 ? 4 : 1));
+  if (g_block == 1 || g_block == 2 || g_block == 4 || g_block == 8)
+    return (2 * st2_cdiv(B, g_block) * NSL <= MAX_COOP_WG) ? g_block : 0;
+  if (B <= 1) return 1;
+  if (2 * st2_cdiv(B, 4) * NSL <= MAX_COOP_WG / 2) return 4;  // up to 32 utterances: 128 workgroups
+  return B > 48 ? 0 : 8;
 }
 
 }  // namespace
@@ -369,6 +376,8 @@ extern "C" int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, c
       return launch_coop<8>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
     case 4:
       return launch_coop<4>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
+    case 2:
+      return launch_coop<2>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
     case 1:
       return launch_coop<1>(G, g_bs, g_cs, whh_t, len, B, N, Y, y_bs, y_cs, scratch, (size_t)scratch_bytes, s);
     default:

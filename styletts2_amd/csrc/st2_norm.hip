@@ -98,10 +98,15 @@ __global__ __launch_bounds__(64 * CW) void colnorm_stats_kernel(const float* __r
 // k in [ks*K/4, (ks+1)*K/4) for 8 batch rows (style vectors in LDS, read as 16-byte broadcasts; four independent
 // coalesced weight loads in flight), the four partials are combined through LDS in slice order (fixed order =>
 // bitwise reproducible).
+// Latency, not bandwidth, bounds these mat-vecs (B <= 32 rows against a <= 2048 x J matrix, 41 launches per bench step): a
+// thread walks its k slice with dependent-free but serially issued row loads, so the launch takes (k per thread / loads in
+// flight) L2 round trips.  16 k slices per workgroup (1024 threads; round 2: 4 slices, 256 threads) cut a K = 1024 walk
+// from 64 to 16 iterations of 4 row loads: 40 -> ~15 us per launch.  Partial sums meet in LDS in a fixed order.
 constexpr int FC_BT = 8;
 constexpr int FC_J = 64;
-constexpr int FC_KS = 4;
-__global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__ s, int B, int K,
+constexpr int FC_KS = 16;
+constexpr int FC_NT = FC_J * FC_KS;
+__global__ __launch_bounds__(FC_NT) void style_fc_kernel(const float* __restrict__ s, int B, int K,
                                                        const float* __restrict__ wt, const float* __restrict__ bias,
                                                        int J, int act, float* __restrict__ h) {
   extern __shared__ __attribute__((aligned(16))) float sl[];  // [FC_BT][K] then [FC_KS][FC_BT][FC_J]
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__
   const int jc = min(j, J - 1);
   const int b0 = blockIdx.y * FC_BT;
   const int nb = min(FC_BT, B - b0);
-  for (int e = threadIdx.x; e < FC_BT * K; e += 256) {
+  for (int e = threadIdx.x; e < FC_BT * K; e += FC_NT) {
     const int bb = e / K, k = e % K;
     sl[e] = bb < nb ? s[(int64_t)(b0 + bb) * K + k] : 0.f;
   }
@@ -150,20 +155,17 @@ __global__ __launch_bounds__(256) void style_fc_kernel(const float* __restrict__
 #pragma unroll
   for (int bb = 0; bb < FC_BT; ++bb) red[(ks * FC_BT + bb) * FC_J + jj] = acc[bb];
   __syncthreads();
-  // thread (jj, ks) finishes batch rows ks and ks + 4
-  if (j < J) {
+  // thread (jj, ks < FC_BT) finishes batch row ks: the k slices are summed in slice order
+  if (j < J && ks < FC_BT) {
     const float bj = bias ? bias[j] : 0.f;
+    const int bb = ks;
+    if (bb < nb) {
+      float v = red[(0 * FC_BT + bb) * FC_J + jj];
 #pragma unroll
-    for (int half = 0; half < FC_BT / FC_KS; ++half) {
-      const int bb = ks + half * FC_KS;
-      if (bb < nb) {
-        float v = red[(0 * FC_BT + bb) * FC_J + jj];
-#pragma unroll
-        for (int q = 1; q < FC_KS; ++q) v += red[(q * FC_BT + bb) * FC_J + jj];
-        v += bj;
-        if (act == ST2_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        h[(int64_t)(b0 + bb) * J + j] = v;
-      }
+      for (int q = 1; q < FC_KS; ++q) v += red[(q * FC_BT + bb) * FC_J + jj];
+      v += bj;
+      if (act == ST2_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      h[(int64_t)(b0 + bb) * J + j] = v;
     }
   }
 }
@@ -245,7 +247,13 @@ extern "C" int st2_style_fc(const float* sv, int32_t B, int32_t K, const float* 
   ST2_REQUIRE(act == ST2_ACT_NONE || act == ST2_ACT_GELU, "st2_style_fc: act must be NONE or GELU");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t smem = ((size_t)FC_BT * K + (size_t)FC_KS * FC_BT * FC_J) * sizeof(float);
-  hipLaunchKernelGGL(style_fc_kernel, dim3(st2_cdiv(J, FC_J), st2_cdiv(B, FC_BT)), dim3(256), smem, s, sv, B, K, wt,
+  static bool attr_done = false;
+  if (!attr_done) {  // up to 8 x 2048 staged inputs + 16 x 8 x 64 partial sums: 96 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&style_fc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(style_fc_kernel, dim3(st2_cdiv(J, FC_J), st2_cdiv(B, FC_BT)), dim3(FC_NT), smem, s, sv, B, K, wt,
                      bias, J, act, h);
   ST2_CHECK_LAUNCH("st2_style_fc");
   return 0;

@@ -30,7 +30,7 @@ for N in (100, 400):
                                                                       ops.lstm_coop_status() if mode != "single" else 0),
               flush=True)
     _lib.load().st2_lstm_coop_set_exchange(2)
-    for blk in (4, 8):  # utterances per cooperative group: 4 -> twice the groups (128 workgroups at B = 32), half the mat-vec
+    for blk in (2, 4, 8):  # utterances per cooperative group: 4 -> twice the groups (128 workgroups at B = 32), half the mat-vec
         _lib.load().st2_lstm_coop_set_block(blk)
         _hooks.lstm = "coop"
         for _ in range(2):
