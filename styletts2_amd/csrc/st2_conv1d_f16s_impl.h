@@ -40,7 +40,10 @@ struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
 };
 
 template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 2) void conv1d_f16s_kernel(const st2_conv_desc d, int* status, int ksplit, float* part) {
+#ifndef ST2_F16S_OCC
+#define ST2_F16S_OCC 2  // workgroups per CU the fused kernel is held to; at 3 (168 VGPRs) every instantiation spills 40-400 B / lane
+#endif
+__global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2_conv_desc d, int* status, int ksplit, float* part) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
