@@ -57,11 +57,29 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   for (int c0 = 0; c0 < NK; c0 += AKT) {
     const int ct = min(AKT, NK - c0);
     __syncthreads();
-    for (int e = tid; e < AD * AKT; e += 256) {
-      const int d = e / AKT, mm = e % AKT;
-      const bool ok = mm < ct;
-      ks[d * ALD + mm] = ok ? k[base + (int64_t)d * cs + c0 + mm] : 0.f;
-      vs[d * ALD + mm] = ok ? v[base + (int64_t)d * cs + c0 + mm] : 0.f;
+    // K / V chunk -> LDS.  The loads of a batch of 8 rows are issued together (16 in flight per thread, unconditional with
+    // a clamped column) before any of them is consumed: one load + one LDS store per iteration made this loop 32 serial
+    // L2 round trips -- most of the 37 us a 100-token launch took (40 launches per bench step).
+    constexpr int ST_U = 8;
+    static_assert((AD * AKT) % (256 * ST_U) == 0, "whole batches");
+    for (int e0 = tid; e0 < AD * AKT; e0 += 256 * ST_U) {
+      float kr[ST_U], vr[ST_U];
+#pragma unroll
+      for (int u = 0; u < ST_U; ++u) {
+        const int e = e0 + u * 256;
+        const int d = e / AKT, mm = e % AKT;
+        const int64_t off = base + (int64_t)d * cs + c0 + min(mm, ct - 1);
+        kr[u] = k[off];
+        vr[u] = v[off];
+      }
+#pragma unroll
+      for (int u = 0; u < ST_U; ++u) {
+        const int e = e0 + u * 256;
+        const int d = e / AKT, mm = e % AKT;
+        const bool ok = mm < ct;
+        ks[d * ALD + mm] = ok ? kr[u] : 0.f;
+        vs[d * ALD + mm] = ok ? vr[u] : 0.f;
+      }
     }
     __syncthreads();
     if (!wave_live) continue;

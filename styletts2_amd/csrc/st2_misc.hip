@@ -70,11 +70,28 @@ __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __re
   const int l_lo = max(o0 - reflect_left, 0);
   const int q_lo = (l_lo + pad) / stride;
   const int nq = CVT_TILE / stride + 3;
-  for (int r = 0; r < stride; ++r) {
-    const float* row = ph + (int64_t)b * p_bs + (int64_t)(r * C + co) * p_cs;
-    for (int i = threadIdx.x; i < nq; i += 256) {
-      const int q = q_lo + i;
-      cvt_tile[r * nqp + i] = q < Lq ? row[q] : 0.f;
+  // stride x nq staged values, flattened; the loads of 8 iterations are issued together (unconditional, clamped column)
+  // before the first LDS store: one load -> one store per iteration serialised `stride` L2 / HBM round trips per tile
+  {
+    const float* pb = ph + (int64_t)b * p_bs + (int64_t)co * p_cs;
+    const int total = stride * nq;
+    constexpr int SB = 8;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * SB) {
+      float t[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = min(e0 + u * 256, total - 1);
+        const int r = e / nq, i = e - r * nq;
+        t[u] = pb[(int64_t)r * C * p_cs + min(q_lo + i, Lq - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = e0 + u * 256;
+        if (e < total) {
+          const int r = e / nq, i = e - r * nq;
+          cvt_tile[r * nqp + i] = (q_lo + i) < Lq ? t[u] : 0.f;
+        }
+      }
     }
   }
   __syncthreads();

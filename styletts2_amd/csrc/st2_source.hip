@@ -129,9 +129,14 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
 }
 
 // ---- iSTFT: one thread per output sample; gathers the <= N/hop frames that overlap it ------------
+// The polar -> cartesian conversion (mag * cos(phase), mag * sin(phase)) of the frames a workgroup's 256 samples touch is
+// done ONCE per (frame, bin) into LDS ([bin][frame], frames along the lanes): per sample it was repeated for every one
+// of the N/hop overlapping frames and N bins -- 20 x the sincos work at n_fft = 20, hop = 5.  Same values, same
+// accumulation order: the waveform is bitwise unchanged.
 __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp, int64_t sp_bs, int sp_cs, int M,
-                                                    int N, int hop, float* __restrict__ wave, int64_t wave_bs) {
+                                                    int N, int hop, float* __restrict__ wave, int64_t wave_bs, int FRP) {
   __shared__ float tw_c[MAXN], tw_s[MAXN], win[MAXN];
+  extern __shared__ float ri[];  // [2][NB][FRP]: re, im of the frames m_base .. m_base + FR - 1
   if (threadIdx.x < N) {
     // cospi/sinpi are exact at multiples of 1/2: the DC and Nyquist bins then have an exactly zero
     // imaginary part, as a real FFT gives, so atan2 returns +pi (not a random +-pi) when Re < 0.
@@ -140,18 +145,37 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
     tw_s[threadIdx.x] = (float)sinpi(a);
     win[threadIdx.x] = (float)(0.5 - 0.5 * cospi(a));
   }
-  __syncthreads();
   const int Lw = hop * (M - 1);
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
-  if (t >= Lw) return;
   const int NB = N / 2 + 1;
+  const float* sb = sp + (int64_t)b * sp_bs;
+  {  // frames touched by this workgroup's samples t0 .. t0 + 255
+    const int t0 = blockIdx.x * 256;
+    const int tp0 = t0 + N / 2, tp1 = min(t0 + 255, Lw - 1) + N / 2;
+    const int m_base = (tp0 - N + 1 <= 0) ? 0 : (tp0 - N + hop) / hop;
+    const int m_last = min(tp1 / hop, M - 1);
+    const int FR = m_last - m_base + 1;  // <= FRP
+    float* re_s = ri;
+    float* im_s = ri + NB * FRP;
+    for (int e = threadIdx.x; e < NB * FR; e += 256) {
+      const int k = e / FR, f = e - k * FR;
+      const float mag = sb[(int64_t)k * sp_cs + m_base + f];
+      const float ph = sb[(int64_t)(NB + k) * sp_cs + m_base + f];
+      re_s[k * FRP + f] = mag * cosf(ph);
+      im_s[k * FRP + f] = mag * sinf(ph);
+    }
+  }
+  __syncthreads();
+  if (t >= Lw) return;
   const int tp = t + N / 2;  // position in the un-trimmed overlap-add buffer
+  const int m_base = ((blockIdx.x * 256 + N / 2) - N + 1 <= 0) ? 0 : ((blockIdx.x * 256 + N / 2) - N + hop) / hop;
+  const float* re_s = ri;
+  const float* im_s = ri + NB * FRP;
   int m_hi = tp / hop;
   if (m_hi > M - 1) m_hi = M - 1;
   int m_lo = (tp - N + hop) / hop;  // ceil((tp - N + 1) / hop) for tp-N+1 >= 0
   if (tp - N + 1 <= 0) m_lo = 0;
-  const float* sb = sp + (int64_t)b * sp_bs;
   const float inv_n = 1.0f / (float)N;
   float y = 0.f, env = 0.f;
   for (int m = m_lo; m <= m_hi; ++m) {
@@ -159,11 +183,10 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
     // irfft bin sum: (1/N) [ Re S0 + (-1)^n Re S_{N/2} + 2 sum_{k=1}^{N/2-1} (Re S_k cos - Im S_k sin) ]
     float acc = 0.f;
     int idx = 0;
+    const int f = m - m_base;
     for (int k = 0; k < NB; ++k) {
-      const float mag = sb[(int64_t)k * sp_cs + m];
-      const float ph = sb[(int64_t)(NB + k) * sp_cs + m];
-      const float re = mag * cosf(ph);
-      const float im = mag * sinf(ph);
+      const float re = re_s[k * FRP + f];
+      const float im = im_s[k * FRP + f];
       if (k == 0 || k == N / 2) {
         acc += re * tw_c[idx];  // imaginary parts of DC / Nyquist are ignored (c2r semantics)
       } else {
@@ -217,8 +240,10 @@ extern "C" int st2_istft(const float* sp, int64_t sp_bs, int32_t sp_cs, int32_t 
               "st2_istft: n_fft=%d hop=%d unsupported", n_fft, hop);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int Lw = hop * (M - 1);
-  hipLaunchKernelGGL(istft_kernel, dim3(st2_cdiv(Lw, 256), B), dim3(256), 0, s, sp, sp_bs, sp_cs, M, n_fft, hop, wave,
-                     wave_bs);
+  const int FRP = (256 / hop + n_fft / hop + 3) | 1;  // frames a 256-sample tile can touch, odd pitch
+  const size_t smem = (size_t)2 * (n_fft / 2 + 1) * FRP * sizeof(float);
+  hipLaunchKernelGGL(istft_kernel, dim3(st2_cdiv(Lw, 256), B), dim3(256), smem, s, sp, sp_bs, sp_cs, M, n_fft, hop, wave,
+                     wave_bs, FRP);
   ST2_CHECK_LAUNCH("st2_istft");
   return 0;
 }
