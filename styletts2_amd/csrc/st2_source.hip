@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ sp
   __syncthreads();
   if (t >= Lw) return;
   const int tp = t + N / 2;  // position in the un-trimmed overlap-add buffer
-  const int m_base = ((blockIdx.x * 256 + N / 2) - N + 1 <= 0) ? 0 : ((blockIdx.x * 256 + N / 2) - N + hop) / hop;
+  const int tp0 = (int)blockIdx.x * 256 + N / 2;  // (int: blockIdx is unsigned, tp0 - N + 1 must be able to go negative)
+  const int m_base = (tp0 - N + 1 <= 0) ? 0 : (tp0 - N + hop) / hop;
   const float* re_s = ri;
   const float* im_s = ri + NB * FRP;
   int m_hi = tp / hop;
