@@ -220,9 +220,14 @@ def roofline(by_class):
     for (ks, ci, co, L, b), durs in by_class.items():
         flop = 2.0 * b * ci * co * ks * L
         avg = sum(durs) / len(durs)
+        # HBM side of the same launch: the planes it reads (4 B per input element), the fp32 output it writes and -- every
+        # second conv of a resblock -- the residual it adds (the 2.5 x of `alg_bytes` below, per class); a class whose
+        # arithmetic intensity is below the machine balance (~90 FLOP/B at 488 TFLOP/s : 5.4 TB/s) is judged on hbm_frac
+        nbytes = 4.0 * b * L * (ci + 1.5 * co)
         rows.append(dict(ks=ks, C_in=ci, C_out=co, L=L, B=b, launches=len(durs), avg_launch_ms=avg,
                          total_ms=sum(durs), share=sum(durs) / total, algorithmic_flop_per_launch=flop,
-                         achieved=flop / (avg * 1e-3) / 1e12, frac=flop / (avg * 1e-3) / 1e12 / peak))
+                         achieved=flop / (avg * 1e-3) / 1e12, frac=flop / (avg * 1e-3) / 1e12 / peak,
+                         flop_per_byte=flop / nbytes, hbm_frac=nbytes / (avg * 1e-3) / 8e12))
     rows.sort(key=lambda r: -r["total_ms"])
     if not rows:
         return {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
