@@ -18,6 +18,13 @@ token ids -> waveform over the per-GPU batch (longform: over the passage); input
 HBM, the random draws the reference makes inside forward (SineGen noise, ADPM2 step noise) are made inside the timed
 region.  Multi-GPU is weak scaling: every rank synthesises its own utterances, no collective in steady state; the
 only collective is the start-up weight broadcast over RCCL.
+
+Schedules (`--schedule`, default `auto`): consecutive steps may share the GPU on one stream, on two streams (front of step
+k+1 under the decoder of step k) or on two streams with complementary CU masks; `auto` times a few steps of each during
+the warm-up and runs the timed region on the fastest -- MI355X boxes differ in how they co-schedule two queues (DESIGN.md
+section 6) -- and reports all of them in `config.schedules_ms_per_step`.  `cpu_baseline` = the UNMODIFIED reference modules on
+the host cores (`kind: "reference"`; from /root/reference, or from oracle/_ref = the same modules as bytecode where only
+that travelled), the oracle port beside it.
 """
 import argparse
 import json
