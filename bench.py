@@ -20,8 +20,8 @@ region.  Multi-GPU is weak scaling: every rank synthesises its own utterances, n
 only collective is the start-up weight broadcast over RCCL.
 
 Schedules (`--schedule`, default `auto`): consecutive steps may share the GPU on one stream, on two streams (front of step
-k+1 under the decoder of step k) or on two streams with complementary CU masks; `auto` times a few steps of each during
-the warm-up and runs the timed region on the fastest -- MI355X boxes differ in how they co-schedule two queues (DESIGN.md
+k+1 under the decoder of step k) or on two streams with complementary CU masks; `auto` times a few steps of the first two
+during the warm-up and runs the timed region on the faster -- MI355X boxes differ in how they co-schedule two queues (DESIGN.md
 section 6) -- and reports all of them in `config.schedules_ms_per_step`.  `cpu_baseline` = the UNMODIFIED reference modules on
 the host cores (`kind: "reference"`; from /root/reference, or from oracle/_ref = the same modules as bytecode where only
 that travelled), the oracle port beside it.
@@ -292,11 +292,14 @@ def main():
                     help="how consecutive steps share the GPU: `single` = everything on one stream; `two-stream` = front "
                          "of step k+1 on a second (high-priority) stream under the decoder of step k, placement left to "
                          "the hardware scheduler; `partitioned` = the same pipeline on two streams with complementary CU "
-                         "masks (--front-cus); `auto` (default) = time --calib-steps steps of each during the warm-up "
-                         "and run the timed region on the fastest (boxes differ in how they co-schedule two queues)")
+                         "masks (--front-cus); `auto` (default) = time --calib-steps steps of `single` and `two-stream` "
+                         "during the warm-up and run the timed region on the faster (boxes differ in how they co-schedule "
+                         "two queues)")
     ap.add_argument("--single-stream", action="store_true", help="same as --schedule single")
     ap.add_argument("--front-cus", type=int, default=64, help="CUs given to the front stream by --schedule partitioned")
     ap.add_argument("--calib-steps", type=int, default=3)
+    ap.add_argument("--calib-partitioned", action="store_true",
+                    help="let --schedule auto also time the CU-partitioned schedule")
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
     ap.add_argument("--eager-front", action="store_true",
                     help="issue the device-only front of a step / sentence (text encoder, PL-BERT, sampler, duration "
@@ -374,7 +377,10 @@ def main():
     sched = {}  # name -> (main stream or None = torch's current, front stream or None)
     ps = None
     if not longform:
-        want = ("single", "two-stream", "partitioned") if a.schedule == "auto" else (a.schedule,)
+        # `auto` calibrates the two schedules that have ever won; the CU-partitioned one (75-126 ms against 66-72 on every
+        # box of round 3, DESIGN.md section 3 iv) is measured on request only (--schedule partitioned / --calib-partitioned)
+        want = (("single", "two-stream") + (("partitioned",) if a.calib_partitioned else ())) if a.schedule == "auto" \
+            else (a.schedule,)
         if "single" in want:
             sched["single"] = (None, None)
         if "two-stream" in want:

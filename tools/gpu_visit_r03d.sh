@@ -12,7 +12,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 { uname -r; cat /sys/class/kfd/kfd/topology/nodes/*/properties 2>/dev/null | grep -i "fw_version\|num_xcc\|max_engine_clk_f\|num_cp_queues"; rocm-smi --showpower --showclocks --showperflevel 2>&1 | grep -i "power\|sclk\|mclk\|level"; rocminfo 2>&1 | grep -i "uuid" | tail -1; } > $OUT/box.txt 2>&1
-echo "== bench (default)"; timeout 400 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+echo "== bench (default)"; timeout 400 python bench.py --no-cpu-baseline --calib-partitioned > $OUT/bench.json 2> $OUT/bench.err
 SLOW=$(python - <<EOF
 import json;r=json.load(open('$OUT/bench.json'));c=r['config']['schedules_ms_per_step']
 print(r['ms_per_step'], r['value'], r['config']['schedule'], c, file=__import__('sys').stderr)
