@@ -17,24 +17,42 @@ __device__ __forceinline__ float torch_remainder1(float x) {
 }
 
 // ---- pass 1: frame-rate phase  phase_f[b][h][k] = ((cumsum_k rad) * 2) * pi_f32 * U ------------
-// one thread per (b, h); the scan is sequential with an fp64 accumulator, each prefix rounded to
-// fp32 exactly as ATen-CPU cumsum does (istftnet.py:183-184).
+// The prefix sums are taken in fp64 and each prefix is rounded to fp32, as ATen-CPU cumsum does (istftnet.py:183-184).
+// One WAVE per (b, h) row: lane i sums its contiguous chunk of the row, the chunk totals are scanned across the wave,
+// then every lane re-walks its chunk from its offset.  (Round 2: one THREAD per row walking 800 frames with a load, a
+// dependent fp64 add and a store per iteration -- 250 us of pure latency per decoder call.)  The fp64 sums are exact to
+// ~1e-13 relative whatever the association (<= 2^10 terms of 24-bit values), far below the fp32 rounding of a prefix, so the
+// stored phases are those of the sequential scan.
 __global__ __launch_bounds__(64) void sinegen_phase_kernel(const float* __restrict__ f0, int B, int F, int U, int H,
                                                            float sample_rate, float* __restrict__ phase_f) {
-  const int idx = blockIdx.x * 64 + threadIdx.x;
-  if (idx >= B * H) return;
-  const int b = idx / H;
-  const int h = idx % H;
+  const int row = blockIdx.x;  // (b, h)
+  const int lane = threadIdx.x;
+  const int b = row / H;
+  const int h = row % H;
   const float mult = (float)(h + 1);
   const float* f = f0 + (int64_t)b * F;
   float* out = phase_f + ((int64_t)b * H + h) * F;
   const float two_pi_part = 3.14159274101257324219f;  // (float)np.pi
   const float fu = (float)U;
-  double acc = 0.0;
-  for (int k = 0; k < F; ++k) {
-    const float fn = f[k] * mult;                      // istftnet.py:228
-    const float rad = torch_remainder1(fn / sample_rate);  // istftnet.py:152
-    acc += (double)rad;
+  const int chunk = (F + 63) / 64;
+  const int k0 = min(lane * chunk, F), k1 = min(k0 + chunk, F);
+  double part = 0.0;
+  for (int k = k0; k < k1; ++k) {
+    const float fn = f[k] * mult;                          // istftnet.py:228
+    part += (double)torch_remainder1(fn / sample_rate);    // istftnet.py:152
+  }
+  // inclusive scan of the chunk totals across the wave (fixed order: Hillis-Steele over 64 lanes), then exclusive offset
+  double incl = part;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  double acc = __shfl_up(incl, 1, 64);  // exclusive offset = the inclusive total of the lane below
+  if (lane == 0) acc = 0.0;
+  for (int k = k0; k < k1; ++k) {
+    const float fn = f[k] * mult;
+    acc += (double)torch_remainder1(fn / sample_rate);
     const float c = (float)acc;
     out[k] = ((c * 2.0f) * two_pi_part) * fu;
   }
@@ -213,7 +231,7 @@ extern "C" int st2_har_source(const float* f0, int32_t B, int32_t F, int32_t U, 
   ST2_REQUIRE(B > 0 && F > 0 && U > 0 && H > 0 && H <= 64, "st2_har_source: bad geometry");
   ST2_REQUIRE((int64_t)F * U < (1LL << 31), "st2_har_source: utterance too long");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(sinegen_phase_kernel, dim3(st2_cdiv(B * H, 64)), dim3(64), 0, s, f0, B, F, U, H, sample_rate,
+  hipLaunchKernelGGL(sinegen_phase_kernel, dim3(B * H), dim3(64), 0, s, f0, B, F, U, H, sample_rate,
                      phase_scratch);
   ST2_CHECK_LAUNCH("st2_har_source(phase)");
   hipLaunchKernelGGL(har_source_kernel, dim3(st2_cdiv((int64_t)F * U, 256), B), dim3(256), 0, s, f0, F, U, H, noise,
