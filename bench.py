@@ -334,8 +334,8 @@ def main():
 
     from benchdata import manifest, synth  # workload definitions: model manifests, seeded synthetic weights
     from styletts2_amd import _hooks, _lib, models, ops, pipeline
-    _hooks.lstm = a.lstm
-    _lib.load().st2_lstm_coop_set_block(a.lstm_block)
+    _hooks.lstm = a.lstm  # the per-kernel Python plans; the C++ plans (the product path) follow the library hook below
+    _lib.load().st2_lstm_coop_set_block(-1 if a.lstm == "single" else a.lstm_block)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

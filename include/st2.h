@@ -323,7 +323,8 @@ int st2_lstm_coop_set_exchange(int mode);
  * Tests set 1 to provoke ST2_STATUS_LSTM_TIMEOUT. */
 int st2_lstm_coop_set_spin_limit(int polls);
 /* Measurement hook (process-wide): utterances per cooperative group, 1 / 2 / 4 / 8; 0 (default) = chosen from the batch
- * size (4 up to 32 utterances, 8 up to 48).  Smaller blocks trade CUs for less mat-vec work per step and workgroup. */
+ * size (4 up to 32 utterances, 8 up to 48); < 0 = no cooperative launches (st2_lstm_coop_scratch_bytes returns 0, the
+ * plans take st2_lstm_bidir).  Smaller blocks trade CUs for less mat-vec work per step and workgroup. */
 int st2_lstm_coop_set_block(int utterances);
 int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
                         int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,

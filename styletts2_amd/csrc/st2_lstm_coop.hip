@@ -329,6 +329,7 @@ constexpr int MAX_COOP_WG = 256;  // workgroups of one cooperative launch (the o
 // fewer utterances per group means a shorter step as long as the groups still fit the chip side by side: at B = 32 blocks
 // of 4 (128 workgroups) run 2.9 us / step against 4.35 us for blocks of 8 (64 workgroups) -- profiles/r03h_probe_lstm.log.
 int block_size(int B) {
+  if (g_block < 0) return 0;  // measurement hook: no cooperative launches at all (callers take st2_lstm_bidir)
   if (g_block == 1 || g_block == 2 || g_block == 4 || g_block == 8)
     return (2 * st2_cdiv(B, g_block) * NSL <= MAX_COOP_WG) ? g_block : 0;
   if (B <= 1) return 1;
