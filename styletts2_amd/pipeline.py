@@ -25,10 +25,11 @@ def _engine_path(dev, taps=None):
 class PartitionedStreams:
     """A pair of HIP streams on complementary compute-unit masks (st2_stream_create_cu_mask, include/st2.h): `front`
     owns `front_cus` of the device's CUs (dealt out evenly over the 8 XCDs by the driver's bit numbering), `main` the
-    rest.  The two-stage pipeline of `inference(front_stream=...)` then no longer depends on the hardware scheduler
-    interleaving two queues: the front's latency-bound kernels (64-workgroup cooperative BiLSTM groups that spin on each
-    other, 100-token transformer layers) cannot be starved of CU slots by the decoder's 12 000-workgroup convs, and the
-    decoder cannot be stalled behind them.  Use as
+    rest.  The two-stage pipeline of `inference(front_stream=...)` then does not depend on the hardware scheduler
+    interleaving two queues.  MEASURED (round 3, DESIGN.md section 3 iv): slower than scheduler-placed two-stream execution
+    on every box seen -- 126 / 90 / 75 ms per bench step with 16 / 32 / 64 front CUs against 68 (and 78 single-stream): the
+    front's kernels are latency-bound but wide, a small partition starves them, a large one starves the decoder.  Kept as an
+    explicit option (`bench.py --schedule partitioned`) for boxes on which two queues do not overlap.  Use as
 
         ps = PartitionedStreams(dev, front_cus=32)
         with torch.cuda.stream(ps.main):
