@@ -16,6 +16,7 @@ if len(sys.argv) > 1:
 from styletts2_amd import ops, weights  # noqa: E402
 
 dev = "cuda"
+torch.manual_seed(0)
 B = 32
 cases = [(64, 120000, 3, 1), (64, 120000, 7, 3), (64, 120000, 11, 5), (32, 240000, 3, 1), (32, 240000, 7, 1), (32, 240000, 11, 1),
          (128, 48001, 3, 1), (128, 40000, 3, 1)]
