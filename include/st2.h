@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 17
+#define ST2_ABI_VERSION 18
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -147,6 +147,11 @@ int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
 int64_t st2_conv1d_f16s_splitk_bytes(const st2_conv_desc* d);
 int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
 int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
+/* Measurement hook (process-wide): which build of the fused kernel a launch takes.  0 (default) = by rule: the
+ * warp-specialised persistent build (512-thread workgroups, one per CU: four waves stage + activate the input, four issue
+ * the MFMAs; bitwise the same results) for AdaIN + Snake convs with k = 3, C_out <= 64 and at least 512 tiles, the one-role
+ * build otherwise; 1 = one-role build always; 2 = warp-specialised for every layer it can run (k = 3 / 7 / 11, C_out <= 64). */
+void st2_conv1d_f16s_set_variant(int variant);
 /* sizeof(st2_conv_desc) as the library was compiled: lets a binding verify its struct mirror. */
 int st2_sizeof_conv_desc(void);
 

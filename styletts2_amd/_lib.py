@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -106,6 +106,7 @@ _SIGNATURES = {
     "st2_conv1d_f16s_splitk_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
+    "st2_conv1d_f16s_set_variant": (None, [C.c_int]),
     "st2_conv1d_xs": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_act_split": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                 f32p, f32p, f32p, C.c_int64, C.c_int32, C.c_int32, f32p, C.c_float, f32p, C.c_int32,

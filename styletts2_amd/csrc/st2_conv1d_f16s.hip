@@ -10,6 +10,10 @@ extern template int st2f16s::launch_by_cout<7, 16>(const st2_conv_desc&, hipStre
 extern template int st2f16s::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t);
 
 
+int st2f16s::g_variant = 0;
+
+extern "C" void st2_conv1d_f16s_set_variant(int v) { st2f16s::g_variant = (v == 1 || v == 2) ? v : 0; }
+
 extern "C" int st2_conv1d_f16s_chunk(int ks) { return ks <= 3 ? 32 : 16; }
 
 extern "C" int st2_conv1d_f16s_co_block(int C_out) { return C_out > 64 ? 128 : (C_out > 32 ? 64 : 32); }

@@ -390,10 +390,36 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
 
 }  // namespace
 
+namespace st2ws {  // st2_conv1d_f16s_ws.h, instantiated in st2_conv1d_f16s_w{0,1,2}.hip
+template <int KS, int CI_T>
+int launch_ws_by_cout(const st2_conv_desc& d, hipStream_t s);
+}
+
 namespace st2f16s {
+
+extern int g_variant;  // st2_conv1d_f16s_set_variant: 0 = rule, 1 = one role per wave always, 2 = warp-specialised when eligible
+
+// The warp-specialised persistent build (st2_conv1d_f16s_ws.h; bitwise the same results) exists for the vocoder's AdaIN + Snake
+// convs with k = 3 / 7 / 11 and C_out <= 64.  BY RULE it takes the k = 3 ones whose grid gives every CU at least two tiles:
+// x1.12-1.20 there (tools/probe_ws.py; inside the HiFi-GAN configuration 0.82 against 1.01 ms at C = 32, L = 240 000).  At
+// k = 7 / 11 it is within +-7 % of the one-role kernel and loses 17 % at dilation 1, at C_out = 128 it loses 9-18 %
+// (profiles/r03A_probe_ws.log): those stay on the one-role kernel; st2_conv1d_f16s_set_variant(2) forces every eligible layer.
+template <int KS>
+inline bool ws_eligible(const st2_conv_desc& d) {
+  if constexpr (KS != 3 && KS != 7 && KS != 11) return false;
+  if (d.pro != ST2_PRO_ADAIN_SNAKE || g_variant == 1 || d.C_in > 256 || d.C_out > 64) return false;
+  if (ksplit_for_geometry(d) > 1) return false;
+  if (g_variant == 2) return true;
+  const int BM = d.C_out > 32 ? 64 : 32;
+  const int BN = d.C_out > 32 ? 256 : 512;
+  return KS == 3 && (int64_t)st2_cdiv(d.L_out, BN) * st2_cdiv(d.C_out, BM) * d.B >= 512;
+}
 
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
+  if constexpr (KS == 3 || KS == 7 || KS == 11) {
+    if (ws_eligible<KS>(d)) return st2ws::launch_ws_by_cout<KS, CI_T>(d, s);
+  }
   if (d.C_out > 64) return launch<KS, CI_T, 4, 1, 4>(d, s);  // 128 co x 128 l
   if (d.C_out > 32) return launch<KS, CI_T, 2, 2, 4>(d, s);  // 64 co x 256 l
   return launch<KS, CI_T, 1, 4, 4>(d, s);                    // 32 co x 512 l

@@ -126,6 +126,66 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
     assert ops.status() == 0, "benign inputs must not raise a device-side status bit"
 
 
+WS_CASES = [
+    # (B, C_in, C_out, L, ks, dil): the warp-specialised persistent build of st2_conv1d_f16s (C_out <= 64, AdaIN + Snake)
+    (32, 64, 64, 30011, 11, 5),   # 3776 tiles, 14-15 per workgroup, the 64 x 256 layout
+    (32, 32, 32, 40001, 7, 3),    # the 32 x 512 layout
+    (40, 64, 48, 3001, 3, 1),     # 12 tiles per batch item: every workgroup crosses batch items (parameter-table slots)
+    (600, 24, 24, 300, 11, 5),    # one tile (two chunks) per batch item: a new parameter table every tile
+    (3, 40, 64, 9001, 7, 1),      # ragged channels; fewer tiles than CUs (forced variant only)
+]
+
+
+@pytest.mark.parametrize("B,C_in,C_out,L,ks,dil", WS_CASES)
+@pytest.mark.parametrize("epi", ["plain", "res_stats", "res2_div"])
+def test_conv1d_f16s_warp_specialised_build_is_bitwise_the_one_role_kernel(B, C_in, C_out, L, ks, dil, epi, monkeypatch):
+    """st2_conv1d_f16s_ws.h stages and multiplies exactly what conv1d_f16s_kernel does (same operands, same MFMA order per
+    accumulator, the shared epilogue): outputs and InstanceNorm statistics must be bit-identical, and within the contract's
+    tolerance of the oracle."""
+    from styletts2_amd import _lib
+    lib = _lib.load()
+    monkeypatch.setattr(_hooks, "conv_path", "fused")
+    gen = torch.Generator().manual_seed(77)
+    pitch = (L + 31) // 32 * 32
+    x = torch.randn(B, C_in, pitch, generator=gen)[:, :, :L]
+    w = torch.randn(C_out, C_in, ks, generator=gen) / math.sqrt(C_in * ks)
+    wt = weights.pack_conv_f16s(w)
+    bias = torch.randn(C_out, generator=gen)
+    h = torch.randn(B, 2 * C_in, generator=gen) * 0.3
+    alpha = torch.rand(C_in, generator=gen) + 0.5
+    res = torch.randn(B, C_out, pitch, generator=gen)[:, :, :L] if epi != "plain" else None
+    res2 = torch.randn(B, C_out, pitch, generator=gen)[:, :, :L] if epi == "res2_div" else None
+    xg = torch.empty((B, C_in, pitch), device=DEV).copy_(torch.nn.functional.pad(x, (0, pitch - L)))[:, :, :L]
+    st = ops.instnorm_stats(xg)
+
+    def dev_rows(t):
+        return None if t is None else torch.empty((B, C_out, pitch), device=DEV).copy_(
+            torch.nn.functional.pad(t, (0, pitch - L)))[:, :, :L]
+
+    kw = dict(dil=dil, pad_left=(ks - 1) * dil // 2, bias=g(bias), pro=ops.PRO_ADAIN_SNAKE, stats=st, gamma=g(h)[:, :C_in],
+              beta=g(h)[:, C_in:], alpha=g(alpha), res=dev_rows(res), res2=dev_rows(res2), div=3.0 if epi == "res2_div" else 1.0,
+              want_stats=epi == "res_stats")
+    outs = {}
+    try:
+        for name, variant in (("one_role", 1), ("ws", 2)):
+            lib.st2_conv1d_f16s_set_variant(variant)
+            out = torch.empty((B, C_out, pitch), device=DEV)[:, :, :L]
+            r = ops.conv1d(xg, wt.to(DEV), C_out, ks, out=out, **kw)
+            torch.cuda.synchronize()
+            outs[name] = (r[0].clone(), r[1].clone()) if kw["want_stats"] else (r.clone(), None)
+    finally:
+        lib.st2_conv1d_f16s_set_variant(0)
+    assert torch.equal(outs["one_role"][0], outs["ws"][0])
+    if kw["want_stats"]:
+        assert torch.equal(outs["one_role"][1], outs["ws"][1])
+    assert ops.status() == 0
+    if B * C_in * L <= 5_000_000:  # the contract itself on the small cases (the large ones ride on the equality above)
+        ref = R.conv1d(x, wt, C_out, ks, dil=dil, pad_left=(ks - 1) * dil // 2, bias=bias, pro=R.PRO_ADAIN_SNAKE,
+                       stats=st.cpu(), gamma=h[:, :C_in], beta=h[:, C_in:], alpha=alpha, res=res, res2=res2,
+                       div=3.0 if epi == "res2_div" else 1.0)
+        assert rel_err(outs["ws"][0], ref) < 3e-6
+
+
 @pytest.mark.parametrize("B,C_in,C_out,L,ks,dil,res", [(2, 128, 128, 2500, 11, 5, True), (1, 256, 256, 515, 3, 1, False),
                                                        (2, 64, 64, 777, 7, 3, True), (1, 32, 22, 1300, 7, 1, False),
                                                        (2, 128, 128, 48001, 11, 1, True),
