@@ -21,6 +21,10 @@ SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_f
 # fused multiply-adds are written explicitly (fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC]
+# The fused conv's prologue is VALU-bound and shares its SIMD with the MFMA stream: SLP-packed f32 (v_pk_mul / v_pk_fma with
+# the v_mov shuffles that feed them) is an anti-lever there (MI355X_MICROARCH.md; profiles/r03D_probe_narrow_libs.log: one-role
+# kernel -4 % at k = 7 / C = 64, -13 % at k = 3 / C = 128 / L = 40 000, the warp-specialised k = 3 / C = 32 build +16 %: not for that one).
+EXTRA_FLAGS = {s: ["-fno-slp-vectorize"] for s in SOURCES if s.startswith("st2_conv1d_f16s_k")}
 
 
 def _hipcc():
@@ -73,18 +77,19 @@ def build_lib(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(src, obj, FLAGS):
-            cmd = [hipcc] + FLAGS + ["-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
+        flags = FLAGS + EXTRA_FLAGS.get(s, [])
+        if force or _stale(src, obj, flags):
+            cmd = [hipcc] + flags + ["-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
             if verbose:
                 print("[st2 build]", " ".join(cmd), flush=True)
             if os.path.exists(obj + ".flags"):
                 os.remove(obj + ".flags")
-            procs.append((s, obj, subprocess.Popen(cmd)))
-    for s, obj, p in procs:
+            procs.append((s, obj, flags, subprocess.Popen(cmd)))
+    for s, obj, flags, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % s)
         with open(obj + ".flags", "w") as f:
-            f.write(" ".join(FLAGS))
+            f.write(" ".join(flags))
     if force or procs or _newer(objs, LIB_PATH):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:

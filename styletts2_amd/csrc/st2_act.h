@@ -7,10 +7,11 @@ typedef _Float16 st2_h8 __attribute__((ext_vector_type(8)));
 
 static __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
-// Largest finite f16 magnitude; operands of the split-f16 convs are clamped to it before the hi cast (NaN passes).
-static __device__ __forceinline__ float st2_clamp_f16(float u) {
-  return u > 65504.f ? 65504.f : (u < -65504.f ? -65504.f : u);
-}
+// Largest finite f16 magnitude; operands of the split-f16 convs are clamped to it before the hi cast.  One v_med3_f32 (the
+// compare / select form costs four VALU instructions and two VCC wait states per element of a prologue that is VALU-bound:
+// DESIGN.md section 3 iv); finite values map exactly as before, a NaN operand becomes -65504 -- like an overflow it differs
+// from the clamped value, so the caller's `clamped != value` test reports it through ST2_STATUS_F16_RANGE.
+static __device__ __forceinline__ float st2_clamp_f16(float u) { return __builtin_amdgcn_fmed3f(u, -65504.f, 65504.f); }
 
 // sin(x)^2 to ~2.4e-7 absolute: n = rint(x/pi), r = x - n*pi (two-term, fma-exact), odd minimax
 // polynomial of degree 9 on [-pi/2, pi/2] (max abs error 1.2e-7, fitted in tools/fit_sin.py).

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
     }
     u = (lok && ci < a.C) ? u * a.x_scale : 0.f;
     // saturate to the f16 range instead of overflowing to inf (hi) / NaN (lo = u - inf): the conv then stays finite
-    // and the condition is reported through the sticky status word (NaN inputs propagate as NaN, like fp32)
+    // and the condition is reported through the sticky status word (so is a NaN operand, which becomes -65504)
     const float uc = st2_clamp_f16(u);
     sat |= uc != u;
     const _Float16 h = (_Float16)uc;

@@ -35,8 +35,8 @@ namespace {
 
 constexpr int NT = 256;
 
-struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B)
-  float mean, rstd, g, beta, alpha, inv_alpha, pad0, pad1;
+struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B); xs = x_scale, 0 for the channel tail of the last chunk
+  float mean, rstd, g, beta, alpha, inv_alpha, xs, pad1;
 };
 
 template <int KS, int CI_T, int WM, int WN, int TN>
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
     for (int ci = tid; ci < C_pad; ci += NT) {
       ChanPar p = {0.f, 1.f, 1.f, 0.f, 1.f, 1.f, 0.f, 0.f};
       if (ci < d.C_in) {
+        p.xs = d.x_scale;
         if (pro == ST2_PRO_COLNORM) {  // per-channel affine of a LayerNorm over channels (statistics are per position)
           const float g = d.gamma[(int64_t)b * d.gb_bs + ci];
           p.g = d.gamma_plus_one ? 1.0f + g : g;
@@ -167,8 +168,12 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
           const float u = (v - cmean) * crstd;
           v = u * p.g + p.beta;
         }
-        // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor
-        v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
+        // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor; with a
+        // parameter table the tail is the table's zero scale (one compare + select less per element)
+        if constexpr (PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE || PRO == ST2_PRO_SNAKE || PRO == ST2_PRO_COLNORM)
+          v = lok ? v * par[ci].xs : 0.f;
+        else
+          v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
         const float vc = st2_clamp_f16(v);  // saturate instead of inf / NaN, reported via st2_status()
         sat |= vc != v;
         const _Float16 h = (_Float16)vc;

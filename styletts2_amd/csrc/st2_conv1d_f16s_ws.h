@@ -74,8 +74,8 @@ constexpr int NCT = 256;        // consumer threads (waves 0-3)
 constexpr int NPR = 256;        // producer threads (waves 4-7; eight producer waves: 3-5 % faster, 30-140 spilled VGPRs)
 constexpr int NTW = NCT + NPR;  // threads per workgroup
 
-struct ChanPar {  // per input channel, staged per batch item in LDS (32 B)
-  float mean, rstd, g, beta, alpha, inv_alpha, pad0, pad1;
+struct ChanPar {  // per input channel, staged per batch item in LDS (32 B); xs = x_scale, 0 for the channel tail of the last chunk
+  float mean, rstd, g, beta, alpha, inv_alpha, xs, pad1;
 };
 
 struct TileGeom {  // tile index -> (batch item, co block, l block); l fastest, so a workgroup's range stays in one batch item
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NTW, 2) void conv1d_f16s_ws_kernel(const st2_conv_d
           p.beta = tp_beta;
           p.alpha = tp_alpha;
           p.inv_alpha = 1.0f / tp_alpha;
+          p.xs = d.x_scale;
         }
         if (ptid < C_pad) par[(size_t)(tp_b & 1) * C_pad + ptid] = p;
         tab_b = tp_b;
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(NTW, 2) void conv1d_f16s_ws_kernel(const st2_conv_d
             v = leaky(u, d.slope);
           else
             v = snake(u, p.alpha, p.inv_alpha);
-          // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor
-          v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
+          // zero padding (and the channel tail, through the table's scale) is applied AFTER the activation, as F.conv1d pads
+          // the activated tensor
+          v = lok ? v * p.xs : 0.f;
           const float vc = st2_clamp_f16(v);  // saturate instead of inf / NaN, reported via st2_status()
           sat |= vc != v;
           const _Float16 h = (_Float16)vc;
