@@ -393,18 +393,25 @@ int launch_ws(const st2_conv_desc& d, hipStream_t s) {
   if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_f16s: part_nt=%d < %d tiles", d.part_nt,
                           st2_cdiv(d.L_out, 128));
   ST2_REQUIRE(C_pad <= NPR, "st2_conv1d_f16s (warp-specialised): C_in=%d exceeds %d", d.C_in, NPR);
-  static int num_cu = 0;  // one workgroup per CU (every device of a process is the same part)
-  if (!num_cu) {
-    int dev = 0;
+  // one workgroup per CU: the CU count and the kernel's LDS attribute are set up once per device (a process normally drives
+  // one GPU, but nothing here may assume it: cf. the capacity cache of st2_lstm_coop.hip)
+  static int num_cu_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    st2_set_error("st2_conv1d_f16s: cannot query the current device");
+    return 1;
+  }
+  if (!num_cu_of[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      st2_set_error("st2_conv1d_f16s: cannot query the device");
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+      st2_set_error("st2_conv1d_f16s: cannot query device %d", dev);
       return 1;
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_f16s_ws_kernel<KS, CI_T, WM, WN, TN, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    num_cu = prop.multiProcessorCount;
+    num_cu_of[dev] = prop.multiProcessorCount;
   }
+  const int num_cu = num_cu_of[dev];
   TileGeom tg;
   tg.tiles_n = st2_cdiv(d.L_out, BN);
   tg.tiles_m = st2_cdiv(d.C_out, BM);
