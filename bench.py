@@ -266,6 +266,37 @@ def roofline(by_class):
                         for r in rows if r["share"] >= 0.02]}
 
 
+def _read_conv_classes(lib):
+    """Per-launch durations recorded by the st2_conv_timing hook, grouped by (ks, C_in, C_out, L, B)."""
+    import ctypes
+
+    from styletts2_amd import _lib
+    n_rec = lib.st2_conv_timing_read(None, 0)
+    rows = (ctypes.c_double * (6 * max(n_rec, 1)))()
+    _lib.check(0 if lib.st2_conv_timing_read(rows, n_rec) == n_rec else 1, "st2_conv_timing_read")
+    by_class = {}
+    for i in range(n_rec):
+        ks, ci, co, L, b, ms = rows[6 * i:6 * i + 6]
+        by_class.setdefault((int(ks), int(ci), int(co), int(L), int(b)), []).append(ms)
+    return by_class
+
+
+def _attach_unoverlapped(roof, unoverlapped):
+    """roof["unoverlapped"] = the dominant class of the timed region as measured in the untimed single-stream steps (an extra:
+    any inconsistency leaves the line as it is)."""
+    try:
+        if not unoverlapped:
+            return
+        un = roofline(unoverlapped)
+        if un.get("frac") is not None and un.get("kernel") == roof.get("kernel"):
+            roof["unoverlapped"] = {"frac": un["frac"], "achieved": un["achieved"], "avg_launch_ms": un["avg_launch_ms"],
+                                    "launches_timed": un["launches_timed"],
+                                    "what": "the same launch class in two untimed single-stream steps (no other queue on "
+                                            "the chip); `frac` above is the timed region's"}
+    except Exception as e:
+        print("[bench] un-overlapped roofline not attached: %r" % (e,), file=sys.stderr, flush=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -467,9 +498,32 @@ def main():
         log("schedule: %s" % active["name"])
     elif not longform:
         active["name"] = a.schedule if a.schedule != "auto" else "two-stream"
+    # The same conv launches WITHOUT the other queue's kernels on their CUs: two untimed single-stream steps with the per-launch
+    # events on (reported beside the timed region's figures as `roofline.unoverlapped`; the contract's `frac` stays the one of
+    # the timed region, where the front of the next batch shares the chip with the decoder's convs and stretches them).
+    lib = _lib.load()
+    unoverlapped = None
+    if not longform and "single" in sched and active["name"] != "single":
+        chosen = active["name"]
+        try:
+            active["name"] = "single"
+            step()
+            lib.st2_conv_timing(1)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            lib.st2_conv_timing(0)
+            if rank == 0:
+                unoverlapped = _read_conv_classes(lib)
+        except Exception as e:  # a measurement extra: never in the way of the timed region
+            lib.st2_conv_timing(0)
+            log("un-overlapped conv timing skipped: %r" % (e,))
+            unoverlapped = None
+        active["name"] = chosen
+        torch.cuda.synchronize()
     first_chunk_ms.clear()
     # roofline leg: per-launch HIP events around every split-f16 conv launch, by shape class
-    lib = _lib.load()
     lib.st2_conv_timing(1)  # C-ABI hook: event pairs inside st2_conv1d_xs itself, so the C++ plans' launches are seen
     torch.cuda.synchronize()
     parallel.barrier()
@@ -499,15 +553,9 @@ def main():
     torch.cuda.synchronize()
 
     if rank == 0:
-        import ctypes
-        n_rec = lib.st2_conv_timing_read(None, 0)
-        rows = (ctypes.c_double * (6 * max(n_rec, 1)))()
-        _lib.check(0 if lib.st2_conv_timing_read(rows, n_rec) == n_rec else 1, "st2_conv_timing_read")
-        by_class = {}
-        for i in range(n_rec):
-            ks, ci, co, L, b, ms = rows[6 * i:6 * i + 6]
-            by_class.setdefault((int(ks), int(ci), int(co), int(L), int(b)), []).append(ms)
+        by_class = _read_conv_classes(lib)
         roof = roofline(by_class)
+        _attach_unoverlapped(roof, unoverlapped)
         roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
         name = active["name"]
         streams = {"single": "1", "two-stream": "2 (front of step k+1 overlaps decoder of step k)",
