@@ -43,7 +43,8 @@ int st2_device_info(int dev, char* name, int cap);
  * completed.  Bits:
  *   ST2_STATUS_F16_RANGE     an operand of a split-f16 conv exceeded the f16 range after scaling (|x * x_scale| >
  *                            65504) and was clamped to +-65504 (st2_act_split, st2_conv1d_f16s): the result is finite
- *                            but not the fp32 conv's; re-run that layer with a smaller x_scale or on st2_conv1d;
+ *                            but not the fp32 conv's; re-run that layer with a smaller x_scale or on st2_conv1d.  A NaN
+ *                            operand raises the same bit (ABI 18: the clamp maps it to -65504);
  *   ST2_STATUS_LSTM_TIMEOUT  a bounded spin of st2_lstm_bidir_coop expired (a group's workgroups were not
  *                            co-resident in time): the outputs of that call are invalid;
  *   ST2_STATUS_DURATION_SUM  a row of the durations handed to st2_expand_by_durations does not sum to T (caller-supplied
