@@ -281,6 +281,26 @@ def _read_conv_classes(lib):
     return by_class
 
 
+def _all_classes(by_class):
+    """Every shape class of a recording (no 2 % cut), largest total time first: ks, C_in, C_out, L, B, launches, ms, frac."""
+    peak = F16_MFMA_PEAK_TFLOPS / F16S_PRODUCTS
+    rows = []
+    for (ks, ci, co, L, b), durs in by_class.items():
+        flop = 2.0 * b * ci * co * ks * L
+        avg = sum(durs) / len(durs)
+        rows.append({"ks": ks, "C_in": ci, "C_out": co, "L": L, "B": b, "launches": len(durs),
+                     "avg_launch_ms": round(avg, 4), "min_launch_ms": round(min(durs), 4),
+                     "max_launch_ms": round(max(durs), 4), "total_ms": round(sum(durs), 3),
+                     "achieved": round(flop / (avg * 1e-3) / 1e12, 2), "frac": round(flop / (avg * 1e-3) / 1e12 / peak, 4)})
+    rows.sort(key=lambda r: -r["total_ms"])
+    return rows
+
+
+def _dom_key(roof):
+    c = (roof.get("classes") or [{}])[0]
+    return (c.get("ks"), c.get("C_in"), c.get("C_out"), c.get("L"))
+
+
 def _attach_unoverlapped(roof, unoverlapped):
     """roof["unoverlapped"] = the dominant class of the timed region as measured in the untimed single-stream steps (an extra:
     any inconsistency leaves the line as it is)."""
@@ -288,11 +308,17 @@ def _attach_unoverlapped(roof, unoverlapped):
         if not unoverlapped:
             return
         un = roofline(unoverlapped)
-        if un.get("frac") is not None and un.get("kernel") == roof.get("kernel"):
-            roof["unoverlapped"] = {"frac": un["frac"], "achieved": un["achieved"], "avg_launch_ms": un["avg_launch_ms"],
-                                    "launches_timed": un["launches_timed"],
-                                    "what": "the same launch class in two untimed single-stream steps (no other queue on "
-                                            "the chip); `frac` above is the timed region's"}
+        if un.get("frac") is not None:
+            # the dominant class of the TIMED region leads (it need not be the dominant one here); every class follows
+            dom = [c for c in _all_classes(unoverlapped) if (c["ks"], c["C_in"], c["C_out"], c["L"]) == _dom_key(roof)]
+            head = dom[0] if dom else None
+            roof["unoverlapped"] = {"frac": head["frac"] if head else None, "achieved": head["achieved"] if head else None,
+                                    "avg_launch_ms": head["avg_launch_ms"] if head else None,
+                                    "launches_timed": head["launches"] if head else 0,
+                                    "classes": _all_classes(unoverlapped),
+                                    "what": "every launch class in two untimed single-stream steps (no other queue on "
+                                            "the chip), the timed region's dominant class first; `frac` above is the "
+                                            "timed region's"}
     except Exception as e:
         print("[bench] un-overlapped roofline not attached: %r" % (e,), file=sys.stderr, flush=True)
 
@@ -340,6 +366,10 @@ def main():
                          "kernel the library falls back to; never the measured configuration")
     ap.add_argument("--lstm-block", type=int, default=0, choices=[0, 1, 2, 4, 8],
                     help="diagnostic: utterances per cooperative BiLSTM group (0 = the library's rule)")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="diagnostic: keep every xs conv on the rule's build instead of measuring the bitwise-equivalent "
+                         "builds per shape class during the set-up step (st2_conv_tune)")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
@@ -357,10 +387,17 @@ def main():
     assert world == a.gpus, "world size %d != --gpus %d" % (world, a.gpus)
     if a.dry_run:
         parallel.barrier()
-        dt = parallel.max_over_ranks(0.001 * (rank + 1), torch.device("cpu"))
+        t_b = time.perf_counter()
+        nb = parallel.broadcast_module_weights(torch.nn.Linear(8, 8), src=0)
+        bc_s = time.perf_counter() - t_b
+        mine = 0.001 * (rank + 1)
+        dt = parallel.max_over_ranks(mine, torch.device("cpu"))
+        per_rank = parallel.gather_over_ranks(mine, torch.device("cpu"))
         parallel.barrier()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": dt}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": dt,
+                              "per_rank_ms_per_step": [round(v * 1e3, 4) for v in per_rank],
+                              "broadcast_s": round(bc_s, 4), "broadcast_bytes": nb}), flush=True)
         return
 
     from benchdata import manifest, synth  # workload definitions: model manifests, seeded synthetic weights
@@ -386,9 +423,28 @@ def main():
     sds = {k: {n: t.clone() for n, t in model[k].state_dict().items()} for k in KEYS} if rank == 0 else None
     for k in KEYS:
         model[k].eval().to(dev)
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
     nbytes = parallel.broadcast_model(model, KEYS, src=0)  # ... and broadcast over RCCL/xGMI (no-op for N=1)
+    torch.cuda.synchronize()
+    broadcast_s = time.perf_counter() - t_b
     sampler = models.make_sampler(model, graph=longform)
-    log("weights ready (%d B broadcast)" % nbytes)
+    log("weights ready (%d B broadcast in %.3f s)" % (nbytes, broadcast_s))
+    # What box is this?  Device properties, sysfs (partition modes, DPM tables, power cap, firmware) and the library's
+    # micro-probe (matrix-pipe clock, cache-level latencies, weight-stream / HBM bandwidth, workgroup census), taken with
+    # the GPU otherwise idle: the line of a run on a box nobody can log into must explain its own per-class conv times.
+    box = None
+    if rank == 0 and not a.no_box_probe:
+        from benchdata import boxinfo
+        try:
+            box = boxinfo.fingerprint(local_rank, probe=True, level=0)
+            pr = box.get("probe", {})
+            log("box probe: %s CUs, mfma random %.0f TFLOP/s @ %.2f GHz, %.1f s" % (
+                pr.get("cus"), pr.get("mfma", {}).get("random", {}).get("tflops", 0.0),
+                pr.get("mfma", {}).get("random", {}).get("clock_ghz", 0.0), pr.get("wall_s", 0.0)))
+        except Exception as e:
+            box = {"error": repr(e)}
+            log("box probe failed: %r" % (e,))
 
     steps_d = cfg["steps"]
     B = 1 if longform else PER_GPU_BATCH
@@ -462,10 +518,21 @@ def main():
                                           embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
                                           front_stream=front_s, front=lf_front)
 
-    if lf_front is not None:  # set-up, not a warm-up step: the hipGraph of the front is recorded here (one eager pass + the
-        out = step()          # capture), so that --warmup 0 does not put a capture inside the timed region
+    # Set-up, not a warm-up step: (i) the xs convs are AUTOTUNED here -- the first launch of every shape class times its
+    # bitwise-equivalent builds (tile shape / occupancy, chunk depth, XCD-aware tile order) on this box and keeps the
+    # fastest (st2_conv_tune; what a serving process does at start-up: boxes differ by up to 1.75 x per class on the rule's
+    # build); (ii) the hipGraph of the front is recorded (one eager pass + the capture), so that --warmup 0 puts neither
+    # inside the timed region.  Nothing else runs on the GPU during this step: the measurements are un-overlapped.
+    import contextlib
+    tune_ctx = contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=True)
+    t_tune = time.perf_counter()
+    with tune_ctx:
+        out = step()
         torch.cuda.synchronize()
-        log("front graph recorded")
+    tune_table = [] if a.no_autotune else ops.conv_tune_table()
+    log("set-up step done in %.2f s (%s%d conv classes tuned, %d off the rule)" % (
+        time.perf_counter() - t_tune, "front graph recorded, " if lf_front is not None else "", len(tune_table),
+        sum(1 for r in tune_table if r["candidates"] and r["chosen"] != r["candidates"][0]["variant"])))
     for i in range(a.warmup):
         out = step()
         torch.cuda.synchronize()
@@ -483,12 +550,21 @@ def main():
     # how their command processor co-schedules two queues, so the schedule is chosen by measurement,
     # the way a serving process would at start-up; all candidates are reported in `config.schedules_ms_per_step`.
     calib = {}
+    sensors = None
     if not longform and a.calib_steps > 0:
+        smp = None
+        if rank == 0 and box is not None:
+            from benchdata import boxinfo
+            smp = boxinfo.Sampler(local_rank)
+            smp.__enter__()
         for name in sched:
             active["name"] = name
             step()  # first use of these streams: allocator warm-up
             calib[name] = time_steps(a.calib_steps)
             log("calibration: %-11s %.2f ms/step" % (name, calib[name]))
+        if smp is not None:
+            smp.__exit__(None, None, None)
+            sensors = smp.summary()
         if world > 1:  # every rank runs the same schedule: rank 0's choice (no collective in steady state either way)
             order = sorted(calib)
             tt = torch.tensor([calib[n] for n in order], device=dev, dtype=torch.float64)
@@ -534,6 +610,7 @@ def main():
     parallel.barrier()
     dt = time.perf_counter() - t0
     lib.st2_conv_timing(0)
+    per_rank = parallel.gather_over_ranks(dt / max(a.steps, 1) * 1e3, dev)  # every rank's own ms/step (rank order)
     dt = parallel.max_over_ranks(dt, dev)
     log("timed %d steps: %.1f ms/step" % (a.steps, dt / a.steps * 1e3))
     if longform:
@@ -573,11 +650,22 @@ def main():
                        "diffusion_steps": steps_d, "decoder": man["config"]["decoder"]["type"],
                        "audio_s_per_step_per_gpu": audio_s, "parallelism": "utterance-sharded x%d" % world,
                        "streams": streams, "schedule": name, "schedule_requested": a.schedule,
-                       "schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()}, "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
+                       "schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()},
+                       "weights": "seeded random init, broadcast %d B from rank 0" % nbytes,
+                       "broadcast_bytes": nbytes, "broadcast_s": round(broadcast_s, 4),
+                       "per_rank_ms_per_step": [round(v, 3) for v in per_rank],
+                       "conv_autotune": ("off (--no-autotune)" if a.no_autotune else
+                                         [{"class": "k%d C%d->%d L%d B%d" % (r["ks"], r["C_in"], r["C_out"], r["L"], r["B"]),
+                                           "chosen": r["chosen_name"],
+                                           "ms": {c["name"]: c["ms"] for c in r["candidates"]}} for r in tune_table]),
                        "plan": _hooks.plan, "lstm": a.lstm, "graphed_front": not a.eager_front,
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,
         }
+        if box is not None:
+            if sensors is not None:
+                box["sensors_during_calibration"] = sensors
+            res["box"] = box
         if longform:
             res["metric"] = "audio-seconds/sec (RTF^-1) end-to-end, long-form streaming passage"
             res["config"]["sentences"] = LONGFORM_SENTENCES

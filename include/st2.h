@@ -17,7 +17,11 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
  *     stream-ordered and asynchronous; no entry point synchronises;
  *   - return value: 0 on success, non-zero on error; st2_last_error() gives the message
- *     of the last failing call on this thread.  No C++ exception crosses the ABI.
+ *     of the last failing call on this thread.  No C++ exception crosses the ABI;
+ *   - devices: every entry point works on the CURRENT HIP device of the calling thread; per-kernel settings
+ *     (dynamic LDS limits, co-residency capacities, the autotuner's table) are kept per device ordinal, so one
+ *     process may drive several GPUs.  The measurement hooks (st2_conv_timing*, st2_conv_tune*) are process-wide
+ *     and meant for one driving thread.
  */
 #ifndef ST2_H
 #define ST2_H
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 18
+#define ST2_ABI_VERSION 19
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -606,6 +610,36 @@ int st2_style_forward(st2_engine* e, int32_t which, const float* mel, int32_t B,
  * (rows may be NULL to count), < 0 on error.  Not thread safe; not legal under stream capture. */
 int st2_conv_timing(int enable);
 int st2_conv_timing_read(double* rows, int32_t cap_rows);
+
+/* ---- start-up autotuner of st2_conv1d_xs (ABI v19) ---------------------------------------------------------------- *
+ * A launch of st2_conv1d_xs exists in several BUILDS that issue the same products in the same order and share one
+ * epilogue -- results are bitwise identical (tests/test_ops_gpu.py) --: 128 x 128 tiles at 3 workgroups / CU or 128 x 256
+ * tiles at 2 (k >= 7), 32- or 16-channel chunks (k = 3), dispatch-order or XCD-aware tile order (launches with 2 / 4 / 8
+ * output row blocks: every XCD keeps ONE row block's weights in its L2).  Which is fastest depends on the shape AND on the
+ * box (MI355X boxes differ by up to 1.75 x on the C = 256 / L = 8 000 layers of Modules/istftnet.py:358-375 with the rule's
+ * build), so a serving process measures at start-up:
+ *   st2_conv_tune(1)   every FIRST launch of a shape class (device, ks, C_in, C_out, L_out, B) on a non-capturing stream
+ *                      times its candidate builds (1 warm-up + 2 x 2 launches each, output into a scratch tensor the
+ *                      library allocates for the duration of tuning mode -- the one exception to "no allocation" besides
+ *                      the status word; the caller's tensors are only read) and records the winner; the call then runs it;
+ *   st2_conv_tune(0)   leaves tuning mode (frees the scratch); recorded classes keep their build, others follow the rule;
+ *   st2_conv_tune(-1)  also forgets the current device's table.
+ * st2_conv_tune_set pins (variant >= 0: bit 0 = 128 x 256 tiles, bit 1 = XCD-aware order, bit 2 = 16-channel chunks) or
+ * erases (variant = -1) one class on the current device; st2_conv_tune_read fills rows of 24 doubles {ks, C_in, C_out,
+ * L_out, B, device, chosen variant, n candidates, (variant, ms / launch) x 8} for the current device and returns the number
+ * of classes (rows may be NULL to count).  Tuning synchronises the stream it measures on; the table is guarded by a mutex. */
+int st2_conv_tune(int mode);
+int st2_conv_tune_set(int32_t ks, int32_t C_in, int32_t C_out, int32_t L_out, int32_t B, int32_t variant);
+int st2_conv_tune_read(double* rows, int32_t cap_rows);
+
+/* ---- box probe (ABI v19; diagnostic: allocates and frees its own device buffers, synchronises the device) ----------- *
+ * Writes a JSON object (NUL terminated, <= cap bytes; 4 KB is enough) of micro-measurements of the current device:
+ * device properties, sustained matrix-pipe clock and TFLOP/s of a bare v_mfma_f32_32x32x16_f16 loop on random / all-zero
+ * operands, dependent-load latency and weight-stream bandwidth for working sets of 0.75 ... 64 MB (level >= 1: also 512
+ * MB), a 512 MB HBM copy, and where the 2 048 workgroups of a 2-per-CU launch run (CUs / XCDs seen, workgroups per CU).
+ * Takes ~0.5 s; bench.py puts it into its JSON line (`box.probe`) so that a run on a box nobody can log into still says
+ * what the box gives the conv path.  No reference call site: measurement only. */
+int st2_probe_box(char* json, int32_t cap, int32_t level);
 
 /* ---- CU-partitioned streams (ABI v17) ---------------------------------------------------------------------------- *
  * A HIP stream whose kernels may only be placed on the compute units whose bit is set in `mask` (n_words x 32 bits, bit i

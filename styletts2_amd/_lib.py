@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -205,6 +205,10 @@ _SIGNATURES = {
                                   C.c_void_p]),
     "st2_conv_timing": (C.c_int, [C.c_int]),
     "st2_conv_timing_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
+    "st2_conv_tune": (C.c_int, [C.c_int]),
+    "st2_conv_tune_set": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "st2_conv_tune_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
+    "st2_probe_box": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),
     "st2_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
     "st2_stream_destroy": (C.c_int, [C.c_void_p]),
     "st2_debug_set_backend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "st2.h"
 
 void st2_set_error(const char* fmt, ...);
@@ -32,6 +33,18 @@ __device__ __forceinline__ void st2_raise_status(int* status, int bit) {
   } while (0)
 
 static inline int st2_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute (dynamic LDS above 64 KB) is a PER-DEVICE setting: every launcher keeps one bit per device ordinal
+// and kernel instantiation, so that a process driving several GPUs sets it on each of them (advisor, round 3).  True on
+// the first launch of this instantiation on the current device (and always for ordinals >= 64: setting it again is legal).
+static inline bool st2_first_use_on_device(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const uint64_t bit = 1ull << dev;
+  if (mask.load(std::memory_order_relaxed) & bit) return false;
+  mask.fetch_or(bit, std::memory_order_relaxed);
+  return true;
+}
 
 // 64-lane butterfly-free tree (fixed order => bitwise reproducible).
 __device__ __forceinline__ double st2_wave_sum(double v) {

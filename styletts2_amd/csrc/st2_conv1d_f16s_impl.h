@@ -369,11 +369,10 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
               d.wq_cin_pad, C_pad);
   ST2_REQUIRE(d.wq_co_pad % BM == 0 && d.wq_co_pad >= d.C_out, "st2_conv1d_f16s: wq_co_pad=%d must be a multiple "
               "of %d covering C_out=%d", d.wq_co_pad, BM, d.C_out);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal
+  if (st2_first_use_on_device(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_f16s: part_nt=%d < %d tiles", d.part_nt,
                           st2_cdiv(d.L_out, 128));

@@ -1,28 +1,192 @@
 // C entry points of the xs conv family; the kernels live in st2_conv1d_xs_impl.h and are instantiated in
-// st2_conv1d_xs_k{0,1,2}.hip.
+// st2_conv1d_xs_k{0..4}.hip.  Also here: the per-launch timing hook of bench.py's roofline leg and the start-up
+// autotuner that picks, per shape class and device, the fastest of the bitwise-equivalent builds of a launch.
 #include "st2_conv1d_xs_impl.h"
 
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
-extern template int st2xs::launch_by_cout<1, 32>(const st2_conv_desc&, hipStream_t);
-extern template int st2xs::launch_by_cout<2, 32>(const st2_conv_desc&, hipStream_t);
-extern template int st2xs::launch_by_cout<3, 32>(const st2_conv_desc&, hipStream_t);
-extern template int st2xs::launch_by_cout<5, 16>(const st2_conv_desc&, hipStream_t);
-extern template int st2xs::launch_by_cout<7, 16>(const st2_conv_desc&, hipStream_t);
-extern template int st2xs::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t);
+extern template int st2xs::launch_by_cout<1, 32>(const st2_conv_desc&, hipStream_t, int);
+extern template int st2xs::launch_by_cout<2, 32>(const st2_conv_desc&, hipStream_t, int);
+extern template int st2xs::launch_by_cout<3, 32>(const st2_conv_desc&, hipStream_t, int);
+extern template int st2xs::launch_by_cout<3, 16>(const st2_conv_desc&, hipStream_t, int);
+extern template int st2xs::launch_by_cout<5, 16>(const st2_conv_desc&, hipStream_t, int);
+extern template int st2xs::launch_by_cout<7, 16>(const st2_conv_desc&, hipStream_t, int);
+extern template int st2xs::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t, int);
 
-
-// Measurement hook (bench.py's roofline leg): HIP events around every st2_conv1d_xs launch, on the launch stream,
-// whoever issues it (the C++ plans of st2_engine.hip or the Python per-kernel plans).  Not thread safe, not legal under
-// stream capture: enabled around the bench's timed region only.
 namespace {
+
+int launch_xs(const st2_conv_desc& d, hipStream_t s, int variant) {
+  switch (d.ks) {
+    case 1:
+      return st2xs::launch_by_cout<1, 32>(d, s, variant);
+    case 2:
+      return st2xs::launch_by_cout<2, 32>(d, s, variant);
+    case 3:
+      if (variant >= 0 && (variant & st2xs::XS_V_CHUNK16)) return st2xs::launch_by_cout<3, 16>(d, s, variant);
+      return st2xs::launch_by_cout<3, 32>(d, s, variant);
+    case 5:
+      return st2xs::launch_by_cout<5, 16>(d, s, variant);
+    case 7:
+      return st2xs::launch_by_cout<7, 16>(d, s, variant);
+    case 11:
+      return st2xs::launch_by_cout<11, 16>(d, s, variant);
+    default:
+      st2_set_error("st2_conv1d_xs: unsupported kernel size %d (have 1,2,3,5,7,11)", d.ks);
+      return 1;
+  }
+}
+
+// ---- measurement hook (bench.py's roofline leg) ---------------------------------------------------------------------
+// HIP events around every st2_conv1d_xs launch, on the launch stream, whoever issues it (the C++ plans of st2_engine.hip
+// or the Python per-kernel plans).  Process-wide and single-threaded by contract (st2.h), not legal under stream capture:
+// enabled around the bench's timed region only.
 struct TimedLaunch {
   int ks, c_in, c_out, L, B;
   hipEvent_t e0, e1;
 };
 std::vector<TimedLaunch> g_timed;
 bool g_timing = false;
-int launch_xs(const st2_conv_desc& d, hipStream_t s);
+
+// ---- start-up autotuner ----------------------------------------------------------------------------------------------
+// Key = (device, ks, C_in, C_out, L_out, B); value = the variant (st2xs::XS_V_* bits) that won the measurement.  Every
+// candidate issues the same products in the same order and the same epilogue, so the choice changes time, never results.
+typedef std::tuple<int, int, int, int, int, int> TuneKey;
+struct TuneEntry {
+  int chosen = st2xs::XS_V_RULE;
+  int n = 0;
+  int variant[8] = {};
+  float ms[8] = {};
+};
+std::mutex g_tune_mu;
+std::map<TuneKey, TuneEntry> g_tune;
+std::atomic<int> g_tune_entries{0};
+std::atomic<int> g_tune_mode{0};
+void* g_scratch = nullptr;  // candidate launches write here, never into the caller's output (it may alias a residual)
+size_t g_scratch_bytes = 0;
+int g_scratch_dev = -1;
+
+int current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+
+// The rule's variant for this launch (what an untuned process runs), as XS_V_* bits.
+int rule_variant(const st2_conv_desc& d) {
+  if (d.C_out > 64 && d.ks >= 7 && (int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024)
+    return st2xs::XS_V_WIDE;
+  return 0;
+}
+
+std::vector<int> candidates(const st2_conv_desc& d) {
+  std::vector<int> c;
+  const int rule = rule_variant(d);
+  c.push_back(rule);
+  if (d.C_out <= 64 || d.ks == 1) return c;  // narrow tiles / token GEMMs: one build each
+  // only launches worth ~20 us or more are measured (the others stay on the rule)
+  if (2.0 * d.B * d.C_in * (double)d.C_out * d.ks * d.L_out < 4e9) return c;
+  const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
+  const int ny = st2_cdiv(d.C_out, 128);
+  const bool swz = (ny == 2 || ny == 4 || ny == 8);
+  auto add = [&](int v) {
+    for (int x : c)
+      if (x == v) return;
+    if ((v & st2xs::XS_V_SWIZZLE) && !swz) return;
+    if (c.size() < 8) c.push_back(v);
+  };
+  if (d.ks >= 7) {
+    add(0);
+    if (wg128 >= 512) add(st2xs::XS_V_WIDE);
+    add(st2xs::XS_V_SWIZZLE);
+    if (wg128 >= 512) add(st2xs::XS_V_WIDE | st2xs::XS_V_SWIZZLE);
+  } else if (d.ks == 3) {
+    add(st2xs::XS_V_CHUNK16);
+    add(st2xs::XS_V_SWIZZLE);
+    add(st2xs::XS_V_CHUNK16 | st2xs::XS_V_SWIZZLE);
+  } else {
+    add(st2xs::XS_V_SWIZZLE);
+  }
+  return c;
+}
+
+bool ensure_scratch(size_t bytes) {
+  const int dev = current_device();
+  if (g_scratch && g_scratch_dev == dev && g_scratch_bytes >= bytes) return true;
+  if (g_scratch) (void)hipFree(g_scratch);
+  g_scratch = nullptr;
+  g_scratch_bytes = 0;
+  if (hipMalloc(&g_scratch, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    g_scratch = nullptr;
+    return false;
+  }
+  g_scratch_bytes = bytes;
+  g_scratch_dev = dev;
+  return true;
+}
+
+// Times every candidate build of this launch on the caller's stream (synchronously: tuning mode is a start-up phase) and
+// returns the winner; the caller's tensors are only READ (outputs go to a scratch tensor of the same strides).
+int tune_launch(const st2_conv_desc& d, hipStream_t s, TuneEntry& e) {
+  const std::vector<int> cands = candidates(d);
+  e.n = (int)cands.size();
+  for (int i = 0; i < e.n; ++i) e.variant[i] = cands[i];
+  e.chosen = cands[0];
+  if (e.n < 2) return e.chosen;
+  const size_t bytes = ((size_t)(d.B - 1) * d.y_bs + (size_t)(d.C_out - 1) * d.y_cs + d.L_out + 64) * sizeof(float);
+  if (!ensure_scratch(bytes)) return e.chosen;  // no memory to measure in: the rule stands
+  st2_conv_desc t = d;
+  t.y = reinterpret_cast<float*>(g_scratch);
+  // the caller's alignment class decides which epilogue build runs: keep it (hipMalloc returns >= 256-byte alignment)
+  t.y += (reinterpret_cast<uintptr_t>(d.y) & 255) / sizeof(float);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return e.chosen;
+  constexpr int GROUPS = 2, PER = 2;
+  for (int i = 0; i < e.n; ++i) {
+    float best = 1e30f;
+    bool ok = launch_xs(t, s, cands[i]) == 0;  // warm-up: code object, LDS attribute, clocks
+    for (int g = 0; ok && g < GROUPS; ++g) {
+      (void)hipEventRecord(e0, s);
+      for (int r = 0; ok && r < PER; ++r) ok = launch_xs(t, s, cands[i]) == 0;
+      (void)hipEventRecord(e1, s);
+      float ms = 0.f;
+      ok = ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      if (ok && ms / PER < best) best = ms / PER;
+    }
+    e.ms[i] = ok ? best : -1.f;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  // the rule's build (candidate 0) keeps the launch unless another one is at least 2 % faster
+  int win = 0;
+  for (int i = 1; i < e.n; ++i)
+    if (e.ms[i] > 0.f && e.ms[win] > 0.f && e.ms[i] < e.ms[win] * (win == 0 ? 0.98f : 1.0f)) win = i;
+  e.chosen = e.ms[win] > 0.f ? cands[win] : cands[0];
+  return e.chosen;
+}
+
+int pick_variant(const st2_conv_desc& d, hipStream_t s) {
+  if (!g_tune_mode.load(std::memory_order_relaxed) && !g_tune_entries.load(std::memory_order_relaxed))
+    return st2xs::XS_V_RULE;
+  const TuneKey key(current_device(), d.ks, d.C_in, d.C_out, d.L_out, d.B);
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  auto it = g_tune.find(key);
+  if (it != g_tune.end()) return it->second.chosen;
+  if (!g_tune_mode.load(std::memory_order_relaxed)) return st2xs::XS_V_RULE;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return st2xs::XS_V_RULE;  // a capture cannot be timed: the class stays untuned for now
+  }
+  TuneEntry e;
+  tune_launch(d, s, e);
+  g_tune[key] = e;
+  g_tune_entries.store((int)g_tune.size(), std::memory_order_relaxed);
+  return e.chosen;
+}
+
 }  // namespace
 
 extern "C" int st2_conv_timing(int enable) {
@@ -55,6 +219,62 @@ extern "C" int st2_conv_timing_read(double* rows, int32_t cap_rows) {
   return n;
 }
 
+extern "C" int st2_conv_tune(int mode) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  if (mode < 0) {  // forget every measurement of the current device
+    const int dev = current_device();
+    for (auto it = g_tune.begin(); it != g_tune.end();) it = std::get<0>(it->first) == dev ? g_tune.erase(it) : std::next(it);
+    g_tune_entries.store((int)g_tune.size(), std::memory_order_relaxed);
+    mode = 0;
+  }
+  g_tune_mode.store(mode != 0, std::memory_order_relaxed);
+  if (!mode && g_scratch) {
+    (void)hipFree(g_scratch);
+    g_scratch = nullptr;
+    g_scratch_bytes = 0;
+  }
+  return 0;
+}
+
+extern "C" int st2_conv_tune_set(int32_t ks, int32_t C_in, int32_t C_out, int32_t L_out, int32_t B, int32_t variant) {
+  ST2_REQUIRE(variant >= -1 && variant < 8, "st2_conv_tune_set: variant %d out of range", variant);
+  const TuneKey key(current_device(), ks, C_in, C_out, L_out, B);
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  if (variant < 0) {
+    g_tune.erase(key);
+  } else {
+    TuneEntry e;
+    e.chosen = variant;
+    e.n = 1;
+    e.variant[0] = variant;
+    e.ms[0] = 0.f;
+    g_tune[key] = e;
+  }
+  g_tune_entries.store((int)g_tune.size(), std::memory_order_relaxed);
+  return 0;
+}
+
+extern "C" int st2_conv_tune_read(double* rows, int32_t cap_rows) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  const int dev = current_device();
+  int n = 0;
+  for (auto& kv : g_tune) {
+    if (std::get<0>(kv.first) != dev) continue;
+    if (rows && n < cap_rows) {
+      double* r = rows + (int64_t)n * 24;
+      r[0] = std::get<1>(kv.first); r[1] = std::get<2>(kv.first); r[2] = std::get<3>(kv.first);
+      r[3] = std::get<4>(kv.first); r[4] = std::get<5>(kv.first); r[5] = dev;
+      r[6] = kv.second.chosen; r[7] = kv.second.n;
+      for (int i = 0; i < 8; ++i) {
+        r[8 + 2 * i] = i < kv.second.n ? kv.second.variant[i] : -1;
+        r[9 + 2 * i] = i < kv.second.n ? kv.second.ms[i] : 0.0;
+      }
+    }
+    ++n;
+  }
+  return n;
+}
+
 extern "C" int st2_conv1d_xs(const st2_conv_desc* dp, void* stream) {
   ST2_REQUIRE(dp != nullptr, "st2_conv1d_xs: null descriptor");
   const st2_conv_desc& d = *dp;
@@ -74,37 +294,16 @@ extern "C" int st2_conv1d_xs(const st2_conv_desc* dp, void* stream) {
               "st2_conv1d_xs: a batch item of y / res / res2 must span < 2^31 elements");
   if (d.part) ST2_REQUIRE((reinterpret_cast<uintptr_t>(d.part) & 7) == 0, "st2_conv1d_xs: part must be 8-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int variant = pick_variant(d, s);
   if (g_timing && d.C_in >= 64 && d.L_out >= 256 && g_timed.size() < 65536) {
     TimedLaunch t{d.ks, d.C_in, d.C_out, d.L_out, d.B, nullptr, nullptr};
     if (hipEventCreate(&t.e0) == hipSuccess && hipEventCreate(&t.e1) == hipSuccess) {
       (void)hipEventRecord(t.e0, s);
-      const int rc = launch_xs(d, s);
+      const int rc = launch_xs(d, s, variant);
       (void)hipEventRecord(t.e1, s);
       g_timed.push_back(t);
       return rc;
     }
   }
-  return launch_xs(d, s);
+  return launch_xs(d, s, variant);
 }
-
-namespace {
-int launch_xs(const st2_conv_desc& d, hipStream_t s) {
-  switch (d.ks) {
-    case 1:
-      return st2xs::launch_by_cout<1, 32>(d, s);
-    case 2:
-      return st2xs::launch_by_cout<2, 32>(d, s);
-    case 3:
-      return st2xs::launch_by_cout<3, 32>(d, s);
-    case 5:
-      return st2xs::launch_by_cout<5, 16>(d, s);
-    case 7:
-      return st2xs::launch_by_cout<7, 16>(d, s);
-    case 11:
-      return st2xs::launch_by_cout<11, 16>(d, s);
-    default:
-      st2_set_error("st2_conv1d_xs: unsupported kernel size %d (have 1,2,3,5,7,11)", d.ks);
-      return 1;
-  }
-}
-}  // namespace

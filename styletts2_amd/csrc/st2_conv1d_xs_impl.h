@@ -46,8 +46,11 @@ constexpr int ABL = ST2_XS_ABLATE;
 // Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
 // one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
 // 0.42 ms vs 0.48 ms on the dominant layer at B = 8).
+// `flags` bit 0 = XCD-aware tile order (see st2xs::XS_V_SWIZZLE): workgroup `lin` of the launch runs on XCD lin % 8
+// (observed dispatch order, MI355X_MICROARCH.md), and a launch whose output rows span ny = 2 / 4 / 8 row blocks gives
+// every XCD ONE of them, so that an XCD's 4 MB L2 holds 1 / ny of the packed weights instead of all of them.
 template <int KS, int CI_T, int WM, int WN, int TN>
-__device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
+__device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int flags) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;     // 8-channel groups per chunk
@@ -67,9 +70,18 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
   const int l31 = lane & 31;
   const int wm = wave / WN;
   const int wn = wave % WN;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
-  const int b = blockIdx.z;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (flags & 1) {  // scalar arithmetic only; the launcher checked gridDim.y in {2, 4, 8} and 8 | workgroup count
+    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+    const unsigned ny = gridDim.y, xcd = lin & 7, slot = lin >> 3;
+    by = xcd % ny;
+    const unsigned r = xcd / ny + (8 / ny) * slot;  // enumerates (l tile, batch item) within this row block
+    bx = r % gridDim.x;
+    bz = r / gridDim.x;
+  }
+  const int n0 = bx * BN;
+  const int m0 = by * BM;
+  const int b = bz;
 
   const int XW = BN + (KS - 1) * d.dil;  // staged positions per row
   const int S = ROWS * XW;               // staged slots per chunk
@@ -258,30 +270,33 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d) {
 }
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
-__global__ __launch_bounds__(NT, 2) void conv1d_xs_kernel(const st2_conv_desc d) {  // >= 2 workgroups per CU
-  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
+__global__ __launch_bounds__(NT, 2) void conv1d_xs_kernel(const st2_conv_desc d, const int flags) {  // >= 2 workgroups per CU
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, flags);
 }
 template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc d) {  // <= 168 VGPRs
-  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
+__global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc d, const int flags) {  // <= 168 VGPRs
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, flags);
 }
 
 template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 4) void conv1d_xs_kernel_o4(const st2_conv_desc d) {  // <= 128 VGPRs: narrow tiles only
-  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d);
+__global__ __launch_bounds__(NT, 4) void conv1d_xs_kernel_o4(const st2_conv_desc d, const int flags) {  // <= 128 VGPRs: narrow tiles only
+  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, flags);
 }
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
-int launch(const st2_conv_desc& d, hipStream_t s) {
+int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   const int XW = BN + (KS - 1) * d.dil;
-  const int C_pad = (d.C_in + CI_T - 1) / CI_T * CI_T;
+  // The packing's k order is (ci / 16, tap, ci % 16) whatever the chunk depth, so a weight padded to 32-channel chunks also
+  // serves the 16-channel-chunk build (its last chunk is then all-zero weights on the planes' zero channel padding).
+  const int C_pad = d.wq_cin_pad;
   constexpr int NS = ((2 * CI_T / 8) * (BN + (KS - 1) * 8) + NT - 1) / NT;
   const size_t smem = (size_t)2 * NS * NT * 16;
   ST2_REQUIRE(smem <= 160 * 1024, "st2_conv1d_xs: tile needs %zu B of LDS (ks=%d dil=%d)", smem, KS, d.dil);
-  ST2_REQUIRE(d.wq_cin_pad == C_pad, "st2_conv1d_xs: packed weight has %d input channels, kernel needs %d",
-              d.wq_cin_pad, C_pad);
+  ST2_REQUIRE(C_pad % CI_T == 0 && C_pad >= d.C_in && C_pad < d.C_in + 32,
+              "st2_conv1d_xs: packed weight has %d input channels, kernel needs C_in=%d padded to a multiple of %d",
+              d.wq_cin_pad, d.C_in, CI_T);
   ST2_REQUIRE(d.wq_co_pad % BM == 0 && d.wq_co_pad >= d.C_out, "st2_conv1d_xs: wq_co_pad=%d must be a multiple "
               "of %d covering C_out=%d", d.wq_co_pad, BM, d.C_out);
   ST2_REQUIRE(d.xs_cg * 8 >= C_pad, "st2_conv1d_xs: xs has %d channel groups, kernel needs %d", d.xs_cg, C_pad / 8);
@@ -293,8 +308,8 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_xs: part_nt=%d < %d tiles", d.part_nt,
                           st2_cdiv(d.L_out, 128));
   if constexpr (TN < 4) ST2_REQUIRE(!d.part, "st2_conv1d_xs: the narrow token tiles do not produce partial sums");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal (hipFuncSetAttribute is per device)
+  if (st2_first_use_on_device(attr_done)) {
     if constexpr (OCC == 4)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -304,15 +319,16 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
     else
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
+  // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a workgroup count divisible by 8
+  const int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0;
   if constexpr (OCC == 4)
-    hipLaunchKernelGGL((conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
+    hipLaunchKernelGGL((conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, flags);
   else if constexpr (OCC == 3)
-    hipLaunchKernelGGL((conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d);
+    hipLaunchKernelGGL((conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, flags);
   else
-    hipLaunchKernelGGL((conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>), grid, dim3(NT), smem, s, d);
+    hipLaunchKernelGGL((conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>), grid, dim3(NT), smem, s, d, flags);
   ST2_CHECK_LAUNCH("st2_conv1d_xs");
   return 0;
 }
@@ -321,18 +337,32 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
 
 namespace st2xs {
 
+// Builds of one launch ("variants": same products in the same order, same epilogue, bitwise the same results --
+// tests/test_ops_gpu.py::test_xs_variants_are_bitwise_identical).  Which one is fastest depends on the box as well as on
+// the shape: driver-class MI355X boxes run the 128 x 256 tile build 1.5-1.75 x slower than builder-class boxes on the
+// C = 256 / L = 8 000 layers and only there, so the choice is MEASURED per shape class at start-up
+// (st2_conv_tune, st2_conv1d_xs.hip) and falls back to the rule below when a class was not tuned.
+//   bit 0  XS_V_WIDE     128 (co) x 256 (l) tiles, 2 workgroups / CU (k >= 7 only) instead of 128 x 128, 3 workgroups / CU
+//   bit 1  XS_V_SWIZZLE  XCD-aware tile order: one row block per XCD (launches with 2 / 4 / 8 row blocks)
+//   bit 2  XS_V_CHUNK16  16-channel chunks for k <= 3 (half the LDS image per barrier, twice the barriers); selects the
+//                        launch_by_cout<KS, 16> instantiation in the dispatcher, ignored here
+enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4 };
+
 template <int KS, int CI_T>
-int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
+int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
+  const bool swz = variant >= 0 && (variant & XS_V_SWIZZLE);
   if (d.C_out > 64) {
     // k >= 7: 32 (co) x 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU: half the weight stream (L2 ->
     // registers) per FLOP; measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32,
     // 1.03 vs 1.10 ms at C = 256, L = 8 000; no gain at k = 3 (tools/xs_bench.hip, profiles/r02i_xs_bench_tn8.log)
-    // ... when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a single utterance
+    // ... BY RULE when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a single utterance
     // (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs
     if constexpr (KS >= 7) {
-      if ((int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024) return launch<KS, CI_T, 4, 1, 8, 2>(d, s);
+      const bool wide = variant >= 0 ? (variant & XS_V_WIDE) != 0
+                                     : (int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024;
+      if (wide) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
     }
-    if constexpr (KS == 1) {
+    if constexpr (KS == 1 && CI_T == 32) {
       // Token GEMMs (the denoiser's / PL-BERT's Linears over the B*N merged tokens: C_out 512..1024 x 3 200 columns): at
       // 128 x 128 they are < 256 workgroups -- fewer than CUs, one per CU, nothing to hide the staging latency of a
       // 768-cycle chunk behind.  128 (co) x 64 (l) tiles double the workgroup count and 64-channel chunks double the
@@ -340,17 +370,17 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s) {
       // 27.9 -> 22.4 (tools/gemm_bench.hip, profiles/r03c_gemm_bench.log); launches that already have >= 256 tiles
       // (C_out >= 2048) are fastest as they are.  Same products in the same order: results are bitwise unchanged.
       if ((int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B < 256 && d.wq_cin_pad % 64 == 0 && !d.part)
-        return launch<1, 64, 4, 1, 2, 3>(d, s);
+        return launch<1, 64, 4, 1, 2, 3>(d, s, swz);
     }
-    return launch<KS, CI_T, 4, 1, 4, 3>(d, s);  // 128 co x 128 l, 3 workgroups / CU
+    return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz);  // 128 co x 128 l, 3 workgroups / CU
   }
   if (d.C_out > 32) {                                           // 64 co x 256 l
     if constexpr (CI_T == 16)
-      return launch<KS, CI_T, 2, 2, 4, 3>(d, s);
+      return launch<KS, CI_T, 2, 2, 4, 3>(d, s, swz);
     else
-      return launch<KS, CI_T, 2, 2, 4, 2>(d, s);  // the 168-VGPR build spills with 32-channel chunks
+      return launch<KS, CI_T, 2, 2, 4, 2>(d, s, swz);  // the 168-VGPR build spills with 32-channel chunks
   }
-  return launch<KS, CI_T, 1, 4, 4, 2>(d, s);  // 32 co x 512 l
+  return launch<KS, CI_T, 1, 4, 4, 2>(d, s, swz);  // 32 co x 512 l
 }
 
 }  // namespace st2xs

@@ -1,5 +1,5 @@
 // Explicit instantiations of the xs conv for kernel sizes [3, 5] (split over translation units for build time).
 #include "st2_conv1d_xs_impl.h"
 
-template int st2xs::launch_by_cout<3, 32>(const st2_conv_desc&, hipStream_t);
-template int st2xs::launch_by_cout<5, 16>(const st2_conv_desc&, hipStream_t);
+template int st2xs::launch_by_cout<3, 32>(const st2_conv_desc&, hipStream_t, int);
+template int st2xs::launch_by_cout<5, 16>(const st2_conv_desc&, hipStream_t, int);

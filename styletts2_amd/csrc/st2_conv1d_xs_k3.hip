@@ -1,4 +1,4 @@
 // Explicit instantiations of the xs conv for kernel size 11 (split over translation units for build time).
 #include "st2_conv1d_xs_impl.h"
 
-template int st2xs::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t);
+template int st2xs::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t, int);

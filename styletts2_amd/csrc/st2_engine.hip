@@ -1166,7 +1166,9 @@ void dn_run(Sess& s, View base, const float* x, const float* m, float* out) {
     // merged columns: st2_act_split picks the affine row of a column from its utterance (gb_seg = N).  That needs the xs
     // pair (>= XS_MIN_L columns); smaller calls (one sentence of the long-form loop) keep the [B][F][N] view.  Measured
     // at B = 32, N = 100: 2 x 99 us (fused kernel on 32 rows of 100 columns, 0.04-0.08 of the roof) -> ~65 us per layer.
-    const bool seg = cfg.multispeaker && s.merged && B > 1 && (int64_t)B * N >= XS_MIN_L;
+    // ... and conv()'s routing rule: nets of <= FUSED_K3_MAX_C features (small / test configurations) send k = 1 convs with
+    // a prologue to the fused kernel, which has no per-segment affine: they keep the per-utterance view (advisor, round 3).
+    const bool seg = cfg.multispeaker && s.merged && B > 1 && (int64_t)B * N >= XS_MIN_L && Fz > FUSED_K3_MAX_C;
     if (seg) o1.gb_seg = o2.gb_seg = N;
     const bool per_utt = cfg.multispeaker && !seg;
     View Xv = per_utt ? X : dn_cv(s, X), qv = per_utt ? qkv : dn_cv(s, qkv);

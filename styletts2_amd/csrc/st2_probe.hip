@@ -1,0 +1,373 @@
+// Box probe: a < 1 s set of micro-measurements that says what THIS MI355X gives the conv path, so that a bench line
+// from a box nobody can log into still explains itself (bench.py `box.probe`, tools/probe_box.py).
+//
+// Why it exists: the same library runs the C = 256 / L = 8 000 vocoder convs 1.5-1.75 x slower on one class of boxes
+// (VERDICT round 3), everything else within 10 %.  Candidate mechanisms are a lower sustained matrix-pipe clock, a slower
+// or smaller-acting L2 / Infinity Cache for the 1.8-2.9 MB weight sets those launches re-read, fewer usable CUs or an
+// uneven workgroup -> XCD deal.  Each has one number here:
+//   mfma       sustained shader clock (s_memtime / s_memrealtime) and TFLOP/s of a bare v_mfma_f32_32x32x16_f16 loop on
+//              random and on all-zero operands (the pipe is power-limited: DESIGN.md section 3)
+//   sets       for working sets of 0.75 / 1.8 / 2.9 / 12.6 / 64 / 512 MB: dependent-load latency (one lane per CU chasing a
+//              random cycle of 128-byte lines: L2 / Infinity Cache / HBM show as steps) and the aggregate GB/s of every
+//              CU streaming the whole set the way the conv streams its weights (32 B per lane, few loads in flight)
+//   hbm_copy   GB/s of a 512 MB -> 512 MB copy
+//   census     a 2 048-workgroup launch at 2 workgroups / CU (the slow class's grid): CUs and XCDs that took workgroups,
+//              workgroups per CU / XCD, rounds
+// This is a diagnostic entry point: it allocates and frees its own device buffers and synchronises the device.
+#include "st2_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void probe_fill_f16(_Float16* p, int64_t n, uint32_t seed, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h = (uint32_t)i * 2654435761u + seed;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+  p[i] = (_Float16)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
+}
+
+// Bare matrix-pipe loop: 4 independent accumulators per wave, operands loaded once.
+__global__ __launch_bounds__(256) void probe_mfma_kernel(const h8* ops, int iters, unsigned long long* stamps, float* sink) {
+  const int lane = threadIdx.x & 63;
+  const h8 a = ops[lane], b = ops[64 + lane];
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[j][r];
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (t == 12345.678f) sink[threadIdx.x] = t;
+  if (threadIdx.x == 0) {
+    stamps[blockIdx.x * 2 + 0] = t1 - t0;
+    stamps[blockIdx.x * 2 + 1] = r1 - r0;
+  }
+}
+
+// One lane per workgroup follows a random cycle through 128-byte lines: ns per dependent load.
+__global__ void probe_chase_kernel(const uint32_t* lines, uint32_t n_lines, int hops, unsigned long long* out, uint32_t* sink) {
+  if (threadIdx.x != 0) return;
+  uint32_t i = (uint32_t)(((uint64_t)blockIdx.x * 2654435761u) % n_lines);
+  for (int k = 0; k < 64; ++k) i = lines[(size_t)i * 32];  // settle (TLB, first touch)
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < hops; ++k) i = lines[(size_t)i * 32];
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x] = r1 - r0;
+  if (i == 0xffffffffu) sink[0] = i;
+}
+
+// Every workgroup streams the whole set `reps` times, 32 B per lane and step with `AHEAD` steps in flight -- the access
+// pattern of the conv's weight stream (st2_conv1d_xs_impl.h: two k-steps ahead).
+template <int AHEAD>
+__global__ __launch_bounds__(256) void probe_stream_kernel(const u32x4* set, uint32_t n_vec, int reps, uint32_t* sink) {
+  const uint32_t stride = 256 * 2;  // 16-byte vectors per step and workgroup
+  const uint32_t steps = n_vec / stride;
+  u32x4 acc = {0, 0, 0, 0};
+  for (int r = 0; r < reps; ++r) {
+    // workgroups start at staggered offsets like conv tiles that drift apart
+    uint32_t s0 = (blockIdx.x * 37u + r * 11u) % steps;
+    u32x4 v[AHEAD][2];
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) {
+      const uint32_t st = (s0 + a) % steps;
+      v[a][0] = set[(size_t)st * stride + threadIdx.x * 2];
+      v[a][1] = set[(size_t)st * stride + threadIdx.x * 2 + 1];
+    }
+    for (uint32_t k = 0; k < steps; k += AHEAD) {
+#pragma unroll
+      for (int a = 0; a < AHEAD; ++a) {
+        acc ^= v[a][0];
+        acc ^= v[a][1];
+        const uint32_t st = (s0 + k + AHEAD + a) % steps;
+        v[a][0] = set[(size_t)st * stride + threadIdx.x * 2];
+        v[a][1] = set[(size_t)st * stride + threadIdx.x * 2 + 1];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) acc ^= v[a][0] ^ v[a][1];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) sink[threadIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n_vec) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (; i + 3 * step < n_vec; i += 4 * step) {
+    const u32x4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+    dst[i] = a; dst[i + step] = b; dst[i + 2 * step] = c; dst[i + 3 * step] = d;
+  }
+  for (; i < n_vec; i += step) dst[i] = src[i];
+}
+
+// Where do the workgroups of a 2 048-workgroup, 2-per-CU launch run?
+__global__ __launch_bounds__(256) void probe_census_kernel(unsigned long long* out, unsigned long long spin_ticks) {
+  extern __shared__ unsigned char census_lds[];
+  if (threadIdx.x == 0) census_lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - r0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 2 + 0] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |
+                              ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
+    out[blockIdx.x * 2 + 1] = r0;
+  }
+}
+
+struct Json {
+  std::string s;
+  void raw(const char* t) { s += t; }
+  void kv(const char* k, double v, const char* fmt = "%.4g") {
+    char b[96];
+    snprintf(b, sizeof b, "\"%s\": ", k);
+    s += b;
+    snprintf(b, sizeof b, fmt, v);
+    s += b;
+  }
+};
+
+#define PCK(x)                                                                   \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) {                                                      \
+      st2_set_error("st2_probe_box: %s: %s", #x, hipGetErrorString(e_));        \
+      cleanup();                                                                 \
+      return 1;                                                                  \
+    }                                                                            \
+  } while (0)
+
+}  // namespace
+
+extern "C" int st2_probe_box(char* json, int32_t cap, int32_t level) {
+  ST2_REQUIRE(json && cap >= 256, "st2_probe_box: need an output buffer of >= 256 bytes");
+  std::vector<void*> bufs;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : bufs) (void)hipFree(p);
+    bufs.clear();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    e0 = e1 = nullptr;
+  };
+  auto alloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    bufs.push_back(p);
+    return p;
+  };
+  int dev = 0;
+  PCK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  PCK(hipGetDeviceProperties(&prop, dev));
+  const int num_cu = prop.multiProcessorCount;
+  PCK(hipEventCreate(&e0));
+  PCK(hipEventCreate(&e1));
+  auto elapsed = [&](float& ms) -> hipError_t {
+    hipError_t e = hipEventSynchronize(e1);
+    return e != hipSuccess ? e : hipEventElapsedTime(&ms, e0, e1);
+  };
+  Json js;
+  js.raw("{");
+  js.kv("cus", num_cu, "%.0f");
+  js.raw(", ");
+  js.kv("clock_mhz", prop.clockRate / 1e3, "%.0f");
+  js.raw(", ");
+  js.kv("mem_clock_mhz", prop.memoryClockRate / 1e3, "%.0f");
+  js.raw(", ");
+  js.kv("l2_bytes", prop.l2CacheSize, "%.0f");
+  js.raw(", ");
+  js.kv("lds_per_cu", (double)prop.maxSharedMemoryPerMultiProcessor, "%.0f");
+  js.raw(", ");
+  js.kv("total_mem_gb", prop.totalGlobalMem / 1e9, "%.1f");
+
+  uint32_t* sink = (uint32_t*)alloc(4096);
+  unsigned long long* stamps = (unsigned long long*)alloc(4096 * 16);
+  if (!sink || !stamps) { st2_set_error("st2_probe_box: out of device memory"); cleanup(); return 1; }
+
+  // ---- matrix pipe --------------------------------------------------------------------------------------------------
+  {
+    h8* ops = (h8*)alloc(128 * 16);
+    if (!ops) { st2_set_error("st2_probe_box: out of device memory"); cleanup(); return 1; }
+    const int wgs = num_cu * 2, iters = 3000;
+    js.raw(", \"mfma\": {");
+    for (int zero = 0; zero < 2; ++zero) {
+      hipLaunchKernelGGL(probe_fill_f16, dim3(4), dim3(256), 0, 0, (_Float16*)ops, (int64_t)1024, 77u, zero ? 0.f : 24.f);
+      hipLaunchKernelGGL(probe_mfma_kernel, dim3(wgs), dim3(256), 0, 0, ops, iters / 4, stamps, (float*)sink);  // warm-up
+      PCK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(probe_mfma_kernel, dim3(wgs), dim3(256), 0, 0, ops, iters, stamps, (float*)sink);
+      PCK(hipEventRecord(e1, 0));
+      float ms = 0.f;
+      PCK(elapsed(ms));
+      std::vector<unsigned long long> h(wgs * 2);
+      PCK(hipMemcpy(h.data(), stamps, wgs * 16, hipMemcpyDeviceToHost));
+      double cyc = 0, ticks = 0;
+      for (int i = 0; i < wgs; ++i) { cyc += (double)h[2 * i]; ticks += (double)h[2 * i + 1]; }
+      const double flop = (double)wgs * 4 * iters * 4 * 2.0 * 32 * 32 * 16;
+      js.raw(zero ? ", \"zero\": {" : "\"random\": {");
+      js.kv("tflops", flop / (ms * 1e-3) / 1e12);
+      js.raw(", ");
+      js.kv("clock_ghz", ticks > 0 ? cyc / ticks * 0.1 : 0.0);  // s_memrealtime ticks at 100 MHz
+      js.raw(", ");
+      js.kv("ms", ms);
+      js.raw("}");
+    }
+    js.raw("}");
+  }
+
+  // ---- working sets: dependent-load latency and weight-stream bandwidth ---------------------------------------------
+  {
+    const double set_mb[] = {0.75, 1.8, 2.9, 12.6, 64.0, 512.0};
+    const int n_sets = level >= 1 ? 6 : 5;
+    const size_t max_bytes = (size_t)(set_mb[n_sets - 1] * 1048576.0);
+    uint32_t* set = (uint32_t*)alloc(max_bytes);
+    if (!set) { st2_set_error("st2_probe_box: out of device memory"); cleanup(); return 1; }
+    std::mt19937 rng(12345);
+    js.raw(", \"sets\": [");
+    for (int si = 0; si < n_sets; ++si) {
+      const size_t bytes = (size_t)(set_mb[si] * 1048576.0) / 1024 * 1024;
+      const uint32_t n_lines = (uint32_t)(bytes / 128);
+      // random single cycle over the lines (Sattolo); word 0 of a line = index of the next line, the rest noise
+      std::vector<uint32_t> perm(n_lines);
+      for (uint32_t i = 0; i < n_lines; ++i) perm[i] = i;
+      for (uint32_t i = n_lines - 1; i > 0; --i) std::swap(perm[i], perm[rng() % i]);
+      std::vector<uint32_t> host((size_t)n_lines * 32);
+      for (size_t i = 0; i < host.size(); ++i) host[i] = (uint32_t)(i * 2654435761u);
+      for (uint32_t i = 0; i < n_lines; ++i) host[(size_t)i * 32] = perm[i];
+      PCK(hipMemcpy(set, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+      const int hops = 2000;
+      hipLaunchKernelGGL(probe_chase_kernel, dim3(num_cu), dim3(64), 0, 0, set, n_lines, hops, stamps, sink);
+      PCK(hipDeviceSynchronize());
+      std::vector<unsigned long long> h(num_cu);
+      PCK(hipMemcpy(h.data(), stamps, num_cu * 8, hipMemcpyDeviceToHost));
+      std::sort(h.begin(), h.end());
+      const double ns_med = (double)h[num_cu / 2] * 10.0 / hops, ns_max = (double)h[num_cu - 1] * 10.0 / hops;
+      // stream: 2 workgroups per CU, every workgroup reads the whole set; ~1.5 GB in total per measurement
+      const uint32_t n_vec = (uint32_t)(bytes / 16) / 512 * 512;
+      const int wgs = num_cu * 2;
+      int reps = (int)std::max<double>(1.0, 3.0e9 / ((double)n_vec * 16 * wgs));
+      if (reps > 64) reps = 64;
+      float ms2 = 0.f, ms8 = 0.f;
+      hipLaunchKernelGGL(probe_stream_kernel<2>, dim3(wgs), dim3(256), 0, 0, (const u32x4*)set, n_vec, 1, sink);
+      PCK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(probe_stream_kernel<2>, dim3(wgs), dim3(256), 0, 0, (const u32x4*)set, n_vec, reps, sink);
+      PCK(hipEventRecord(e1, 0));
+      PCK(elapsed(ms2));
+      PCK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(probe_stream_kernel<8>, dim3(wgs), dim3(256), 0, 0, (const u32x4*)set, n_vec, reps, sink);
+      PCK(hipEventRecord(e1, 0));
+      PCK(elapsed(ms8));
+      const double tot = (double)n_vec * 16 * wgs * reps;
+      js.raw(si ? ", {" : "{");
+      js.kv("mb", set_mb[si]);
+      js.raw(", ");
+      js.kv("chase_ns_median", ns_med);
+      js.raw(", ");
+      js.kv("chase_ns_max", ns_max);
+      js.raw(", ");
+      js.kv("stream2_gbps", tot / (ms2 * 1e-3) / 1e9);
+      js.raw(", ");
+      js.kv("stream8_gbps", tot / (ms8 * 1e-3) / 1e9);
+      js.raw("}");
+    }
+    js.raw("]");
+    // ---- HBM copy: 512 MB -> 512 MB, twice the Infinity Cache each way ----------------------------------------------
+    const size_t cbytes = (size_t)512 << 20;
+    void* csrc = max_bytes >= cbytes ? (void*)set : alloc(cbytes);
+    void* dst = alloc(cbytes);
+    if (csrc && dst) {
+      const uint32_t* set = reinterpret_cast<const uint32_t*>(csrc);
+      const int64_t n_vec = cbytes / 16;
+      hipLaunchKernelGGL(probe_copy_kernel, dim3(num_cu * 16), dim3(256), 0, 0, (const u32x4*)set, (u32x4*)dst, n_vec);
+      PCK(hipEventRecord(e0, 0));
+      for (int r = 0; r < 4; ++r)
+        hipLaunchKernelGGL(probe_copy_kernel, dim3(num_cu * 16), dim3(256), 0, 0, (const u32x4*)set, (u32x4*)dst, n_vec);
+      PCK(hipEventRecord(e1, 0));
+      float ms = 0.f;
+      PCK(elapsed(ms));
+      js.raw(", \"hbm_copy\": {");
+      js.kv("mb", cbytes / 1048576.0);
+      js.raw(", ");
+      js.kv("gbps_read_plus_write", 2.0 * cbytes * 4 / (ms * 1e-3) / 1e9);
+      js.raw("}");
+    }
+  }
+
+  // ---- census of the slow class's grid -------------------------------------------------------------------------------
+  {
+    const int wgs = 2048;
+    const size_t smem = 72 * 1024;  // two workgroups per CU, like the 128 x 256 tile build
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_census_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    unsigned long long* out = (unsigned long long*)alloc(wgs * 16);
+    if (!out) { st2_set_error("st2_probe_box: out of device memory"); cleanup(); return 1; }
+    const unsigned long long spin = 3000;  // 30 us per workgroup
+    hipLaunchKernelGGL(probe_census_kernel, dim3(wgs), dim3(256), smem, 0, out, spin);
+    PCK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(wgs * 2);
+    PCK(hipMemcpy(h.data(), out, wgs * 16, hipMemcpyDeviceToHost));
+    std::map<unsigned long long, int> per_cu;
+    int xcc[16] = {};
+    int xcc_mismatch = 0;  // workgroups NOT on XCD (id % 8)
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int i = 0; i < wgs; ++i) {
+      const unsigned long long id = h[2 * i];
+      const unsigned x = (unsigned)(id >> 32) & 15;
+      const unsigned long long key = ((unsigned long long)x << 32) | (id & 0xFF00);  // (XCC, SE, SH, CU)
+      per_cu[key]++;
+      xcc[x]++;
+      if (x != (unsigned)(i % 8)) ++xcc_mismatch;
+      tmin = std::min(tmin, h[2 * i + 1]);
+      tmax = std::max(tmax, h[2 * i + 1]);
+    }
+    int mn = 1 << 30, mx = 0;
+    for (auto& kv : per_cu) { mn = std::min(mn, kv.second); mx = std::max(mx, kv.second); }
+    int xmn = 1 << 30, xmx = 0, xn = 0;
+    for (int i = 0; i < 16; ++i)
+      if (xcc[i]) { xmn = std::min(xmn, xcc[i]); xmx = std::max(xmx, xcc[i]); ++xn; }
+    js.raw(", \"census\": {");
+    js.kv("workgroups", wgs, "%.0f");
+    js.raw(", ");
+    js.kv("cus_seen", (double)per_cu.size(), "%.0f");
+    js.raw(", ");
+    js.kv("wg_per_cu_min", mn, "%.0f");
+    js.raw(", ");
+    js.kv("wg_per_cu_max", mx, "%.0f");
+    js.raw(", ");
+    js.kv("xcds_seen", xn, "%.0f");
+    js.raw(", ");
+    js.kv("wg_per_xcd_min", xmn, "%.0f");
+    js.raw(", ");
+    js.kv("wg_per_xcd_max", xmx, "%.0f");
+    js.raw(", ");
+    js.kv("wg_not_on_xcd_id_mod_8", xcc_mismatch, "%.0f");
+    js.raw(", ");
+    js.kv("start_span_us", (double)(tmax - tmin) / 100.0);
+    js.raw(", ");
+    js.kv("rounds_of_30us", (double)(tmax - tmin) / (double)spin + 1.0, "%.2f");
+    js.raw("}");
+  }
+  js.raw("}");
+  cleanup();
+  ST2_REQUIRE((int)js.s.size() + 1 <= cap, "st2_probe_box: output needs %zu bytes", js.s.size() + 1);
+  memcpy(json, js.s.c_str(), js.s.size() + 1);
+  return 0;
+}

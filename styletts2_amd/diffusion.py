@@ -493,7 +493,9 @@ class _Transformer(nn.Module):
             # The multispeaker net's AdaLayerNorm affine is per utterance.  With the token-merged storage its q / kv convs
             # still run as ONE GEMM over the B*N columns: st2_act_split takes the affine row of a column from its
             # utterance (gb_seg = N).  Needs the xs pair (>= XS_MIN_L columns); smaller calls keep the [B, F, N] view.
-            seg = self.multispeaker and s.merged and B > 1 and B * N >= ops.XS_MIN_L
+            # ... and a net wide enough that ops.conv1d does not route its k = 1 convs to the fused kernel (no gb_seg there)
+            seg = (self.multispeaker and s.merged and B > 1 and B * N >= ops.XS_MIN_L
+                   and not ops.prefer_fused(ops.PRO_COLNORM, Fz, 1))
             stv = st if (self.multispeaker and not seg) else st.view(1, B * N, 2)
             qkv = A(3 * mid)
             if self.multispeaker:

@@ -76,6 +76,71 @@ def check_status():
     raise _lib.St2Error("device-side status 0x%x: %s" % (st, "; ".join(msgs)))
 
 
+class conv_autotune:
+    """`with ops.conv_autotune(): forward(...)` -- start-up autotuning of the xs convs (include/st2.h `st2_conv_tune`): the
+    first launch of every shape class inside the block times its bitwise-equivalent builds on this box and keeps the
+    fastest; later calls (inside or outside the block, eager or graph-captured) run it.  Boxes of the same SKU differ by
+    up to 1.75 x on individual classes with the rule's build, so a serving process runs one forward per batch shape in
+    here before taking traffic.  `reset=True` forgets earlier measurements of the current device first."""
+
+    def __init__(self, reset=False):
+        self.reset = reset
+
+    def __enter__(self):
+        lib = _lib.load()
+        if self.reset:
+            _lib.check(lib.st2_conv_tune(-1), "st2_conv_tune")
+        _lib.check(lib.st2_conv_tune(1), "st2_conv_tune")
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        _lib.check(_lib.load().st2_conv_tune(0), "st2_conv_tune")
+        return False
+
+
+TUNE_VARIANT_BITS = {1: "128x256 tiles, 2 wg/CU", 2: "XCD-aware tile order", 4: "16-channel chunks"}
+
+
+def tune_variant_name(v):
+    if v < 0:
+        return "rule"
+    names = [n for b, n in TUNE_VARIANT_BITS.items() if v & b]
+    return " + ".join(names) if names else "128x128 tiles, 3 wg/CU, dispatch order"
+
+
+def conv_tune_table():
+    """The autotuner's table for the current device: a list of dicts {ks, C_in, C_out, L, B, chosen, candidates: [{variant,
+    name, ms}]} (ms = 0 for classes pinned by hand)."""
+    import ctypes
+    lib = _lib.load()
+    n = lib.st2_conv_tune_read(None, 0)
+    rows = (ctypes.c_double * (24 * max(n, 1)))()
+    n = min(n, lib.st2_conv_tune_read(rows, n))
+    out = []
+    for i in range(n):
+        r = rows[24 * i:24 * i + 24]
+        cands = [{"variant": int(r[8 + 2 * j]), "name": tune_variant_name(int(r[8 + 2 * j])), "ms": round(r[9 + 2 * j], 5)}
+                 for j in range(int(r[7]))]
+        out.append({"ks": int(r[0]), "C_in": int(r[1]), "C_out": int(r[2]), "L": int(r[3]), "B": int(r[4]),
+                    "chosen": int(r[6]), "chosen_name": tune_variant_name(int(r[6])), "candidates": cands})
+    return out
+
+
+def conv_tune_set(ks, C_in, C_out, L_out, B, variant):
+    """Pins (variant >= 0) or erases (-1) the build of one shape class on the current device (tests, A/B probes)."""
+    _lib.check(_lib.load().st2_conv_tune_set(ks, C_in, C_out, L_out, B, variant), "st2_conv_tune_set")
+
+
+def probe_box(level=0):
+    """Micro-measurements of the current device as a dict (include/st2.h `st2_probe_box`; ~0.5 s, synchronises)."""
+    import ctypes
+    import json
+    buf = ctypes.create_string_buffer(16384)
+    _lib.check(_lib.load().st2_probe_box(buf, len(buf), level), "st2_probe_box")
+    return json.loads(buf.value.decode())
+
+
 XS_HALO = 32  # zero columns in front of every xs row (>= the largest pad_left on the path: 25)
 FUSED_MAX_C, FUSED_K3_MAX_C = 64, 128  # see prefer_fused()
 XS_MIN_L = 256  # shorter rows stay on the fused kernel: an xs row is >= 640 slots

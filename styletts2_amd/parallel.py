@@ -82,3 +82,13 @@ def max_over_ranks(value, device):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, device):
+    """[value of rank 0, ..., value of rank W-1] on every rank (a list of one for world size 1)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

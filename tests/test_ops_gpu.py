@@ -761,3 +761,98 @@ def test_lstm_bidir_matches_torch_lstm(B, N, ragged, mode, monkeypatch):
     if not ragged:
         y, _ = lstm(g(x))
         assert torch.equal(y, out)  # bitwise reproducible
+
+
+XS_VARIANT_CASES = [
+    # (B, C, L, ks, dil, aligned rows): C_out = 256 -> 2 row blocks (the XCD-aware order applies), grids divisible by 8 or not
+    (8, 256, 1000, 7, 1, True),
+    (4, 256, 1531, 11, 5, True),    # odd length: edge tiles, the generic epilogue
+    (8, 256, 2000, 3, 3, True),
+    (3, 256, 777, 7, 3, False),     # unaligned dense tensors (4-byte epilogue), grid not divisible by 8 (swizzle refused)
+    (2, 512, 640, 3, 1, True),      # 4 row blocks
+    (4, 1090, 400, 3, 1, True),     # ragged C_in: the 16-channel build walks one all-zero chunk of the 32-channel packing
+    (6, 128, 3001, 11, 1, True),    # one row block: the swizzle bit is a no-op
+]
+
+
+@pytest.mark.parametrize("B,C,L,ks,dil,aligned", XS_VARIANT_CASES)
+def test_xs_variants_are_bitwise_identical(B, C, L, ks, dil, aligned):
+    """Every build the autotuner may pick (include/st2.h st2_conv_tune: tile shape / occupancy, chunk depth, XCD-aware tile
+    order) issues the same products in the same order through the same epilogue: output AND InstanceNorm statistics are
+    bit-identical to the rule's build -- the choice is a matter of time only."""
+    gen = torch.Generator().manual_seed(4242 + ks)
+    C_out = 256 if C == 1090 else C
+    pitch = (L + 31) // 32 * 32 if aligned else L
+    x = torch.randn(B, C, L, generator=gen) * 1.5
+    w = torch.randn(C_out, C, ks, generator=gen) / math.sqrt(C * ks)
+    wt = weights.pack_conv_f16s(w).to(DEV)
+    bias = g(torch.randn(C_out, generator=gen))
+    res = torch.empty(B, C_out, pitch, device=DEV)[:, :, :L].copy_(torch.randn(B, C_out, L, generator=gen))
+    xs = ops.activate(g(x))
+    pad = (ks - 1) * dil // 2
+    outs = {}
+    variants = [-1, 0, 2] + ([1, 3] if ks >= 7 else []) + ([4, 6] if ks == 3 else [])
+    try:
+        for v in variants:
+            ops.conv_tune_set(ks, C, C_out, L, B, v)
+            out = torch.full((B, C_out, pitch), float("nan"), device=DEV)[:, :, :L]
+            y, st = ops.conv1d_xs(xs, wt, C_out, ks, dil=dil, pad_left=pad, bias=bias, res=res, out=out, want_stats=True)
+            torch.cuda.synchronize()
+            outs[v] = (y.clone(), st.clone())
+    finally:
+        ops.conv_tune_set(ks, C, C_out, L, B, -1)
+    ref = R.conv1d(x, weights.pack_conv_f16s(w), C_out, ks, dil=dil, pad_left=pad, bias=bias.cpu(), res=res.cpu(), pro=R.PRO_NONE)
+    assert rel_err(outs[-1][0], ref) < 3e-6
+    for v in variants[1:]:
+        assert torch.equal(outs[v][0], outs[-1][0]), "variant %d differs from the rule's build" % v
+        assert torch.equal(outs[v][1], outs[-1][1]), "variant %d: statistics differ" % v
+    assert ops.status() == 0
+
+
+def test_conv_autotune_measures_keeps_results_and_survives_aliasing():
+    """st2_conv_tune(1): the first launch of a class times its candidate builds into a SCRATCH output -- the caller's
+    tensors are only read, so a conv that accumulates into its own output (res2 aliases y: the MRF sum of
+    Modules/istftnet.py:366-373) is applied exactly once -- records them, and later launches run the winner with unchanged
+    results."""
+    B, C, L, ks, dil = 8, 256, 4000, 7, 3
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(B, C, L, generator=gen)
+    w = torch.randn(C, C, ks, generator=gen) / math.sqrt(C * ks)
+    wt = weights.pack_conv_f16s(w).to(DEV)
+    acc0 = torch.randn(B, C, L, generator=gen)
+    xs = ops.activate(g(x))
+    pad = (ks - 1) * dil // 2
+
+    def run():
+        acc = g(acc0).clone()
+        ops.conv1d_xs(xs, wt, C, ks, dil=dil, pad_left=pad, res2=acc, out=acc)  # acc += conv(x)
+        torch.cuda.synchronize()
+        return acc
+    ops.conv_tune_set(ks, C, C, L, B, -1)
+    plain = run()
+    with ops.conv_autotune(reset=True):
+        tuned_first = run()
+        tuned_again = run()
+    after = run()
+    table = [r for r in ops.conv_tune_table() if (r["ks"], r["C_in"], r["L"], r["B"]) == (ks, C, L, B)]
+    try:
+        assert len(table) == 1 and len(table[0]["candidates"]) >= 3, table
+        assert all(c["ms"] > 0 for c in table[0]["candidates"]), table
+        assert table[0]["chosen"] in [c["variant"] for c in table[0]["candidates"]]
+        for t in (tuned_first, tuned_again, after):
+            assert torch.equal(t, plain)
+    finally:
+        from styletts2_amd import _lib
+        _lib.load().st2_conv_tune(-1)
+    assert ops.conv_tune_table() == []
+
+
+def test_probe_box_reports_a_plausible_mi355x():
+    """st2_probe_box: the micro-probe bench.py embeds in its JSON line.  Sanity bounds only (this is a measurement)."""
+    p = ops.probe_box(0)
+    assert p["cus"] >= 64 and p["census"]["cus_seen"] <= p["cus"] and p["census"]["workgroups"] == 2048
+    assert p["mfma"]["random"]["tflops"] > 100 and 0.5 < p["mfma"]["random"]["clock_ghz"] < 3.0
+    assert p["mfma"]["zero"]["tflops"] >= p["mfma"]["random"]["tflops"] * 0.9
+    assert len(p["sets"]) == 5 and all(s["chase_ns_median"] > 50 and s["stream8_gbps"] > 100 for s in p["sets"])
+    assert p["sets"][0]["chase_ns_median"] < p["sets"][-1]["chase_ns_median"] * 1.2  # a cache level is not slower than HBM
+    assert p["hbm_copy"]["gbps_read_plus_write"] > 500

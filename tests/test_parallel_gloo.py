@@ -86,6 +86,9 @@ def test_bench_self_spawns_n_ranks():
     import sys
     res = _bench_dry_run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"])
     assert res["n_gpus"] == 2 and abs(res["max_over_ranks"] - 0.002) < 1e-9  # rank 1's value won the MAX reduction
+    # the fields that make a SCALE record self-explanatory: every rank's own time, the start-up broadcast's cost
+    assert res["per_rank_ms_per_step"] == [1.0, 2.0]
+    assert res["broadcast_bytes"] == (8 * 8 + 8) * 4 and res["broadcast_s"] >= 0.0
 
 
 def test_bench_under_torch_distributed_run():
@@ -93,4 +96,4 @@ def test_bench_under_torch_distributed_run():
     res = _bench_dry_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
                           "--dry-run"])
-    assert res["n_gpus"] == 2
+    assert res["n_gpus"] == 2 and res["per_rank_ms_per_step"] == [1.0, 2.0] and res["broadcast_bytes"] == 288

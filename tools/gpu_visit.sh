@@ -1,36 +1,73 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, stage probe, bench line, rocprofv3 kernel stats of the same bench command,
-# then PMC passes (separate runs, --pmc only) over the dominant-launch probe.
-# Usage (from the repo root on the GPU box): bash tools/gpu_visit.sh [tag] [skip-list]
-set -u
-TAG=${1:-r01c}
-SKIP=${2:-}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-has() { [[ ",$SKIP," == *",$1,"* ]]; }
-if ! has pytest; then echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log; tail -12 $OUT/pytest_gpu.log; fi
-if ! has smoke; then echo "== smoke"; timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -3 $OUT/smoke.log; fi
-if ! has probe; then echo "== probe e2e"; timeout 300 python tools/probe_e2e.py > $OUT/probe_e2e.log 2>&1; tail -6 $OUT/probe_e2e.log
-  echo "== probe lstm"; timeout 300 python tools/probe_lstm.py > $OUT/probe_lstm.log 2>&1; tail -8 $OUT/probe_lstm.log
-  echo "== probe conv"; PROBE_KERNELS=f16s timeout 300 python tools/probe_conv.py > $OUT/probe_conv.log 2>&1; tail -40 $OUT/probe_conv.log; fi
-if ! has bench; then echo "== bench (default: two streams, high-priority front)"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cut -c1-400 $OUT/bench.json; tail -4 $OUT/bench.err
-  echo "== bench --front-priority 0"; timeout 600 python bench.py --front-priority 0 --no-cpu-baseline > $OUT/bench_prio0.json 2> $OUT/bench_prio0.err; cut -c1-230 $OUT/bench_prio0.json
-  echo "== bench --single-stream"; timeout 600 python bench.py --single-stream --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err; cut -c1-230 $OUT/bench_single.json
-  echo "== probe e2e libritts (HiFi-GAN, 10 steps)"; PROBE_TAG=libritts PROBE_STEPS=10 timeout 600 python tools/probe_e2e.py > $OUT/probe_e2e_libritts.log 2>&1; tail -3 $OUT/probe_e2e_libritts.log; fi
-if ! has rocprof; then echo "== rocprof stats (default bench command)"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/bench_prof.json 2> $R/$OUT/bench_prof.err ); echo "rocprof exit $?"
-  for f in $(find /tmp/prof_$TAG -name '*kernel_stats.csv'); do cp $f $OUT/; done
-  echo "== rocprof stats (--single-stream: un-overlapped per-kernel durations)"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1_$TAG -o bench1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream > $R/$OUT/bench_prof_single.json 2> $R/$OUT/bench_prof_single.err ); echo "rocprof exit $?"
-  for f in $(find /tmp/prof1_$TAG -name '*kernel_stats.csv'); do cp $f $OUT/bench_single_kernel_stats.csv; done
-  head -12 $OUT/bench_single_kernel_stats.csv 2>/dev/null | cut -c1-180; fi
-if ! has pmc; then
-  i=0
-  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
-    i=$((i+1)); echo "== pmc pass $i: $set"
-    ( cd /tmp && timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_${TAG}_$i -o pmc -- python $R/tools/probe_dom.py > $R/$OUT/pmc_$i.log 2>&1 ); echo "pmc exit $?"
-    python tools/pmc_summary.py /tmp/pmc_${TAG}_$i > $OUT/pmc_$i.txt 2>&1; grep -v "at::\|elementwise" $OUT/pmc_$i.txt | cut -c1-60,100-200 | head -40
-    grep probe_dom $OUT/pmc_$i.log
+# One GPU visit = `gpurun -- bash tools/gpu_visit.sh TAG STAGE [STAGE ...]`; every stage writes gpurun_out/${TAG}_*.
+# (Rounds 1-3 kept one script per visit, 58 of them: they are in the history, `git log -- tools/`.)
+#
+#   probe            tools/probe_box.py FIRST: box fingerprint + the discriminating conv class in every build; a slow box
+#                    (rule build of k7 / C256 / L8000 > 0.9 ms) runs `slowkit` on the spot
+#   slowkit          counters and ablations of that launch class: rocprofv3 --pmc passes (TCC hit / miss, FETCH_SIZE,
+#                    busy cycles), tools/bin/xs_bench_{0,1,2,4,8,15} on the shape, per-workgroup timeline (xs_bench_64)
+#   tests[:FILES]    pytest -m gpu (all, or the comma-separated test files)
+#   smoke            __graft_entry__.smoke()
+#   bench[:ARGS]     the driver's command `python bench.py --gpus 1 --steps 20 --warmup 5` (+ comma-separated extra args)
+#   bench_ab         the same without the autotuner (--no-autotune), for the A/B on this box
+#   configs          one short bench line per other configuration (libritts_hifigan, libritts_istftnet, longform)
+#   stats            rocprofv3 --kernel-trace --stats of a short single-stream bench (per-kernel table)
+#   pmc              FETCH_SIZE / WRITE_SIZE / busy-cycle passes over tools/probe_dom.py (profiles/pmc_dominant.json)
+#   gemm             tools/bin/gemm_bench (token GEMM shapes)
+#   cmd:COMMAND      anything else (spaces as '+')
+TAG=${1:?tag}; shift
+OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+run_slowkit() {
+  for m in 0 1 2 4 8 15; do
+    [ -x tools/bin/xs_bench_$m ] && timeout 120 tools/bin/xs_bench_$m 7 1 256 8000 32 1 1 10 2>&1 | tail -1 | tee -a $OUT/${TAG}_slowkit_xs_bench.log
   done
-  python tools/pmc_summary.py --json $OUT/pmc_dominant.json --kernel "conv1d_xs_kernel" /tmp/pmc_${TAG}_1 /tmp/pmc_${TAG}_2 | tail -1
-fi
+  for v in 0 1 2 3; do
+    [ -x tools/bin/xs_bench_0 ] && XS_VARIANT=$v timeout 120 tools/bin/xs_bench_0 7 1 256 8000 32 1 1 10 2>&1 | tail -1 | sed "s/^/variant $v: /" | tee -a $OUT/${TAG}_slowkit_xs_bench.log
+  done
+  [ -x tools/bin/xs_bench_64 ] && timeout 120 tools/bin/xs_bench_64 7 1 256 8000 32 1 1 3 0 $OUT/${TAG}_slowkit_timeline.txt | tail -2
+  for ctr in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
+    n=$(echo $ctr | tr ' ' '_')
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$n -o pmc -- python $OLDPWD/tools/probe_box.py --quick --level 0 > /dev/null 2>&1 )
+    python tools/pmc_summary.py /tmp/pmc_$n 2>/dev/null | grep -i "conv1d_xs" | head -8 | sed "s/^/[$n] /" | tee -a $OUT/${TAG}_slowkit_pmc.txt
+  done
+}
+for st in "$@"; do
+  name=${st%%:*}; arg=""; [[ "$st" == *:* ]] && arg=${st#*:}
+  echo "=== stage $st ($(date +%T))"
+  case $name in
+    probe)
+      timeout 600 python tools/probe_box.py --out $OUT/${TAG}_box.json --level 1 2> $OUT/${TAG}_box.err | tail -1 | tee $OUT/${TAG}_box_class.txt
+      grep -q "BOX_CLASS slow" $OUT/${TAG}_box_class.txt && { echo "SLOW BOX: running the kit"; run_slowkit; } ;;
+    slowkit) run_slowkit ;;
+    tests)
+      files="tests"; [ -n "$arg" ] && files=$(echo $arg | tr ',' ' ')
+      timeout 2400 python -m pytest $files -m gpu -x -q 2>&1 | tail -15 | tee $OUT/${TAG}_pytest.log ;;
+    smoke) timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $OUT/${TAG}_smoke.log ;;
+    bench)
+      extra=$(echo $arg | tr ',' ' ')
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 $extra > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+      tail -4 $OUT/${TAG}_bench.err; python tools/bench_summary.py $OUT/${TAG}_bench.json ;;
+    bench_ab)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-autotune --no-cpu-baseline --no-box-probe > $OUT/${TAG}_bench_noautotune.json 2> $OUT/${TAG}_bench_noautotune.err
+      python tools/bench_summary.py $OUT/${TAG}_bench_noautotune.json ;;
+    configs)
+      for c in libritts_hifigan libritts_istftnet longform; do
+        timeout 600 python bench.py --config $c --no-cpu-baseline --no-box-probe > $OUT/${TAG}_bench_$c.json 2> $OUT/${TAG}_bench_$c.err
+        python tools/bench_summary.py $OUT/${TAG}_bench_$c.json
+      done ;;
+    stats)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule single --no-cpu-baseline --no-box-probe > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
+      f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_single_kernel_stats.csv && head -25 $f ;;
+    pmc)
+      for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        n=$(echo $ctr | tr ' ' '_')
+        ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmcd_$n -o pmc -- python $OLDPWD/tools/probe_dom.py > /dev/null 2>&1 )
+        python tools/pmc_summary.py /tmp/pmcd_$n 2>/dev/null | tee $OUT/${TAG}_pmc_$n.txt | head -12
+      done ;;
+    gemm) [ -x tools/bin/gemm_bench ] && timeout 300 tools/bin/gemm_bench $(echo $arg | tr ',' ' ') 2>&1 | tee $OUT/${TAG}_gemm_bench.log ;;
+    cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -40 | tee $OUT/${TAG}_cmd.log ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
+echo "=== visit $TAG done ($(date +%T))"

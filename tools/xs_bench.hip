@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
   auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
   const int ks = arg(1, 11), dil = arg(2, 1), C = arg(3, 128), L = arg(4, 48001), B = arg(5, 32);
   const int use_res = arg(6, 1), use_stats = arg(7, 1), reps = arg(8, 10);
+  const int xs_variant = getenv("XS_VARIANT") ? atoi(getenv("XS_VARIANT")) : -1;  // st2xs::XS_V_* bits, -1 = the rule
   const float dscale = arg(9, 0) ? 0.f : 1.f;  // 10th argument 1: all-zero operands (what does the data cost in clock?)
   const int chunk = ks <= 3 ? 32 : 16;
   const int C_pad = (C + chunk - 1) / chunk * chunk;
@@ -103,12 +104,12 @@ int main(int argc, char** argv) {
   auto run = [&]() -> int {
 #ifdef XS_BENCH_KS  // build one kernel size only (compile time)
     if (ks != XS_BENCH_KS) { fprintf(stderr, "this binary was built for ks = %d\n", XS_BENCH_KS); return 1; }
-    return st2xs::launch_by_cout<XS_BENCH_KS, (XS_BENCH_KS <= 3 ? 32 : 16)>(d, 0);
+    return st2xs::launch_by_cout<XS_BENCH_KS, (XS_BENCH_KS <= 3 ? 32 : 16)>(d, 0, xs_variant);
 #else
     switch (ks) {
-      case 3: return st2xs::launch_by_cout<3, 32>(d, 0);
-      case 7: return st2xs::launch_by_cout<7, 16>(d, 0);
-      case 11: return st2xs::launch_by_cout<11, 16>(d, 0);
+      case 3: return st2xs::launch_by_cout<3, 32>(d, 0, xs_variant);
+      case 7: return st2xs::launch_by_cout<7, 16>(d, 0, xs_variant);
+      case 11: return st2xs::launch_by_cout<11, 16>(d, 0, xs_variant);
       default: fprintf(stderr, "ks must be 3, 7 or 11\n"); return 1;
     }
 #endif
