@@ -5,6 +5,11 @@ import json
 import sys
 
 
+def _short(name):
+    return name.replace(" tiles, 3 wg/CU, dispatch order", "").replace(" tiles, 2 wg/CU", "").replace(
+        "XCD-aware tile order", "xcd").replace("16-channel chunks", "c16").replace(" + ", "+")
+
+
 def main():
     for path in sys.argv[1:]:
         try:
@@ -27,7 +32,7 @@ def main():
         if isinstance(tune, list):
             for r in tune:
                 if len(r["ms"]) > 1:
-                    print("   tune %-28s -> %-40s %s" % (r["class"], r["chosen"], {k[:14]: round(v, 4) for k, v in r["ms"].items()}))
+                    print("   tune %-28s -> %-40s %s" % (r["class"], r["chosen"], {_short(k): round(v, 4) for k, v in r["ms"].items()}))
         box = d.get("box") or {}
         pr = box.get("probe") or {}
         if pr and "error" not in pr:

@@ -4,6 +4,7 @@
 #
 #   probe            tools/probe_box.py FIRST: box fingerprint + the discriminating conv class in every build; a slow box
 #                    (rule build of k7 / C256 / L8000 > 0.9 ms) runs `slowkit` on the spot
+#   hunt             the quick probe only; a slow box then gets the full probe, the kit and both bench lines
 #   slowkit          counters and ablations of that launch class: rocprofv3 --pmc passes (TCC hit / miss, FETCH_SIZE,
 #                    busy cycles), tools/bin/xs_bench_{0,1,2,4,8,15} on the shape, per-workgroup timeline (xs_bench_64)
 #   tests[:FILES]    pytest -m gpu (all, or the comma-separated test files)
@@ -40,6 +41,14 @@ for st in "$@"; do
       timeout 600 python tools/probe_box.py --out $OUT/${TAG}_box.json --level 1 2> $OUT/${TAG}_box.err | tail -1 | tee $OUT/${TAG}_box_class.txt
       grep -q "BOX_CLASS slow" $OUT/${TAG}_box_class.txt && { echo "SLOW BOX: running the kit"; run_slowkit; } ;;
     slowkit) run_slowkit ;;
+    hunt)  # cheap: ~20 s on a fast box; on a slow one the whole kit + both bench lines + kernel statistics
+      timeout 300 python tools/probe_box.py --quick --level 0 --out $OUT/${TAG}_box.json 2> $OUT/${TAG}_box.err | tail -1 | tee $OUT/${TAG}_box_class.txt
+      if grep -q "BOX_CLASS slow" $OUT/${TAG}_box_class.txt; then
+        echo "SLOW BOX: kit + bench lines"
+        timeout 600 python tools/probe_box.py --level 1 --out $OUT/${TAG}_box_full.json 2>> $OUT/${TAG}_box.err | tail -1
+        run_slowkit
+        bash tools/gpu_visit.sh $TAG bench:--no-cpu-baseline bench_ab
+      fi ;;
     tests)
       files="tests"; [ -n "$arg" ] && files=$(echo $arg | tr ',' ' ')
       timeout 2400 python -m pytest $files -m gpu -x -q 2>&1 | tail -15 | tee $OUT/${TAG}_pytest.log ;;
