@@ -73,12 +73,7 @@ int current_device() {
   return hipGetDevice(&dev) == hipSuccess ? dev : 0;
 }
 
-// The rule's variant for this launch (what an untuned process runs), as XS_V_* bits.
-int rule_variant(const st2_conv_desc& d) {
-  if (d.C_out > 64 && d.ks >= 7 && (int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024)
-    return st2xs::XS_V_WIDE;
-  return 0;
-}
+using st2xs::rule_variant;  // the build an untuned process runs (st2_conv1d_xs_impl.h)
 
 std::vector<int> candidates(const st2_conv_desc& d) {
   std::vector<int> c;

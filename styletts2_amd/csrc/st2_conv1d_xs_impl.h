@@ -348,19 +348,31 @@ namespace st2xs {
 //                        launch_by_cout<KS, 16> instantiation in the dispatcher, ignored here
 enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4 };
 
+// The build an UNTUNED process runs (tests, one-off calls; a serving process measures: st2_conv_tune).  k >= 7: 32 (co) x
+// 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU -- half the weight stream (L2 -> registers) per FLOP;
+// measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32 (tools/xs_bench.hip,
+// profiles/r02i_xs_bench_tn8.log) -- when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a
+// single utterance (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs.  Launches with
+// 2 / 4 / 8 output row blocks (C_out = 256 ... 1024 at k >= 7: the first vocoder stage) take 128 x 128 tiles in XCD-aware
+// order instead: within 2 % of the best build on a healthy box (0.63 vs 0.66 ms at k = 7, 0.91 vs 0.89 at k = 11, C = 256,
+// L = 8 000) and 1.25-1.6 x faster than the wide tiles on boxes with a degraded shader engine, whose 8 CUs run the
+// epilogue's scattered stores 12 x slower and, with 2 workgroups per CU in lock-step rounds, stall their whole XCD
+// (profiles/r04h1_*: 0.65 vs 1.08 ms; every driver box of rounds 1-3 was of that class).
+inline int rule_variant(const st2_conv_desc& d) {
+  if (d.C_out <= 64 || d.ks < 7) return 0;
+  const int ny = st2_cdiv(d.C_out, 128);
+  const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * ny * d.B;
+  if ((ny == 2 || ny == 4 || ny == 8) && wg128 % 8 == 0) return XS_V_SWIZZLE;
+  return (int64_t)st2_cdiv(d.L_out, 256) * ny * d.B >= 1024 ? XS_V_WIDE : 0;
+}
+
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
-  const bool swz = variant >= 0 && (variant & XS_V_SWIZZLE);
+  if (variant < 0) variant = rule_variant(d);
+  const bool swz = (variant & XS_V_SWIZZLE) != 0;
   if (d.C_out > 64) {
-    // k >= 7: 32 (co) x 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU: half the weight stream (L2 ->
-    // registers) per FLOP; measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32,
-    // 1.03 vs 1.10 ms at C = 256, L = 8 000; no gain at k = 3 (tools/xs_bench.hip, profiles/r02i_xs_bench_tn8.log)
-    // ... BY RULE when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a single utterance
-    // (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs
     if constexpr (KS >= 7) {
-      const bool wide = variant >= 0 ? (variant & XS_V_WIDE) != 0
-                                     : (int64_t)st2_cdiv(d.L_out, 256) * st2_cdiv(d.C_out, 128) * d.B >= 1024;
-      if (wide) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
+      if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
     }
     if constexpr (KS == 1 && CI_T == 32) {
       // Token GEMMs (the denoiser's / PL-BERT's Linears over the B*N merged tokens: C_out 512..1024 x 3 200 columns): at

@@ -6,6 +6,8 @@
 // shapes / chunk depths on those shapes, no PyTorch:
 //   ./gemm_bench [C_out=2048] [C_in=1024] [L=3200] [B=1] [reps=20]
 #include "../styletts2_amd/csrc/st2_conv1d_xs_impl.h"
+#define ST2_STATUS_GEMM_TIMEOUT 8  // experiment-only status bit
+#include "gemm_sk_experiment.h"  // persistent stream-K build: measured, not adopted (profiles/LAB_NOTES.md, round 4)
 
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +48,18 @@ __global__ void fill_f32(float* p, int64_t n, uint32_t seed) {
   p[i] = ((int)(h & 0xffff) - 32768) * (1.f / 32768.f);
 }
 
+template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
+int lx(const st2_conv_desc& d, hipStream_t s) {
+  return launch<KS, CI_T, WM, WN, TN, OCC>(d, s, false);
+}
+static int g_num_cu = 256;
+template <int CI_T>
+int launch_sk(const st2_conv_desc& d, hipStream_t s) {
+  const int w = st2sk::pick_workers(d, g_num_cu, CI_T);
+  if (!w) return 1;
+  return st2sk::launch<CI_T>(d, w, s);
+}
+
 struct Variant {
   const char* name;
   int (*fn)(const st2_conv_desc&, hipStream_t);
@@ -57,32 +71,39 @@ int main(int argc, char** argv) {
   const int Co = arg(1, 2048), Ci = arg(2, 1024), L = arg(3, 3200), B = arg(4, 1), reps = arg(5, 20);
 #ifdef K3_BENCH
   const Variant vars[] = {
-      {"128x128 c32 occ3 (library)", &launch<3, 32, 4, 1, 4, 3>, 128, 32},
-      {"128x128 c32 occ2", &launch<3, 32, 4, 1, 4, 2>, 128, 32},
-      {"128x64  c32 occ3", &launch<3, 32, 4, 1, 2, 3>, 128, 32},
-      {"128x64  c32 occ4", &launch<3, 32, 4, 1, 2, 4>, 128, 32},
-      {"64x128  c32 occ3", &launch<3, 32, 2, 2, 2, 3>, 64, 32},
-      {"64x128  c32 occ4", &launch<3, 32, 2, 2, 2, 4>, 64, 32},
-      {"64x64   c32 occ4", &launch<3, 32, 2, 2, 1, 4>, 64, 32},
-      {"128x256 c32 occ2", &launch<3, 32, 4, 1, 8, 2>, 128, 32},
-      {"128x128 c16 occ3", &launch<3, 16, 4, 1, 4, 3>, 128, 16},
-      {"128x64  c16 occ4", &launch<3, 16, 4, 1, 2, 4>, 128, 16},
+      {"128x128 c32 occ3 (library)", &lx<3, 32, 4, 1, 4, 3>, 128, 32},
+      {"128x128 c32 occ2", &lx<3, 32, 4, 1, 4, 2>, 128, 32},
+      {"128x64  c32 occ3", &lx<3, 32, 4, 1, 2, 3>, 128, 32},
+      {"128x64  c32 occ4", &lx<3, 32, 4, 1, 2, 4>, 128, 32},
+      {"64x128  c32 occ3", &lx<3, 32, 2, 2, 2, 3>, 64, 32},
+      {"64x128  c32 occ4", &lx<3, 32, 2, 2, 2, 4>, 64, 32},
+      {"64x64   c32 occ4", &lx<3, 32, 2, 2, 1, 4>, 64, 32},
+      {"128x256 c32 occ2", &lx<3, 32, 4, 1, 8, 2>, 128, 32},
+      {"128x128 c16 occ3", &lx<3, 16, 4, 1, 4, 3>, 128, 16},
+      {"128x64  c16 occ4", &lx<3, 16, 4, 1, 2, 4>, 128, 16},
   };
   const int KSZ = 3;
 #else
   const int KSZ = 1;
   const Variant vars[] = {
-      {"128x128 c32 occ3 (library)", &launch<1, 32, 4, 1, 4, 3>, 128, 32},
-      {"128x128 c32 occ2", &launch<1, 32, 4, 1, 4, 2>, 128, 32},
-      {"128x128 c64 occ3", &launch<1, 64, 4, 1, 4, 3>, 128, 64},
-      {"128x64  c32 occ3", &launch<1, 32, 4, 1, 2, 3>, 128, 32},
-      {"128x64  c64 occ3", &launch<1, 64, 4, 1, 2, 3>, 128, 64},
-      {"64x128  c32 occ3", &launch<1, 32, 2, 2, 2, 3>, 64, 32},
-      {"64x128  c64 occ3", &launch<1, 64, 2, 2, 2, 3>, 64, 64},
-      {"64x64   c32 occ3", &launch<1, 32, 2, 2, 1, 3>, 64, 32},
-      {"64x64   c64 occ3", &launch<1, 64, 2, 2, 1, 3>, 64, 64},
-      {"128x32  c64 occ3", &launch<1, 64, 4, 1, 1, 3>, 128, 64},
+      {"128x128 c32 occ3 (library)", &lx<1, 32, 4, 1, 4, 3>, 128, 32},
+      {"128x128 c32 occ2", &lx<1, 32, 4, 1, 4, 2>, 128, 32},
+      {"128x128 c64 occ3", &lx<1, 64, 4, 1, 4, 3>, 128, 64},
+      {"128x64  c32 occ3", &lx<1, 32, 4, 1, 2, 3>, 128, 32},
+      {"128x64  c64 occ3", &lx<1, 64, 4, 1, 2, 3>, 128, 64},
+      {"64x128  c32 occ3", &lx<1, 32, 2, 2, 2, 3>, 64, 32},
+      {"64x128  c64 occ3", &lx<1, 64, 2, 2, 2, 3>, 64, 64},
+      {"64x64   c32 occ3", &lx<1, 32, 2, 2, 1, 3>, 64, 32},
+      {"64x64   c64 occ3", &lx<1, 64, 2, 2, 1, 3>, 64, 64},
+      {"128x32  c64 occ3", &lx<1, 64, 4, 1, 1, 3>, 128, 64},
+      {"stream-K 256x128 c32", &launch_sk<32>, 128, 32},
+      {"stream-K 256x128 c64", &launch_sk<64>, 128, 64},
   };
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+    if (getenv("SK_WORKERS")) g_num_cu = atoi(getenv("SK_WORKERS"));
+  }
 #endif
   const int halo = 32;
   const int Lp = halo + (L + 1 + 511) / 512 * 512 + 96;
@@ -114,6 +135,10 @@ int main(int argc, char** argv) {
   if (use_res) { CK(hipMalloc(&res, y_elems * 4)); hipLaunchKernelGGL(fill_f32, dim3((y_elems + 255) / 256), dim3(256), 0, 0, res, y_elems, 7u); }
   if (use_part) CK(hipMalloc(&part, (int64_t)B * Co * ((L + 127) / 128) * 2 * 4));
   std::vector<float> ref;
+  void* sk_ws = nullptr;
+  const int64_t sk_bytes = st2sk::workspace_bytes(st2sk::MAX_WORKERS);
+  CK(hipMalloc(&sk_ws, sk_bytes));
+  CK(hipMemset(sk_ws, 0, st2sk::FLAG_BYTES));
   for (const Variant& v : vars) {
     st2_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -124,6 +149,7 @@ int main(int argc, char** argv) {
     d.y = y; d.y_bs = (int64_t)Co * pitch; d.y_cs = pitch;
     d.div = 1.0f;
     d.xs = xs; d.xs_cg = cg; d.xs_lp = Lp; d.xs_halo = halo;
+    d.splitk_ws = sk_ws; d.splitk_ws_bytes = sk_bytes;
     if (use_res) { d.res = res; d.res_bs = (int64_t)Co * pitch; d.res_cs = pitch; }
     if (use_part && v.co_blk >= 0) { d.part = part; d.part_nt = (L + 127) / 128; }
     CK(hipMemset(y, 0, y_elems * 4));
@@ -135,7 +161,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(h.data(), y, h.size() * 4, hipMemcpyDeviceToHost));
     double md = 0;
     if (ref.empty()) ref = h;
-    else for (int co = 0; co < Co; ++co) for (int l = 0; l < L; ++l) md = fmax(md, fabs((double)h[(size_t)co * pitch + l] - ref[(size_t)co * pitch + l]));
+    else {
+      double mr = 0;
+      for (int co = 0; co < Co; ++co) for (int l = 0; l < L; ++l) {
+        md = fmax(md, fabs((double)h[(size_t)co * pitch + l] - ref[(size_t)co * pitch + l]));
+        mr = fmax(mr, fabs((double)ref[(size_t)co * pitch + l]));
+      }
+      md /= fmax(mr, 1e-30);  // relative to the largest output
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -146,7 +179,7 @@ int main(int argc, char** argv) {
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-    printf("%s M=%d K=%d N=%d B=%d res=%d part=%d  %-28s %8.1f us  %6.1f TFLOP/s (%.3f of 833)  max|dy vs library| %.2e\n", KSZ == 3 ? "k3_bench" : "gemm_bench", Co, Ci, L, B, use_res, use_part,
+    printf("%s M=%d K=%d N=%d B=%d res=%d part=%d  %-28s %8.1f us  %6.1f TFLOP/s (%.3f of 833)  max|dy| / max|y| vs library %.2e\n", KSZ == 3 ? "k3_bench" : "gemm_bench", Co, Ci, L, B, use_res, use_part,
            v.name, ms * 1e3, flop / ms / 1e9, flop / ms / 1e9 / (2500.0 / 3), md);
   }
   return 0;

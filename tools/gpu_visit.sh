@@ -29,7 +29,7 @@ run_slowkit() {
   [ -x tools/bin/xs_bench_64 ] && timeout 120 tools/bin/xs_bench_64 7 1 256 8000 32 1 1 3 0 $OUT/${TAG}_slowkit_timeline.txt | tail -2
   for ctr in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
     n=$(echo $ctr | tr ' ' '_')
-    ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$n -o pmc -- python $OLDPWD/tools/probe_box.py --quick --level 0 > /dev/null 2>&1 )
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$n -o pmc -- python $OLDPWD/tools/probe_box.py --quick --level 0 > /dev/null 2>&1 )
     python tools/pmc_summary.py /tmp/pmc_$n 2>/dev/null | grep -i "conv1d_xs" | head -8 | sed "s/^/[$n] /" | tee -a $OUT/${TAG}_slowkit_pmc.txt
   done
 }
@@ -66,16 +66,16 @@ for st in "$@"; do
         python tools/bench_summary.py $OUT/${TAG}_bench_$c.json
       done ;;
     stats)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule single --no-cpu-baseline --no-box-probe > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule single --calib-steps 0 --no-cpu-baseline --no-box-probe > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
       f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_single_kernel_stats.csv && head -25 $f ;;
     pmc)
       for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         n=$(echo $ctr | tr ' ' '_')
-        ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmcd_$n -o pmc -- python $OLDPWD/tools/probe_dom.py > /dev/null 2>&1 )
+        ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmcd_$n -o pmc -- python $OLDPWD/tools/probe_dom.py > /dev/null 2>&1 )
         python tools/pmc_summary.py /tmp/pmcd_$n 2>/dev/null | tee $OUT/${TAG}_pmc_$n.txt | head -12
       done ;;
     gemm) [ -x tools/bin/gemm_bench ] && timeout 300 tools/bin/gemm_bench $(echo $arg | tr ',' ' ') 2>&1 | tee $OUT/${TAG}_gemm_bench.log ;;
-    cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -40 | tee $OUT/${TAG}_cmd.log ;;
+    cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -300 | tee $OUT/${TAG}_cmd.log ;;
     *) echo "unknown stage $st" ;;
   esac
 done
