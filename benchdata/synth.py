@@ -87,6 +87,27 @@ def init_synthetic_(module, seed):
     return module
 
 
+def init_trained_like_(module, seed, gain_sigma=0.7, alpha_decades=1.0):
+    """`init_synthetic_`, then the two free parameters that decide how much of the f16 range a split-f16 conv operand uses
+    in a TRAINED checkpoint (Modules/istftnet.py:27-62) get realistic spreads instead of their initial values: weight-norm
+    gains `weight_g` are multiplied by log-normal factors exp(N(0, gain_sigma)) (trained gains differ by octaves between rows)
+    and Snake `alpha` is drawn log-uniform in 10^[-alpha_decades, +alpha_decades] (the reference initialises it to 1)."""
+    init_synthetic_(module, seed)
+    sd = module.state_dict()
+    out = {}
+    for name, t in sd.items():
+        if name.endswith("weight_g"):
+            f = np.exp(_rng(seed, name + ".gain").standard_normal(tuple(t.shape)) * gain_sigma).astype(np.float32)
+            out[name] = t * torch.from_numpy(f)
+        elif any(part.startswith("alpha") for part in name.split(".")[-2:]):  # alpha1.0 / alpha2.2 / alpha (ParameterLists)
+            u = _rng(seed, name + ".alpha").uniform(-alpha_decades, alpha_decades, tuple(t.shape)).astype(np.float32)
+            out[name] = torch.from_numpy(10.0 ** u).reshape(t.shape)
+        else:
+            out[name] = t
+    module.load_state_dict(out)
+    return module
+
+
 def init_spectral_norm_(module, seed):
     """Synthetic initialisation for modules under old-style spectral norm (`weight_orig` / `weight_u` / `weight_v`:
     the style encoders, models.py:97-164): seeded `weight_orig` / biases as in `init_synthetic_`, then u, v = the

@@ -11,7 +11,10 @@
 // Arithmetic is op for op that of the fused prologue in st2_conv1d_f16s.hip (same helpers, st2_act.h).
 #include "st2_common.h"
 #include "st2_act.h"
+#include <algorithm>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -122,6 +125,41 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   }
 }
 
+// ---- operand-range telemetry (st2_debug_headroom, st2.h) --------------------------------------------------------------
+// max |hi| over the hi planes of one act_split output = the largest scaled operand of the conv that consumes it, as the f16
+// it became.  One atomicMax on the bit pattern of the non-negative float per workgroup.
+__global__ __launch_bounds__(256) void xs_absmax_kernel(const st2_h8* __restrict__ xs, int64_t slots_per_item, int64_t item_stride,
+                                                        unsigned* out) {
+  const st2_h8* p = xs + (int64_t)blockIdx.y * item_stride;  // the hi plane of batch item blockIdx.y
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < slots_per_item; i += (int64_t)gridDim.x * 256) {
+    const st2_h8 v = p[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+struct HeadroomRecord {
+  int kind, pro, B, C, L;  // kind 0 = st2_act_split (xs path), 1 = st2_conv1d_f16s (prologue inside the conv)
+  float x_scale;
+};
+bool g_headroom = false;
+std::vector<HeadroomRecord> g_hr;
+unsigned* g_hr_dev = nullptr;  // one max per record
+constexpr int HR_CAP = 4096;
+void* g_hr_scratch = nullptr;  // planes of the fused-path convs (debug mode only)
+size_t g_hr_scratch_bytes = 0;
+
+void headroom_record(int kind, const ActArgs& a, int B, hipStream_t s) {
+  if ((int)g_hr.size() >= HR_CAP || !g_hr_dev) return;
+  const int64_t plane = (int64_t)a.xs_cg * a.Lp;
+  hipLaunchKernelGGL(xs_absmax_kernel, dim3((unsigned)std::min<int64_t>((plane + 255) / 256, 1024), B), dim3(256), 0, s, a.xs, plane,
+                     2 * plane, g_hr_dev + g_hr.size());
+  g_hr.push_back({kind, 0, B, a.C, a.L, a.x_scale});
+}
+
 template <int PRO>
 void launch_act(const ActArgs& a, int B, hipStream_t s) {
   hipLaunchKernelGGL((act_split_kernel<PRO>), dim3(st2_cdiv(a.Lp, 256), a.xs_cg, B), dim3(256), 0, s, a);
@@ -160,7 +198,76 @@ extern "C" int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t
     default: launch_act<ST2_PRO_NONE>(a, B, s); break;
   }
   ST2_CHECK_LAUNCH("st2_act_split");
+  if (g_headroom) {
+    headroom_record(0, a, B, s);
+    if (!g_hr.empty()) g_hr.back().pro = pro;
+  }
   return 0;
+}
+
+// Telemetry for the fused conv (st2_conv1d_f16s.hip calls this in debug mode): the same prologue into scratch planes.
+int st2_headroom_of_fused_conv(const st2_conv_desc& d, hipStream_t s) {
+  if (!g_headroom || !d.x) return 0;
+  const int cg = (d.C_in + 31) / 32 * 4, halo = 0;
+  const int Lp = (d.L_in + 7) / 8 * 8;
+  const size_t bytes = (size_t)d.B * 2 * cg * Lp * 16;
+  if (bytes > g_hr_scratch_bytes) {
+    if (g_hr_scratch) (void)hipFree(g_hr_scratch);
+    g_hr_scratch = nullptr;
+    g_hr_scratch_bytes = 0;
+    if (hipMalloc(&g_hr_scratch, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    g_hr_scratch_bytes = bytes;
+  }
+  const size_t before = g_hr.size();
+  const int rc = st2_act_split(d.x, d.x_bs, d.x_cs, d.B, d.C_in, d.L_in, d.pro, d.slope, d.stats, d.gamma, d.beta, d.gb_bs, 0,
+                               d.gamma_plus_one, d.alpha, d.x_scale, g_hr_scratch, cg, Lp, halo, s);
+  if (rc == 0 && g_hr.size() == before + 1) g_hr.back().kind = 1;
+  return rc;
+}
+
+extern "C" int st2_debug_headroom(int enable) {
+  if (enable) {
+    g_hr.clear();
+    if (!g_hr_dev && hipMalloc(&g_hr_dev, HR_CAP * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      g_hr_dev = nullptr;
+      st2_set_error("st2_debug_headroom: cannot allocate the record buffer");
+      return 1;
+    }
+    if (hipMemset(g_hr_dev, 0, HR_CAP * sizeof(unsigned)) != hipSuccess) {
+      st2_set_error("st2_debug_headroom: %s", hipGetErrorString(hipGetLastError()));
+      return 1;
+    }
+  } else if (g_hr_scratch) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g_hr_scratch);
+    g_hr_scratch = nullptr;
+    g_hr_scratch_bytes = 0;
+  }
+  g_headroom = enable != 0;
+  return 0;
+}
+
+extern "C" int st2_debug_headroom_read(double* rows, int32_t cap_rows) {
+  ST2_REQUIRE(!g_headroom, "st2_debug_headroom_read: stop the recording first (st2_debug_headroom(0))");
+  const int n = (int)g_hr.size();
+  if (!rows || n == 0) return n;
+  std::vector<unsigned> h(n);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), g_hr_dev, n * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) {
+    st2_set_error("st2_debug_headroom_read: %s", hipGetErrorString(hipGetLastError()));
+    return -1;
+  }
+  for (int i = 0; i < n && i < cap_rows; ++i) {
+    float m;
+    memcpy(&m, &h[i], 4);
+    double* r = rows + (int64_t)i * 8;
+    r[0] = g_hr[i].kind; r[1] = g_hr[i].pro; r[2] = g_hr[i].B; r[3] = g_hr[i].C; r[4] = g_hr[i].L; r[5] = g_hr[i].x_scale;
+    r[6] = m; r[7] = m / 65504.0;
+  }
+  return n;
 }
 
 extern "C" int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats,

@@ -11,6 +11,7 @@ extern template int st2f16s::launch_by_cout<11, 16>(const st2_conv_desc&, hipStr
 
 
 int st2f16s::g_variant = 0;
+int st2_headroom_of_fused_conv(const st2_conv_desc& d, hipStream_t s);  // st2_actsplit.hip: no-op unless st2_debug_headroom(1)
 
 extern "C" void st2_conv1d_f16s_set_variant(int v) { st2f16s::g_variant = (v == 1 || v == 2) ? v : 0; }
 
@@ -45,6 +46,7 @@ extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {
                   (!d.res2 || (int64_t)d.C_out * d.res2_cs < (1ll << 31)),
               "st2_conv1d_f16s: a batch item of y / res / res2 must span < 2^31 elements");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (st2_headroom_of_fused_conv(d, s) != 0) return 1;
   switch (d.ks) {
     case 1:
       return st2f16s::launch_by_cout<1, 32>(d, s);

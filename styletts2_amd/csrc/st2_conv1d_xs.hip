@@ -85,23 +85,32 @@ std::vector<int> candidates(const st2_conv_desc& d) {
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
   const int ny = st2_cdiv(d.C_out, 128);
   const bool swz = (ny == 2 || ny == 4 || ny == 8);
+  const bool per = d.splitk_ws && d.splitk_ws_bytes >= 8;  // the tile queue's counters: persistent twins are candidates
   auto add = [&](int v) {
     for (int x : c)
       if (x == v) return;
     if ((v & st2xs::XS_V_SWIZZLE) && !swz) return;
+    if ((v & st2xs::XS_V_PERSIST) && !per) return;
     if (c.size() < 8) c.push_back(v);
   };
+  const int P = st2xs::XS_V_PERSIST;
   if (d.ks >= 7) {
     add(0);
     if (wg128 >= 512) add(st2xs::XS_V_WIDE);
     add(st2xs::XS_V_SWIZZLE);
     if (wg128 >= 512) add(st2xs::XS_V_WIDE | st2xs::XS_V_SWIZZLE);
+    add(P);
+    if (wg128 >= 512) add(P | st2xs::XS_V_WIDE);
+    add(P | st2xs::XS_V_SWIZZLE);
   } else if (d.ks == 3) {
     add(st2xs::XS_V_CHUNK16);
     add(st2xs::XS_V_SWIZZLE);
-    add(st2xs::XS_V_CHUNK16 | st2xs::XS_V_SWIZZLE);
+    add(P);
+    add(P | st2xs::XS_V_SWIZZLE);
+    add(P | st2xs::XS_V_CHUNK16);
   } else {
     add(st2xs::XS_V_SWIZZLE);
+    add(P);
   }
   return c;
 }
@@ -232,7 +241,7 @@ extern "C" int st2_conv_tune(int mode) {
 }
 
 extern "C" int st2_conv_tune_set(int32_t ks, int32_t C_in, int32_t C_out, int32_t L_out, int32_t B, int32_t variant) {
-  ST2_REQUIRE(variant >= -1 && variant < 8, "st2_conv_tune_set: variant %d out of range", variant);
+  ST2_REQUIRE(variant >= -1 && variant < 16, "st2_conv_tune_set: variant %d out of range", variant);
   const TuneKey key(current_device(), ks, C_in, C_out, L_out, B);
   std::lock_guard<std::mutex> lock(g_tune_mu);
   if (variant < 0) {

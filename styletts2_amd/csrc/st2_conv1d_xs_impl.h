@@ -46,11 +46,11 @@ constexpr int ABL = ST2_XS_ABLATE;
 // Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
 // one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
 // 0.42 ms vs 0.48 ms on the dominant layer at B = 8).
-// `flags` bit 0 = XCD-aware tile order (see st2xs::XS_V_SWIZZLE): workgroup `lin` of the launch runs on XCD lin % 8
-// (observed dispatch order, MI355X_MICROARCH.md), and a launch whose output rows span ny = 2 / 4 / 8 row blocks gives
-// every XCD ONE of them, so that an XCD's 4 MB L2 holds 1 / ny of the packed weights instead of all of them.
+// (bx, by, bz) = the tile's (l tile, row block, batch item): the launch wrappers below derive it from blockIdx (with or
+// without the XCD-aware remap) or from a tile queue (persistent builds).
 template <int KS, int CI_T, int WM, int WN, int TN>
-__device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int flags) {
+__device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const unsigned bx, const unsigned by, const unsigned bz,
+                                               const int tid) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;     // 8-channel groups per chunk
@@ -63,22 +63,12 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   h8* lds = reinterpret_cast<h8*>(smem_raw);  // [2 buffers][NS*NT >= ROWS*XW] slots of 16 B, image = [ROWS][XW]
 
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int kg = lane >> 5;
   const int l31 = lane & 31;
   const int wm = wave / WN;
   const int wn = wave % WN;
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (flags & 1) {  // scalar arithmetic only; the launcher checked gridDim.y in {2, 4, 8} and 8 | workgroup count
-    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
-    const unsigned ny = gridDim.y, xcd = lin & 7, slot = lin >> 3;
-    by = xcd % ny;
-    const unsigned r = xcd / ny + (8 / ny) * slot;  // enumerates (l tile, batch item) within this row block
-    bx = r % gridDim.x;
-    bz = r / gridDim.x;
-  }
   const int n0 = bx * BN;
   const int m0 = by * BM;
   const int b = bz;
@@ -269,22 +259,75 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int
   tl_write();
 }
 
-template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
-__global__ __launch_bounds__(NT, 2) void conv1d_xs_kernel(const st2_conv_desc d, const int flags) {  // >= 2 workgroups per CU
-  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, flags);
-}
-template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 3) void conv1d_xs_kernel_o3(const st2_conv_desc d, const int flags) {  // <= 168 VGPRs
-  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, flags);
+// Tile of workgroup / queue position `lin` in a grid of nx x ny x nz tiles.  `flags` bit 0 = XCD-aware order (see
+// st2xs::XS_V_SWIZZLE): workgroup `lin` of a launch runs on XCD lin % 8 (observed dispatch order, MI355X_MICROARCH.md), and a
+// launch whose output rows span ny = 2 / 4 / 8 row blocks gives every XCD ONE of them, so that an XCD's 4 MB L2 holds 1 / ny of
+// the packed weights instead of all of them.  Scalar arithmetic only; the launcher checked ny and 8 | tile count.
+__device__ __forceinline__ void xs_tile_of(unsigned lin, unsigned nx, unsigned ny, int flags, unsigned& bx, unsigned& by,
+                                           unsigned& bz) {
+  if (flags & 1) {
+    const unsigned xcd = lin & 7, slot = lin >> 3;
+    by = xcd % ny;
+    const unsigned r = xcd / ny + (8 / ny) * slot;  // enumerates (l tile, batch item) within this row block
+    bx = r % nx;
+    bz = r / nx;
+  } else {
+    bx = lin % nx;
+    const unsigned r = lin / nx;
+    by = r % ny;
+    bz = r / ny;
+  }
 }
 
-template <int KS, int CI_T, int WM, int WN, int TN>
-__global__ __launch_bounds__(NT, 4) void conv1d_xs_kernel_o4(const st2_conv_desc d, const int flags) {  // <= 128 VGPRs: narrow tiles only
-  conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, flags);
-}
+#define ST2_XS_ONE_TILE_KERNEL(NAME, WGS_PER_CU)                                                                        \
+  template <int KS, int CI_T, int WM, int WN, int TN>                                                                   \
+  __global__ __launch_bounds__(NT, WGS_PER_CU) void NAME(const st2_conv_desc d, const int flags) {                     \
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;                                                         \
+    if (flags & 1) xs_tile_of(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x, gridDim.y, flags, bx, by, bz);         \
+    conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, bx, by, bz, threadIdx.x);                                                   \
+  }
+ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o2, 2)  // >= 2 workgroups per CU (the variants with wide staging tiles)
+ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o3, 3)  // <= 168 VGPRs
+ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o4, 4)  // <= 128 VGPRs: narrow tiles only
+
+// PERSISTENT builds (variant bit XS_V_PERSIST): the grid is one workgroup per resident slot (workgroups / CU x CUs) and every
+// workgroup pulls tiles from a queue -- one device-scope atomicAdd per tile on ctr[0] -- until it is empty.  What that buys:
+// (i) no workgroup turnaround between tiles (4.5 k of a 132 k-cycle slot, profiles/r02_conv_kernel_study.md); (ii) a CU that
+// is slow -- round 4 found boxes where the 8 CUs of one shader engine run the epilogue's scattered stores 12 x slower
+// (profiles/r04h1_*) -- simply takes fewer tiles, where the hardware dispatcher deals every XCD an equal share of the grid
+// and lets the others wait for its slowest.  Same tiles, same arithmetic: bitwise the one-tile-per-workgroup result.
+// ctr = {next tile, workgroups done}: zero at launch; the last workgroup out puts both back to zero, so the same 8 bytes
+// serve every launch of a stream (st2.h: d.splitk_ws).
+#define ST2_XS_PERSISTENT_KERNEL(NAME, WGS_PER_CU)                                                                      \
+  template <int KS, int CI_T, int WM, int WN, int TN>                                                                   \
+  __global__ __launch_bounds__(NT, WGS_PER_CU) void NAME(const st2_conv_desc d, const int flags, const unsigned nx,     \
+                                                         const unsigned ny, const unsigned total, unsigned* ctr) {      \
+    __shared__ unsigned next_tile;                                                                                      \
+    for (;;) {                                                                                                          \
+      if (threadIdx.x == 0) next_tile = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
+      __syncthreads();                                                                                                  \
+      const unsigned lin = next_tile;                                                                                   \
+      if (lin >= total) break;                                                                                          \
+      unsigned bx, by, bz;                                                                                              \
+      xs_tile_of(lin, nx, ny, flags, bx, by, bz);                                                                       \
+      /* the thread index is laundered per tile: otherwise the optimiser hoists every lane-dependent address of the    \
+         body AND of its epilogue out of the tile loop, keeps them live through the k loop and spills 31-36 VGPRs */   \
+      int tid = threadIdx.x;                                                                                            \
+      asm volatile("" : "+v"(tid));                                                                                     \
+      conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, bx, by, bz, tid);                                                         \
+      __syncthreads(); /* next_tile and the LDS image are reused */                                                     \
+    }                                                                                                                   \
+    if (threadIdx.x == 0 &&                                                                                             \
+        __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {             \
+      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                          \
+      __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                      \
+    }                                                                                                                   \
+  }
+ST2_XS_PERSISTENT_KERNEL(conv1d_xs_kernel_p2, 2)
+ST2_XS_PERSISTENT_KERNEL(conv1d_xs_kernel_p3, 3)
 
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
-int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
+int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false, bool persist = false) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   const int XW = BN + (KS - 1) * d.dil;
@@ -308,6 +351,45 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
   if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_xs: part_nt=%d < %d tiles", d.part_nt,
                           st2_cdiv(d.L_out, 128));
   if constexpr (TN < 4) ST2_REQUIRE(!d.part, "st2_conv1d_xs: the narrow token tiles do not produce partial sums");
+  dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
+  const int64_t total = (int64_t)grid.x * grid.y * grid.z;
+  // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a tile count divisible by 8
+  const int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && total % 8 == 0;
+  if constexpr ((OCC == 2 || OCC == 3) && WM == 4 && TN >= 4 && KS != 1) {  // the 128-row tiles of the big layers only
+    if (persist && d.splitk_ws && d.splitk_ws_bytes >= 8 && total < (1ll << 31)) {
+      void (*kern)(const st2_conv_desc, int, unsigned, unsigned, unsigned, unsigned*);
+      if constexpr (OCC == 3)
+        kern = &conv1d_xs_kernel_p3<KS, CI_T, WM, WN, TN>;
+      else
+        kern = &conv1d_xs_kernel_p2<KS, CI_T, WM, WN, TN>;
+      static std::atomic<uint64_t> attr_done_p{0};  // one bit per device ordinal
+      static int slots_of[64] = {};                 // resident workgroups of this build per device (occupancy query, once)
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (st2_first_use_on_device(attr_done_p) || dev < 0 || dev >= 64 || !slots_of[dev]) {
+        // (the queue's 4 bytes of static LDS count against the 160 KB: asking for all of it as dynamic LDS is refused)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 256) != hipSuccess)
+          (void)hipGetLastError();
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NT, smem) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0) {
+          (void)hipGetLastError();
+          per_cu = 0;
+        }
+        if (dev >= 0 && dev < 64) slots_of[dev] = per_cu > 0 ? std::min(per_cu, OCC) * prop.multiProcessorCount : -1;
+      }
+      const int slots = dev >= 0 && dev < 64 ? slots_of[dev] : -1;
+      if (slots > 0) {
+        const unsigned wgs = (unsigned)std::min<int64_t>(slots, total);
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(NT), smem, s, d, flags, grid.x, grid.y, (unsigned)total,
+                           reinterpret_cast<unsigned*>(d.splitk_ws));
+        ST2_CHECK_LAUNCH("st2_conv1d_xs (persistent)");
+        return 0;
+      }
+    }
+  }
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal (hipFuncSetAttribute is per device)
   if (st2_first_use_on_device(attr_done)) {
     if constexpr (OCC == 4)
@@ -317,18 +399,15 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     else
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o2<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
-  // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a workgroup count divisible by 8
-  const int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && ((int64_t)grid.x * grid.y * grid.z) % 8 == 0;
   if constexpr (OCC == 4)
     hipLaunchKernelGGL((conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, flags);
   else if constexpr (OCC == 3)
     hipLaunchKernelGGL((conv1d_xs_kernel_o3<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, flags);
   else
-    hipLaunchKernelGGL((conv1d_xs_kernel<KS, CI_T, WM, WN, TN, 2>), grid, dim3(NT), smem, s, d, flags);
+    hipLaunchKernelGGL((conv1d_xs_kernel_o2<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, flags);
   ST2_CHECK_LAUNCH("st2_conv1d_xs");
   return 0;
 }
@@ -346,7 +425,9 @@ namespace st2xs {
 //   bit 1  XS_V_SWIZZLE  XCD-aware tile order: one row block per XCD (launches with 2 / 4 / 8 row blocks)
 //   bit 2  XS_V_CHUNK16  16-channel chunks for k <= 3 (half the LDS image per barrier, twice the barriers); selects the
 //                        launch_by_cout<KS, 16> instantiation in the dispatcher, ignored here
-enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4 };
+//   bit 3  XS_V_PERSIST  persistent workgroups pulling tiles from a queue (C_out > 64 builds; needs the 8 zero bytes of
+//                        d.splitk_ws, else the one-tile-per-workgroup form of the same build runs)
+enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4, XS_V_PERSIST = 8 };
 
 // The build an UNTUNED process runs (tests, one-off calls; a serving process measures: st2_conv_tune).  k >= 7: 32 (co) x
 // 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU -- half the weight stream (L2 -> registers) per FLOP;
@@ -369,10 +450,10 @@ inline int rule_variant(const st2_conv_desc& d) {
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
   if (variant < 0) variant = rule_variant(d);
-  const bool swz = (variant & XS_V_SWIZZLE) != 0;
+  const bool swz = (variant & XS_V_SWIZZLE) != 0, per = (variant & XS_V_PERSIST) != 0;
   if (d.C_out > 64) {
     if constexpr (KS >= 7) {
-      if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
+      if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz, per);
     }
     if constexpr (KS == 1 && CI_T == 32) {
       // Token GEMMs (the denoiser's / PL-BERT's Linears over the B*N merged tokens: C_out 512..1024 x 3 200 columns): at
@@ -384,7 +465,10 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
       if ((int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B < 256 && d.wq_cin_pad % 64 == 0 && !d.part)
         return launch<1, 64, 4, 1, 2, 3>(d, s, swz);
     }
-    return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz);  // 128 co x 128 l, 3 workgroups / CU
+    if constexpr (KS == 1)
+      return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz);  // (token GEMMs: one build, no persistent twin)
+    else
+      return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz, per);  // 128 co x 128 l, 3 workgroups / CU
   }
   if (d.C_out > 32) {                                           // 64 co x 256 l
     if constexpr (CI_T == 16)

@@ -99,13 +99,15 @@ class conv_autotune:
         return False
 
 
-TUNE_VARIANT_BITS = {1: "128x256 tiles, 2 wg/CU", 2: "XCD-aware tile order", 4: "16-channel chunks"}
+TUNE_VARIANT_BITS = {1: "128x256 tiles, 2 wg/CU", 2: "XCD-aware tile order", 4: "16-channel chunks", 8: "persistent tile queue"}
 
 
 def tune_variant_name(v):
     if v < 0:
         return "rule"
     names = [n for b, n in TUNE_VARIANT_BITS.items() if v & b]
+    if not v & 1 and v & 8:
+        names.insert(0, "128x128 tiles")
     return " + ".join(names) if names else "128x128 tiles, 3 wg/CU, dispatch order"
 
 
@@ -130,6 +132,33 @@ def conv_tune_table():
 def conv_tune_set(ks, C_in, C_out, L_out, B, variant):
     """Pins (variant >= 0) or erases (-1) the build of one shape class on the current device (tests, A/B probes)."""
     _lib.check(_lib.load().st2_conv_tune_set(ks, C_in, C_out, L_out, B, variant), "st2_conv_tune_set")
+
+
+class headroom:
+    """`with ops.headroom() as h: forward(...)` then `h.rows`: how close every split-f16 conv operand of that forward came
+    to the f16 range (include/st2.h `st2_debug_headroom`; debug hook: extra launches, a scratch allocation, synchronises).
+    rows = [{index, kind ("act_split" | "fused conv"), pro, B, C, L, x_scale, max_abs, frac}], frac = max |x_scale * pro(x)| /
+    65504; a layer at frac >= 1 was clamped (ST2_STATUS_F16_RANGE)."""
+
+    def __enter__(self):
+        _lib.check(_lib.load().st2_debug_headroom(1), "st2_debug_headroom")
+        self.rows = []
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        lib = _lib.load()
+        torch.cuda.synchronize()
+        _lib.check(lib.st2_debug_headroom(0), "st2_debug_headroom")
+        n = lib.st2_debug_headroom_read(None, 0)
+        buf = (ctypes.c_double * (8 * max(n, 1)))()
+        n = min(n, lib.st2_debug_headroom_read(buf, n))
+        pro_names = ["none", "leaky", "adain+leaky", "adain+snake", "snake", "layernorm"]
+        for i in range(max(n, 0)):
+            r = buf[8 * i:8 * i + 8]
+            self.rows.append({"index": i, "kind": "fused conv" if int(r[0]) else "act_split", "pro": pro_names[int(r[1])],
+                              "B": int(r[2]), "C": int(r[3]), "L": int(r[4]), "x_scale": r[5], "max_abs": r[6], "frac": r[7]})
+        return False
 
 
 def probe_box(level=0):
@@ -264,10 +293,25 @@ def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, ou
         nt = (L_out + 127) // 128
         part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
         d.part, d.part_nt = part.data_ptr(), nt
+    ctr = _tile_queue(out.device)
+    d.splitk_ws, d.splitk_ws_bytes = ctr.data_ptr(), ctr.numel() * 4
     _launch_conv(lib.st2_conv1d_xs, "st2_conv1d_xs", d)
     if want_stats:
         return out, stats_finalize(part, L_out)
     return out
+
+
+_TILE_QUEUES = {}
+
+
+def _tile_queue(device):
+    """The 8 zero bytes a persistent build of st2_conv1d_xs keeps its tile queue in (include/st2.h: zero before a launch, left
+    zero by it): one block per (device, stream) -- launches of one stream are ordered, two streams never share a block."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _TILE_QUEUES.get(key)
+    if t is None:
+        t = _TILE_QUEUES[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return t
 
 
 def _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope):

@@ -103,7 +103,7 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
     objdump, readelf = os.path.join(tools, "llvm-objdump"), os.path.join(tools, "llvm-readelf")
     if not (os.path.exists(objdump) and os.path.exists(readelf)):
         pytest.skip("ROCm LLVM binutils not installed")
-    objs = [os.path.join(ROOT, "styletts2_amd", "csrc", "build", "st2_conv1d_xs_k%d.o" % i) for i in range(4)]
+    objs = [os.path.join(ROOT, "styletts2_amd", "csrc", "build", "st2_conv1d_xs_k%d.o" % i) for i in range(5)]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("objects not built (run __graft_entry__.build())")
     seen = 0
@@ -119,8 +119,13 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
         for name, priv, vgpr, spill in kernels:
             if "conv1d_xs_kernel" not in name:
                 continue
-            # every build of the family keeps its epilogue in registers: the 3-workgroups-per-CU builds within 168 VGPRs,
-            # the 2-workgroups-per-CU builds (32 x 256 wave tiles, narrow layers) within 256
+            # every one-tile-per-workgroup build keeps its epilogue in registers: the 3-workgroups-per-CU builds within 168
+            # VGPRs, the 2-workgroups-per-CU builds (32 x 256 wave tiles, narrow layers) within 256.  The persistent twins of
+            # the 168-VGPR builds (_p3: the same body inside a tile-queue loop, whose loop-invariant scalars cost registers)
+            # may park a few dwords in scratch in the prologue / epilogue -- never inside the k loop (checked below).
+            if "conv1d_xs_kernel_p3" in name:
+                assert int(priv) <= 64 and int(vgpr) <= 168, "%s: %s B scratch, %s VGPRs" % (name, priv, vgpr)
+                continue
             assert int(spill) == 0 and int(priv) == 0, "%s spills %s VGPRs (%s B scratch)" % (name, spill, priv)
             if "conv1d_xs_kernel_o3" not in name:
                 assert int(vgpr) <= 256, "%s uses %s VGPRs" % (name, vgpr)
@@ -128,12 +133,24 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
             seen += 1
             assert int(vgpr) <= 168, "%s uses %s VGPRs: 2 workgroups per CU, not 3" % (name, vgpr)
         dis = subprocess.check_output([objdump, "-d", co], text=True)
-        in_o3 = False
+        cur, body = None, []
+
+        def check(cur, body):
+            if cur is None:
+                return
+            mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+            sc = [i for i, l in enumerate(body) if "scratch_" in l]
+            if "conv1d_xs_kernel_o3" in cur:
+                assert not sc, "%s: scratch instruction in a 168-VGPR build" % cur
+            elif "conv1d_xs_kernel_p" in cur and mf:
+                assert not [i for i in sc if mf[0] < i < mf[-1]], "%s: scratch instruction inside the k loop" % cur
         for line in dis.splitlines():
             if line.endswith(">:"):
-                in_o3 = "conv1d_xs_kernel_o3" in line
-            elif in_o3:
-                assert "scratch_" not in line, line
+                check(cur, body)
+                cur, body = line, []
+            else:
+                body.append(line)
+        check(cur, body)
         os.remove(co)
     assert seen >= 9, "expected the o3 builds of every kernel size, saw %d" % seen
 

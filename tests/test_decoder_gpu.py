@@ -98,3 +98,39 @@ def test_decoder_is_deterministic_and_rejects_training_mode():
     dec.train()
     with pytest.raises(RuntimeError):
         dec(asr.to(DEV), F0.to(DEV), N.to(DEV), s.to(DEV))
+
+
+def test_headroom_report_on_a_trained_like_checkpoint():
+    """st2_debug_headroom: per conv launch, the largest split-f16 operand of one decoder call as a fraction of the f16
+    range.  On a "trained-like" synthetic checkpoint (log-normal weight-norm gains, Snake alpha log-uniform in [0.1, 10]:
+    the free parameters of Modules/istftnet.py:27-62) every layer must stay inside the range -- the report and the sticky
+    status word have to agree -- and the decoder must still meet the oracle at the waveform bar."""
+    import synth
+    from _util import decoder_kwargs, manifest, rms
+    from oracle import st2_oracle as O
+    from styletts2_amd import ops
+    from styletts2_amd.decoder import Decoder
+    man = manifest("ljspeech")
+    dec = Decoder(**decoder_kwargs(man["config"]["decoder"]))
+    synth.init_trained_like_(dec, 1)
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    dec = dec.eval().to("cuda")
+    asr, F0, N, s, noise = synth.decoder_inputs(2, 24, 3)
+    with torch.no_grad():
+        to = {}
+        ref = O.decoder(sd, man["config"]["decoder"], asr, F0, N, s, noise=noise, taps=to)
+        ref = O.decoder(sd, man["config"]["decoder"], asr, F0, N, s, noise=noise, har=to["har"])
+    ops.status(clear=True)
+    with ops.headroom() as h:
+        out = dec(asr.cuda(), F0.cuda(), N.cuda(), s.cuda(), noise=noise.cuda(), har=to["har"].cuda())
+    torch.cuda.synchronize()
+    assert len(h.rows) >= 40, "every conv of the call is reported (%d rows)" % len(h.rows)
+    assert {r["kind"] for r in h.rows} == {"act_split", "fused conv"}
+    worst = max(r["frac"] for r in h.rows)
+    assert 0.0 < worst < 1.0, "a layer left the f16 range: %g" % worst
+    assert ops.status(clear=True) == 0, "in-range operands must not raise ST2_STATUS_F16_RANGE"
+    assert rms(out.cpu() - ref) < 1e-4 * max(1.0, rms(ref)), (rms(out.cpu() - ref), rms(ref))
+    # and the hook is off again: a second call records nothing
+    dec(asr.cuda(), F0.cuda(), N.cuda(), s.cuda(), noise=noise.cuda())
+    from styletts2_amd import _lib
+    assert _lib.load().st2_debug_headroom_read(None, 0) == len(h.rows)
