@@ -529,7 +529,11 @@ def main():
     with tune_ctx:
         out = step()
         torch.cuda.synchronize()
-    tune_table = [] if a.no_autotune else ops.conv_tune_table()
+    try:
+        tune_table = [] if a.no_autotune else ops.conv_tune_table()
+    except Exception as e:  # the table is a report; the builds it chose are already in the library
+        tune_table = []
+        log("autotune table unreadable: %r" % (e,))
     log("set-up step done in %.2f s (%s%d conv classes tuned, %d off the rule)" % (
         time.perf_counter() - t_tune, "front graph recorded, " if lf_front is not None else "", len(tune_table),
         sum(1 for r in tune_table if r["candidates"] and r["chosen"] != r["candidates"][0]["variant"])))
@@ -554,17 +558,24 @@ def main():
     if not longform and a.calib_steps > 0:
         smp = None
         if rank == 0 and box is not None:
-            from benchdata import boxinfo
-            smp = boxinfo.Sampler(local_rank)
-            smp.__enter__()
+            try:  # a diagnostic: never in the way of the measurement
+                from benchdata import boxinfo
+                smp = boxinfo.Sampler(local_rank)
+                smp.__enter__()
+            except Exception as e:
+                smp = None
+                log("sensor sampler unavailable: %r" % (e,))
         for name in sched:
             active["name"] = name
             step()  # first use of these streams: allocator warm-up
             calib[name] = time_steps(a.calib_steps)
             log("calibration: %-11s %.2f ms/step" % (name, calib[name]))
         if smp is not None:
-            smp.__exit__(None, None, None)
-            sensors = smp.summary()
+            try:
+                smp.__exit__(None, None, None)
+                sensors = smp.summary()
+            except Exception as e:
+                log("sensor summary unavailable: %r" % (e,))
         if world > 1:  # every rank runs the same schedule: rank 0's choice (no collective in steady state either way)
             order = sorted(calib)
             tt = torch.tensor([calib[n] for n in order], device=dev, dtype=torch.float64)

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include "st2_common.h"
 
 static thread_local char g_err[512] = "";
@@ -70,6 +72,18 @@ extern "C" int st2_status(int clear) {
 }
 
 // ---- CU-partitioned streams (st2.h, ABI v17) -----------------------------------------------------------------------
+// Streams created with a CU mask, and how many CUs each owns: a cooperative launch (st2_lstm_bidir_coop) on such a stream
+// must fit ITS CUs, not the device's (advisor, round 3: on a 16-64-CU partition the spin-waiting groups would otherwise be
+// only partially resident and time out).
+static std::mutex g_mask_mu;
+static std::map<void*, int> g_masked_streams;
+
+int st2_stream_cu_count(void* stream) {  // 0 = not a CU-masked stream of this library
+  std::lock_guard<std::mutex> lock(g_mask_mu);
+  auto it = g_masked_streams.find(stream);
+  return it == g_masked_streams.end() ? 0 : it->second;
+}
+
 extern "C" int st2_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** stream) {
   if (!mask || n_words <= 0 || !stream) {
     st2_set_error("st2_stream_create_cu_mask: bad arguments");
@@ -89,11 +103,21 @@ extern "C" int st2_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, 
     return 1;
   }
   *stream = s;
+  int cus = 0;
+  for (int i = 0; i < n_words; ++i) cus += __builtin_popcount(mask[i]);
+  {
+    std::lock_guard<std::mutex> lock(g_mask_mu);
+    g_masked_streams[s] = cus;
+  }
   return 0;
 }
 
 extern "C" int st2_stream_destroy(void* stream) {
   if (!stream) return 0;
+  {
+    std::lock_guard<std::mutex> lock(g_mask_mu);
+    g_masked_streams.erase(stream);
+  }
   hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) {
     st2_set_error("st2_stream_destroy: %s", hipGetErrorString(e));

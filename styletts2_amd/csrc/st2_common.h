@@ -6,6 +6,7 @@
 #include "st2.h"
 
 void st2_set_error(const char* fmt, ...);
+int st2_stream_cu_count(void* stream);  // st2_api.hip: CUs of a stream made by st2_stream_create_cu_mask, 0 otherwise
 int* st2_status_device_ptr();  // st2_api.hip: device view of the sticky status word (nullptr without a device)
 
 // Kernel side: raise status bit `bit` (ST2_STATUS_*).  Every bit has its own 32-bit slot in the host-mapped block so

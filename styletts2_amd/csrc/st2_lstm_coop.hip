@@ -23,6 +23,7 @@
 // starts at t = length - 1); arithmetic per gate row is a fixed-order fp32 sum (k ascending inside a 32-slice, the
 // 8 slices ascending), bitwise reproducible.
 #include "st2_common.h"
+#include <algorithm>
 #include <atomic>
 
 namespace {
@@ -293,7 +294,15 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
     capacity = per_cu * prop.multiProcessorCount;
     if (dev >= 0 && dev < MAX_DEV && capacity > 0) capacity_of[dev].store(capacity, std::memory_order_relaxed);
   }
-  ST2_REQUIRE(groups * NSL <= capacity, "st2_lstm_bidir_coop: %d workgroups cannot be co-resident on this device "
+  // a CU-masked stream (st2_stream_create_cu_mask) owns only its CUs: the co-residency bound is theirs
+  if (const int masked = st2_stream_cu_count(s)) {
+    int num_cu = 0;
+    if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && num_cu > 0)
+      capacity = (int)((int64_t)capacity * std::min(masked, num_cu) / num_cu);
+    else
+      (void)hipGetLastError();
+  }
+  ST2_REQUIRE(groups * NSL <= capacity, "st2_lstm_bidir_coop: %d workgroups cannot be co-resident on this device / stream "
               "(capacity %d): use st2_lstm_bidir", groups * NSL, capacity);
   int* status = reinterpret_cast<int*>(scratch);
   int* counters = status + 1;

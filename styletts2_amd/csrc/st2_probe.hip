@@ -136,20 +136,31 @@ __global__ __launch_bounds__(256) void probe_census_kernel(unsigned long long* o
 // The conv epilogue's store pattern (st2_conv_epilogue.h: a lane owns one output row, a wave instruction writes 32 rows x
 // 32 bytes) on a [B][256][8000] tensor, one 128 x 256 tile per workgroup, timed per workgroup: on round 4's slow-class box
 // the 8 CUs of one shader engine took 12 x the cycles of every other CU for exactly this phase (profiles/r04h1_*).
+// `row_major` = the same 128 x 256 tile written one row per wave instruction (64 lanes x 16 bytes = 1 KB contiguous): the
+// control experiment -- is it the scatter (32 rows = 32 pages per instruction) that the degraded CUs cannot take?
 __global__ __launch_bounds__(256) void probe_scatter_kernel(float* y, int pitch, int rows_per_item, int n_tiles,
-                                                             unsigned long long* out) {
+                                                             unsigned long long* out, int row_major) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 5, l31 = lane & 31;
   const int tile = blockIdx.x % n_tiles, rb = (blockIdx.x / n_tiles) % (rows_per_item / 128), b = blockIdx.x / (n_tiles * (rows_per_item / 128));
   float* base = y + ((size_t)b * rows_per_item + rb * 128 + wave * 32 + l31) * pitch + tile * 256 + 4 * kg;
+  float* rbase = y + ((size_t)b * rows_per_item + rb * 128 + wave * 32) * pitch + tile * 256 + 4 * lane;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f4 v = {(float)j, (float)q, (float)lane, (float)blockIdx.x};
-      *reinterpret_cast<f4*>(base + j * 32 + 8 * q) = v;
+  if (row_major) {
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const f4 v = {(float)i, (float)wave, (float)lane, (float)blockIdx.x};
+      *reinterpret_cast<f4*>(rbase + (size_t)i * pitch) = v;
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f4 v = {(float)j, (float)q, (float)lane, (float)blockIdx.x};
+        *reinterpret_cast<f4*>(base + j * 32 + 8 * q) = v;
+      }
+  }
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) {
@@ -344,44 +355,46 @@ extern "C" int st2_probe_box(char* json, int32_t cap, int32_t level) {
     float* y = (float*)alloc((size_t)B * rows * pitch * 4);
     unsigned long long* out = (unsigned long long*)alloc((size_t)wgs * 16);
     if (y && out) {
-      for (int rep = 0; rep < 2; ++rep)
-        hipLaunchKernelGGL(probe_scatter_kernel, dim3(wgs), dim3(256), 0, 0, y, pitch, rows, n_tiles, out);
-      PCK(hipDeviceSynchronize());
-      std::vector<unsigned long long> h((size_t)wgs * 2);
-      PCK(hipMemcpy(h.data(), out, (size_t)wgs * 16, hipMemcpyDeviceToHost));
-      std::map<unsigned long long, std::vector<double>> per_cu;
-      std::vector<double> all;
-      for (int i = 0; i < wgs; ++i) {
-        const unsigned long long id = h[2 * i];
-        const unsigned long long key = (((id >> 32) & 15) << 32) | (id & 0xFF00);
-        per_cu[key].push_back((double)h[2 * i + 1]);
-        all.push_back((double)h[2 * i + 1]);
-      }
-      std::sort(all.begin(), all.end());
-      const double med = all[all.size() / 2];
-      js.raw(", \"scatter_store\": {");
-      js.kv("workgroups", wgs, "%.0f");
-      js.raw(", ");
-      js.kv("cycles_per_wg_median", med, "%.0f");
-      js.raw(", ");
-      js.kv("cycles_per_wg_max", all.back(), "%.0f");
-      js.raw(", \"slow_cus\": [");
-      int n_slow = 0;
-      for (auto& kv : per_cu) {
-        std::vector<double>& v = kv.second;
-        std::sort(v.begin(), v.end());
-        const double m = v[v.size() / 2];
-        if (m > 2.0 * med) {
-          char b[128];
-          snprintf(b, sizeof b, "%s{\"xcc\": %d, \"se\": %d, \"sh\": %d, \"cu\": %d, \"x_median\": %.1f}", n_slow ? ", " : "",
-                   (int)(kv.first >> 32), (int)((kv.first >> 13) & 7), (int)((kv.first >> 12) & 1), (int)((kv.first >> 8) & 15), m / med);
-          if (n_slow < 64) js.raw(b);
-          ++n_slow;
+      for (int mode = 0; mode < 2; ++mode) {
+        for (int rep = 0; rep < 2; ++rep)
+          hipLaunchKernelGGL(probe_scatter_kernel, dim3(wgs), dim3(256), 0, 0, y, pitch, rows, n_tiles, out, mode);
+        PCK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)wgs * 2);
+        PCK(hipMemcpy(h.data(), out, (size_t)wgs * 16, hipMemcpyDeviceToHost));
+        std::map<unsigned long long, std::vector<double>> per_cu;
+        std::vector<double> all;
+        for (int i = 0; i < wgs; ++i) {
+          const unsigned long long id = h[2 * i];
+          const unsigned long long key = (((id >> 32) & 15) << 32) | (id & 0xFF00);
+          per_cu[key].push_back((double)h[2 * i + 1]);
+          all.push_back((double)h[2 * i + 1]);
         }
+        std::sort(all.begin(), all.end());
+        const double med = all[all.size() / 2];
+        js.raw(mode ? ", \"row_store\": {" : ", \"scatter_store\": {");
+        js.kv("workgroups", wgs, "%.0f");
+        js.raw(", ");
+        js.kv("cycles_per_wg_median", med, "%.0f");
+        js.raw(", ");
+        js.kv("cycles_per_wg_max", all.back(), "%.0f");
+        js.raw(", \"slow_cus\": [");
+        int n_slow = 0;
+        for (auto& kv : per_cu) {
+          std::vector<double>& v = kv.second;
+          std::sort(v.begin(), v.end());
+          const double m = v[v.size() / 2];
+          if (m > 2.0 * med) {
+            char b[128];
+            snprintf(b, sizeof b, "%s{\"xcc\": %d, \"se\": %d, \"sh\": %d, \"cu\": %d, \"x_median\": %.1f}", n_slow ? ", " : "",
+                     (int)(kv.first >> 32), (int)((kv.first >> 13) & 7), (int)((kv.first >> 12) & 1), (int)((kv.first >> 8) & 15), m / med);
+            if (n_slow < 64) js.raw(b);
+            ++n_slow;
+          }
+        }
+        js.raw("], ");
+        js.kv("n_slow_cus", n_slow, "%.0f");
+        js.raw("}");
       }
-      js.raw("], ");
-      js.kv("n_slow_cus", n_slow, "%.0f");
-      js.raw("}");
     }
   }
 

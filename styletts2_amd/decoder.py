@@ -17,6 +17,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .layers import transient_state
 from . import ops
 from . import weights as W
 from .layers import (AdaINParams, AdaINResBlock1Params, AdainResBlk1dParams, PlainConv1d, PlainLinear, WNConv1d,
@@ -266,6 +267,7 @@ class Generator(nn.Module):
                           alpha=pk.alphas[self.num_upsamples], act=ops.ACT_TANH)
 
 
+@transient_state
 class Decoder(nn.Module):
     """Drop-in for the reference Decoder (both vocoder variants)."""
 

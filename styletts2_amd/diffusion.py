@@ -20,6 +20,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .layers import transient_state
 from . import ops
 from . import weights as W
 from .layers import PlainConv1d, PlainLinear
@@ -98,6 +99,7 @@ class KDiffusion(nn.Module):
         return ops.axpbypcz(x_noisy.contiguous(), c_skip, x_pred, c_out)
 
 
+@transient_state
 class DiffusionSampler(nn.Module):
     """sampler.py:550-586."""
 
@@ -324,6 +326,7 @@ class _Block(nn.Module):
                                           PlainLinear(features * multiplier, features))
 
 
+@transient_state
 class _Transformer(nn.Module):
     multispeaker = False
 

@@ -99,3 +99,26 @@ class AdainResBlk1dParams(nn.Module):
         if upsample:
             self.pool = WNConvTranspose1d(dim_in, 1, 3, dim_in)
         self.dim_in, self.dim_out, self.upsample, self.learned_sc = dim_in, dim_out, upsample, dim_in != dim_out
+
+
+# ---- per-process caches never travel -------------------------------------------------------------------------------
+# Modules keep lazily built, process-local state next to their parameters: packed weights (`_pk`), st2_engine handles
+# (ctypes pointers: `_eng`, `_engine`, `_front_engine`, `_style_engine`) and a weakref to the module that owns their C++
+# plan (`_owner`).  None of it can be pickled or deep-copied, and none of it should be: a copy repacks on first use.
+TRANSIENT_ATTRS = ("_pk", "_eng", "_engine", "_engine_stale", "_front_engine", "_style_engine", "_owner")
+
+
+def transient_state(cls):
+    """Class decorator: `torch.save(module)`, `pickle` and `copy.deepcopy` see the transient attributes as None."""
+    inherited = getattr(cls, "__getstate__", None)  # e.g. nn.RNNBase drops its own weakrefs there; object has none (3.10)
+
+    def __getstate__(self):
+        d = dict(inherited(self)) if inherited is not None and inherited is not getattr(object, "__getstate__", None) \
+            else self.__dict__.copy()
+        for k in TRANSIENT_ATTRS:
+            if k in d:
+                d[k] = None
+        return d
+    cls.__getstate__ = __getstate__
+    return cls
+

@@ -38,6 +38,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .layers import transient_state
 from . import _hooks, ops
 from . import weights as W
 
@@ -88,6 +89,7 @@ class _ResBlk(nn.Module):
 
 
 
+@transient_state
 class StyleEncoder(nn.Module):
     """models.py:139-164: mel [B, 1, 80, T] -> style [B, style_dim].  T >= 80 frames (the 5x5 valid conv after four
     halvings needs a 5-wide map)."""

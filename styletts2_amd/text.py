@@ -18,6 +18,7 @@ import weakref
 import torch
 import torch.nn as nn
 
+from .layers import transient_state
 from . import _hooks, ops
 from . import weights as W
 from .decoder import StyleBank, _PackedAdainResBlk, _PackedConv, run_adain_resblk
@@ -53,6 +54,7 @@ def _device_lengths(lengths, n, device):
     return lc.to(torch.int32).to(device)
 
 
+@transient_state
 class EngineLSTM(nn.LSTM):
     """nn.LSTM(1 layer, bidirectional, batch_first) parameter holder -- same state_dict keys as the reference's
     nn.LSTM -- whose arithmetic runs on the HIP kernels: the input projection of every time step is one k=1
@@ -140,6 +142,7 @@ class _PackedCache:
         return pk
 
 
+@transient_state
 class TextEncoder(_PackedCache, nn.Module):
     """models.py:284-345: Embedding -> depth x [weight-norm Conv1d k5 -> LayerNorm(C) -> LeakyReLU(0.2)] -> BiLSTM."""
 
@@ -192,6 +195,7 @@ class _AdaLayerNorm(nn.Module):
         raise NotImplementedError("AdaLayerNorm runs inside DurationEncoder.forward (st2_colnorm_stats / st2_colnorm_apply)")
 
 
+@transient_state
 class DurationEncoder(nn.Module):
     """models.py:517-569: nlayers x [BiLSTM(d_model+sty -> d_model), AdaLayerNorm, concat style]."""
 
@@ -236,6 +240,7 @@ class DurationEncoder(nn.Module):
         return h.transpose(1, 2)
 
 
+@transient_state
 class EngineLinear(_PackedCache, nn.Linear):
     """nn.Linear parameter holder (same state_dict keys) whose forward is a k=1 split-f16 MFMA conv over the merged
     leading dimensions (`bert_encoder`, models.py:689; `duration_proj.linear_layer`, models.py:34-44)."""
@@ -270,6 +275,7 @@ class _LinearNorm(nn.Module):
         return self.linear_layer(x)
 
 
+@transient_state
 class ProsodyPredictor(_PackedCache, nn.Module):
     """models.py:440-515.  `text_encoder`, `lstm`, `duration_proj`, `F0Ntrain` are called individually by the
     inference glue (Demo/Inference_LJSpeech.ipynb:294-311), so they keep the reference signatures."""
@@ -288,6 +294,10 @@ class ProsodyPredictor(_PackedCache, nn.Module):
         self.N_proj = PlainConv1d(d_hid // 2, 1, 1)
         self._pk = None
         self.text_encoder.__dict__["_owner"] = weakref.ref(self)  # its C++ plan lives in this module's engine handle
+
+    def __setstate__(self, state):  # a copy owns its own text_encoder: point its plan at THIS predictor
+        super().__setstate__(state)
+        self.text_encoder.__dict__["_owner"] = weakref.ref(self)
 
     def _pred_engine(self, device):
         """The st2_engine handle holding the whole predictor (st2_duration_forward, st2_prosody_forward)."""
@@ -337,6 +347,7 @@ def build_plbert(plbert_params):
     The 12 layers share one weight set (ALBERT), packed once per load."""
     from transformers import AlbertConfig, AlbertModel
 
+    @transient_state
     class CustomAlbert(AlbertModel):
         def _apply(self, fn, *a, **k):
             self._pk = None

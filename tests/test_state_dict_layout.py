@@ -45,3 +45,41 @@ def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
     for k, v in model.text_encoder.state_dict().items():
         assert torch.equal(v, fresh.text_encoder.state_dict()[k])
     assert not torch.equal(model.bert_encoder.weight, fresh.bert_encoder.weight)  # ignored module untouched
+
+
+def test_modules_pickle_and_deepcopy_without_their_process_local_caches():
+    """Packed weights, st2_engine handles (ctypes pointers) and the owner weakref of `DurationEncoder` are process-local
+    caches (styletts2_amd/layers.py `transient_state`): `torch.save(module)`, `pickle` and `copy.deepcopy` drop them, a copy
+    of the predictor owns its own text_encoder, and the copy's parameters equal the original's (advisor, round 3)."""
+    import copy
+    import io
+
+    import torch
+
+    from benchdata import manifest, synth
+    from styletts2_amd import models
+    man = manifest("ljspeech")
+    args = models.recursive_munch(man["config"])
+    model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))
+    for i, k in enumerate(["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]):
+        m = model[k]
+        synth.init_synthetic_(m, 10 + i)
+        # what a GPU run would have cached, where the product caches it: must not travel
+        holder = m.diffusion.net if k == "diffusion" else m
+        holder.__dict__["_engine"] = ("stamp", object())
+        c = copy.deepcopy(m)
+        others = [c]
+        if k != "bert":  # PL-BERT's class is created inside build_plbert (lazy `transformers` import): it travels as a
+            buf = io.BytesIO()  # state_dict, like the reference's own Utils/PLBERT/util.py:load_plbert does
+            torch.save(m, buf)
+            buf.seek(0)
+            others.append(torch.load(buf, weights_only=False))
+        for other in others:
+            oh = other.diffusion.net if k == "diffusion" else other
+            assert oh.__dict__.get("_engine") is None and oh.__dict__.get("_pk") is None
+            sa, sb = m.state_dict(), other.state_dict()
+            assert sa.keys() == sb.keys() and all(torch.equal(sa[n], sb[n]) for n in sa)
+        del holder.__dict__["_engine"]
+    p2 = copy.deepcopy(model.predictor)
+    assert p2.text_encoder.__dict__["_owner"]() is p2
+    assert model.predictor.text_encoder.__dict__["_owner"]() is model.predictor

@@ -42,6 +42,11 @@ def main():
                 pr.get("hbm_copy", {}).get("gbps_read_plus_write", 0.0),
                 {k: pr["census"][k] for k in ("cus_seen", "wg_per_cu_min", "wg_per_cu_max", "wg_not_on_xcd_id_mod_8",
                                               "rounds_of_30us") if k in pr.get("census", {})}))
+            for k in ("scatter_store", "row_store"):
+                if k in pr:
+                    print("   %s: median %s cycles / workgroup, max %s, slow CUs %s %s" % (
+                        k, pr[k].get("cycles_per_wg_median"), pr[k].get("cycles_per_wg_max"), pr[k].get("n_slow_cus"),
+                        pr[k].get("slow_cus")[:8]))
             sf = box.get("sysfs", {})
             print("   sysfs: %s" % {k: sf[k] for k in ("current_compute_partition", "current_memory_partition", "power1_cap",
                                                          "vbios_version") if k in sf})
