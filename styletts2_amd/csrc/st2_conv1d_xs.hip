@@ -80,8 +80,9 @@ std::vector<int> candidates(const st2_conv_desc& d) {
   const int rule = rule_variant(d);
   c.push_back(rule);
   if (d.C_out <= 64 || d.ks == 1) return c;  // narrow tiles / token GEMMs: one build each
-  // only launches worth ~20 us or more are measured (the others stay on the rule)
-  if (2.0 * d.B * d.C_in * (double)d.C_out * d.ks * d.L_out < 4e9) return c;
+  // only launches of ~100 us or more are measured -- below that two event pairs of two launches do not resolve a 2 %
+  // difference (single-utterance launches of the long-form loop read 0.02-0.1 ms for the same build) -- the rest follow the rule
+  if (2.0 * d.B * d.C_in * (double)d.C_out * d.ks * d.L_out < 2e10) return c;
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
   const int ny = st2_cdiv(d.C_out, 128);
   const bool swz = (ny == 2 || ny == 4 || ny == 8);

@@ -815,7 +815,7 @@ def test_conv_autotune_measures_keeps_results_and_survives_aliasing():
     tensors are only read, so a conv that accumulates into its own output (res2 aliases y: the MRF sum of
     Modules/istftnet.py:366-373) is applied exactly once -- records them, and later launches run the winner with unchanged
     results."""
-    B, C, L, ks, dil = 8, 256, 4000, 7, 3
+    B, C, L, ks, dil = 8, 256, 4000, 7, 3  # 29 GFLOP: above the tuner's 20 GFLOP floor
     gen = torch.Generator().manual_seed(99)
     x = torch.randn(B, C, L, generator=gen)
     w = torch.randn(C, C, ks, generator=gen) / math.sqrt(C * ks)
