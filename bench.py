@@ -369,6 +369,10 @@ def main():
     ap.add_argument("--no-autotune", action="store_true",
                     help="diagnostic: keep every xs conv on the rule's build instead of measuring the bitwise-equivalent "
                          "builds per shape class during the set-up step (st2_conv_tune)")
+    ap.add_argument("--cu-mask", choices=["auto", "off"], default="auto",
+                    help="`auto` (default): run the CU health probe (st2_probe_cu_health); if it finds degraded CUs, streams "
+                         "confined to the healthy ones are calibrated beside the plain schedules and the fastest runs; `off`: "
+                         "plain streams only")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
@@ -463,6 +467,22 @@ def main():
         a.schedule = "two-stream"  # synthesize_long owns its side stream
     sched = {}  # name -> (main stream or None = torch's current, front stream or None)
     ps = None
+    # Degraded CUs (on some boxes one shader engine runs the conv epilogue 10-12 x slower and, because the
+    # dispatcher deals every XCD an equal share of a grid, holds back every launch): probe, and if any are found offer the
+    # same schedules on streams confined to the healthy CUs -- chosen only if the calibration says they are faster.
+    cu_health, healthy = None, None
+    if a.cu_mask == "auto":
+        try:
+            rep, mask_words, n_excl = ops.probe_cu_health()
+            cu_health = rep
+            log("CU health: %d slow CUs of %d (launch %.0f us, XCD ends %s us)" % (rep["n_slow_cus"], rep["cus"],
+                                                                                  rep["launch_us"], rep["xcd_end_us"]))
+            if n_excl > 0:
+                healthy = pipeline.MaskedStreams(dev, mask_words)
+                log("streams on the %d healthy CUs are schedule candidates" % healthy.cus)
+        except Exception as e:  # a diagnostic: never in the way of the measurement
+            log("CU health probe unavailable: %r" % (e,))
+            healthy = None
     if not longform:
         # `auto` calibrates the two schedules that have ever won; the CU-partitioned one (75-126 ms against 66-72 on every
         # box of round 3, DESIGN.md section 3 iv) is measured on request only (--schedule partitioned / --calib-partitioned)
@@ -480,11 +500,16 @@ def main():
                 log("partitioned streams unavailable: %s" % e)
                 if a.schedule == "partitioned":
                     raise
+        if healthy is not None and a.schedule == "auto":
+            sched["two-stream/healthy-CUs"] = (healthy.main, healthy.front)
+            sched["single/healthy-CUs"] = (healthy.main, None)
         for m, f in sched.values():
             for st in (m, f):
                 if st is not None:
                     st.wait_stream(torch.cuda.current_stream(dev))
-    active = {"name": a.schedule if a.schedule != "auto" else "two-stream"}
+    # the set-up step (autotuning) runs on the streams most likely to win: masked ones where degraded CUs were found
+    active = {"name": a.schedule if a.schedule != "auto" else
+              ("two-stream/healthy-CUs" if "two-stream/healthy-CUs" in sched else "two-stream")}
 
     first_chunk_ms = []
     # The device-only front of a step / sentence (text encoder, PL-BERT, diffusion sampler, style mixing, duration
@@ -504,9 +529,11 @@ def main():
                 if k == 0:
                     w[-1].item()  # the first sentence's waveform has left the GPU queue: a streaming consumer has it
                     first_chunk_ms.append((time.perf_counter() - t_start) * 1e3)
-            waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
-                                                durations=durs, overlap=a.schedule != "single", bucket=16,
-                                                on_chunk=on_chunk, front=lf_front)
+            with torch.cuda.stream(healthy.main if healthy is not None else torch.cuda.current_stream(dev)):
+                waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
+                                                    durations=durs, overlap=a.schedule != "single", bucket=16,
+                                                    on_chunk=on_chunk, front=lf_front,
+                                                    side_stream=healthy.front if healthy is not None else None)
             return waves
     else:
         audio_s = B * AUDIO_S_PER_UTT
@@ -576,11 +603,8 @@ def main():
                 sensors = smp.summary()
             except Exception as e:
                 log("sensor summary unavailable: %r" % (e,))
-        if world > 1:  # every rank runs the same schedule: rank 0's choice (no collective in steady state either way)
-            order = sorted(calib)
-            tt = torch.tensor([calib[n] for n in order], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            calib = dict(zip(order, tt.tolist()))
+        # N > 1: every rank picks the fastest of ITS OWN candidates (its GPU may or may not have degraded CUs; nothing in
+        # steady state crosses GPUs, so ranks need not agree); the line reports rank 0's calibration and choice
         active["name"] = min(calib, key=calib.get) if a.schedule == "auto" else a.schedule
         log("schedule: %s" % active["name"])
     elif not longform:
@@ -590,10 +614,11 @@ def main():
     # the timed region, where the front of the next batch shares the chip with the decoder's convs and stretches them).
     lib = _lib.load()
     unoverlapped = None
-    if not longform and "single" in sched and active["name"] != "single":
+    single_name = "single/healthy-CUs" if ("healthy" in active["name"] and "single/healthy-CUs" in sched) else "single"
+    if not longform and single_name in sched and active["name"] != single_name:
         chosen = active["name"]
         try:
-            active["name"] = "single"
+            active["name"] = single_name
             step()
             lib.st2_conv_timing(1)
             torch.cuda.synchronize()
@@ -647,7 +672,10 @@ def main():
         roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
         name = active["name"]
         streams = {"single": "1", "two-stream": "2 (front of step k+1 overlaps decoder of step k)",
-                   "partitioned": "2 on complementary CU masks (front %d CUs, decoder the rest)" % a.front_cus}[name]
+                   "partitioned": "2 on complementary CU masks (front %d CUs, decoder the rest)" % a.front_cus,
+                   "single/healthy-CUs": "1, confined to the CUs the health probe found sound",
+                   "two-stream/healthy-CUs": "2 (front of step k+1 overlaps decoder of step k), both confined to the CUs "
+                                             "the health probe found sound"}[name]
         res = {
             "metric": "audio-seconds/sec (RTF^-1) end-to-end, 10 s utterance batch",
             "value": world * audio_s * a.steps / dt,
@@ -673,6 +701,11 @@ def main():
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,
         }
+        if cu_health is not None:
+            if box is None:
+                box = {}
+            box["cu_health"] = cu_health
+            box["healthy_cu_streams"] = None if healthy is None else {"cus": healthy.cus, "used": "healthy-CUs" in name or longform}
         if box is not None:
             if sensors is not None:
                 box["sensors_during_calibration"] = sensors
@@ -686,6 +719,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(man, sds, cfg)
         print(json.dumps(res), flush=True)
+    if healthy is not None:
+        torch.cuda.synchronize()
+        healthy.close()
     if ps is not None:  # the CU-masked streams are this process's: destroyed before the runtime's own exit handlers run
         torch.cuda.synchronize()
         ps.close()

@@ -125,6 +125,13 @@ def fingerprint(dev_index=0, probe=True, level=0):
             out["probe"]["wall_s"] = round(time.time() - t, 2)
         except Exception as e:  # a diagnostic must never be in the way of the measurement
             out["probe"] = {"error": repr(e)}
+        try:
+            from styletts2_amd import ops
+            rep, mask, n = ops.probe_cu_health()
+            rep["healthy_mask"] = ["0x%08x" % w for w in mask]
+            out["cu_health"] = rep
+        except Exception as e:
+            out["cu_health"] = {"error": repr(e)}
     return out
 
 

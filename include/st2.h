@@ -656,6 +656,17 @@ int st2_debug_headroom_read(double* rows, int32_t cap_rows);
  * what the box gives the conv path.  No reference call site: measurement only. */
 int st2_probe_box(char* json, int32_t cap, int32_t level);
 
+/* ---- CU health probe (ABI v19; diagnostic: allocates ~0.9 GB for its duration, synchronises the device) --------------- *
+ * Some MI355X boxes have a shader engine whose 8 CUs run the conv epilogue 10-12 x slower than every other CU (DESIGN.md
+ * section 6); the hardware dispatcher deals every XCD an equal share of a grid, so one such group holds back every launch.
+ * This runs an instrumented copy of the conv kernel (per-workgroup cycle stamps + HW_ID) on the launch class that separates
+ * the boxes, reports the CUs whose median epilogue takes > 3 x the chip's median as JSON, finds their CU-mask bits by running
+ * a one-workgroup kernel on single-bit-masked streams, and returns in mask_out (mask_words >= 8 words) the CU mask of the
+ * device WITHOUT them and their number in *n_excluded (0 = healthy box, mask = all CUs).  A stream made from that mask by
+ * st2_stream_create_cu_mask never places a workgroup on a degraded CU; bench.py calibrates schedules on such streams beside
+ * the plain ones and runs the fastest.  Takes ~0.1 s on a healthy box. */
+int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, int32_t mask_words, int32_t* n_excluded);
+
 /* ---- CU-partitioned streams (ABI v17) ---------------------------------------------------------------------------- *
  * A HIP stream whose kernels may only be placed on the compute units whose bit is set in `mask` (n_words x 32 bits, bit i
  * = CU i in the driver's numbering, which deals consecutive bits out round-robin over the 8 XCDs and their shader

@@ -209,6 +209,7 @@ _SIGNATURES = {
     "st2_conv_tune_set": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "st2_conv_tune_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_probe_box": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),
+    "st2_probe_cu_health": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_int32)]),
     "st2_debug_headroom": (C.c_int, [C.c_int]),
     "st2_debug_headroom_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),

@@ -134,6 +134,20 @@ def conv_tune_set(ks, C_in, C_out, L_out, B, variant):
     _lib.check(_lib.load().st2_conv_tune_set(ks, C_in, C_out, L_out, B, variant), "st2_conv_tune_set")
 
 
+def probe_cu_health():
+    """(report dict, CU mask as a list of 32-bit words, number of excluded CUs) -- include/st2.h `st2_probe_cu_health`: which
+    CUs of this box run the conv path's workgroups abnormally slowly, and the CU mask of the device without them."""
+    import ctypes
+    import json
+    buf = ctypes.create_string_buffer(16384)
+    mask = (ctypes.c_uint32 * 16)()
+    n = ctypes.c_int32(0)
+    _lib.check(_lib.load().st2_probe_cu_health(buf, len(buf), mask, 16, ctypes.byref(n)), "st2_probe_cu_health")
+    rep = json.loads(buf.value.decode())
+    words = (rep["cus"] + 31) // 32
+    return rep, [int(mask[i]) for i in range(words)], int(n.value)
+
+
 class headroom:
     """`with ops.headroom() as h: forward(...)` then `h.rows`: how close every split-f16 conv operand of that forward came
     to the f16 range (include/st2.h `st2_debug_headroom`; debug hook: extra launches, a scratch allocation, synchronises).

@@ -68,6 +68,43 @@ class PartitionedStreams:
         self._handles = []
 
 
+class MaskedStreams:
+    """HIP streams confined to one CU mask (st2_stream_create_cu_mask): `main` and `front`, both on the SAME set of CUs --
+    the device without its degraded CUs, as `ops.probe_cu_health()` returns it.  On boxes with a slow shader engine the
+    hardware dispatcher otherwise hands that engine's CUs their share of every grid and every launch waits for them
+    (DESIGN.md section 6).  Use as
+
+        rep, mask, n = ops.probe_cu_health()
+        if n:
+            ms = MaskedStreams(dev, mask)
+            with torch.cuda.stream(ms.main):
+                wave = inference(..., front_stream=ms.front)
+    """
+
+    def __init__(self, dev, mask_words, n_streams=2):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = torch.device(dev)
+        self._handles, streams = [], []
+        with torch.cuda.device(dev):
+            for _ in range(n_streams):
+                mask = (C.c_uint32 * len(mask_words))(*mask_words)
+                h = C.c_void_p()
+                _lib.check(lib.st2_stream_create_cu_mask(mask, len(mask_words), C.byref(h)), "st2_stream_create_cu_mask")
+                self._handles.append(h)
+                streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+        self.main, self.front = streams[0], streams[1] if n_streams > 1 else None
+        self.cus = sum(bin(w).count("1") for w in mask_words)
+
+    def close(self):
+        from . import _lib
+        lib = _lib.load()
+        for h in self._handles:
+            lib.st2_stream_destroy(h)
+        self._handles = []
+
+
 def _pad_mask(lengths, N):
     """utils.length_to_mask (reference utils.py:42-46: True where position >= length) at a fixed width N: a bucketed
     batch may be wider than its longest utterance."""
@@ -418,7 +455,7 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
 @torch.no_grad()
 def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, t=0.7, diffusion_steps=5,
                     embedding_scale=1.0, noises=None, step_noises=None, sine_noises=None, durations=None, trim=None,
-                    overlap=True, on_chunk=None, bucket=0, front=None):
+                    overlap=True, on_chunk=None, bucket=0, front=None, side_stream=None):
     """Long-form synthesis (BASELINE.json configs[4]; Demo/Inference_LibriTTS.ipynb LFinference + its driver loop,
     Demo/Inference_LJSpeech.ipynb "Long-form generation"): `sentences` is a list of token tensors [N_i] (id 0
     prepended); each sentence is synthesised with the previous sentence's mixed style carried over
@@ -443,7 +480,8 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         trim = 100 if multispeaker else 0
     use_streams = overlap and dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if use_streams else None
-    side = torch.cuda.Stream(dev) if use_streams else None
+    side = (side_stream if side_stream is not None else torch.cuda.Stream(dev)) if use_streams else None  # (a caller may
+    #                                                  hand in a CU-masked side stream: pipeline.MaskedStreams)
     if use_streams:
         side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
     # per-sentence inputs are prepared (padded to the bucket, moved to the device) BEFORE the streaming loop: a pageable

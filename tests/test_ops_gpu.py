@@ -858,3 +858,30 @@ def test_probe_box_reports_a_plausible_mi355x():
     assert len(p["sets"]) == 5 and all(s["chase_ns_median"] > 50 and s["stream8_gbps"] > 100 for s in p["sets"])
     assert p["sets"][0]["chase_ns_median"] < p["sets"][-1]["chase_ns_median"] * 1.2  # a cache level is not slower than HBM
     assert p["hbm_copy"]["gbps_read_plus_write"] > 500
+
+
+def test_cu_health_probe_and_masked_streams():
+    """st2_probe_cu_health runs an instrumented copy of the conv kernel and returns the CU mask of the device without its
+    degraded CUs (none on a healthy box); a stream made from that mask computes what the default stream computes."""
+    from styletts2_amd import pipeline
+    rep, mask, n = ops.probe_cu_health()
+    cus = rep["cus"]
+    assert rep["workgroups"] == 2048 and rep["epilogue_cycles_median"] > 1000 and len(rep["xcd_end_us"]) == 8
+    assert 0 <= n <= cus // 8 and n <= rep["n_slow_cus"]
+    assert sum(bin(w).count("1") for w in mask) == cus - n
+    ms = pipeline.MaskedStreams(DEV, mask)
+    try:
+        gen = torch.Generator().manual_seed(3)
+        x = g(torch.randn(4, 256, 2000, generator=gen))
+        w = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=gen) / math.sqrt(256 * 7)).to(DEV)
+        xs = ops.activate(x)
+        ref = ops.conv1d_xs(xs, w, 256, 7, pad_left=3)
+        torch.cuda.synchronize()
+        ms.main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ms.main):
+            xs2 = ops.activate(x)
+            out = ops.conv1d_xs(xs2, w, 256, 7, pad_left=3)
+        ms.main.synchronize()
+        assert torch.equal(out, ref)
+    finally:
+        ms.close()

@@ -47,6 +47,11 @@ def main():
                     print("   %s: median %s cycles / workgroup, max %s, slow CUs %s %s" % (
                         k, pr[k].get("cycles_per_wg_median"), pr[k].get("cycles_per_wg_max"), pr[k].get("n_slow_cus"),
                         pr[k].get("slow_cus")[:8]))
+            ch = box.get("cu_health")
+            if ch:
+                print("   cu_health: %s slow CUs %s, XCD ends %s us; healthy-CU streams %s" % (
+                    ch.get("n_slow_cus"), [(c["xcc"], c["se"], c["cu"], c["x_median"]) for c in ch.get("slow_cus", [])][:8],
+                    ch.get("xcd_end_us"), box.get("healthy_cu_streams")))
             sf = box.get("sysfs", {})
             print("   sysfs: %s" % {k: sf[k] for k in ("current_compute_partition", "current_memory_partition", "power1_cap",
                                                          "vbios_version") if k in sf})

@@ -48,6 +48,13 @@ for st in "$@"; do
         timeout 600 python tools/probe_box.py --level 1 --out $OUT/${TAG}_box_full.json 2>> $OUT/${TAG}_box.err | tail -1
         run_slowkit
         bash tools/gpu_visit.sh $TAG bench:--no-cpu-baseline bench_ab
+        # the same box without the healthy-CU streams, and the long-form configuration both ways
+        timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cu-mask off --no-cpu-baseline --no-box-probe > $OUT/${TAG}_bench_nomask.json 2> $OUT/${TAG}_bench_nomask.err
+        python tools/bench_summary.py $OUT/${TAG}_bench_nomask.json | head -8
+        for m in auto off; do
+          timeout 600 python bench.py --config longform --cu-mask $m --no-cpu-baseline --no-box-probe > $OUT/${TAG}_bench_longform_mask_$m.json 2> $OUT/${TAG}_bench_longform_mask_$m.err
+          python tools/bench_summary.py $OUT/${TAG}_bench_longform_mask_$m.json | head -1
+        done
       fi ;;
     tests)
       files="tests"; [ -n "$arg" ] && files=$(echo $arg | tr ',' ' ')

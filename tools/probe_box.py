@@ -89,7 +89,11 @@ def main():
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         open(a.out, "w").write(text + "\n")
     rule_ms = fp["conv_classes"][0]["ms"].get("128x256 tiles, 2 wg/CU", 0.0)
-    cls = "slow" if rule_ms > SLOW_MS else "fast"
+    n_slow = (fp.get("cu_health") or {}).get("n_slow_cus", 0) or 0
+    cls = "slow" if (rule_ms > SLOW_MS or n_slow > 0) else "fast"
+    print("cu_health: %s slow CUs %s, XCD ends %s us" % (n_slow, [(c["xcc"], c["se"], c["cu"], c["x_median"]) for c in
+                                                                  (fp.get("cu_health") or {}).get("slow_cus", [])][:8],
+                                                          (fp.get("cu_health") or {}).get("xcd_end_us")), file=sys.stderr)
     if a.kit or cls == "slow":
         print("# full kit for this box (run inside the same visit):", file=sys.stderr)
         print("#   bash tools/gpu_visit.sh slowkit", file=sys.stderr)
