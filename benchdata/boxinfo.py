@@ -115,7 +115,7 @@ def host():
     return out
 
 
-def fingerprint(dev_index=0, probe=True, level=0):
+def fingerprint(dev_index=0, probe=True, level=0, health=True):
     out = {"torch": torch_props(dev_index), "sysfs": sysfs(dev_index), "host": host()}
     if probe:
         try:
@@ -126,6 +126,8 @@ def fingerprint(dev_index=0, probe=True, level=0):
         except Exception as e:  # a diagnostic must never be in the way of the measurement
             out["probe"] = {"error": repr(e)}
         try:
+            if not health:
+                raise RuntimeError("skipped on request")
             from styletts2_amd import ops
             rep, mask, n = ops.probe_cu_health()
             rep["healthy_mask"] = ["0x%08x" % w for w in mask]

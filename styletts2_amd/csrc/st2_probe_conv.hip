@@ -157,47 +157,59 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
   }
 
   // ---- CU-mask bits of the degraded CUs: one-workgroup kernels on single-bit-masked streams ------------------------------
-  std::map<unsigned long long, int> bit_of;  // cu_key -> mask bit
-  int mapped = 0;
+  std::map<unsigned long long, int> bit_of;  // cu_key | 1 << 63 -> mask bit
+  int mapped = 0, map_tried = 0, map_stream_fail = 0, map_run_fail = 0;
   if (!slow.empty()) {
     std::vector<int> xcds;
     for (auto& s : slow) {
       const int x = (int)(s.key >> 32);
       if (std::find(xcds.begin(), xcds.end(), x) == xcds.end()) xcds.push_back(x);
     }
-    unsigned long long* who = nullptr;
-    HCK(hipHostMalloc(reinterpret_cast<void**>(&who), 8, hipHostMallocMapped));
+    unsigned long long* who = (unsigned long long*)alloc(8);  // device memory, read back per probe
+    if (!who) {
+      st2_set_error("st2_probe_cu_health: out of device memory");
+      cleanup();
+      return 1;
+    }
     auto probe_bit = [&](int bit) -> bool {
       std::vector<uint32_t> m(words, 0u);
       m[bit / 32] = 1u << (bit % 32);
       hipStream_t s = nullptr;
+      ++map_tried;
       if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, m.data()) != hipSuccess) {
         (void)hipGetLastError();
+        ++map_stream_fail;
         return false;
       }
-      *who = 0;
+      unsigned long long v = 0;
+      bool ok = hipMemsetAsync(who, 0, 8, s) == hipSuccess;
       hipLaunchKernelGGL(pc_whoami, dim3(1), dim3(64), 0, s, who);
-      const bool ok = hipStreamSynchronize(s) == hipSuccess && *who != 0;
+      ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(&v, who, 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+           hipStreamSynchronize(s) == hipSuccess;
       (void)hipStreamDestroy(s);
-      if (ok) bit_of[cu_key(*who)] = bit;
-      return ok;
+      if (!ok) {
+        (void)hipGetLastError();
+        ++map_run_fail;
+        return false;
+      }
+      bit_of[cu_key(v) | (1ull << 63)] = bit;  // (bit 63: "stamped", so that XCC 0 / CU 0 is not mistaken for "nothing")
+      return true;
     };
     // the driver deals consecutive bits out round-robin over the XCDs: try bits = xcd (mod 8) first, then everything else
     for (int x : xcds)
       for (int bit = x; bit < num_cu; bit += 8) probe_bit(bit);
     bool all_found = true;
-    for (auto& s : slow) all_found &= bit_of.count(s.key) != 0;
+    for (auto& s : slow) all_found &= bit_of.count(s.key | (1ull << 63)) != 0;
     if (!all_found)
       for (int bit = 0; bit < num_cu && !all_found; ++bit) {
         probe_bit(bit);
         all_found = true;
-        for (auto& s : slow) all_found &= bit_of.count(s.key) != 0;
+        for (auto& s : slow) all_found &= bit_of.count(s.key | (1ull << 63)) != 0;
       }
-    (void)hipHostFree(who);
     // never hand back a mask that excludes more than an eighth of the chip: that is not "a few degraded CUs"
     if ((int)slow.size() <= num_cu / 8)
       for (auto& s : slow) {
-        auto it = bit_of.find(s.key);
+        auto it = bit_of.find(s.key | (1ull << 63));
         if (it == bit_of.end()) continue;
         mask_out[it->second / 32] &= ~(1u << (it->second % 32));
         ++mapped;
@@ -217,13 +229,15 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
   }
   js += "], \"slow_cus\": [";
   for (size_t i = 0; i < slow.size() && i < 64; ++i) {
-    auto it = bit_of.find(slow[i].key);
+    auto it = bit_of.find(slow[i].key | (1ull << 63));
     snprintf(b, sizeof b, "%s{\"xcc\": %d, \"se\": %d, \"sh\": %d, \"cu\": %d, \"x_median\": %.1f, \"mask_bit\": %d}", i ? ", " : "",
              (int)(slow[i].key >> 32), (int)((slow[i].key >> 13) & 7), (int)((slow[i].key >> 12) & 1), (int)((slow[i].key >> 8) & 15),
              slow[i].x, it == bit_of.end() ? -1 : it->second);
     js += b;
   }
-  snprintf(b, sizeof b, "], \"n_slow_cus\": %d, \"n_excluded\": %d, \"cus\": %d}", (int)slow.size(), mapped, num_cu);
+  snprintf(b, sizeof b, "], \"n_slow_cus\": %d, \"n_excluded\": %d, \"cus\": %d, \"mask_probes\": {\"tried\": %d, "
+           "\"stream_create_failed\": %d, \"run_failed\": %d, \"cus_mapped\": %d}}", (int)slow.size(), mapped, num_cu, map_tried,
+           map_stream_fail, map_run_fail, (int)bit_of.size());
   js += b;
   cleanup();
   ST2_REQUIRE((int)js.size() + 1 <= cap, "st2_probe_cu_health: output needs %zu bytes", js.size() + 1);

@@ -29,7 +29,7 @@ run_slowkit() {
   [ -x tools/bin/xs_bench_64 ] && timeout 120 tools/bin/xs_bench_64 7 1 256 8000 32 1 1 3 0 $OUT/${TAG}_slowkit_timeline.txt | tail -2
   for ctr in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
     n=$(echo $ctr | tr ' ' '_')
-    ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$n -o pmc -- python $OLDPWD/tools/probe_box.py --quick --level 0 > /dev/null 2>&1 )
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$n -o pmc -- python $OLDPWD/tools/probe_box.py --quick --level 0 --no-health > /dev/null 2>&1 )
     python tools/pmc_summary.py /tmp/pmc_$n 2>/dev/null | grep -i "conv1d_xs" | head -8 | sed "s/^/[$n] /" | tee -a $OUT/${TAG}_slowkit_pmc.txt
   done
 }

@@ -68,11 +68,13 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--quick", action="store_true", help="only the discriminating class")
+    ap.add_argument("--no-health", action="store_true", help="skip st2_probe_cu_health (CU-masked streams do not survive "
+                                                             "rocprofv3 --pmc: the slow kit's counter passes use this)")
     ap.add_argument("--kit", action="store_true", help="print the full-kit commands for a slow box")
     a = ap.parse_args()
     from benchdata import boxinfo
     t0 = time.time()
-    fp = boxinfo.fingerprint(0, probe=True, level=a.level)
+    fp = boxinfo.fingerprint(0, probe=True, level=a.level, health=not a.no_health)
     fp["conv_classes"] = []
     for ks, C, L, dil in (CLASSES[:1] if a.quick else CLASSES):
         variants = (0, 1, 2, 3) if ks >= 7 else ((0, 4, 2, 6) if ks == 3 else (0, 2))
