@@ -39,9 +39,10 @@ __global__ void pc_fill_f32(float* p, int64_t n, uint32_t seed) {
   h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
   p[i] = ((int)(h & 0xffff) - 32768) * (1.f / 32768.f);
 }
-__global__ void pc_whoami(unsigned long long* out) {
+__global__ void pc_whoami(unsigned long long* out) {  // one stamp per workgroup: workgroup b is dispatched to XCD b % 8
   if (threadIdx.x == 0)
-    out[0] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
+    out[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |
+                      ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (1ull << 63);
 }
 
 // (XCC, SE, SH, CU) of a workgroup from its HW_ID | XCC_ID << 32 stamp
@@ -165,7 +166,11 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
       const int x = (int)(s.key >> 32);
       if (std::find(xcds.begin(), xcds.end(), x) == xcds.end()) xcds.push_back(x);
     }
-    unsigned long long* who = (unsigned long long*)alloc(8);  // device memory, read back per probe
+    // Bit i of a CU mask belongs to XCD i % 8 (the driver deals the bits out round-robin over the XCDs); which CU of that XCD
+    // it is, is measured: a stream with ONLY that bit set runs an 8-workgroup kernel -- workgroup b goes to XCD b % 8, an XCD
+    // whose share of the mask is empty runs unrestricted (observed: r04m1, 288 one-workgroup probes landed on XCD 0 only) --
+    // and the workgroup that reports XCD i % 8 names the CU.
+    unsigned long long* who = (unsigned long long*)alloc(64);
     if (!who) {
       st2_set_error("st2_probe_cu_health: out of device memory");
       cleanup();
@@ -181,10 +186,10 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
         ++map_stream_fail;
         return false;
       }
-      unsigned long long v = 0;
-      bool ok = hipMemsetAsync(who, 0, 8, s) == hipSuccess;
-      hipLaunchKernelGGL(pc_whoami, dim3(1), dim3(64), 0, s, who);
-      ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(&v, who, 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+      unsigned long long v[8] = {};
+      bool ok = hipMemsetAsync(who, 0, 64, s) == hipSuccess;
+      hipLaunchKernelGGL(pc_whoami, dim3(8), dim3(64), 0, s, who);
+      ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(v, who, 64, hipMemcpyDeviceToHost, s) == hipSuccess &&
            hipStreamSynchronize(s) == hipSuccess;
       (void)hipStreamDestroy(s);
       if (!ok) {
@@ -192,8 +197,13 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
         ++map_run_fail;
         return false;
       }
-      bit_of[cu_key(v) | (1ull << 63)] = bit;  // (bit 63: "stamped", so that XCC 0 / CU 0 is not mistaken for "nothing")
-      return true;
+      bool found = false;
+      for (int w = 0; w < 8; ++w)
+        if ((v[w] >> 63) && (int)((v[w] >> 32) & 15) == bit % 8) {
+          bit_of[cu_key(v[w]) | (1ull << 63)] = bit;
+          found = true;
+        }
+      return found;
     };
     // the driver deals consecutive bits out round-robin over the XCDs: try bits = xcd (mod 8) first, then everything else
     for (int x : xcds)

@@ -46,8 +46,8 @@ for st in "$@"; do
       if grep -q "BOX_CLASS slow" $OUT/${TAG}_box_class.txt; then
         echo "SLOW BOX: kit + bench lines"
         timeout 600 python tools/probe_box.py --level 1 --out $OUT/${TAG}_box_full.json 2>> $OUT/${TAG}_box.err | tail -1
-        run_slowkit
-        bash tools/gpu_visit.sh $TAG bench:--no-cpu-baseline bench_ab
+        [ -n "${ST2_HUNT_KIT:-}" ] && run_slowkit
+        bash tools/gpu_visit.sh $TAG bench:--no-cpu-baseline
         # the same box without the healthy-CU streams, and the long-form configuration both ways
         timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cu-mask off --no-cpu-baseline --no-box-probe > $OUT/${TAG}_bench_nomask.json 2> $OUT/${TAG}_bench_nomask.err
         python tools/bench_summary.py $OUT/${TAG}_bench_nomask.json | head -8
