@@ -507,9 +507,10 @@ def main():
             for st in (m, f):
                 if st is not None:
                     st.wait_stream(torch.cuda.current_stream(dev))
-    # the set-up step (autotuning) runs on the streams most likely to win: masked ones where degraded CUs were found
-    active = {"name": a.schedule if a.schedule != "auto" else
-              ("two-stream/healthy-CUs" if "two-stream/healthy-CUs" in sched else "two-stream")}
+    # the set-up step (autotuning) runs on the plain streams: in the throughput configurations the CU-masked schedules have
+    # lost every calibration so far (74.1 vs 69.0 ms on a box with 8 CUs at 3.5 x, profiles/r04m1_*) -- a masked queue costs
+    # more than the stragglers it avoids -- while the latency-bound long-form loop gains 9 % from them (94.9 vs 103.7 ms)
+    active = {"name": a.schedule if a.schedule != "auto" else "two-stream"}
 
     first_chunk_ms = []
     # The device-only front of a step / sentence (text encoder, PL-BERT, diffusion sampler, style mixing, duration
