@@ -80,7 +80,8 @@ for st in "$@"; do
         n=$(echo $ctr | tr ' ' '_')
         ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmcd_$n -o pmc -- python $OLDPWD/tools/probe_dom.py > /dev/null 2>&1 )
         python tools/pmc_summary.py /tmp/pmcd_$n 2>/dev/null | tee $OUT/${TAG}_pmc_$n.txt | head -12
-      done ;;
+      done
+      python tools/pmc_summary.py --json $OUT/${TAG}_pmc_dominant.json --kernel "conv1d_xs_kernel" /tmp/pmcd_FETCH_SIZE /tmp/pmcd_WRITE_SIZE | tail -2 ;;
     gemm) [ -x tools/bin/gemm_bench ] && timeout 300 tools/bin/gemm_bench $(echo $arg | tr ',' ' ') 2>&1 | tee $OUT/${TAG}_gemm_bench.log ;;
     cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -300 | tee $OUT/${TAG}_cmd.log ;;
     *) echo "unknown stage $st" ;;
