@@ -357,6 +357,9 @@ def main():
     ap.add_argument("--calib-steps", type=int, default=3)
     ap.add_argument("--calib-partitioned", action="store_true",
                     help="let --schedule auto also time the CU-partitioned schedule")
+    ap.add_argument("--calib-decoder-priority", action="store_true",
+                    help="let --schedule auto also time two streams with the DECODER's queue at high priority and the front's at "
+                         "normal priority")
     ap.add_argument("--front-priority", type=int, default=-1, help="HIP stream priority of the front stream (-1 = high)")
     ap.add_argument("--eager-front", action="store_true",
                     help="issue the device-only front of a step / sentence (text encoder, PL-BERT, sampler, duration "
@@ -492,6 +495,10 @@ def main():
             sched["single"] = (None, None)
         if "two-stream" in want:
             sched["two-stream"] = (None, torch.cuda.Stream(dev, priority=a.front_priority))
+            if a.schedule == "auto" and a.calib_decoder_priority:
+                # the reverse assignment: the decoder's queue high, the front's normal (the front has slack: ~15 ms of
+                # latency-bound kernels per ~65 ms step)
+                sched["two-stream/decoder-priority"] = (torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0))
         if "partitioned" in want:
             try:
                 ps = pipeline.PartitionedStreams(dev, a.front_cus)
@@ -674,6 +681,8 @@ def main():
         name = active["name"]
         streams = {"single": "1", "two-stream": "2 (front of step k+1 overlaps decoder of step k)",
                    "partitioned": "2 on complementary CU masks (front %d CUs, decoder the rest)" % a.front_cus,
+                   "two-stream/decoder-priority": "2 (front of step k+1 overlaps decoder of step k; the decoder's queue at high "
+                                                  "priority, the front's at normal)",
                    "single/healthy-CUs": "1, confined to the CUs the health probe found sound",
                    "two-stream/healthy-CUs": "2 (front of step k+1 overlaps decoder of step k), both confined to the CUs "
                                              "the health probe found sound"}[name]
