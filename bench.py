@@ -373,7 +373,7 @@ def main():
                     help="diagnostic: keep every xs conv on the rule's build instead of measuring the bitwise-equivalent "
                          "builds per shape class during the set-up step (st2_conv_tune)")
     ap.add_argument("--cu-mask", choices=["auto", "off"], default="auto",
-                    help="`auto` (default): run the CU health probe (st2_probe_cu_health); if it finds degraded CUs, streams "
+                    help="`auto` (default): run the CU health probe (st2_probe_cu_health); if it finds slow CUs, streams "
                          "confined to the healthy ones are calibrated beside the plain schedules and the fastest runs; `off`: "
                          "plain streams only")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
@@ -470,9 +470,9 @@ def main():
         a.schedule = "two-stream"  # synthesize_long owns its side stream
     sched = {}  # name -> (main stream or None = torch's current, front stream or None)
     ps = None
-    # Degraded CUs (on some boxes one shader engine runs the conv epilogue 10-12 x slower and, because the
-    # dispatcher deals every XCD an equal share of a grid, holds back every launch): probe, and if any are found offer the
-    # same schedules on streams confined to the healthy CUs -- chosen only if the calibration says they are faster.
+    # CU health: the conv kernel with per-workgroup stamps says when every XCD finished and whether any
+    # CU ran its workgroups > 3 x slower than the chip's median; if so the same schedules are also offered on streams confined
+    # to the other CUs -- chosen only if the calibration says they are faster (they never were in throughput mode).
     cu_health, healthy = None, None
     if a.cu_mask == "auto":
         try:
@@ -515,8 +515,7 @@ def main():
                 if st is not None:
                     st.wait_stream(torch.cuda.current_stream(dev))
     # the set-up step (autotuning) runs on the plain streams: in the throughput configurations the CU-masked schedules have
-    # lost every calibration so far (74.1 vs 69.0 ms on a box with 8 CUs at 3.5 x, profiles/r04m1_*) -- a masked queue costs
-    # more than the stragglers it avoids -- while the latency-bound long-form loop gains 9 % from them (94.9 vs 103.7 ms)
+    # lost every calibration so far (74.1 vs 69.0 ms, profiles/r04m1_*)
     active = {"name": a.schedule if a.schedule != "auto" else "two-stream"}
 
     first_chunk_ms = []
@@ -611,7 +610,7 @@ def main():
                 sensors = smp.summary()
             except Exception as e:
                 log("sensor summary unavailable: %r" % (e,))
-        # N > 1: every rank picks the fastest of ITS OWN candidates (its GPU may or may not have degraded CUs; nothing in
+        # N > 1: every rank picks the fastest of ITS OWN candidates (its GPU may or may not report slow CUs; nothing in
         # steady state crosses GPUs, so ranks need not agree); the line reports rank 0's calibration and choice
         active["name"] = min(calib, key=calib.get) if a.schedule == "auto" else a.schedule
         log("schedule: %s" % active["name"])

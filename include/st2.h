@@ -619,9 +619,9 @@ int st2_conv_timing_read(double* rows, int32_t cap_rows);
  * tiles at 2 (k >= 7), 32- or 16-channel chunks (k = 3), dispatch-order or XCD-aware tile order (launches with 2 / 4 / 8
  * output row blocks: every XCD keeps ONE row block's weights in its L2), one tile per workgroup or PERSISTENT workgroups that
  * pull tiles from a queue (needs d.splitk_ws = 8 bytes {next tile, workgroups done}, zero before the launch; the launch
- * leaves them zero, so one such block serves every launch of a stream -- a slow CU then simply takes fewer tiles).  Which is fastest depends on the shape AND on the
- * box (MI355X boxes differ by up to 1.75 x on the C = 256 / L = 8 000 layers of Modules/istftnet.py:358-375 with the rule's
- * build), so a serving process measures at start-up:
+ * leaves them zero, so one such block serves every launch of a stream -- whoever is slow then simply takes fewer tiles).  Which is fastest depends on the shape AND on the
+ * box (before round 4's row-end fix of the epilogue MI355X boxes differed by up to 1.75 x on the C = 256 / L = 8 000 layers of
+ * Modules/istftnet.py:358-375 with the then rule's build; a few percent since), so a serving process measures at start-up:
  *   st2_conv_tune(1)   every FIRST launch of a shape class (device, ks, C_in, C_out, L_out, B) on a non-capturing stream
  *                      times its candidate builds (1 warm-up + 2 x 2 launches each, output into a scratch tensor the
  *                      library allocates for the duration of tuning mode -- the one exception to "no allocation" besides
@@ -657,14 +657,13 @@ int st2_debug_headroom_read(double* rows, int32_t cap_rows);
 int st2_probe_box(char* json, int32_t cap, int32_t level);
 
 /* ---- CU health probe (ABI v19; diagnostic: allocates ~0.9 GB for its duration, synchronises the device) --------------- *
- * Some MI355X boxes have a shader engine whose 8 CUs run the conv epilogue 10-12 x slower than every other CU (DESIGN.md
- * section 6); the hardware dispatcher deals every XCD an equal share of a grid, so one such group holds back every launch.
- * This runs an instrumented copy of the conv kernel (per-workgroup cycle stamps + HW_ID) on the launch class that separates
- * the boxes, reports the CUs whose median epilogue takes > 3 x the chip's median as JSON, finds their CU-mask bits by running
- * a one-workgroup kernel on single-bit-masked streams, and returns in mask_out (mask_words >= 8 words) the CU mask of the
- * device WITHOUT them and their number in *n_excluded (0 = healthy box, mask = all CUs).  A stream made from that mask by
- * st2_stream_create_cu_mask never places a workgroup on a degraded CU; bench.py calibrates schedules on such streams beside
- * the plain ones and runs the fastest.  Takes ~0.1 s on a healthy box. */
+ * Runs an instrumented copy of the conv kernel (per-workgroup cycle stamps + HW_ID) on the launch class that separated
+ * the box classes of rounds 1-3 (k = 7, C = 256, L = 8 000, 128 x 256 tiles), reports as JSON when every XCD finished and the
+ * CUs whose median epilogue takes > 3 x the chip's median, finds their CU-mask bits by measurement (8-workgroup probes on
+ * single-bit-masked streams: bit i belongs to XCD i % 8) and returns in mask_out (mask_words >= 8 words) the CU mask of the
+ * device WITHOUT them and their number in *n_excluded (0 = nothing slow, mask = all CUs).  It is how round 4 found that the
+ * "slow CUs" of the slow box class were the row-end tiles of the launch -- since the epilogue fix it
+ * reads 0 on every box seen -- and it stays as the check that finds a genuinely degraded CU.  Takes ~0.1 s. */
 int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, int32_t mask_words, int32_t* n_excluded);
 
 /* ---- CU-partitioned streams (ABI v17) ---------------------------------------------------------------------------- *

@@ -292,10 +292,11 @@ ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o4, 4)  // <= 128 VGPRs: narrow tiles on
 
 // PERSISTENT builds (variant bit XS_V_PERSIST): the grid is one workgroup per resident slot (workgroups / CU x CUs) and every
 // workgroup pulls tiles from a queue -- one device-scope atomicAdd per tile on ctr[0] -- until it is empty.  What that buys:
-// (i) no workgroup turnaround between tiles (4.5 k of a 132 k-cycle slot, profiles/r02_conv_kernel_study.md); (ii) a CU that
-// is slow -- round 4 found boxes where the 8 CUs of one shader engine run the epilogue's scattered stores 12 x slower
-// (profiles/r04h1_*) -- simply takes fewer tiles, where the hardware dispatcher deals every XCD an equal share of the grid
-// and lets the others wait for its slowest.  Same tiles, same arithmetic: bitwise the one-tile-per-workgroup result.
+// (i) no workgroup turnaround between tiles (4.5 k of a 132 k-cycle slot, profiles/r02_conv_kernel_study.md); (ii) tiles or
+// CUs that are slow -- round 4's row-end tiles, 3.5-12 x in the epilogue before the fix (profiles/r04h1_*) -- do not hold
+// up their XCD: the hardware dispatcher deals every XCD an equal share of the grid in order, the queue deals by readiness.
+// Same tiles, same arithmetic: bitwise the one-tile-per-workgroup result.  Measured: no gain on the shapes of the path since
+// the epilogue fix (profiles/r04q_bench.json tune table); kept as an autotuner candidate.
 // ctr = {next tile, workgroups done}: zero at launch; the last workgroup out puts both back to zero, so the same 8 bytes
 // serve every launch of a stream (st2.h: d.splitk_ws).
 #define ST2_XS_PERSISTENT_KERNEL(NAME, WGS_PER_CU)                                                                      \
@@ -435,10 +436,10 @@ enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4, XS_V_P
 // profiles/r02i_xs_bench_tn8.log) -- when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a
 // single utterance (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs.  Launches with
 // 2 / 4 / 8 output row blocks (C_out = 256 ... 1024 at k >= 7: the first vocoder stage) take 128 x 128 tiles in XCD-aware
-// order instead: within 2 % of the best build on a healthy box (0.63 vs 0.66 ms at k = 7, 0.91 vs 0.89 at k = 11, C = 256,
-// L = 8 000) and 1.25-1.6 x faster than the wide tiles on boxes with a degraded shader engine, whose 8 CUs run the
-// epilogue's scattered stores 12 x slower and, with 2 workgroups per CU in lock-step rounds, stall their whole XCD
-// (profiles/r04h1_*: 0.65 vs 1.08 ms; every driver box of rounds 1-3 was of that class).
+// order instead: within 2 % of the best build everywhere measured (0.63 vs 0.66 ms at k = 7, 0.91 vs 0.89 at k = 11, C = 256,
+// L = 8 000) and the build least exposed to dispatch-order aliasing -- with 256-column tiles a row of L = 8 000 is 32 tiles,
+// a multiple of 8, so every row-end tile of the launch lands on the same XCD (what made the "slow box class" of rounds 1-3
+// before st2_conv_epilogue.h learnt to treat row ends by column blocks: DESIGN.md section 6).
 inline int rule_variant(const st2_conv_desc& d) {
   if (d.C_out <= 64 || d.ks < 7) return 0;
   const int ny = st2_cdiv(d.C_out, 128);

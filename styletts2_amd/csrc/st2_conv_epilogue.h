@@ -54,14 +54,26 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
                       (!rb || (((reinterpret_cast<uintptr_t>(d.res) | (uintptr_t)(d.res_bs * 4) | (uintptr_t)(d.res_cs * 4)) & 15) == 0 &&
                                d.res_shift == 0)) &&
                       (!r2b || ((reinterpret_cast<uintptr_t>(d.res2) | (uintptr_t)(d.res2_bs * 4) | (uintptr_t)(d.res2_cs * 4)) & 15) == 0);
-  const bool full_tile = m0 + BM <= d.C_out && n0 + BN <= d.L_out && vec_ok;  // workgroup-uniform
+  // Which of this WAVE's 32-column blocks are complete.  A tile at the end of a row used to take the generic build as a
+  // whole -- 4-byte predicated accesses for all TN blocks, 3.5 x the cycles of the straight-line build on every box and
+  // 10-12 x on some -- and, where the tile count per row is a multiple of 8 (L = 8 000 in 256-column tiles), every such
+  // tile of a launch lands on the same XCD and the same shader engine, which then finishes at twice the time of the other
+  // seven (profiles/r04h1_*, r04j_*: what rounds 1-3 knew as "the slow box class").  Now blocks [0, jn_full) take the
+  // straight-line build, blocks past the row end are skipped, and only a block that STRADDLES the row end (none at L =
+  // 8 000; one column's worth at L = 48 001) takes the generic code.  Same values, same order of the partial sums.
+  const int avail = d.L_out - (n0 + wn * (32 * TN));  // valid columns of this wave's part of the tile (may be <= 0)
+  const int jn_full = avail >= 32 * TN ? TN : (avail > 0 ? avail / 32 : 0);
+  const int j_strad = (jn_full < TN && avail > jn_full * 32) ? jn_full : -1;
+  const bool rows_ok = m0 + BM <= d.C_out;
   // The epilogue comes in straight-line builds.  Which terms exist (residual, MRF accumulator, divide) is uniform per
   // launch; tested per element it turns the loop into thousands of one-store basic blocks whose residual loads are
   // each waited for on the spot.  So interior tiles -- every tile but the last along l / co -- of aligned tensors
   // dispatch ONCE to a build with those terms as compile-time constants: no bounds tests, 32-bit offsets from scalar
   // bases, a column block's residual loads issued together ahead of its arithmetic.  Edge tiles, unaligned tensors and
   // rare combinations take the generic build (MODE < 0: run-time flags, per-element bounds, 4-byte accesses).
-  auto epilogue_as = [&](auto act_tag, auto mode_tag) __attribute__((always_inline)) {
+  float s1 = 0.f, s2 = 0.f;              // running (sum, sum of squares) of this lane's stored values ...
+  float s1d[NPT] = {}, s2d[NPT] = {};    // ... and the finished 128-column sums: shared by the builds a tile may combine
+  auto epilogue_as = [&](auto act_tag, auto mode_tag, const int j_lo, const int j_hi) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
     constexpr bool FULL = MODE >= 0;
@@ -80,8 +92,6 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
     const int yo = coc * d.y_cs + lw;
     const int ro = coc * d.res_cs;   // + (l >> res_shift)
     const int r2o = coc * d.res2_cs + lw;
-    float s1 = 0.f, s2 = 0.f;
-    float s1d[NPT] = {}, s2d[NPT] = {};  // finished 128-column sums
     auto finish = [&](float v) __attribute__((always_inline)) -> float {
       if (use_div) v = v / d.div;
       if constexpr (ACT == -1) {  // generic build: one body for every activation (run-time switch, wave-uniform)
@@ -113,17 +123,21 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
       // k loop (per-workgroup s_memtime stamps, tools/xs_bench.hip), i.e. a fifth of every workgroup slot's time.
 #pragma unroll
       for (int jh = 0; jh < TN; jh += JB) {
+        if (jh >= j_hi) break;  // (wave-uniform) blocks past the row end: nothing to load, store or sum
         f32x4 rv[JB][4];
         if (use_res) {
 #pragma unroll
           for (int jj = 0; jj < JB; ++jj)
+            if (jh + jj < j_hi) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              rv[jj][q] = *reinterpret_cast<const f32x4*>(rb + ro + lw + (jh + jj) * 32 + 8 * q);
+              for (int q = 0; q < 4; ++q)
+                rv[jj][q] = *reinterpret_cast<const f32x4*>(rb + ro + lw + (jh + jj) * 32 + 8 * q);
+            }
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
           const int j = jh + jj;
+          if (j >= j_hi) break;
           f32x4 r2v[4];
           if (use_res2) {
 #pragma unroll
@@ -162,7 +176,7 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
         constexpr int idx = decltype(idx_tag)::value;
         constexpr int j = idx / 16, q = (idx % 16) / 4, e = idx % 4;
         const int l = lw + j * 32 + 8 * q + e;
-        const bool ok = rok && l < d.L_out;
+        const bool ok = rok && l < d.L_out && j >= j_lo && j < j_hi;
         float t = fmaf(acc[j][4 * q + e], osc_r, bias_r);
         if (use_res) t += ok ? rb[ro + (l >> d.res_shift)] : 0.f;
         if (use_res2) t = (ok ? r2b[r2o + j * 32 + 8 * q + e] : 0.f) + t;
@@ -174,16 +188,26 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
         }
         if constexpr (e == 3) asm volatile("" : "+v"(s1), "+v"(s2));
         if constexpr (idx % 64 == 63) {
-          s1d[j >> 2] = s1;
-          s2d[j >> 2] = s2;
-          s1 = 0.f;
-          s2 = 0.f;
+          if (j >= j_lo && j < j_hi) {  // this pass owns the end of the 128-column group (wave-uniform)
+            s1d[j >> 2] = s1;
+            s2d[j >> 2] = s2;
+            s1 = 0.f;
+            s2 = 0.f;
+          }
         }
       });
     }
+  };
+  // j_last = the last column block any pass processed: a 128-column group that ends inside the row is closed by the pass that
+  // reaches its fourth block; the group the row ends in is closed here (same running sum, same order as one generic pass)
+  auto write_part = [&](const int j_last) __attribute__((always_inline)) {
     if (want_part) {  // wave-uniform: (sum, sumsq) of row co over 128 columns = this lane + its kg partner
 #pragma unroll
       for (int t = 0; t < NPT; ++t) {
+        if (j_last >= 0 && (j_last & 3) != 3 && (j_last >> 2) == t) {
+          s1d[t] = s1;
+          s2d[t] = s2;
+        }
         const float a1 = s1d[t] + __shfl_xor(s1d[t], 32, 64);
         const float a2 = s2d[t] + __shfl_xor(s2d[t], 32, 64);
         if (kg == 0 && co < d.C_out && ptile + t < d.part_nt) {
@@ -198,45 +222,53 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
     const int mode = (rb ? 1 : 0) | (r2b ? 2 : 0) | (d.div != 1.0f ? 4 : 0);
     if constexpr (ACT == ST2_ACT_NONE) {
       switch (mode) {
-        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{});
-        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{});
-        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{});
-        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{});
-        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{});
-        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{});
-        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{});
-        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{});
+        case 0: return epilogue_as(act_tag, std::integral_constant<int, 0>{}, 0, jn_full);
+        case 1: return epilogue_as(act_tag, std::integral_constant<int, 1>{}, 0, jn_full);
+        case 2: return epilogue_as(act_tag, std::integral_constant<int, 2>{}, 0, jn_full);
+        case 3: return epilogue_as(act_tag, std::integral_constant<int, 3>{}, 0, jn_full);
+        case 4: return epilogue_as(act_tag, std::integral_constant<int, 4>{}, 0, jn_full);
+        case 5: return epilogue_as(act_tag, std::integral_constant<int, 5>{}, 0, jn_full);
+        case 6: return epilogue_as(act_tag, std::integral_constant<int, 6>{}, 0, jn_full);
+        default: return epilogue_as(act_tag, std::integral_constant<int, 7>{}, 0, jn_full);
       }
     } else {
-      return epilogue_as(act_tag, std::integral_constant<int, 0>{});
+      return epilogue_as(act_tag, std::integral_constant<int, 0>{}, 0, jn_full);
     }
   };
-  // edge tiles, unaligned tensors, an activation combined with residual / divide: ONE generic body (the 64 predicated
-  // element blocks of a generic build are the bulk of this kernel's code)
-  if (!full_tile || (d.act != ST2_ACT_NONE && (rb || r2b || d.div != 1.0f))) {
-    epilogue_as(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
-    return;
+  // Incomplete row blocks, unaligned tensors, an activation combined with residual / divide: the generic body for the whole
+  // wave tile; otherwise the straight-line build for the complete column blocks and the generic body for the one block that
+  // straddles the row end, if any.  ONE call site of the generic body (its 64 predicated element blocks are the bulk of
+  // this kernel's code): the range it covers is data.
+  int g_lo = 0, g_hi = TN;
+  if (rows_ok && vec_ok && !(d.act != ST2_ACT_NONE && (rb || r2b || d.div != 1.0f))) {
+    if (jn_full > 0) {
+      switch (d.act) {
+        case ST2_ACT_GELU:
+          epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
+          break;
+        case ST2_ACT_EXP_SIN:
+          epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
+          break;
+        case ST2_ACT_TANH:
+          epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
+          break;
+        case ST2_ACT_LEAKY:
+          epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
+          break;
+        case ST2_ACT_GELU_TANH:
+          epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
+          break;
+        default:
+          epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
+          break;
+      }
+    }
+    g_lo = j_strad >= 0 ? j_strad : 0;
+    g_hi = j_strad >= 0 ? j_strad + 1 : 0;
   }
-  switch (d.act) {
-    case ST2_ACT_GELU:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU>{});
-      break;
-    case ST2_ACT_EXP_SIN:
-      epilogue(std::integral_constant<int, ST2_ACT_EXP_SIN>{});
-      break;
-    case ST2_ACT_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_TANH>{});
-      break;
-    case ST2_ACT_LEAKY:
-      epilogue(std::integral_constant<int, ST2_ACT_LEAKY>{});
-      break;
-    case ST2_ACT_GELU_TANH:
-      epilogue(std::integral_constant<int, ST2_ACT_GELU_TANH>{});
-      break;
-    default:
-      epilogue(std::integral_constant<int, ST2_ACT_NONE>{});
-      break;
-  }
+  if (g_hi > g_lo)  // (wave-uniform)
+    epilogue_as(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}, g_lo, g_hi);
+  write_part(g_hi > g_lo ? g_hi - 1 : jn_full - 1);
 }
 
 }  // namespace

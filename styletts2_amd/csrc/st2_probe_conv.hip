@@ -1,17 +1,16 @@
-// CU health probe: which compute units of THIS box run the conv path's workgroups abnormally slowly, and the CU mask that
-// leaves them out (st2_probe_cu_health, st2.h).
+// CU health probe: when did every XCD finish, and which compute units ran the conv path's workgroups abnormally slowly
+// (st2_probe_cu_health, st2.h) -- with the CU mask that leaves those out.
 //
-// Round 4 found MI355X boxes on which the 8 CUs of ONE shader engine take 10-12 x the cycles of every other CU for the
-// conv epilogue (profiles/r04h1_*, r04j_*: XCD 7 / SE 0 on one box, XCD 7 / SE 3 on another), at unchanged clocks and with
-// every micro-benchmark of the memory system reading normal -- plain scattered-store / row-store kernels do not show it
-// (st2_probe_box `scatter_store` / `row_store`), the conv kernel itself does.  So the probe IS the conv kernel: this
-// translation unit holds a private, instrumented copy of st2_conv1d_xs_impl.h (ST2_XS_ABLATE = 64: per-workgroup s_memtime
-// stamps at start / k-loop end / exit + HW_ID / XCC_ID) and runs the launch that separates the box classes -- k = 7, C = 256,
-// L = 8 000, B = 32, 128 x 256 tiles, residual + statistics epilogue -- on synthetic operands.  CUs whose median epilogue
-// takes > 3 x the chip's median are reported; their CU-mask bits are found by running a one-workgroup kernel on
-// single-bit-masked streams of the affected XCDs (the driver's bit -> CU numbering is not documented; measured, not assumed).
-// A stream created with the returned mask (st2_stream_create_cu_mask) never places a workgroup on a degraded CU: the
-// hardware dispatcher otherwise deals every XCD an equal share of a grid and lets it wait for its slowest CUs.
+// The probe IS the conv kernel: this translation unit holds a private, instrumented copy of st2_conv1d_xs_impl.h
+// (ST2_XS_ABLATE = 64: per-workgroup s_memtime stamps at start / k-loop end / exit + HW_ID / XCC_ID) and runs the launch that
+// separated the box classes of rounds 1-3 -- k = 7, C = 256, L = 8 000, B = 32, 128 x 256 tiles, residual + statistics
+// epilogue -- on synthetic operands.  History: on the slow class XCD 7 finished that launch at 1 082 us against ~560 for the
+// others, with 8 CUs of one shader engine at 10-12 x the epilogue cycles (profiles/r04h1_*, r04j_*); this probe then found the
+// same group at 3.5 x on EVERY box, which gave the mechanism away -- those were the row-end tiles of the launch (32 tiles per
+// row: tile 31 of every row goes to XCD 7, and to the same CUs) on a slow generic epilogue, not degraded hardware
+// (DESIGN.md section 6).  With the epilogue fixed it reads 0 slow CUs; it stays as the check for a genuinely bad CU: CUs
+// whose median epilogue takes > 3 x the chip's median are reported and their CU-mask bits found by running an 8-workgroup
+// kernel on single-bit-masked streams (the driver's bit -> CU numbering is not documented; measured, not assumed).
 // Diagnostic entry point: allocates ~0.9 GB for its duration, synchronises the device.
 #define ST2_XS_ABLATE 64
 #include "st2_conv1d_xs_impl.h"
@@ -157,7 +156,7 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
     if (m > 3.0 * med) slow.push_back({kv.first, m / med});
   }
 
-  // ---- CU-mask bits of the degraded CUs: one-workgroup kernels on single-bit-masked streams ------------------------------
+  // ---- CU-mask bits of the slow CUs: 8-workgroup kernels on single-bit-masked streams ------------------------------
   std::map<unsigned long long, int> bit_of;  // cu_key | 1 << 63 -> mask bit
   int mapped = 0, map_tried = 0, map_stream_fail = 0, map_run_fail = 0;
   if (!slow.empty()) {
@@ -216,7 +215,7 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
         all_found = true;
         for (auto& s : slow) all_found &= bit_of.count(s.key | (1ull << 63)) != 0;
       }
-    // never hand back a mask that excludes more than an eighth of the chip: that is not "a few degraded CUs"
+    // never hand back a mask that excludes more than an eighth of the chip: that is not "a few slow CUs"
     if ((int)slow.size() <= num_cu / 8)
       for (auto& s : slow) {
         auto it = bit_of.find(s.key | (1ull << 63));

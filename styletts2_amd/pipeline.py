@@ -70,9 +70,9 @@ class PartitionedStreams:
 
 class MaskedStreams:
     """HIP streams confined to one CU mask (st2_stream_create_cu_mask): `main` and `front`, both on the SAME set of CUs --
-    the device without its degraded CUs, as `ops.probe_cu_health()` returns it.  On boxes with a slow shader engine the
-    hardware dispatcher otherwise hands that engine's CUs their share of every grid and every launch waits for them
-    (DESIGN.md section 6).  Use as
+    e.g. the device without the CUs `ops.probe_cu_health()` reports as slow.  Measured: in batch
+    throughput a masked queue loses (the dispatcher still deals a masked XCD its eighth of every grid); no box has reported
+    a slow CU since round 4's epilogue fix.  Use as
 
         rep, mask, n = ops.probe_cu_health()
         if n:

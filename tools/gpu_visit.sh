@@ -41,6 +41,16 @@ for st in "$@"; do
       timeout 600 python tools/probe_box.py --out $OUT/${TAG}_box.json --level 1 2> $OUT/${TAG}_box.err | tail -1 | tee $OUT/${TAG}_box_class.txt
       grep -q "BOX_CLASS slow" $OUT/${TAG}_box_class.txt && { echo "SLOW BOX: running the kit"; run_slowkit; } ;;
     slowkit) run_slowkit ;;
+    hunt_strong)  # is this a box of the strong class?  tools/bin/xs_bench_old_epilogue = the conv kernel as it was BEFORE the
+      # row-end fix of the epilogue (whole-tile generic code at the end of a row): 128 x 256 tiles at k7 / C256 / L8000 took
+      # 0.66 ms on most boxes and 1.07-1.11 ms on the strong class.  On such a box: the current library's probe and bench lines.
+      old=$(XS_VARIANT=1 timeout 120 tools/bin/xs_bench_old_epilogue 7 1 256 8000 32 1 1 10 2>&1 | grep -o "[0-9.]* ms / launch" | cut -d" " -f1)
+      echo "old epilogue, 128x256 tiles: $old ms" | tee $OUT/${TAG}_old_epilogue.txt
+      if python -c "import sys; sys.exit(0 if float('${old:-0}') > 0.9 else 1)"; then
+        echo "STRONG BOX"
+        timeout 600 python tools/probe_box.py --level 0 --out $OUT/${TAG}_box.json 2> $OUT/${TAG}_box.err | tail -1
+        bash tools/gpu_visit.sh $TAG bench:--no-cpu-baseline bench_ab
+      fi ;;
     hunt)  # cheap: ~20 s on a fast box; on a slow one the whole kit + both bench lines + kernel statistics
       timeout 300 python tools/probe_box.py --quick --level 0 --out $OUT/${TAG}_box.json 2> $OUT/${TAG}_box.err | tail -1 | tee $OUT/${TAG}_box_class.txt
       if grep -q "BOX_CLASS slow" $OUT/${TAG}_box_class.txt; then
