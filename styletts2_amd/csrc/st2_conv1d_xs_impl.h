@@ -435,17 +435,18 @@ enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4, XS_V_P
 // measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32 (tools/xs_bench.hip,
 // profiles/r02i_xs_bench_tn8.log) -- when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a
 // single utterance (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs.  Launches with
-// 2 / 4 / 8 output row blocks (C_out = 256 ... 1024 at k >= 7: the first vocoder stage) take 128 x 128 tiles in XCD-aware
-// order instead: within 2 % of the best build everywhere measured (0.63 vs 0.66 ms at k = 7, 0.91 vs 0.89 at k = 11, C = 256,
-// L = 8 000) and the build least exposed to dispatch-order aliasing -- with 256-column tiles a row of L = 8 000 is 32 tiles,
-// a multiple of 8, so every row-end tile of the launch lands on the same XCD (what made the "slow box class" of rounds 1-3
-// before st2_conv_epilogue.h learnt to treat row ends by column blocks: DESIGN.md section 6).
+// 2 / 4 / 8 output row blocks (C_out = 256 ... 1024: the first vocoder stage) add the XCD-aware order: every XCD keeps one
+// row block's weights in its L2 (k = 7, C = 256, L = 8 000: 0.570 vs 0.598 ms; k = 11: 0.851 vs 0.848, profiles/r04q_bench.json).
+// (Between rounds 2 and 4 the wide tiles were a trap on that stage: 32 tiles per row put every row-end tile on XCD 7, where
+// the then whole-tile generic epilogue ran 3.5-12 x slower -- the "slow box class", DESIGN.md section 6 -- fixed in
+// st2_conv_epilogue.h, which treats row ends by column blocks.)
 inline int rule_variant(const st2_conv_desc& d) {
   if (d.C_out <= 64 || d.ks < 7) return 0;
   const int ny = st2_cdiv(d.C_out, 128);
-  const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * ny * d.B;
-  if ((ny == 2 || ny == 4 || ny == 8) && wg128 % 8 == 0) return XS_V_SWIZZLE;
-  return (int64_t)st2_cdiv(d.L_out, 256) * ny * d.B >= 1024 ? XS_V_WIDE : 0;
+  const bool wide = (int64_t)st2_cdiv(d.L_out, 256) * ny * d.B >= 1024;
+  const int64_t tiles = (int64_t)st2_cdiv(d.L_out, wide ? 256 : 128) * ny * d.B;
+  const bool swz = (ny == 2 || ny == 4 || ny == 8) && tiles % 8 == 0;
+  return (wide ? XS_V_WIDE : 0) | (swz ? XS_V_SWIZZLE : 0);
 }
 
 template <int KS, int CI_T>
