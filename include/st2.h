@@ -122,9 +122,7 @@ typedef struct st2_conv_desc {
   /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
      part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) over the 128 columns of that tile */
   float* part; int32_t part_nt;
-  /* st2_conv1d_xs: optional 8 bytes {next tile, workgroups done} for the persistent builds (see st2_conv_tune), zero before
-     the launch and left zero by it.
-     st2_conv1d_f16s only, optional: workspace for split-K launches.  A layer whose grid leaves most of the chip idle and
+  /* st2_conv1d_f16s only, optional: workspace for split-K launches.  A layer whose grid leaves most of the chip idle and
      whose k loop is long (C_in >= 8 chunks, < 128 workgroups: the 1024 -> 2048 Linears of the denoiser over the ~100
      tokens of one utterance) runs as up to 8 K slices per tile + a fixed-order reduction that applies the epilogue; the
      split is a function of the geometry alone (every plan picks the same one: results are reproducible bit for bit) and
@@ -616,20 +614,17 @@ int st2_conv_timing_read(double* rows, int32_t cap_rows);
 /* ---- start-up autotuner of st2_conv1d_xs (ABI v19) ---------------------------------------------------------------- *
  * A launch of st2_conv1d_xs exists in several BUILDS that issue the same products in the same order and share one
  * epilogue -- results are bitwise identical (tests/test_ops_gpu.py) --: 128 x 128 tiles at 3 workgroups / CU or 128 x 256
- * tiles at 2 (k >= 7), 32- or 16-channel chunks (k = 3), dispatch-order or XCD-aware tile order (launches with 2 / 4 / 8
- * output row blocks: every XCD keeps ONE row block's weights in its L2), one tile per workgroup or PERSISTENT workgroups that
- * pull tiles from a queue (needs d.splitk_ws = 8 bytes {next tile, workgroups done}, zero before the launch; the launch
- * leaves them zero, so one such block serves every launch of a stream -- whoever is slow then simply takes fewer tiles).  Which is fastest depends on the shape AND on the
- * box (before round 4's row-end fix of the epilogue MI355X boxes differed by up to 1.75 x on the C = 256 / L = 8 000 layers of
- * Modules/istftnet.py:358-375 with the then rule's build; a few percent since), so a serving process measures at start-up:
+ * tiles at 2 (k >= 7), in dispatch order or XCD-aware tile order (launches with 2 / 4 / 8 output row blocks: every XCD keeps
+ * ONE row block's weights in its L2).  Which is fastest depends on the shape AND on the box by a few percent (and, before
+ * round 4's row-end fix of the epilogue, by up to 1.75 x on the C = 256 / L = 8 000 layers of Modules/istftnet.py:358-375),
+ * so a serving process measures at start-up:
  *   st2_conv_tune(1)   every FIRST launch of a shape class (device, ks, C_in, C_out, L_out, B) on a non-capturing stream
  *                      times its candidate builds (1 warm-up + 2 x 2 launches each, output into a scratch tensor the
  *                      library allocates for the duration of tuning mode -- the one exception to "no allocation" besides
  *                      the status word; the caller's tensors are only read) and records the winner; the call then runs it;
  *   st2_conv_tune(0)   leaves tuning mode (frees the scratch); recorded classes keep their build, others follow the rule;
  *   st2_conv_tune(-1)  also forgets the current device's table.
- * st2_conv_tune_set pins (variant >= 0: bit 0 = 128 x 256 tiles, bit 1 = XCD-aware order, bit 2 = 16-channel chunks, bit 3 =
- * persistent tile queue) or
+ * st2_conv_tune_set pins (variant >= 0: bit 0 = 128 x 256 tiles, bit 1 = XCD-aware order) or
  * erases (variant = -1) one class on the current device; st2_conv_tune_read fills rows of 24 doubles {ks, C_in, C_out,
  * L_out, B, device, chosen variant, n candidates, (variant, ms / launch) x 8} for the current device and returns the number
  * of classes (rows may be NULL to count).  Tuning synchronises the stream it measures on; the table is guarded by a mutex. */

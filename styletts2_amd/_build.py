@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libst2_hip.so")
 SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_f16s_k0.hip", "st2_conv1d_f16s_k1.hip",
            "st2_conv1d_f16s_k2.hip", "st2_conv1d_f16s_w0.hip", "st2_conv1d_f16s_w1.hip", "st2_conv1d_f16s_w2.hip",
            "st2_conv1d_xs.hip", "st2_conv1d_xs_k0.hip", "st2_conv1d_xs_k1.hip",
-           "st2_conv1d_xs_k2.hip", "st2_conv1d_xs_k3.hip", "st2_conv1d_xs_k4.hip", "st2_actsplit.hip", "st2_norm.hip", "st2_misc.hip", "st2_glue.hip", "st2_style.hip", "st2_engine.hip", "st2_source.hip", "st2_attention.hip", "st2_lstm.hip", "st2_lstm_coop.hip", "st2_probe.hip", "st2_probe_conv.hip"]
+           "st2_conv1d_xs_k2.hip", "st2_conv1d_xs_k3.hip", "st2_actsplit.hip", "st2_norm.hip", "st2_misc.hip", "st2_glue.hip", "st2_style.hip", "st2_engine.hip", "st2_source.hip", "st2_attention.hip", "st2_lstm.hip", "st2_lstm_coop.hip", "st2_probe.hip", "st2_probe_conv.hip"]
 # -ffp-contract=off: the SineGen phase path must reproduce ATen-CPU rounding (no implicit FMA);
 # fused multiply-adds are written explicitly (fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",

@@ -1,5 +1,5 @@
 // C entry points of the xs conv family; the kernels live in st2_conv1d_xs_impl.h and are instantiated in
-// st2_conv1d_xs_k{0..4}.hip.  Also here: the per-launch timing hook of bench.py's roofline leg and the start-up
+// st2_conv1d_xs_k{0..3}.hip.  Also here: the per-launch timing hook of bench.py's roofline leg and the start-up
 // autotuner that picks, per shape class and device, the fastest of the bitwise-equivalent builds of a launch.
 #include "st2_conv1d_xs_impl.h"
 
@@ -11,7 +11,6 @@
 extern template int st2xs::launch_by_cout<1, 32>(const st2_conv_desc&, hipStream_t, int);
 extern template int st2xs::launch_by_cout<2, 32>(const st2_conv_desc&, hipStream_t, int);
 extern template int st2xs::launch_by_cout<3, 32>(const st2_conv_desc&, hipStream_t, int);
-extern template int st2xs::launch_by_cout<3, 16>(const st2_conv_desc&, hipStream_t, int);
 extern template int st2xs::launch_by_cout<5, 16>(const st2_conv_desc&, hipStream_t, int);
 extern template int st2xs::launch_by_cout<7, 16>(const st2_conv_desc&, hipStream_t, int);
 extern template int st2xs::launch_by_cout<11, 16>(const st2_conv_desc&, hipStream_t, int);
@@ -25,7 +24,6 @@ int launch_xs(const st2_conv_desc& d, hipStream_t s, int variant) {
     case 2:
       return st2xs::launch_by_cout<2, 32>(d, s, variant);
     case 3:
-      if (variant >= 0 && (variant & st2xs::XS_V_CHUNK16)) return st2xs::launch_by_cout<3, 16>(d, s, variant);
       return st2xs::launch_by_cout<3, 32>(d, s, variant);
     case 5:
       return st2xs::launch_by_cout<5, 16>(d, s, variant);
@@ -86,32 +84,19 @@ std::vector<int> candidates(const st2_conv_desc& d) {
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
   const int ny = st2_cdiv(d.C_out, 128);
   const bool swz = (ny == 2 || ny == 4 || ny == 8);
-  const bool per = d.splitk_ws && d.splitk_ws_bytes >= 8;  // the tile queue's counters: persistent twins are candidates
   auto add = [&](int v) {
     for (int x : c)
       if (x == v) return;
     if ((v & st2xs::XS_V_SWIZZLE) && !swz) return;
-    if ((v & st2xs::XS_V_PERSIST) && !per) return;
     if (c.size() < 8) c.push_back(v);
   };
-  const int P = st2xs::XS_V_PERSIST;
   if (d.ks >= 7) {
     add(0);
     if (wg128 >= 512) add(st2xs::XS_V_WIDE);
     add(st2xs::XS_V_SWIZZLE);
     if (wg128 >= 512) add(st2xs::XS_V_WIDE | st2xs::XS_V_SWIZZLE);
-    add(P);
-    if (wg128 >= 512) add(P | st2xs::XS_V_WIDE);
-    add(P | st2xs::XS_V_SWIZZLE);
-  } else if (d.ks == 3) {
-    add(st2xs::XS_V_CHUNK16);
-    add(st2xs::XS_V_SWIZZLE);
-    add(P);
-    add(P | st2xs::XS_V_SWIZZLE);
-    add(P | st2xs::XS_V_CHUNK16);
   } else {
     add(st2xs::XS_V_SWIZZLE);
-    add(P);
   }
   return c;
 }
@@ -242,7 +227,7 @@ extern "C" int st2_conv_tune(int mode) {
 }
 
 extern "C" int st2_conv_tune_set(int32_t ks, int32_t C_in, int32_t C_out, int32_t L_out, int32_t B, int32_t variant) {
-  ST2_REQUIRE(variant >= -1 && variant < 16, "st2_conv_tune_set: variant %d out of range", variant);
+  ST2_REQUIRE(variant >= -1 && variant < 4, "st2_conv_tune_set: variant %d out of range", variant);
   const TuneKey key(current_device(), ks, C_in, C_out, L_out, B);
   std::lock_guard<std::mutex> lock(g_tune_mu);
   if (variant < 0) {

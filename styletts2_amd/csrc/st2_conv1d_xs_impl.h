@@ -46,8 +46,8 @@ constexpr int ABL = ST2_XS_ABLATE;
 // Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
 // one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
 // 0.42 ms vs 0.48 ms on the dominant layer at B = 8).
-// (bx, by, bz) = the tile's (l tile, row block, batch item): the launch wrappers below derive it from blockIdx (with or
-// without the XCD-aware remap) or from a tile queue (persistent builds).
+// (bx, by, bz) = the tile's (l tile, row block, batch item): the launch wrappers below derive it from blockIdx, with or
+// without the XCD-aware remap.
 template <int KS, int CI_T, int WM, int WN, int TN>
 __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const unsigned bx, const unsigned by, const unsigned bz,
                                                const int tid) {
@@ -290,50 +290,13 @@ ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o2, 2)  // >= 2 workgroups per CU (the v
 ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o3, 3)  // <= 168 VGPRs
 ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o4, 4)  // <= 128 VGPRs: narrow tiles only
 
-// PERSISTENT builds (variant bit XS_V_PERSIST): the grid is one workgroup per resident slot (workgroups / CU x CUs) and every
-// workgroup pulls tiles from a queue -- one device-scope atomicAdd per tile on ctr[0] -- until it is empty.  What that buys:
-// (i) no workgroup turnaround between tiles (4.5 k of a 132 k-cycle slot, profiles/r02_conv_kernel_study.md); (ii) tiles or
-// CUs that are slow -- round 4's row-end tiles, 3.5-12 x in the epilogue before the fix (profiles/r04h1_*) -- do not hold
-// up their XCD: the hardware dispatcher deals every XCD an equal share of the grid in order, the queue deals by readiness.
-// Same tiles, same arithmetic: bitwise the one-tile-per-workgroup result.  Measured: no gain on the shapes of the path since
-// the epilogue fix (profiles/r04q_bench.json tune table); kept as an autotuner candidate.
-// ctr = {next tile, workgroups done}: zero at launch; the last workgroup out puts both back to zero, so the same 8 bytes
-// serve every launch of a stream (st2.h: d.splitk_ws).
-#define ST2_XS_PERSISTENT_KERNEL(NAME, WGS_PER_CU)                                                                      \
-  template <int KS, int CI_T, int WM, int WN, int TN>                                                                   \
-  __global__ __launch_bounds__(NT, WGS_PER_CU) void NAME(const st2_conv_desc d, const int flags, const unsigned nx,     \
-                                                         const unsigned ny, const unsigned total, unsigned* ctr) {      \
-    __shared__ unsigned next_tile;                                                                                      \
-    for (;;) {                                                                                                          \
-      if (threadIdx.x == 0) next_tile = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
-      __syncthreads();                                                                                                  \
-      const unsigned lin = next_tile;                                                                                   \
-      if (lin >= total) break;                                                                                          \
-      unsigned bx, by, bz;                                                                                              \
-      xs_tile_of(lin, nx, ny, flags, bx, by, bz);                                                                       \
-      /* the thread index is laundered per tile: otherwise the optimiser hoists every lane-dependent address of the    \
-         body AND of its epilogue out of the tile loop, keeps them live through the k loop and spills 31-36 VGPRs */   \
-      int tid = threadIdx.x;                                                                                            \
-      asm volatile("" : "+v"(tid));                                                                                     \
-      conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, bx, by, bz, tid);                                                         \
-      __syncthreads(); /* next_tile and the LDS image are reused */                                                     \
-    }                                                                                                                   \
-    if (threadIdx.x == 0 &&                                                                                             \
-        __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {             \
-      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                          \
-      __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                      \
-    }                                                                                                                   \
-  }
-ST2_XS_PERSISTENT_KERNEL(conv1d_xs_kernel_p2, 2)
-ST2_XS_PERSISTENT_KERNEL(conv1d_xs_kernel_p3, 3)
-
 template <int KS, int CI_T, int WM, int WN, int TN, int OCC>
-int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false, bool persist = false) {
+int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   const int XW = BN + (KS - 1) * d.dil;
-  // The packing's k order is (ci / 16, tap, ci % 16) whatever the chunk depth, so a weight padded to 32-channel chunks also
-  // serves the 16-channel-chunk build (its last chunk is then all-zero weights on the planes' zero channel padding).
+  // The packing's k order is (ci / 16, tap, ci % 16) whatever the chunk depth: any padding to a multiple of the chunk serves
+  // (extra chunks are all-zero weights on the planes' zero channel padding).
   const int C_pad = d.wq_cin_pad;
   constexpr int NS = ((2 * CI_T / 8) * (BN + (KS - 1) * 8) + NT - 1) / NT;
   const size_t smem = (size_t)2 * NS * NT * 16;
@@ -356,41 +319,6 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false, bool per
   const int64_t total = (int64_t)grid.x * grid.y * grid.z;
   // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a tile count divisible by 8
   const int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && total % 8 == 0;
-  if constexpr ((OCC == 2 || OCC == 3) && WM == 4 && TN >= 4 && KS != 1) {  // the 128-row tiles of the big layers only
-    if (persist && d.splitk_ws && d.splitk_ws_bytes >= 8 && total < (1ll << 31)) {
-      void (*kern)(const st2_conv_desc, int, unsigned, unsigned, unsigned, unsigned*);
-      if constexpr (OCC == 3)
-        kern = &conv1d_xs_kernel_p3<KS, CI_T, WM, WN, TN>;
-      else
-        kern = &conv1d_xs_kernel_p2<KS, CI_T, WM, WN, TN>;
-      static std::atomic<uint64_t> attr_done_p{0};  // one bit per device ordinal
-      static int slots_of[64] = {};                 // resident workgroups of this build per device (occupancy query, once)
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      if (st2_first_use_on_device(attr_done_p) || dev < 0 || dev >= 64 || !slots_of[dev]) {
-        // (the queue's 4 bytes of static LDS count against the 160 KB: asking for all of it as dynamic LDS is refused)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 256) != hipSuccess)
-          (void)hipGetLastError();
-        int per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NT, smem) != hipSuccess ||
-            hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0) {
-          (void)hipGetLastError();
-          per_cu = 0;
-        }
-        if (dev >= 0 && dev < 64) slots_of[dev] = per_cu > 0 ? std::min(per_cu, OCC) * prop.multiProcessorCount : -1;
-      }
-      const int slots = dev >= 0 && dev < 64 ? slots_of[dev] : -1;
-      if (slots > 0) {
-        const unsigned wgs = (unsigned)std::min<int64_t>(slots, total);
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(NT), smem, s, d, flags, grid.x, grid.y, (unsigned)total,
-                           reinterpret_cast<unsigned*>(d.splitk_ws));
-        ST2_CHECK_LAUNCH("st2_conv1d_xs (persistent)");
-        return 0;
-      }
-    }
-  }
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal (hipFuncSetAttribute is per device)
   if (st2_first_use_on_device(attr_done)) {
     if constexpr (OCC == 4)
@@ -424,11 +352,9 @@ namespace st2xs {
 // (st2_conv_tune, st2_conv1d_xs.hip) and falls back to the rule below when a class was not tuned.
 //   bit 0  XS_V_WIDE     128 (co) x 256 (l) tiles, 2 workgroups / CU (k >= 7 only) instead of 128 x 128, 3 workgroups / CU
 //   bit 1  XS_V_SWIZZLE  XCD-aware tile order: one row block per XCD (launches with 2 / 4 / 8 row blocks)
-//   bit 2  XS_V_CHUNK16  16-channel chunks for k <= 3 (half the LDS image per barrier, twice the barriers); selects the
-//                        launch_by_cout<KS, 16> instantiation in the dispatcher, ignored here
-//   bit 3  XS_V_PERSIST  persistent workgroups pulling tiles from a queue (C_out > 64 builds; needs the 8 zero bytes of
-//                        d.splitk_ws, else the one-tile-per-workgroup form of the same build runs)
-enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_CHUNK16 = 4, XS_V_PERSIST = 8 };
+// Tried as further variants in round 4 and removed again (bitwise equivalent, never a winner by the tuner's 2 % margin on any
+// box: profiles/LAB_NOTES.md): 16-channel chunks at k = 3, and persistent workgroups pulling tiles from an atomic queue.
+enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2 };
 
 // The build an UNTUNED process runs (tests, one-off calls; a serving process measures: st2_conv_tune).  k >= 7: 32 (co) x
 // 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU -- half the weight stream (L2 -> registers) per FLOP;
@@ -452,10 +378,10 @@ inline int rule_variant(const st2_conv_desc& d) {
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
   if (variant < 0) variant = rule_variant(d);
-  const bool swz = (variant & XS_V_SWIZZLE) != 0, per = (variant & XS_V_PERSIST) != 0;
+  const bool swz = (variant & XS_V_SWIZZLE) != 0;
   if (d.C_out > 64) {
     if constexpr (KS >= 7) {
-      if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz, per);
+      if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
     }
     if constexpr (KS == 1 && CI_T == 32) {
       // Token GEMMs (the denoiser's / PL-BERT's Linears over the B*N merged tokens: C_out 512..1024 x 3 200 columns): at
@@ -467,10 +393,7 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
       if ((int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B < 256 && d.wq_cin_pad % 64 == 0 && !d.part)
         return launch<1, 64, 4, 1, 2, 3>(d, s, swz);
     }
-    if constexpr (KS == 1)
-      return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz);  // (token GEMMs: one build, no persistent twin)
-    else
-      return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz, per);  // 128 co x 128 l, 3 workgroups / CU
+    return launch<KS, CI_T, 4, 1, 4, 3>(d, s, swz);  // 128 co x 128 l, 3 workgroups / CU
   }
   if (d.C_out > 32) {                                           // 64 co x 256 l
     if constexpr (CI_T == 16)

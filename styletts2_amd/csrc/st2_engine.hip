@@ -146,7 +146,6 @@ struct Ctx {
   void* stream = nullptr;
   int rc = 0;
   bool dry = false;
-  void* tile_queue = nullptr;  // 64 zero bytes at the head of the workspace: the persistent xs conv builds' tile queue
 };
 
 View new_ncl(Ctx& c, int B, int C, int L, bool padded = true) {
@@ -725,22 +724,6 @@ int pack_denoiser(st2_engine& e, Blob& blob, std::string* err) {
   return 0;
 }
 
-// First allocation of every plan: the tile queue of the persistent xs conv builds (st2.h: 8 bytes, zero before a launch and
-// left zero by it -- every launch of the plan's stream shares them), zeroed here once per plan call.  The memset is a
-// stream operation (legal under capture: a memset node); the CPU test backend runs on host memory.
-void ctx_begin(Ctx& c) {
-  c.tile_queue = c.a.alloc(64);
-  if (c.dry || c.a.overflow || !c.tile_queue) return;
-  if (g_be.conv1d_xs == &st2_conv1d_xs) {
-    if (hipMemsetAsync(c.tile_queue, 0, 64, reinterpret_cast<hipStream_t>(c.stream)) != hipSuccess) {
-      (void)hipGetLastError();
-      c.tile_queue = nullptr;  // no queue: the one-tile-per-workgroup builds run
-    }
-  } else {
-    memset(c.tile_queue, 0, 64);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // conv dispatch == styletts2_amd.ops.conv1d for split-f16 weights
 // ------------------------------------------------------------------------------------------------------------------
@@ -806,7 +789,6 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
       part = c.a.f32((int64_t)y.B * y.C * nt * 2);
       d.part = part; d.part_nt = nt;
     }
-    if (c.tile_queue) { d.splitk_ws = c.tile_queue; d.splitk_ws_bytes = 64; }
     RUN(c, g_be.conv1d_xs(&d, c.stream));
     if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
   } else {
@@ -2044,7 +2026,6 @@ extern "C" int64_t st2_decoder_workspace_bytes(st2_engine* e, int32_t B, int32_t
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   decoder_plan(c, *e, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, T, nullptr, nullptr);
   return c.a.peak + 256;
 }
@@ -2060,7 +2041,6 @@ extern "C" int st2_decoder_forward(st2_engine* e, const float* asr, const float*
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = decoder_plan(c, *e, asr, f0, n, s, sine_noise, har_inject, B, T, wave, taps);
   ST2_REQUIRE(!c.a.overflow, "st2_decoder_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_decoder_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -2072,7 +2052,6 @@ extern "C" int64_t st2_text_workspace_bytes(st2_engine* e, int32_t B, int32_t N)
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   text_plan(c, *e, nullptr, nullptr, B, N, nullptr);
   return c.a.peak + 256;
 }
@@ -2086,7 +2065,6 @@ extern "C" int st2_text_forward(st2_engine* e, const int64_t* tokens, const int3
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = text_plan(c, *e, tokens, lengths, B, N, t_en);
   ST2_REQUIRE(!c.a.overflow, "st2_text_forward: workspace of %lld B is too small (need %lld B, see st2_text_workspace_bytes)",
               (long long)workspace_bytes, (long long)c.a.peak);
@@ -2098,7 +2076,6 @@ extern "C" int64_t st2_bert_workspace_bytes(st2_engine* e, int32_t B, int32_t N)
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   bert_plan(c, *e, nullptr, nullptr, B, N);
   return c.a.peak + 256;
 }
@@ -2113,7 +2090,6 @@ extern "C" int st2_bert_forward(st2_engine* e, const int64_t* tokens, const int3
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   View X = bert_plan(c, *e, tokens, lengths, B, N);
   View dst = wrap(hidden_cm, B, e->bert.H, N);
   RUN(c, g_be.copy_ncl(X.p, X.bs, X.cs, dst.p, dst.bs, dst.cs, B, e->bert.H, N, c.stream));
@@ -2127,7 +2103,6 @@ extern "C" int64_t st2_style_workspace_bytes(st2_engine* e, int32_t which, int32
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   style_plan(c, *e, e->style[which], nullptr, B, n_mels, T, nullptr);
   return c.a.peak + 256;
 }
@@ -2143,7 +2118,6 @@ extern "C" int st2_style_forward(st2_engine* e, int32_t which, const float* mel,
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = style_plan(c, *e, e->style[which], mel, B, n_mels, T, style);
   ST2_REQUIRE(!c.a.overflow, "st2_style_forward: workspace of %lld B is too small (need %lld B, see st2_style_workspace_bytes)",
               (long long)workspace_bytes, (long long)c.a.peak);
@@ -2171,7 +2145,6 @@ extern "C" int64_t st2_front_workspace_bytes(st2_engine* e, const st2_front_args
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   std::vector<double> table((size_t)(a->steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
   static const float dummy = 0.f;
   static int64_t dummy_dur;
@@ -2197,7 +2170,6 @@ extern "C" int st2_front_forward(st2_engine* e, const st2_front_args* a, void* w
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = front_plan(c, *e, *a);
   ST2_REQUIRE(!c.a.overflow, "st2_front_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_front_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -2209,7 +2181,6 @@ extern "C" int64_t st2_duration_workspace_bytes(st2_engine* e, int32_t B, int32_
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   static int64_t dummy_dur;
   duration_plan(c, *e, wrap(nullptr, B, e->cfg.pred_hidden, N), nullptr, nullptr, B, N, 0, nullptr, &dummy_dur);
   return c.a.peak + 256;
@@ -2226,7 +2197,6 @@ extern "C" int st2_duration_forward(st2_engine* e, const float* d_en, const floa
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = duration_plan(c, *e, wrap(d_en, B, e->cfg.pred_hidden, N), s, lengths, B, N, tail, d_cm, durations);
   ST2_REQUIRE(!c.a.overflow, "st2_duration_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_duration_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -2238,7 +2208,6 @@ extern "C" int64_t st2_prosody_workspace_bytes(st2_engine* e, int32_t B, int32_t
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   prosody_plan(c, *e, nullptr, nullptr, nullptr, nullptr, B, N, T, 0, nullptr, nullptr, nullptr);
   return c.a.peak + 256;
 }
@@ -2255,7 +2224,6 @@ extern "C" int st2_prosody_forward(st2_engine* e, const float* d_cm, const float
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = prosody_plan(c, *e, d_cm, t_en, durations, s, B, N, T, shift, asr, f0, n);
   ST2_REQUIRE(!c.a.overflow, "st2_prosody_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_prosody_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -2300,7 +2268,6 @@ extern "C" int64_t st2_sampler_workspace_bytes(st2_engine* e, int32_t B, int32_t
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   std::vector<double> table((size_t)(steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
   static const float dummy = 0.f;
   sampler_plan(c, *e, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, B, N, steps, embedding_scale, table.data(), 1.0, nullptr,
@@ -2322,7 +2289,6 @@ extern "C" int st2_sampler_run(st2_engine* e, const float* noise, const float* e
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = sampler_plan(c, *e, noise, embedding, nullptr, features, step_noise, lengths, B, N, steps, embedding_scale, table,
                               sigma0, out, step_taps);
   ST2_REQUIRE(!c.a.overflow, "st2_sampler_run: workspace of %lld B is too small (need %lld B, see "

@@ -120,7 +120,7 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
   d.part = part; d.part_nt = nt;
   d.stats = reinterpret_cast<const float*>(tl);  // ST2_XS_ABLATE & 64: the timeline buffer
   for (int rep = 0; rep < 2; ++rep)  // warm-up + the measured launch (the stamps of the last one stay)
-    if (launch<7, 16, 4, 1, 8, 2>(d, 0, false, false) != 0) {
+    if (launch<7, 16, 4, 1, 8, 2>(d, 0, false) != 0) {
       cleanup();
       return 1;
     }

@@ -78,8 +78,8 @@ def check_status():
 
 class conv_autotune:
     """`with ops.conv_autotune(): forward(...)` -- start-up autotuning of the xs convs (include/st2.h `st2_conv_tune`): the
-    first launch of every shape class inside the block times its bitwise-equivalent builds on this box and keeps the
-    fastest; later calls (inside or outside the block, eager or graph-captured) run it.  Boxes of the same SKU differ by
+    first launch of every shape class inside the block times its bitwise-equivalent builds (tile shape / occupancy,
+    dispatch-order or XCD-aware tile order) on this box and keeps the fastest; later calls (inside or outside the block, eager or graph-captured) run it.  Boxes of the same SKU differ by
     up to 1.75 x on individual classes with the rule's build, so a serving process runs one forward per batch shape in
     here before taking traffic.  `reset=True` forgets earlier measurements of the current device first."""
 
@@ -99,15 +99,13 @@ class conv_autotune:
         return False
 
 
-TUNE_VARIANT_BITS = {1: "128x256 tiles, 2 wg/CU", 2: "XCD-aware tile order", 4: "16-channel chunks", 8: "persistent tile queue"}
+TUNE_VARIANT_BITS = {1: "128x256 tiles, 2 wg/CU", 2: "XCD-aware tile order"}
 
 
 def tune_variant_name(v):
     if v < 0:
         return "rule"
     names = [n for b, n in TUNE_VARIANT_BITS.items() if v & b]
-    if not v & 1 and v & 8:
-        names.insert(0, "128x128 tiles")
     return " + ".join(names) if names else "128x128 tiles, 3 wg/CU, dispatch order"
 
 
@@ -307,25 +305,10 @@ def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, ou
         nt = (L_out + 127) // 128
         part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
         d.part, d.part_nt = part.data_ptr(), nt
-    ctr = _tile_queue(out.device)
-    d.splitk_ws, d.splitk_ws_bytes = ctr.data_ptr(), ctr.numel() * 4
     _launch_conv(lib.st2_conv1d_xs, "st2_conv1d_xs", d)
     if want_stats:
         return out, stats_finalize(part, L_out)
     return out
-
-
-_TILE_QUEUES = {}
-
-
-def _tile_queue(device):
-    """The 8 zero bytes a persistent build of st2_conv1d_xs keeps its tile queue in (include/st2.h: zero before a launch, left
-    zero by it): one block per (device, stream) -- launches of one stream are ordered, two streams never share a block."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    t = _TILE_QUEUES.get(key)
-    if t is None:
-        t = _TILE_QUEUES[key] = torch.zeros(16, dtype=torch.int32, device=device)
-    return t
 
 
 def _fill_epilogue(d, B, C_out, L_out, res, res_shift, res2, div, act, act_split, act_slope):

@@ -770,15 +770,15 @@ XS_VARIANT_CASES = [
     (8, 256, 2000, 3, 3, True),
     (3, 256, 777, 7, 3, False),     # unaligned dense tensors (4-byte epilogue), grid not divisible by 8 (swizzle refused)
     (2, 512, 640, 3, 1, True),      # 4 row blocks
-    (4, 1090, 400, 3, 1, True),     # ragged C_in: the 16-channel build walks one all-zero chunk of the 32-channel packing
+    (4, 1090, 400, 3, 1, True),     # ragged C_in (zero-padded last chunk), 2 row blocks
     (6, 128, 3001, 11, 1, True),    # one row block: the swizzle bit is a no-op
 ]
 
 
 @pytest.mark.parametrize("B,C,L,ks,dil,aligned", XS_VARIANT_CASES)
 def test_xs_variants_are_bitwise_identical(B, C, L, ks, dil, aligned):
-    """Every build the autotuner may pick (include/st2.h st2_conv_tune: tile shape / occupancy, chunk depth, XCD-aware tile
-    order) issues the same products in the same order through the same epilogue: output AND InstanceNorm statistics are
+    """Every build the autotuner may pick (include/st2.h st2_conv_tune: tile shape / occupancy, XCD-aware tile order)
+    issues the same products in the same order through the same epilogue: output AND InstanceNorm statistics are
     bit-identical to the rule's build -- the choice is a matter of time only."""
     gen = torch.Generator().manual_seed(4242 + ks)
     C_out = 256 if C == 1090 else C
@@ -791,7 +791,7 @@ def test_xs_variants_are_bitwise_identical(B, C, L, ks, dil, aligned):
     xs = ops.activate(g(x))
     pad = (ks - 1) * dil // 2
     outs = {}
-    variants = [-1, 0, 2, 8, 10] + ([1, 3, 9, 11] if ks >= 7 else []) + ([4, 6, 12] if ks == 3 else [])  # bit 3: persistent
+    variants = [-1, 0, 2] + ([1, 3] if ks >= 7 else [])
     try:
         for v in variants:
             ops.conv_tune_set(ks, C, C_out, L, B, v)
@@ -803,7 +803,6 @@ def test_xs_variants_are_bitwise_identical(B, C, L, ks, dil, aligned):
         ops.conv_tune_set(ks, C, C_out, L, B, -1)
     ref = R.conv1d(x, weights.pack_conv_f16s(w), C_out, ks, dil=dil, pad_left=pad, bias=bias.cpu(), res=res.cpu(), pro=R.PRO_NONE)
     assert rel_err(outs[-1][0], ref) < 3e-6
-    assert int(ops._tile_queue(xs.data.device).abs().sum()) == 0, "a persistent launch must leave its tile queue zero"
     for v in variants[1:]:
         assert torch.equal(outs[v][0], outs[-1][0]), "variant %d differs from the rule's build" % v
         assert torch.equal(outs[v][1], outs[-1][1]), "variant %d: statistics differ" % v
@@ -837,8 +836,7 @@ def test_conv_autotune_measures_keeps_results_and_survives_aliasing():
     after = run()
     table = [r for r in ops.conv_tune_table() if (r["ks"], r["C_in"], r["L"], r["B"]) == (ks, C, L, B)]
     try:
-        assert len(table) == 1 and len(table[0]["candidates"]) >= 5, table
-        assert any(c["variant"] & 8 for c in table[0]["candidates"]), "the persistent twins are candidates"
+        assert len(table) == 1 and len(table[0]["candidates"]) >= 3, table
         assert all(c["ms"] > 0 for c in table[0]["candidates"]), table
         assert table[0]["chosen"] in [c["variant"] for c in table[0]["candidates"]]
         for t in (tuned_first, tuned_again, after):

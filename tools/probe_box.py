@@ -42,8 +42,6 @@ def time_class(ks, C, L, dil, B=32, variants=(0, 1, 2, 3), reps=5):
     pad = (ks - 1) * dil // 2
     res_ms = {}
     for v in variants:
-        if v & 4 and ks != 3:
-            continue
         if v & 1 and ks < 7:
             continue
         ops.conv_tune_set(ks, C, C, L, B, v)
@@ -77,7 +75,7 @@ def main():
     fp = boxinfo.fingerprint(0, probe=True, level=a.level, health=not a.no_health)
     fp["conv_classes"] = []
     for ks, C, L, dil in (CLASSES[:1] if a.quick else CLASSES):
-        variants = (0, 1, 2, 3) if ks >= 7 else ((0, 4, 2, 6) if ks == 3 else (0, 2))
+        variants = (0, 1, 2, 3) if ks >= 7 else (0, 2)
         with boxinfo.Sampler(0) as smp:
             ms = time_class(ks, C, L, dil, variants=variants)
         flop = 2.0 * 32 * C * C * ks * L
