@@ -553,7 +553,7 @@ def main():
                                           front_stream=front_s, front=lf_front)
 
     # Set-up, not a warm-up step: (i) the xs convs are AUTOTUNED here -- the first launch of every shape class times its
-    # bitwise-equivalent builds (tile shape / occupancy, chunk depth, XCD-aware tile order) on this box and keeps the
+    # bitwise-equivalent builds (tile shape / occupancy, dispatch-order or XCD-aware tile order) on this box and keeps the
     # fastest (st2_conv_tune; what a serving process does at start-up: boxes differ by up to 1.75 x per class on the rule's
     # build); (ii) the hipGraph of the front is recorded (one eager pass + the capture), so that --warmup 0 puts neither
     # inside the timed region.  Nothing else runs on the GPU during this step: the measurements are un-overlapped.
