@@ -12,7 +12,8 @@
 #   bench[:ARGS]     the driver's command `python bench.py --gpus 1 --steps 20 --warmup 5` (+ comma-separated extra args)
 #   bench_ab         the same without the autotuner (--no-autotune), for the A/B on this box
 #   configs          one short bench line per other configuration (libritts_hifigan, libritts_istftnet, longform)
-#   stats            rocprofv3 --kernel-trace --stats of a short single-stream bench (per-kernel table)
+#   stats[:SCHED]    rocprofv3 --kernel-trace --stats of a short bench on one schedule (default single): per-kernel table +
+#                    tools/trace_gaps.py (busy / idle / overlapped time of the steady-state steps)
 #   pmc              FETCH_SIZE / WRITE_SIZE / busy-cycle passes over tools/probe_dom.py (profiles/pmc_dominant.json)
 #   gemm             tools/bin/gemm_bench (token GEMM shapes)
 #   cmd:COMMAND      anything else (spaces as '+')
@@ -83,8 +84,10 @@ for st in "$@"; do
         python tools/bench_summary.py $OUT/${TAG}_bench_$c.json
       done ;;
     stats)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule single --calib-steps 0 --no-cpu-baseline --no-box-probe > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
-      f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_single_kernel_stats.csv && head -25 $f ;;
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule ${arg:-single} --calib-steps 0 --no-cpu-baseline --no-box-probe > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
+      f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_single_kernel_stats.csv && head -25 $f
+      t=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/trace_gaps.py $t | tee $OUT/${TAG}_trace_gaps.txt
+      rm -rf /tmp/prof_$TAG ;;
     pmc)
       for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         n=$(echo $ctr | tr ' ' '_')
