@@ -46,10 +46,10 @@ constexpr int ABL = ST2_XS_ABLATE;
 // Two builds of the body: one held to 2 workgroups per CU (<= 256 registers; the variants with wide staging tiles) and
 // one capped at 168 VGPRs (3 workgroups per CU: a third wave per SIMD to hide LDS / L2 latency behind; measured
 // 0.42 ms vs 0.48 ms on the dominant layer at B = 8).
-// (bx, by, bz) = the tile's (l tile, row block, batch item): the launch wrappers below derive it from blockIdx, with or
-// without the XCD-aware remap.
+// (n0, by, bz) = the tile's (first column, row block, batch item): the launch wrappers below derive it from blockIdx, with
+// or without the XCD-aware remap.  TN need not be the launch's: a tile at the end of a row may run a narrower body.
 template <int KS, int CI_T, int WM, int WN, int TN>
-__device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const unsigned bx, const unsigned by, const unsigned bz,
+__device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int n0, const unsigned by, const unsigned bz,
                                                const int tid) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
@@ -69,7 +69,6 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const uns
   const int l31 = lane & 31;
   const int wm = wave / WN;
   const int wn = wave % WN;
-  const int n0 = bx * BN;
   const int m0 = by * BM;
   const int b = bz;
 
@@ -279,12 +278,27 @@ __device__ __forceinline__ void xs_tile_of(unsigned lin, unsigned nx, unsigned n
   }
 }
 
+// Row ends: a tile whose valid columns fit a quarter of the tile width (L = 400 in 128-column tiles: 16 columns; L = 8 000
+// in 256-column tiles: 64) runs the body with a quarter of the column blocks -- the same k loop over the same staged rows,
+// the same products in the same order for the columns that exist, and (the tile starts a 128-column group of its own) the
+// same partial sums -- instead of multiplying three quarters of a tile of zero padding: 1 in 4 tiles at L = 400, 1 in 7 at
+// L = 800, 1 in 32 on the first vocoder stage.
+#ifndef ST2_XS_ROWEND
+#define ST2_XS_ROWEND 1
+#endif
 #define ST2_XS_ONE_TILE_KERNEL(NAME, WGS_PER_CU)                                                                        \
   template <int KS, int CI_T, int WM, int WN, int TN>                                                                   \
   __global__ __launch_bounds__(NT, WGS_PER_CU) void NAME(const st2_conv_desc d, const int flags) {                     \
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;                                                         \
     if (flags & 1) xs_tile_of(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x, gridDim.y, flags, bx, by, bz);         \
-    conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, bx, by, bz, threadIdx.x);                                                   \
+    const int n0 = (int)bx * (32 * TN * WN);                                                                            \
+    if constexpr (ST2_XS_ROWEND && WN == 1 && TN >= 4) {                                                                \
+      if (d.L_out - n0 <= 32 * (TN / 4)) { /* workgroup-uniform */                                                      \
+        conv1d_xs_body<KS, CI_T, WM, WN, TN / 4>(d, n0, by, bz, threadIdx.x);                                           \
+        return;                                                                                                         \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    conv1d_xs_body<KS, CI_T, WM, WN, TN>(d, n0, by, bz, threadIdx.x);                                                   \
   }
 ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o2, 2)  // >= 2 workgroups per CU (the variants with wide staging tiles)
 ST2_XS_ONE_TILE_KERNEL(conv1d_xs_kernel_o3, 3)  // <= 168 VGPRs

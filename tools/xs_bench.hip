@@ -132,6 +132,18 @@ int main(int argc, char** argv) {
   printf("xs_bench abl=%d ks=%d dil=%d C=%d L=%d B=%d res=%d stats=%d: %.4f ms / launch, %.1f algorithmic TFLOP/s "
          "(%.3f of 833)\n", ST2_XS_ABLATE, ks, dil, C, L, B, use_res, use_stats, ms, flop / ms / 1e9,
          flop / ms / 1e9 / (2500.0 / 3));
+  {  // FNV-1a over the bits of the valid part of y and of the partial sums: builds that claim bitwise equality print the same
+    std::vector<float> hy((size_t)B * C * pitch), hp((size_t)B * C * nt * 2);
+    CK(hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long hsh = 1469598103934665603ull;
+    auto mix = [&](float v) { unsigned u; memcpy(&u, &v, 4); hsh = (hsh ^ u) * 1099511628211ull; };
+    for (int64_t r = 0; r < (int64_t)B * C; ++r)
+      for (int l = 0; l < L; ++l) mix(hy[(size_t)r * pitch + l]);
+    if (use_stats)
+      for (float v : hp) mix(v);
+    printf("checksum %016llx\n", hsh);
+  }
   if (ST2_XS_ABLATE & 64) {  // dump the last launch's timeline: one line per workgroup
     std::vector<unsigned long long> h(n_wg * 8);
     CK(hipMemcpy(h.data(), tl, n_wg * 64, hipMemcpyDeviceToHost));
