@@ -614,7 +614,7 @@ int st2_conv_timing_read(double* rows, int32_t cap_rows);
 /* ---- start-up autotuner of st2_conv1d_xs (ABI v19) ---------------------------------------------------------------- *
  * A launch of st2_conv1d_xs exists in several BUILDS that issue the same products in the same order and share one
  * epilogue -- results are bitwise identical (tests/test_ops_gpu.py) --: 128 x 128 tiles at 3 workgroups / CU or 128 x 256
- * tiles at 2 (k >= 7), in dispatch order or XCD-aware tile order (launches with 2 / 4 / 8 output row blocks: every XCD keeps
+ * tiles at 2 (k = 3, 7, 11), in dispatch order or XCD-aware tile order (launches with 2 / 4 / 8 output row blocks: every XCD keeps
  * ONE row block's weights in its L2).  Which is fastest depends on the shape AND on the box by a few percent (and, before
  * round 4's row-end fix of the epilogue, by up to 1.75 x on the C = 256 / L = 8 000 layers of Modules/istftnet.py:358-375),
  * so a serving process measures at start-up:

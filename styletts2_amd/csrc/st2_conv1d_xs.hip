@@ -96,6 +96,8 @@ std::vector<int> candidates(const st2_conv_desc& d) {
     add(st2xs::XS_V_SWIZZLE);
     if (wg128 >= 512) add(st2xs::XS_V_WIDE | st2xs::XS_V_SWIZZLE);
   } else {
+    add(0);
+    if (d.ks == 3 && wg128 >= 512 && d.L_out >= 512) add(st2xs::XS_V_WIDE);  // short rows waste the second half-tile
     add(st2xs::XS_V_SWIZZLE);
   }
   return c;

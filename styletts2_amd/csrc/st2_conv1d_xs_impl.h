@@ -364,7 +364,7 @@ namespace st2xs {
 // the shape: driver-class MI355X boxes run the 128 x 256 tile build 1.5-1.75 x slower than builder-class boxes on the
 // C = 256 / L = 8 000 layers and only there, so the choice is MEASURED per shape class at start-up
 // (st2_conv_tune, st2_conv1d_xs.hip) and falls back to the rule below when a class was not tuned.
-//   bit 0  XS_V_WIDE     128 (co) x 256 (l) tiles, 2 workgroups / CU (k >= 7 only) instead of 128 x 128, 3 workgroups / CU
+//   bit 0  XS_V_WIDE     128 (co) x 256 (l) tiles, 2 workgroups / CU (k = 3, 7, 11) instead of 128 x 128, 3 workgroups / CU
 //   bit 1  XS_V_SWIZZLE  XCD-aware tile order: one row block per XCD (launches with 2 / 4 / 8 row blocks)
 // Tried as further variants in round 4 and removed again (bitwise equivalent, never a winner by the tuner's 2 % margin on any
 // box: profiles/LAB_NOTES.md): 16-channel chunks at k = 3, and persistent workgroups pulling tiles from an atomic queue.
@@ -381,8 +381,10 @@ enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2 };
 // the then whole-tile generic epilogue ran 3.5-12 x slower -- the "slow box class", DESIGN.md section 6 -- fixed in
 // st2_conv_epilogue.h, which treats row ends by column blocks.)
 inline int rule_variant(const st2_conv_desc& d) {
-  if (d.C_out <= 64 || d.ks < 7) return 0;
+  if (d.C_out <= 64 || (d.ks < 7 && d.ks != 3)) return 0;
   const int ny = st2_cdiv(d.C_out, 128);
+  if (d.ks == 3)  // long rows only: 0.400 -> 0.372 ms at C = 256, L = 8 000, -4 % at L = 800, +13 ... +70 % at L = 400 (r04ae)
+    return (d.L_out >= 4096 && (int64_t)st2_cdiv(d.L_out, 256) * ny * d.B >= 1024) ? XS_V_WIDE : 0;
   const bool wide = (int64_t)st2_cdiv(d.L_out, 256) * ny * d.B >= 1024;
   const int64_t tiles = (int64_t)st2_cdiv(d.L_out, wide ? 256 : 128) * ny * d.B;
   const bool swz = (ny == 2 || ny == 4 || ny == 8) && tiles % 8 == 0;
@@ -394,7 +396,7 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
   if (variant < 0) variant = rule_variant(d);
   const bool swz = (variant & XS_V_SWIZZLE) != 0;
   if (d.C_out > 64) {
-    if constexpr (KS >= 7) {
+    if constexpr (KS >= 7 || KS == 3) {
       if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
     }
     if constexpr (KS == 1 && CI_T == 32) {

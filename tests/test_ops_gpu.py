@@ -791,7 +791,7 @@ def test_xs_variants_are_bitwise_identical(B, C, L, ks, dil, aligned):
     xs = ops.activate(g(x))
     pad = (ks - 1) * dil // 2
     outs = {}
-    variants = [-1, 0, 2] + ([1, 3] if ks >= 7 else [])
+    variants = [-1, 0, 2] + ([1, 3] if ks >= 7 or ks == 3 else [])
     try:
         for v in variants:
             ops.conv_tune_set(ks, C, C_out, L, B, v)
