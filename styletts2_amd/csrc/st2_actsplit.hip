@@ -29,6 +29,9 @@ struct ActArgs {
   int* status;  // sticky status word (st2_status), may be null
 };
 
+#ifndef ST2_ACT_NT
+#define ST2_ACT_NT 3  // bit 0 = nontemporal loads of x, bit 1 = nontemporal stores of the planes
+#endif
 template <int PRO>
 __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
   const int pos = blockIdx.x * 256 + threadIdx.x;
@@ -46,7 +49,11 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
     // read once, written once: nontemporal hints on both sides (-7 % at C = 128 / L = 48 001, -15 % at C = 256 / L = 8 000
     // alone, -0.35 ms per bench step; profiles/r04aa_nt_*.log).  The conv's own stores and staging loads LOSE with the
     // same hint (+10 % / +2 %): its output is re-read as the next layer's residual and its tiles overlap in the halo.
+#if ST2_ACT_NT & 1
     v[e] = __builtin_nontemporal_load(&xb[(int64_t)ci * a.x_cs]);
+#else
+    v[e] = xb[(int64_t)ci * a.x_cs];
+#endif
   }
   float cmean = 0.f, crstd = 1.f;
   if constexpr (PRO == ST2_PRO_COLNORM) {
@@ -100,8 +107,13 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
   if (__any(sat) && (threadIdx.x & 63) == 0) st2_raise_status(a.status, ST2_STATUS_F16_RANGE);
   const int64_t plane = (int64_t)a.xs_cg * a.Lp;
   st2_h8* dst = a.xs + ((int64_t)b * 2 * a.xs_cg + cg) * a.Lp + pos;
+#if ST2_ACT_NT & 2
   __builtin_nontemporal_store(hi, &dst[0]);
   __builtin_nontemporal_store(lo, &dst[plane]);
+#else
+  dst[0] = hi;
+  dst[plane] = lo;
+#endif
 }
 
 // stats[row] = (mean, rstd) from per-tile partial (sum, sumsq); one wave per row, fp64, fixed order.
