@@ -27,7 +27,11 @@ def timed(fn, n=4):
 
 
 B = 32
-for (C, L) in ((64, 120000), (32, 240000), (128, 48001)):
+SHAPES = ((64, 120000), (32, 240000), (128, 48001))
+if os.environ.get("PROBE_C"):  # e.g. PROBE_C=128 PROBE_KS=3: one side of the rule only
+    SHAPES = tuple(s for s in SHAPES if s[0] == int(os.environ["PROBE_C"]))
+KS = tuple(int(k) for k in os.environ.get("PROBE_KS", "3,7,11").split(","))
+for (C, L) in SHAPES:
     pitch = (L + 31) // 32 * 32
     x = torch.randn(B, C, pitch, device=dev)[:, :, :L]
     out = torch.empty((B, C, pitch), device=dev)[:, :, :L]
@@ -35,10 +39,10 @@ for (C, L) in ((64, 120000), (32, 240000), (128, 48001)):
     h = torch.randn(B, 2 * C, device=dev) * 0.3
     alpha = torch.rand(C, device=dev) + 0.5
     bias = torch.randn(C, device=dev)
-    for ks in (3, 7, 11):
+    for ks in KS:
         w = torch.randn(C, C, ks, device=dev) / math.sqrt(C * ks)
         wt = weights.pack_conv_f16s(w).to(dev)
-        for dil in (1, 3):
+        for dil in (1, 3, 5):
             pad = (ks - 1) * dil // 2
             pk = dict(pro=ops.PRO_ADAIN_SNAKE, stats=st, gamma=h[:, :C], beta=h[:, C:], alpha=alpha)
             for want in (False, True):
