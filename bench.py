@@ -254,9 +254,11 @@ def roofline(by_class):
             "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": traffic, "traffic_note": note,
             "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 products per fp32-class multiply",
-            "ceiling_note": "a bare MFMA loop of this kernel (everything else compiled out) reaches 0.586 of `peak` on "
-                            "random operands on MI355X: the shader clock is power-limited to 1.46 GHz (2.18 GHz on zero "
-                            "operands); profiles/r02_conv_kernel_study.md",
+            "ceiling_note": "a bare MFMA loop of this kernel (everything else compiled out: tools/xs_bench.hip, ablation mask 15) "
+                            "reaches 0.585 of `peak` on random operands on MI355X -- the matrix pipe's clock is power-limited "
+                            "(1.64 GHz on random operands, 2.18 GHz on zeros; `ceiling_live` = this box's probe) -- and the "
+                            "kernel 72 % of that loop (epilogue 12.7 %, activation staging 5 %, weight stream 4.5 %): "
+                            "profiles/r04ac_ablations.log",
             "mfma_tflops_executed": dom["achieved"] * F16S_PRODUCTS,
             "launches_timed": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
             "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
@@ -676,6 +678,14 @@ def main():
         by_class = _read_conv_classes(lib)
         roof = roofline(by_class)
         _attach_unoverlapped(roof, unoverlapped)
+        try:  # the probe's dependent-free MFMA loop on random operands on THIS box: what `peak` is at the clock the chip sustains
+            mf = (box or {}).get("probe", {}).get("mfma", {}).get("random", {})
+            if mf.get("tflops"):
+                roof["ceiling_live"] = {"mfma_tflops_random_operands": mf["tflops"], "clock_ghz": mf.get("clock_ghz"),
+                                        "frac_of_peak": mf["tflops"] / F16S_PRODUCTS / roof["peak"],
+                                        "kernel_frac_of_it": roof["frac"] * roof["peak"] * F16S_PRODUCTS / mf["tflops"]}
+        except Exception as e:  # a report, never in the way of the line
+            log("ceiling_live unavailable: %r" % (e,))
         roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
         name = active["name"]
         streams = {"single": "1", "two-stream": "2 (front of step k+1 overlaps decoder of step k)",

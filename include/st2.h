@@ -619,7 +619,7 @@ int st2_conv_timing_read(double* rows, int32_t cap_rows);
  * round 4's row-end fix of the epilogue, by up to 1.75 x on the C = 256 / L = 8 000 layers of Modules/istftnet.py:358-375),
  * so a serving process measures at start-up:
  *   st2_conv_tune(1)   every FIRST launch of a shape class (device, ks, C_in, C_out, L_out, B) on a non-capturing stream
- *                      times its candidate builds (1 warm-up + 2 x 2 launches each, output into a scratch tensor the
+ *                      times its candidate builds (1 warm-up + 3 x 2 launches each, round-robin, output into a scratch tensor the
  *                      library allocates for the duration of tuning mode -- the one exception to "no allocation" besides
  *                      the status word; the caller's tensors are only read) and records the winner; the call then runs it;
  *   st2_conv_tune(0)   leaves tuning mode (frees the scratch); recorded classes keep their build, others follow the rule;

@@ -22,6 +22,10 @@ def main():
         print("%s: %.2f ms/step = %.0f %s, schedule %s %s, frac %.3f, conv %.1f ms/step" % (
             path, d["ms_per_step"], d["value"], d["unit"], cfg.get("schedule"), cfg.get("schedules_ms_per_step"),
             roof.get("frac") or 0.0, roof.get("conv_ms_per_step_all_classes") or 0.0))
+        cl = roof.get("ceiling_live")
+        if cl:
+            print("   live ceiling: %.0f TFLOP/s f16 on random operands @ %.2f GHz = %.3f of the roof; dominant class at %.2f of it" % (
+                cl["mfma_tflops_random_operands"], cl.get("clock_ghz") or 0.0, cl["frac_of_peak"], cl["kernel_frac_of_it"]))
         un = {(c["ks"], c["C_in"], c["C_out"], c["L"]): c for c in (roof.get("unoverlapped") or {}).get("classes", [])}
         for c in roof.get("classes", []):
             u = un.get((c["ks"], c["C_in"], c["C_out"], c["L"]))
