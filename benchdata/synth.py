@@ -108,6 +108,28 @@ def init_trained_like_(module, seed, gain_sigma=0.7, alpha_decades=1.0):
     return module
 
 
+def scale_params_(module, rules):
+    """Multiplies every parameter whose name contains a key of `rules` and ends in weight / weight_g / bias / gamma / beta by
+    that key's factor (first match wins; `weight_v` is left alone: the gain carries a weight-normed layer's scale).  Tests use
+    it to build checkpoints whose un-normalised conv inputs (GELU / LeakyReLU outputs, generator stage outputs) sit at 1e-2 ...
+    1e-3 instead of O(1): a trained checkpoint is free to put them there, and the by-rule operand scale of the split-f16
+    convs is then 5-500 x less precise than fp32 (pipeline.calibrate is what fixes it).  Returns the names it touched."""
+    touched = []
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.split(".")[-1] not in ("weight", "weight_g", "bias", "gamma", "beta"):
+                continue
+            for key, f in rules.items():
+                if key in name:
+                    p.mul_(float(f))
+                    touched.append(name)
+                    break
+    for m in module.modules():  # packed copies of the old values (engine-backed modules cache them)
+        if hasattr(m, "refresh"):
+            m.refresh()
+    return touched
+
+
 def init_spectral_norm_(module, seed):
     """Synthetic initialisation for modules under old-style spectral norm (`weight_orig` / `weight_u` / `weight_v`:
     the style encoders, models.py:97-164): seeded `weight_orig` / biases as in `init_synthetic_`, then u, v = the

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 19
+#define ST2_ABI_VERSION 20
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -112,7 +112,8 @@ typedef struct st2_conv_desc {
   int32_t act; int32_t act_split; float act_slope;
   /* st2_conv1d_f16s only: split-f16 packed weights (see below); ignored by st2_conv1d */
   const void* wq; int32_t wq_co_pad; int32_t wq_cin_pad;
-  float x_scale;                     /* power of two applied to pro(x) before the hi/lo split (8 by default) */
+  float x_scale;                     /* power of two applied to pro(x) before the hi/lo split (by rule 8 after a normalising
+                                        prologue, else 1; per layer after st2_calibrate) */
   float out_scale;                   /* applied to the accumulator first: 1 / (x_scale * weight scale), or 1 / x_scale
                                         when w_row_scale carries the per-row weight scales */
   const float* w_row_scale;          /* [wq_co_pad] or NULL: 1 / (per-output-row weight scale); the accumulator of row co
@@ -632,15 +633,52 @@ int st2_conv_tune(int mode);
 int st2_conv_tune_set(int32_t ks, int32_t C_in, int32_t C_out, int32_t L_out, int32_t B, int32_t variant);
 int st2_conv_tune_read(double* rows, int32_t cap_rows);
 
-/* ---- operand-range telemetry (ABI v19; debug: allocates, synchronises; not for the serving path) -------------------------- *
- * The split-f16 convs carry x_scale * pro(x) as f16 hi + lo and clamp at +-65504 (ST2_STATUS_F16_RANGE).  How close a given
- * checkpoint comes to that bound -- Snake alpha and weight-norm gains are free parameters, Modules/istftnet.py:27-62 -- is
- * what this hook reports: between st2_debug_headroom(1) and (0) every st2_act_split / st2_conv1d_f16s launch also records the
- * largest scaled operand it produced; st2_debug_headroom_read fills rows of 8 doubles {kind (0 = activation pass of the xs
- * path, 1 = prologue of the fused conv), prologue, B, C_in, L, x_scale, max |operand|, max |operand| / 65504} in launch order
- * and returns their number.  tools/headroom_report.py prints the table for a checkpoint. */
+/* ---- operand-range telemetry, both ends (ABI v20; debug: allocates, synchronises; not for the serving path) ------------------ *
+ * The split-f16 convs carry u = x_scale * pro(x) as f16 hi + lo.  The format has two ends: above 65504 the kernels clamp
+ * (ST2_STATUS_F16_RANGE); below ~2^-3 the lo half becomes a subnormal f16 and the operand keeps an ABSOLUTE error of 2^-25
+ * instead of 2^-22 relative -- a layer whose scaled input sits at 1e-3 is 100 x less precise than fp32 although nothing
+ * overflows.  Where a checkpoint puts each layer (Snake alpha, weight-norm gains, GELU / LeakyReLU outputs are free,
+ * Modules/istftnet.py:27-62) is what this hook reports: between st2_debug_headroom(1) and (0) every st2_act_split /
+ * st2_conv1d_f16s launch also measures the planes it produced; st2_debug_headroom_read fills rows of ST2_HEADROOM_COLS doubles
+ *   [0] kind (0 = activation pass of the xs path, 1 = prologue of the fused conv)   [1] prologue   [2] B  [3] C_in  [4] L
+ *   [5] x_scale   [6] max |u|   [7] max |u| / 65504 (>= 1: clamped)
+ *   [8] relative RMS error the split adds to the operand: sqrt(sum ulp(lo)^2 / 12 / sum u^2) (fp32 storage itself: 3.4e-8;
+ *       every element's lo normal: ~4e-8)
+ *   [9] share of the operand's energy carried by elements whose lo half is subnormal or zero
+ *   [10] conv site (st2_calibration_read index) when an engine plan issued the launch, else -1   [11] that engine (identity)
+ * in launch order and returns their number.  tools/headroom_report.py prints the table for a checkpoint. */
+#define ST2_HEADROOM_COLS 12
 int st2_debug_headroom(int enable);
 int st2_debug_headroom_read(double* rows, int32_t cap_rows);
+
+/* ---- per-layer operand scales (ABI v20) ------------------------------------------------------------------------------------ *
+ * Every F.conv1d / nn.Linear of the reference is fp32 (Modules/istftnet.py:68-74,376-377, Modules/diffusion/modules.py:
+ * 484-490).  The split-f16 convs match that over the whole fp32 range only if each conv's input is scaled into the part of
+ * the f16 range where both halves are normal numbers.  By rule (no calibration) x_scale is 8 after a normalising prologue and
+ * 1 otherwise -- right for O(1) tensors, up to 500 x less precise than fp32 for a layer whose input sits at 1e-4.  A serving
+ * process therefore calibrates once per checkpoint:
+ *     st2_debug_headroom(1);  one or more forward calls on representative inputs;  st2_debug_headroom(0);
+ *     st2_calibrate(e, 3, &clamped);            (repeat the three lines while clamped > 0: at most twice)
+ * Every conv site of the engine (= every split-f16 packed weight, in packing order) that was launched gets
+ *     x_scale = 2^floor(log2(2^(16 - margin_bits) / max |pro(x)|))     (margin_bits = 3: max |u| in (4096, 8192])
+ * from the largest operand any of its launches produced (a PL-BERT weight runs 12 times, a denoiser weight once per
+ * evaluation: the maximum counts); the clamp and the status bit stay as the safety net for inputs beyond 2^margin_bits x the
+ * calibration's.  Scales are powers of two -- the accumulator is rescaled exactly -- and live in the engine: every later
+ * forward (eager or captured; capture AFTER calibrating, the scale is a kernel argument) uses them; results stay
+ * reproducible bit for bit for a given table.  Returns the number of sites set (< 0 on error).
+ *   st2_calibration_read   rows of ST2_CALIBRATION_COLS doubles {C_in, C_out, ks, x_scale (0 = by rule), max |pro(x)| seen};
+ *                          returns the number of sites (rows may be NULL to count);
+ *   st2_calibration_site_name   the reference state_dict key the site's weight was packed from;
+ *   st2_calibration_write  installs a table (n = number of sites, entries 0 or a power of two; n = 0 clears): how rank 0's
+ *                          calibration reaches the other ranks and how a table saved beside a checkpoint is restored;
+ *   st2_calibration_scale  the formula above for one value (0 for max_abs <= 0).
+ * st2_finalize_weights keeps the table when the new weights have the same conv layout, clears it otherwise. */
+#define ST2_CALIBRATION_COLS 5
+int st2_calibrate(st2_engine* e, int32_t margin_bits, int32_t* n_clamped);
+int st2_calibration_read(st2_engine* e, double* rows, int32_t cap_rows);
+int st2_calibration_site_name(st2_engine* e, int32_t site, char* name, int32_t cap);
+int st2_calibration_write(st2_engine* e, const float* scales, int32_t n);
+float st2_calibration_scale(float max_abs, int32_t margin_bits);
 
 /* ---- box probe (ABI v19; diagnostic: allocates and frees its own device buffers, synchronises the device) ----------- *
  * Writes a JSON object (NUL terminated, <= cap bytes; 4 KB is enough) of micro-measurements of the current device:

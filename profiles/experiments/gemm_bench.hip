@@ -5,7 +5,7 @@
 // on 256 CUs, one per CU, nothing to hide the staging latency behind).  Times the library's kernel template at other tile
 // shapes / chunk depths on those shapes, no PyTorch:
 //   ./gemm_bench [C_out=2048] [C_in=1024] [L=3200] [B=1] [reps=20]
-#include "../styletts2_amd/csrc/st2_conv1d_xs_impl.h"
+#include "../../styletts2_amd/csrc/st2_conv1d_xs_impl.h"
 #define ST2_STATUS_GEMM_TIMEOUT 8  // experiment-only status bit
 #include "gemm_sk_experiment.h"  // persistent stream-K build: measured, not adopted (profiles/LAB_NOTES.md, round 4)
 

@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def test_wino_bench_builds_and_selftests(tmp_path):
@@ -17,7 +17,7 @@ def test_wino_bench_builds_and_selftests(tmp_path):
         pytest.skip("hipcc not installed")
     exe = os.path.join(str(tmp_path), "wino_bench")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function",
-                           os.path.join(ROOT, "tools", "wino_bench.hip"), "-o", exe])
+                           os.path.join(ROOT, "profiles", "experiments", "wino_bench.hip"), "-o", exe])
     r = subprocess.run([exe, "selftest", "quick"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all cases OK" in r.stdout and "MISMATCH" not in r.stdout

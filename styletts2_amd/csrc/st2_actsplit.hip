@@ -141,38 +141,79 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
 }
 
 // ---- operand-range telemetry (st2_debug_headroom, st2.h) --------------------------------------------------------------
-// max |hi| over the hi planes of one act_split output = the largest scaled operand of the conv that consumes it, as the f16
-// it became.  One atomicMax on the bit pattern of the non-negative float per workgroup.
-__global__ __launch_bounds__(256) void xs_absmax_kernel(const st2_h8* __restrict__ xs, int64_t slots_per_item, int64_t item_stride,
-                                                        unsigned* out) {
-  const st2_h8* p = xs + (int64_t)blockIdx.y * item_stride;  // the hi plane of batch item blockIdx.y
+// Both ends of the f16 range, from the planes one act_split launch wrote (u = hi + lo is the scaled operand the conv multiplies):
+//   max |hi|                      the top: how close the layer comes to the clamp at 65504;
+//   sum u^2                       operand energy;
+//   sum ulp(lo)^2 / 12            energy of the split's rounding error: lo carries 11 bits while it is a normal f16 (|lo| >= 2^-14:
+//                                 ulp = 2^(e - 10)), a fixed 2^-24 below that -- an operand below ~2^-3 keeps an ABSOLUTE error of
+//                                 2^-25 instead of 2^-22 relative.  sqrt(this / sum u^2) is the relative RMS error the split adds to
+//                                 the operand (fp32 storage itself: 2^-24 / sqrt(3) = 3.4e-8);
+//   sum u^2 over |lo| < 2^-14     the share of the operand's energy carried by elements whose lo half is subnormal or zero.
+// One record per launch: an atomicMax on the bit pattern of the non-negative float, three double atomicAdds per wave.
+struct HeadroomSums {
+  unsigned max_bits, pad;
+  double su2, se2, ssub;
+};
+__global__ __launch_bounds__(256) void xs_probe_kernel(const st2_h8* __restrict__ xs, int64_t slots_per_item, int64_t item_stride,
+                                                       HeadroomSums* out) {
+  const st2_h8* hi_p = xs + (int64_t)blockIdx.y * item_stride;  // the hi plane of batch item blockIdx.y; lo follows it
+  const st2_h8* lo_p = hi_p + slots_per_item;
   float m = 0.f;
+  double su2 = 0.0, se2 = 0.0, ssub = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < slots_per_item; i += (int64_t)gridDim.x * 256) {
-    const st2_h8 v = p[i];
+    const st2_h8 h = hi_p[i], l = lo_p[i];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    for (int e = 0; e < 8; ++e) {
+      const float hf = (float)h[e], lf = (float)l[e];
+      m = fmaxf(m, fabsf(hf));
+      if (hf == 0.f && lf == 0.f) continue;  // padding / exact zeros: no energy, no error
+      const float u = hf + lf;
+      const float al = fabsf(lf);
+      const bool sub = al < 6.103515625e-05f;  // 2^-14
+      int ex = -14;
+      if (!sub) {
+        (void)frexpf(al, &ex);  // al = f * 2^ex, f in [0.5, 1)
+        ex -= 1;
+      }
+      const float ulp = ldexpf(1.0f, ex - 10);
+      su2 += (double)u * u;
+      se2 += (double)ulp * ulp * (1.0 / 12.0);
+      if (sub) ssub += (double)u * u;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  su2 = st2_wave_sum(su2);
+  se2 = st2_wave_sum(se2);
+  ssub = st2_wave_sum(ssub);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out->max_bits, __float_as_uint(m));
+    atomicAdd(&out->su2, su2);
+    atomicAdd(&out->se2, se2);
+    atomicAdd(&out->ssub, ssub);
+  }
 }
 
 struct HeadroomRecord {
   int kind, pro, B, C, L;  // kind 0 = st2_act_split (xs path), 1 = st2_conv1d_f16s (prologue inside the conv)
   float x_scale;
+  const void* engine;      // the st2_engine whose plan issued the launch and its conv site (st2_headroom_set_site), or null / -1
+  int site;
 };
 bool g_headroom = false;
 std::vector<HeadroomRecord> g_hr;
-unsigned* g_hr_dev = nullptr;  // one max per record
+HeadroomSums* g_hr_dev = nullptr;  // one per record
 constexpr int HR_CAP = 4096;
 void* g_hr_scratch = nullptr;  // planes of the fused-path convs (debug mode only)
 size_t g_hr_scratch_bytes = 0;
+thread_local const void* t_site_engine = nullptr;  // set by the engine's conv() around its launches (same thread)
+thread_local int t_site = -1;
 
 void headroom_record(int kind, const ActArgs& a, int B, hipStream_t s) {
   if ((int)g_hr.size() >= HR_CAP || !g_hr_dev) return;
   const int64_t plane = (int64_t)a.xs_cg * a.Lp;
-  hipLaunchKernelGGL(xs_absmax_kernel, dim3((unsigned)std::min<int64_t>((plane + 255) / 256, 1024), B), dim3(256), 0, s, a.xs, plane,
+  hipLaunchKernelGGL(xs_probe_kernel, dim3((unsigned)std::min<int64_t>((plane + 255) / 256, 1024), B), dim3(256), 0, s, a.xs, plane,
                      2 * plane, g_hr_dev + g_hr.size());
-  g_hr.push_back({kind, 0, B, a.C, a.L, a.x_scale});
+  g_hr.push_back({kind, 0, B, a.C, a.L, a.x_scale, t_site_engine, t_site});
 }
 
 template <int PRO>
@@ -246,13 +287,13 @@ int st2_headroom_of_fused_conv(const st2_conv_desc& d, hipStream_t s) {
 extern "C" int st2_debug_headroom(int enable) {
   if (enable) {
     g_hr.clear();
-    if (!g_hr_dev && hipMalloc(&g_hr_dev, HR_CAP * sizeof(unsigned)) != hipSuccess) {
+    if (!g_hr_dev && hipMalloc(&g_hr_dev, HR_CAP * sizeof(HeadroomSums)) != hipSuccess) {
       (void)hipGetLastError();
       g_hr_dev = nullptr;
       st2_set_error("st2_debug_headroom: cannot allocate the record buffer");
       return 1;
     }
-    if (hipMemset(g_hr_dev, 0, HR_CAP * sizeof(unsigned)) != hipSuccess) {
+    if (hipMemset(g_hr_dev, 0, HR_CAP * sizeof(HeadroomSums)) != hipSuccess) {
       st2_set_error("st2_debug_headroom: %s", hipGetErrorString(hipGetLastError()));
       return 1;
     }
@@ -266,21 +307,31 @@ extern "C" int st2_debug_headroom(int enable) {
   return 0;
 }
 
+void st2_headroom_set_site(const void* engine, int site) {
+  t_site_engine = engine;
+  t_site = site;
+}
+
 extern "C" int st2_debug_headroom_read(double* rows, int32_t cap_rows) {
   ST2_REQUIRE(!g_headroom, "st2_debug_headroom_read: stop the recording first (st2_debug_headroom(0))");
   const int n = (int)g_hr.size();
   if (!rows || n == 0) return n;
-  std::vector<unsigned> h(n);
-  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), g_hr_dev, n * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) {
+  std::vector<HeadroomSums> h(n);
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(h.data(), g_hr_dev, n * sizeof(HeadroomSums), hipMemcpyDeviceToHost) != hipSuccess) {
     st2_set_error("st2_debug_headroom_read: %s", hipGetErrorString(hipGetLastError()));
     return -1;
   }
   for (int i = 0; i < n && i < cap_rows; ++i) {
     float m;
-    memcpy(&m, &h[i], 4);
-    double* r = rows + (int64_t)i * 8;
+    memcpy(&m, &h[i].max_bits, 4);
+    double* r = rows + (int64_t)i * ST2_HEADROOM_COLS;
     r[0] = g_hr[i].kind; r[1] = g_hr[i].pro; r[2] = g_hr[i].B; r[3] = g_hr[i].C; r[4] = g_hr[i].L; r[5] = g_hr[i].x_scale;
     r[6] = m; r[7] = m / 65504.0;
+    r[8] = h[i].su2 > 0.0 ? sqrt(h[i].se2 / h[i].su2) : 0.0;
+    r[9] = h[i].su2 > 0.0 ? h[i].ssub / h[i].su2 : 0.0;
+    r[10] = g_hr[i].site;
+    r[11] = (double)(uintptr_t)g_hr[i].engine;  // identity only (an address fits a double's 53 bits on this platform)
   }
   return n;
 }

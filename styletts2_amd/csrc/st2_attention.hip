@@ -160,10 +160,10 @@ extern "C" int st2_attention_keylen(const float* q, const float* k, const float*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   constexpr size_t smem = (size_t)2 * AD * ALD * sizeof(float);
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal
-  if (st2_first_use_on_device(attr_done)) {
+  st2_once_per_device(attr_done, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  }
+  });
   hipLaunchKernelGGL(attention_kernel, dim3(st2_cdiv(N, AQB), H, B), dim3(256), smem, s, q, k, v, bs, cs, o, o_bs,
                      o_cs, N, scale, reinterpret_cast<const int*>(key_len));
   ST2_CHECK_LAUNCH("st2_attention");

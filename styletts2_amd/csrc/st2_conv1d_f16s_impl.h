@@ -370,10 +370,10 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   ST2_REQUIRE(d.wq_co_pad % BM == 0 && d.wq_co_pad >= d.C_out, "st2_conv1d_f16s: wq_co_pad=%d must be a multiple "
               "of %d covering C_out=%d", d.wq_co_pad, BM, d.C_out);
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal
-  if (st2_first_use_on_device(attr_done)) {
+  st2_once_per_device(attr_done, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
+  });
   if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_f16s: part_nt=%d < %d tiles", d.part_nt,
                           st2_cdiv(d.L_out, 128));
   const int ksplit = d.part ? 1 : pick_ksplit(d);  // the reduction kernel does not emit statistics

@@ -334,7 +334,7 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
   // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a tile count divisible by 8
   const int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && total % 8 == 0;
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal (hipFuncSetAttribute is per device)
-  if (st2_first_use_on_device(attr_done)) {
+  st2_once_per_device(attr_done, [&] {
     if constexpr (OCC == 4)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -344,7 +344,7 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
     else
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_xs_kernel_o2<KS, CI_T, WM, WN, TN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
+  });
   if constexpr (OCC == 4)
     hipLaunchKernelGGL((conv1d_xs_kernel_o4<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, flags);
   else if constexpr (OCC == 3)
@@ -404,7 +404,7 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
       // 128 x 128 they are < 256 workgroups -- fewer than CUs, one per CU, nothing to hide the staging latency of a
       // 768-cycle chunk behind.  128 (co) x 64 (l) tiles double the workgroup count and 64-channel chunks double the
       // work between barriers: 1024 x 1024: 35.8 -> 28.9 us, 512 x 1024: 32.7 -> 17.7, 1024 x 2048: 63.6 -> 50.4, 768 x 768:
-      // 27.9 -> 22.4 (tools/gemm_bench.hip, profiles/r03c_gemm_bench.log); launches that already have >= 256 tiles
+      // 27.9 -> 22.4 (profiles/experiments/gemm_bench.hip, profiles/r03c_gemm_bench.log); launches that already have >= 256 tiles
       // (C_out >= 2048) are fastest as they are.  Same products in the same order: results are bitwise unchanged.
       if ((int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B < 256 && d.wq_cin_pad % 64 == 0 && !d.part)
         return launch<1, 64, 4, 1, 2, 3>(d, s, swz);

@@ -11,9 +11,11 @@
 // for the HIP kernels and run these plans on host memory, which validates wiring, packing and workspace aliasing
 // without a GPU.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -180,8 +182,14 @@ struct HostTensor {
   int64_t numel() const { return (int64_t)data.size(); }
 };
 
+struct ConvSite {  // one split-f16 packed conv weight = one calibration site (st2_calibration_read)
+  std::string name;    // the reference state_dict key it was packed from
+  int C_in = 0, C_out = 0, ks = 0;
+};
+
 struct Blob {
   std::vector<char> host;
+  std::vector<ConvSite> sites;  // in packing order: the index is the site id (a function of the model layout alone)
   int64_t add(const void* src, int64_t bytes) {
     int64_t off = ((int64_t)host.size() + 255) & ~(int64_t)255;
     host.resize((size_t)(off + bytes));
@@ -194,6 +202,7 @@ struct Blob {
 struct SplitW {  // st2.h: split-f16 packed conv weight
   int64_t wq = -1, row_scale = -1;
   int C_in = 0, C_out = 0, ks = 0, co_pad = 0, cin_pad = 0;
+  int site = -1;  // index into st2_engine::sites
 };
 
 struct PConv {
@@ -223,9 +232,11 @@ int f16s_co_block(int C_out) { return C_out > 64 ? 128 : (C_out > 32 ? 64 : 32);
 
 // weights.pack_conv_f16s, bit for bit: per-row power-of-two scale, hi = f16(w*s), lo = f16(w*s - hi),
 // layout [ci/16][tap][k-half][co][hi8 | lo8]
-SplitW pack_split(Blob& blob, const float* w, int C_out, int C_in, int ks) {
+SplitW pack_split(Blob& blob, const std::string& name, const float* w, int C_out, int C_in, int ks) {
   SplitW r;
   r.C_in = C_in; r.C_out = C_out; r.ks = ks;
+  r.site = (int)blob.sites.size();
+  blob.sites.push_back({name, C_in, C_out, ks});
   const int cb = f16s_chunk(ks), rb = f16s_co_block(C_out);
   r.cin_pad = (C_in + cb - 1) / cb * cb;
   r.co_pad = (C_out + rb - 1) / rb * rb;
@@ -397,6 +408,13 @@ struct st2_engine {
   PBert bert;
   PStyleEnc style[2];  // 0 = style_encoder (acoustic), 1 = predictor_encoder (prosodic)
   int64_t zeros = -1;  // 4096 zero floats (map borders)
+  // Calibration sites = the split-f16 conv weights in packing order, and the calibrated power-of-two operand scale of each
+  // (st2_calibrate / st2_calibration_write; 0 = not calibrated: the rule x_scale_for(pro)).  seen = max |pro(x)| at calibration.
+  std::vector<ConvSite> sites;
+  std::vector<float> site_scale, site_seen;
+  float x_scale(int site, float by_rule) const {
+    return site >= 0 && site < (int)site_scale.size() && site_scale[(size_t)site] > 0.f ? site_scale[(size_t)site] : by_rule;
+  }
   template <class T>
   T* P(int64_t off) const { return off < 0 ? nullptr : reinterpret_cast<T*>(wbase + off); }
   const float* F(int64_t off) const { return P<const float>(off); }
@@ -475,7 +493,7 @@ struct Packer {
     if (!t) return SplitW();
     if (t->shape.size() < 2) { fail(name + " has shape " + shape_str(t->shape) + ", a conv / linear weight is at least 2-D"); return SplitW(); }
     const int C_out = (int)t->shape[0], C_in = (int)t->shape[1], k = t->shape.size() > 2 ? (int)t->shape[2] : 1;
-    return pack_split(blob, t->data.data(), C_out, C_in, k);
+    return pack_split(blob, name, t->data.data(), C_out, C_in, k);
   }
   PConv conv(const std::string& prefix, bool bias = true, int co = -1, int ci = -1, int ks = -1) {
     PConv c;
@@ -621,9 +639,9 @@ int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
       if (stride_f0 > 1) {
         if (K != 2 * stride_f0) { *err = "noise_convs kernel must be 2*stride"; return 1; }
         std::vector<float> wp = polyphase_strided(w->data.data(), C_out, C_in, stride_f0);
-        g.noise_wt.push_back(pack_split(blob, wp.data(), C_out, C_in * stride_f0, 2));
+        g.noise_wt.push_back(pack_split(blob, G + "noise_convs." + std::to_string(i) + ".weight", wp.data(), C_out, C_in * stride_f0, 2));
       } else {
-        g.noise_wt.push_back(pack_split(blob, w->data.data(), C_out, C_in, K));
+        g.noise_wt.push_back(pack_split(blob, G + "noise_convs." + std::to_string(i) + ".weight", w->data.data(), C_out, C_in, K));
       }
     } else {
       g.noise_wt.push_back(SplitW());
@@ -638,7 +656,7 @@ int pack_decoder(st2_engine& e, Blob& blob, std::string* err) {
       const int C_in = (int)w->shape[0], C_out = (int)w->shape[1], K = (int)w->shape[2];
       if (K != 2 * u) { *err = "ups kernel must be 2*stride"; return 1; }
       std::vector<float> wp = polyphase_convt(w->data.data(), C_in, C_out, u);
-      g.ups_wt.push_back(pack_split(blob, wp.data(), u * C_out, C_in, 2));
+      g.ups_wt.push_back(pack_split(blob, G + "ups." + std::to_string(i) + ".weight", wp.data(), u * C_out, C_in, 2));
     } else {
       g.ups_wt.push_back(SplitW());
     }
@@ -757,8 +775,9 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
   memset(&d, 0, sizeof(d));
   d.B = x.B; d.C_in = x.C; d.C_out = y.C; d.L_in = x.L; d.L_out = y.L; d.ks = w.ks; d.dil = o.dil; d.pad_left = o.pad_left;
   d.wq = e.P<const void>(w.wq); d.wq_co_pad = w.co_pad; d.wq_cin_pad = w.cin_pad;
-  d.x_scale = x_scale_for(o.pro);
+  d.x_scale = e.x_scale(w.site, x_scale_for(o.pro));  // calibrated per layer, else the rule (both powers of two)
   d.out_scale = 1.0f / d.x_scale;
+  if (!c.dry) st2_headroom_set_site(&e, w.site);  // telemetry / calibration: which conv the next launches belong to
   d.w_row_scale = e.F(w.row_scale);
   d.bias = o.bias;
   d.y = y.p; d.y_bs = y.bs; d.y_cs = y.cs;
@@ -817,6 +836,7 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
   }
   c.a.off = mark;  // planes / partial sums are dead once the launches are queued (stream order protects reuse)
+  if (!c.dry) st2_headroom_set_site(nullptr, -1);
 }
 
 float* new_stats(Ctx& c, int B, int C) { return c.a.f32((int64_t)B * C * 2); }
@@ -1313,7 +1333,7 @@ PLstm pack_lstm(Packer& pk, const std::string& prefix) {
   std::vector<float> w((size_t)2 * G4 * I);  // cat([W_ih, W_ih_reverse]) as a k = 1 conv weight [8H][I][1]
   std::copy(wf->data.begin(), wf->data.end(), w.begin());
   std::copy(wr->data.begin(), wr->data.end(), w.begin() + (size_t)G4 * I);
-  l.w_ih = pack_split(pk.blob, w.data(), 2 * G4, I, 1);
+  l.w_ih = pack_split(pk.blob, prefix + ".weight_ih_l0", w.data(), 2 * G4, I, 1);
   std::vector<float> b((size_t)2 * G4);
   for (int i = 0; i < G4; ++i) {
     b[(size_t)i] = bif->data[(size_t)i] + bhf->data[(size_t)i];
@@ -1566,7 +1586,7 @@ int pack_bert(st2_engine& e, Blob& blob, std::string* err) {
     std::copy(qb->data.begin(), qb->data.end(), bias.begin());
     std::copy(kb->data.begin(), kb->data.end(), bias.begin() + b.H);
     std::copy(vb->data.begin(), vb->data.end(), bias.begin() + 2 * b.H);
-    b.qkv = pack_split(blob, cat.data(), 3 * b.H, b.H, 1);
+    b.qkv = pack_split(blob, L + "attention.query|key|value.weight", cat.data(), 3 * b.H, b.H, 1);
     b.qkv_b = blob.add_f32(bias);
   }
   b.dense = pk.conv_w(L + "attention.dense.weight", b.H, b.H, 1); b.dense_b = pk.vec(L + "attention.dense.bias", b.H);
@@ -1723,7 +1743,7 @@ int pack_style(st2_engine& e, Blob& blob, int which, std::string* err) {
     const HostTensor* t = pk.get(name);
     if (!t || t->shape.size() != 4) { pk.ok = false; if (pk.missing.empty()) pk.missing = name + " (4-D expected)"; return SplitW(); }
     const std::vector<float> v = rows_as_channels(*t);
-    return pack_split(blob, v.data(), (int)t->shape[0], (int)(t->shape[1] * t->shape[2]), (int)t->shape[3]);
+    return pack_split(blob, name, v.data(), (int)t->shape[0], (int)(t->shape[1] * t->shape[2]), (int)t->shape[3]);
   };
   const HostTensor* first = pk.get(R + "shared.0.weight");
   if (!first || first->shape.size() != 4 || first->shape[1] != 1 || first->shape[2] != 3 || first->shape[3] != 3) {
@@ -1946,16 +1966,20 @@ struct PackedSet {
   PBert bert;
   PStyleEnc style[2];
   int64_t zeros = -1;
+  std::vector<ConvSite> sites;
+  std::vector<float> site_scale, site_seen;
 };
 
 namespace {
 PackedSet packed_of(const st2_engine& e) {
   PackedSet p;
+  p.sites = e.sites; p.site_scale = e.site_scale; p.site_seen = e.site_seen;
   p.dec = e.dec; p.dn = e.dn; p.pred = e.pred; p.dur = e.dur; p.text = e.text; p.bert = e.bert;
   p.style[0] = e.style[0]; p.style[1] = e.style[1]; p.zeros = e.zeros;
   return p;
 }
 void commit_packed(st2_engine& e, const PackedSet& p) {
+  e.sites = p.sites; e.site_scale = p.site_scale; e.site_seen = p.site_seen;
   e.dec = p.dec; e.dn = p.dn; e.pred = p.pred; e.dur = p.dur; e.text = p.text; e.bert = p.bert;
   e.style[0] = p.style[0]; e.style[1] = p.style[1]; e.zeros = p.zeros;
 }
@@ -2018,6 +2042,92 @@ extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
   if (e->wbase) g_be.dev_free(e->wbase);  // only now: the new blob is complete on the device
   e->wbase = static_cast<char*>(p);
   e->wbytes = bytes;
+  // New weights: new sites.  A calibration of the previous weights survives only when the layout is the same conv for conv
+  // (the usual reload of another checkpoint of one architecture keeps its table until the caller re-calibrates or clears it).
+  bool same = blob.sites.size() == e->sites.size();
+  for (size_t i = 0; same && i < blob.sites.size(); ++i)
+    same = blob.sites[i].name == e->sites[i].name && blob.sites[i].C_in == e->sites[i].C_in &&
+           blob.sites[i].C_out == e->sites[i].C_out && blob.sites[i].ks == e->sites[i].ks;
+  e->sites = blob.sites;
+  if (!same) {
+    e->site_scale.assign(e->sites.size(), 0.f);
+    e->site_seen.assign(e->sites.size(), 0.f);
+  }
+  return 0;
+}
+
+// ---- per-layer operand scales (st2.h: st2_calibrate) ---------------------------------------------------------------------
+extern "C" float st2_calibration_scale(float max_abs, int32_t margin_bits) {
+  if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 0.f;
+  margin_bits = std::min(std::max(margin_bits, 0), 10);
+  int ex = 0;
+  (void)frexpf(max_abs, &ex);  // max_abs = f * 2^ex, f in [0.5, 1): max_abs * 2^(16 - margin - ex) lies in [2^(15-m), 2^(16-m))
+  return ldexpf(1.0f, std::min(std::max(16 - margin_bits - ex, -60), 60));
+}
+
+extern "C" int st2_calibrate(st2_engine* e, int32_t margin_bits, int32_t* n_clamped) {
+  if (!e) { st2_set_error("st2_calibrate: null engine"); return -1; }
+  const int n = st2_debug_headroom_read(nullptr, 0);
+  if (n < 0) return -1;
+  std::vector<double> rows((size_t)std::max(n, 1) * ST2_HEADROOM_COLS);
+  if (n > 0 && st2_debug_headroom_read(rows.data(), n) < 0) return -1;
+  const double me = (double)(uintptr_t)e;
+  std::vector<float> seen(e->sites.size(), 0.f);
+  int clamped = 0;
+  for (int i = 0; i < n; ++i) {
+    const double* r = rows.data() + (size_t)i * ST2_HEADROOM_COLS;
+    const int site = (int)r[10];
+    if (r[11] != me || site < 0 || site >= (int)seen.size() || !(r[5] > 0.0)) continue;
+    if (r[6] >= 65504.0) ++clamped;  // the operand hit the clamp at the scale it ran with: this pass only bounds it from below
+    seen[(size_t)site] = std::max(seen[(size_t)site], (float)(r[6] / r[5]));  // max |pro(x)| over every launch of the site
+  }
+  e->site_scale.resize(e->sites.size(), 0.f);
+  e->site_seen.resize(e->sites.size(), 0.f);
+  int set = 0;
+  for (size_t i = 0; i < seen.size(); ++i) {
+    if (!(seen[i] > 0.f)) continue;  // never launched in the recorded calls (or all-zero operand): keeps what it had
+    e->site_seen[i] = seen[i];
+    e->site_scale[i] = st2_calibration_scale(seen[i], margin_bits);
+    ++set;
+  }
+  if (n_clamped) *n_clamped = clamped;
+  return set;
+}
+
+extern "C" int st2_calibration_read(st2_engine* e, double* rows, int32_t cap_rows) {
+  if (!e) return -1;
+  const int n = (int)e->sites.size();
+  for (int i = 0; rows && i < n && i < cap_rows; ++i) {
+    double* r = rows + (size_t)i * ST2_CALIBRATION_COLS;
+    r[0] = e->sites[(size_t)i].C_in; r[1] = e->sites[(size_t)i].C_out; r[2] = e->sites[(size_t)i].ks;
+    r[3] = i < (int)e->site_scale.size() ? e->site_scale[(size_t)i] : 0.0;
+    r[4] = i < (int)e->site_seen.size() ? e->site_seen[(size_t)i] : 0.0;
+  }
+  return n;
+}
+
+extern "C" int st2_calibration_site_name(st2_engine* e, int32_t site, char* name, int32_t cap) {
+  ST2_REQUIRE(e && name && cap > 0 && site >= 0 && site < (int)e->sites.size(), "st2_calibration_site_name: bad arguments");
+  snprintf(name, (size_t)cap, "%s", e->sites[(size_t)site].name.c_str());
+  return 0;
+}
+
+extern "C" int st2_calibration_write(st2_engine* e, const float* scales, int32_t n) {
+  ST2_REQUIRE(e && (n == 0 || scales) && n >= 0, "st2_calibration_write: bad arguments");
+  if (n == 0) {  // back to the rule
+    e->site_scale.assign(e->sites.size(), 0.f);
+    e->site_seen.assign(e->sites.size(), 0.f);
+    return 0;
+  }
+  ST2_REQUIRE(n == (int)e->sites.size(), "st2_calibration_write: %d scales for %d conv sites (another model layout?)", n,
+              (int)e->sites.size());
+  for (int i = 0; i < n; ++i) {
+    int ex = 0;
+    const bool pow2 = scales[i] == 0.f || (scales[i] > 0.f && std::isfinite(scales[i]) && frexpf(scales[i], &ex) == 0.5f);
+    ST2_REQUIRE(pow2, "st2_calibration_write: scale %d = %g is not a power of two (0 = by rule)", i, (double)scales[i]);
+  }
+  e->site_scale.assign(scales, scales + n);
+  e->site_seen.assign(e->sites.size(), 0.f);
   return 0;
 }
 

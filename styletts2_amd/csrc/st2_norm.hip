@@ -248,10 +248,10 @@ extern "C" int st2_style_fc(const float* sv, int32_t B, int32_t K, const float* 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t smem = ((size_t)FC_BT * K + (size_t)FC_KS * FC_BT * FC_J) * sizeof(float);
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal
-  if (st2_first_use_on_device(attr_done)) {  // up to 8 x 2048 staged inputs + 16 x 8 x 64 partial sums: 96 KB
+  st2_once_per_device(attr_done, [&] {  // up to 8 x 2048 staged inputs + 16 x 8 x 64 partial sums: 96 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&style_fc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-  }
+  });
   hipLaunchKernelGGL(style_fc_kernel, dim3(st2_cdiv(J, FC_J), st2_cdiv(B, FC_BT)), dim3(FC_NT), smem, s, sv, B, K, wt,
                      bias, J, act, h);
   ST2_CHECK_LAUNCH("st2_style_fc");

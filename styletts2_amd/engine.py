@@ -10,6 +10,7 @@ plan tests substitute per-kernel contracts for the HIP wrappers; the real wrappe
 """
 import ctypes as C
 import math
+import weakref
 
 import torch
 
@@ -37,6 +38,13 @@ def _folded_state(module):
     return out
 
 
+_LIVE = weakref.WeakSet()  # every Engine of the process (pipeline.calibrate folds one recording into each of them)
+
+
+def live_engines():
+    return [e for e in _LIVE if getattr(e, "h", None)]
+
+
 class Engine:
     """One st2_engine handle (packed weights of a decoder and / or a denoiser on the current device)."""
 
@@ -46,6 +54,46 @@ class Engine:
         self.h = C.c_void_p()
         _lib.check(self.lib.st2_create(C.byref(cfg), C.byref(self.h)), "st2_create")
         self.device = None
+        self.calib_gen = 0  # bumped whenever the per-layer operand scales change: recorded graphs hold the old ones
+        _LIVE.add(self)
+
+    # -- per-layer operand scales of the split-f16 convs (include/st2.h st2_calibrate) -------------------------------------
+    def calibrate(self, margin_bits=3):
+        """Folds the headroom records of the forwards just run under `ops.headroom()` into this engine's per-conv x_scale
+        table.  Returns (sites set, launches that ran into the f16 clamp at their old scale: > 0 = record and call again)."""
+        clamped = C.c_int32(0)
+        n = self.lib.st2_calibrate(self.h, int(margin_bits), C.byref(clamped))
+        if n < 0:
+            _lib.check(1, "st2_calibrate")
+        if n > 0:
+            self.calib_gen += 1
+        return n, int(clamped.value)
+
+    def calibration(self):
+        """[{site, name, C_in, C_out, ks, x_scale (0.0 = by rule), seen (max |pro(x)| at calibration)}] for every conv site."""
+        n = self.lib.st2_calibration_read(self.h, None, 0)
+        W = _lib.CALIBRATION_COLS
+        buf = (C.c_double * (W * max(n, 1)))()
+        n = min(n, self.lib.st2_calibration_read(self.h, buf, n))
+        name = C.create_string_buffer(256)
+        out = []
+        for i in range(max(n, 0)):
+            _lib.check(self.lib.st2_calibration_site_name(self.h, i, name, len(name)), "st2_calibration_site_name")
+            r = buf[W * i:W * i + W]
+            out.append({"site": i, "name": name.value.decode(), "C_in": int(r[0]), "C_out": int(r[1]), "ks": int(r[2]),
+                        "x_scale": r[3], "seen": r[4]})
+        return out
+
+    def calibration_scales(self):
+        return [r["x_scale"] for r in self.calibration()]
+
+    def set_calibration(self, scales):
+        """Installs a table (one power of two or 0.0 = rule per site, as `calibration_scales()` returned it on a process
+        holding the same model), or clears it (None / empty)."""
+        scales = list(scales or [])
+        arr = (C.c_float * max(len(scales), 1))(*scales)
+        _lib.check(self.lib.st2_calibration_write(self.h, arr, len(scales)), "st2_calibration_write")
+        self.calib_gen += 1
 
     def __del__(self):
         try:

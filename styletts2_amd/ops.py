@@ -50,6 +50,12 @@ def x_scale_for(pro):
     return F16S_X_SCALE if pro in (PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_COLNORM) else 1.0
 
 
+def calibrated_x_scale(max_abs, margin_bits=3):
+    """`st2_calibration_scale`: the power of two that puts max |pro(x)| = `max_abs` into the top octave below 2^(16 -
+    margin_bits) of the f16 range -- what `Engine.calibrate` installs per conv site (0.0 for max_abs <= 0: keep the rule)."""
+    return float(_lib.load().st2_calibration_scale(float(max_abs), int(margin_bits)))
+
+
 def status(clear=False):
     """The library's sticky device-side status word (include/st2.h `st2_status`): no synchronisation; a bit is visible
     once the kernel that raised it has completed."""
@@ -147,10 +153,13 @@ def probe_cu_health():
 
 
 class headroom:
-    """`with ops.headroom() as h: forward(...)` then `h.rows`: how close every split-f16 conv operand of that forward came
-    to the f16 range (include/st2.h `st2_debug_headroom`; debug hook: extra launches, a scratch allocation, synchronises).
-    rows = [{index, kind ("act_split" | "fused conv"), pro, B, C, L, x_scale, max_abs, frac}], frac = max |x_scale * pro(x)| /
-    65504; a layer at frac >= 1 was clamped (ST2_STATUS_F16_RANGE)."""
+    """`with ops.headroom() as h: forward(...)` then `h.rows`: where every split-f16 conv operand of that forward sat in the
+    f16 range, BOTH ends (include/st2.h `st2_debug_headroom`; debug hook: extra launches, a scratch allocation, synchronises).
+    rows = [{index, kind ("act_split" | "fused conv"), pro, B, C, L, x_scale, max_abs, frac, rel_err, sub_share, site}]:
+    frac = max |x_scale * pro(x)| / 65504 (>= 1: clamped, ST2_STATUS_F16_RANGE); rel_err = relative RMS error the hi/lo split
+    adds to the operand (fp32 storage: 3.4e-8; all lo halves normal: ~4e-8; an operand at 1e-3 with x_scale 1: ~2e-5);
+    sub_share = share of the operand's energy in elements whose lo half is a subnormal f16; site = the engine's conv site
+    (Engine.calibration() index) or -1 for per-kernel calls."""
 
     def __enter__(self):
         _lib.check(_lib.load().st2_debug_headroom(1), "st2_debug_headroom")
@@ -163,13 +172,15 @@ class headroom:
         torch.cuda.synchronize()
         _lib.check(lib.st2_debug_headroom(0), "st2_debug_headroom")
         n = lib.st2_debug_headroom_read(None, 0)
-        buf = (ctypes.c_double * (8 * max(n, 1)))()
+        W = _lib.HEADROOM_COLS
+        buf = (ctypes.c_double * (W * max(n, 1)))()
         n = min(n, lib.st2_debug_headroom_read(buf, n))
         pro_names = ["none", "leaky", "adain+leaky", "adain+snake", "snake", "layernorm"]
         for i in range(max(n, 0)):
-            r = buf[8 * i:8 * i + 8]
+            r = buf[W * i:W * i + W]
             self.rows.append({"index": i, "kind": "fused conv" if int(r[0]) else "act_split", "pro": pro_names[int(r[1])],
-                              "B": int(r[2]), "C": int(r[3]), "L": int(r[4]), "x_scale": r[5], "max_abs": r[6], "frac": r[7]})
+                              "B": int(r[2]), "C": int(r[3]), "L": int(r[4]), "x_scale": r[5], "max_abs": r[6], "frac": r[7],
+                              "rel_err": r[8], "sub_share": r[9], "site": int(r[10]), "engine": int(r[11])})
         return False
 
 
@@ -228,9 +239,9 @@ def xs_row_slots(L):
 
 
 def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
-              c_pad=32, gb_seg=0):
+              c_pad=32, gb_seg=0, x_scale=None):
     """`st2_act_split`: x [B, C, L] fp32 -> XsTensor holding split_f16(x_scale * pro(x)) with the conv's zero padding
-    (x_scale = x_scale_for(pro)).  `gb_seg` > 0 (PRO_COLNORM on a token-merged view [1, C, G * gb_seg]): gamma / beta
+    (x_scale = x_scale_for(pro) unless the caller passes a calibrated power of two, `calibrated_x_scale`).  `gb_seg` > 0 (PRO_COLNORM on a token-merged view [1, C, G * gb_seg]): gamma / beta
     are [G, C] and row l // gb_seg applies at position l (per-utterance AdaLayerNorm affine, include/st2.h)."""
     lib = _lib.load()
     _chk(x, "x", 3)
@@ -256,10 +267,11 @@ def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, g
     if pro in (PRO_ADAIN_SNAKE, PRO_SNAKE):
         _chk(alpha, "alpha", 1)
         assert alpha.numel() == Cc and alpha.is_contiguous()
+    xsc = float(x_scale) if x_scale else x_scale_for(pro)
     _lib.check(lib.st2_act_split(x.data_ptr(), x.stride(0), x.stride(1), B, Cc, L, pro, slope, _ptr(stats),
                                  _ptr(gamma), _ptr(beta), gbs, int(gb_seg), 1 if gamma_plus_one else 0, _ptr(alpha),
-                                 x_scale_for(pro), data.data_ptr(), cg, Lp, XS_HALO, _stream()), "st2_act_split")
-    return XsTensor(data, Cc, L, XS_HALO, x_scale_for(pro))
+                                 xsc, data.data_ptr(), cg, Lp, XS_HALO, _stream()), "st2_act_split")
+    return XsTensor(data, Cc, L, XS_HALO, xsc)
 
 
 def stats_finalize(part, L, eps=1e-5, out=None):
@@ -331,7 +343,7 @@ def _launch_conv(fn, fname, d):
 def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=None,
            pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, gamma_plus_one=False, alpha=None,
            res=None, res_shift=0, res2=None, div=1.0, act=ACT_NONE, act_split=0, act_slope=0.0, want_stats=False,
-           gb_seg=0):
+           gb_seg=0, x_scale=None):
     """Fused Conv1d, see `st2_conv1d` / `st2_conv1d_f16s` / `st2_conv1d_xs` in include/st2.h.  wt is either the
     packed K-major fp32 weight [C_in*ks, w_ld] of weights.pack_conv() (exact-fp32 MFMA kernel) or a
     weights.SplitConvWeight from weights.pack_conv_f16s() (split-f16 MFMA kernels, fp32-class accuracy at 5.3x the
@@ -344,7 +356,7 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     if (split and pad_left <= XS_HALO and L_in >= XS_MIN_L and (pro != PRO_NONE or C_in >= XS_MIN_C_PLAIN)
             and conv_path() == "xs" and not prefer_fused(pro, C_in, ks)):
         xs = activate(x, pro=pro, slope=slope, stats=stats, gamma=gamma, beta=beta,
-                      gamma_plus_one=gamma_plus_one, alpha=alpha, gb_seg=gb_seg)
+                      gamma_plus_one=gamma_plus_one, alpha=alpha, gb_seg=gb_seg, x_scale=x_scale)
         return conv1d_xs(xs, wt, C_out, ks, dil=dil, pad_left=pad_left, L_out=L_out, bias=bias, out=out, res=res,
                          res_shift=res_shift, res2=res2, div=div, act=act, act_split=act_split, act_slope=act_slope,
                          want_stats=want_stats)
@@ -371,7 +383,7 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     d.x, d.x_bs, d.x_cs = x.data_ptr(), x.stride(0), x.stride(1)
     if split:
         d.wq, d.wq_co_pad, d.wq_cin_pad = wt.wq.data_ptr(), wt.co_pad, wt.cin_pad
-        d.x_scale = x_scale_for(pro)
+        d.x_scale = float(x_scale) if x_scale else x_scale_for(pro)
         d.out_scale, d.w_row_scale = 1.0 / d.x_scale, wt.row_scale.data_ptr()
         fn, fname = lib.st2_conv1d_f16s, "st2_conv1d_f16s"
     else:

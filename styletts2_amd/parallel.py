@@ -92,3 +92,25 @@ def gather_over_ranks(value, device):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(x.item()) for x in out]
+
+
+def broadcast_calibration(model, device, src=0):
+    """Rank `src` calibrated the split-f16 operand scales (pipeline.calibrate); every rank installs the same table so that all
+    shards compute bit-identical functions of their inputs.  One small broadcast at start-up (a few hundred floats), none in
+    steady state.  Returns the number of scales sent (0 for world size 1)."""
+    from . import pipeline
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    engs = pipeline.model_engines(model, device)
+    keys = sorted(engs)
+    sizes = [len(engs[k].calibration()) for k in keys]
+    flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        flat = torch.tensor([s for k in keys for s in engs[k].calibration_scales()], dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=src)
+    host = flat.cpu().tolist()
+    off = 0
+    for k, n in zip(keys, sizes):
+        engs[k].set_calibration(host[off:off + n])
+        off += n
+    return len(host)

@@ -243,7 +243,10 @@ class GraphedFront:
 
     def _stale(self, g, dev):
         if g["engine"] is not None or self._engine_mode():  # recorded over / now running on the C++ front: same handle?
-            return not self._engine_mode() or _front_engine(self.model, dev) is not g["engine"]
+            if not self._engine_mode():
+                return True
+            eng = _front_engine(self.model, dev)
+            return eng is not g["engine"] or eng.calib_gen != g["calib_gen"]  # the operand scales are kernel arguments
         return any(getattr(m, "_pk", None) is not pk for m, pk in g["packs"])
 
     @torch.no_grad()
@@ -296,7 +299,8 @@ class GraphedFront:
         # the graph's kernels read the packed weights: keep the Python caches / the C++ engine handle they live in alive,
         # and compare identities at replay (a reload or .to() rebuilds them)
         eng = _front_engine(self.model, dev) if self._engine_mode() else None
-        return dict(graph=graph, static=st, out=out, gen=self._generation(), packs=self._pack_refs(), engine=eng)
+        return dict(graph=graph, static=st, out=out, gen=self._generation(), packs=self._pack_refs(), engine=eng,
+                    calib_gen=None if eng is None else eng.calib_gen)
 
 
 @torch.no_grad()
@@ -529,3 +533,59 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         if on_chunk is not None:
             on_chunk(k, wave)
     return waves, s_prev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-layer operand scales of the split-f16 convs (include/st2.h st2_calibrate)
+# ---------------------------------------------------------------------------------------------------------------------
+def calibrate(run, margin_bits=3, max_passes=3, engines=None):
+    """Start-up calibration of a serving process: `run()` issues one or more representative forwards through the product
+    path (e.g. `lambda: inference(model, sampler, tokens, ...)`, plus `style.compute_style(model, wave)` for a zero-shot
+    model); every split-f16 conv of every live engine that was launched gets its own power-of-two operand scale from the
+    largest input it saw (the reference's convs are fp32 at every magnitude, Modules/istftnet.py:68-74; by rule the scale is
+    8 / 1, which is fp32-class for O(1) tensors only).  A pass whose launches ran into the f16 clamp at their old scale only
+    bounds those layers from below, so the recording is repeated (at most `max_passes` times).  Calibrate BEFORE recording
+    hipGraphs (GraphedFront re-records by itself); results stay bitwise reproducible for a given table.  Returns
+    {"passes", "sites_set", "clamped_last_pass", "headroom": rows of the last pass (ops.headroom)}."""
+    from . import engine
+    rows, nset, clamped, passes = [], 0, 0, 0
+    for _ in range(max(1, int(max_passes))):
+        ops.status(clear=True)
+        with ops.headroom() as h:
+            run()
+        ops.status(clear=True)  # a clamp during calibration is what the pass is there to find
+        rows, passes = h.rows, passes + 1
+        nset = clamped = 0
+        for eng in (engines if engines is not None else engine.live_engines()):
+            n, c = eng.calibrate(margin_bits)
+            nset, clamped = nset + n, clamped + c
+        if clamped == 0:
+            break
+    return {"passes": passes, "sites_set": nset, "clamped_last_pass": clamped, "headroom": rows}
+
+
+def model_engines(model, dev):
+    """{"front": ..., "decoder": ..., "style": ...}: the st2_engine handles behind a model's product path on `dev`, built if
+    they are not yet (same caches as the forward calls use)."""
+    from . import engine, style
+    dec = model.decoder
+    if getattr(dec, "_eng", None) is None or dec._eng.device != dev:
+        dec._eng = engine.build_decoder_engine(dec, dev)
+    out = {"front": _front_engine(model, dev), "decoder": dec._eng}
+    if isinstance(model.get("style_encoder"), style.StyleEncoder) and isinstance(model.get("predictor_encoder"), style.StyleEncoder):
+        out["style"] = style._style_engine(model, dev)
+    return out
+
+
+def calibration_state(model, dev):
+    """JSON-serialisable {"front": [x_scale per conv site], "decoder": [...], ...} (0.0 = by rule): what a process saves
+    beside a checkpoint, and what rank 0 sends to the other ranks (`parallel.broadcast_calibration`)."""
+    return {k: e.calibration_scales() for k, e in model_engines(model, dev).items()}
+
+
+def load_calibration_state(model, dev, state):
+    """Installs a table made by `calibration_state` on a process holding the same model (same conv layout: checked)."""
+    engs = model_engines(model, dev)
+    for k, scales in state.items():
+        if k in engs:
+            engs[k].set_calibration(scales)

@@ -10,5 +10,3 @@ for m in $MASKS; do
 done
 wait
 ls -la tools/bin
-# the F(3,3) experiment (tools/wino_bench.hip)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-function -Iinclude tools/wino_bench.hip -o tools/bin/wino_bench

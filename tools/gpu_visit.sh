@@ -15,7 +15,6 @@
 #   stats[:SCHED]    rocprofv3 --kernel-trace --stats of a short bench on one schedule (default single): per-kernel table +
 #                    tools/trace_gaps.py (busy / idle / overlapped time of the steady-state steps)
 #   pmc              FETCH_SIZE / WRITE_SIZE / busy-cycle passes over tools/probe_dom.py (profiles/pmc_dominant.json)
-#   gemm             tools/bin/gemm_bench (token GEMM shapes)
 #   cmd:COMMAND      anything else (spaces as '+')
 TAG=${1:?tag}; shift
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
@@ -95,7 +94,6 @@ for st in "$@"; do
         python tools/pmc_summary.py /tmp/pmcd_$n 2>/dev/null | tee $OUT/${TAG}_pmc_$n.txt | head -12
       done
       python tools/pmc_summary.py --json $OUT/${TAG}_pmc_dominant.json --kernel "conv1d_xs_kernel" /tmp/pmcd_FETCH_SIZE /tmp/pmcd_WRITE_SIZE | tail -2 ;;
-    gemm) [ -x tools/bin/gemm_bench ] && timeout 300 tools/bin/gemm_bench $(echo $arg | tr ',' ' ') 2>&1 | tee $OUT/${TAG}_gemm_bench.log ;;
     cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -300 | tee $OUT/${TAG}_cmd.log ;;
     *) echo "unknown stage $st" ;;
   esac
