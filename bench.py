@@ -22,7 +22,9 @@ only collective is the start-up weight broadcast over RCCL.
 Schedules (`--schedule`, default `auto`): consecutive steps may share the GPU on one stream, on two streams (front of step
 k+1 under the decoder of step k) or on two streams with complementary CU masks; `auto` times a few steps of the first two
 during the warm-up and runs the timed region on the faster -- MI355X boxes differ in how they co-schedule two queues (DESIGN.md
-section 6) -- and reports all of them in `config.schedules_ms_per_step`.  `cpu_baseline` = the UNMODIFIED reference modules on
+section 6) -- and reports all of them in `config.schedules_ms_per_step`.  `other_configs` (N = 1, after the timed region of the
+default command): short legs (3 warm-up + 5 steps, autotuned, schedule calibrated) of BASELINE.json configs[2..4] and a B = 1 /
+10 s latency point, so that ONE driver run carries all five workloads; the headline fields stay configs[1].  `cpu_baseline` = the UNMODIFIED reference modules on
 the host cores (`kind: "reference"`; from /root/reference, or from oracle/_ref = the same modules as bytecode where only
 that travelled), the oracle port beside it.
 """
@@ -318,9 +320,10 @@ def _attach_unoverlapped(roof, unoverlapped):
                                     "avg_launch_ms": head["avg_launch_ms"] if head else None,
                                     "launches_timed": head["launches"] if head else 0,
                                     "classes": _all_classes(unoverlapped),
-                                    "what": "every launch class in two untimed single-stream steps (no other queue on "
-                                            "the chip), the timed region's dominant class first; `frac` above is the "
-                                            "timed region's"}
+                                    "what": "every launch class -- the front's token GEMMs (k = 1) included: its graph is "
+                                            "replaced by eager issue for these steps -- in two untimed single-stream steps "
+                                            "(no other queue on the chip), the timed region's dominant class first; `frac` "
+                                            "above is the timed region's"}
     except Exception as e:
         print("[bench] un-overlapped roofline not attached: %r" % (e,), file=sys.stderr, flush=True)
 
@@ -338,6 +341,190 @@ def _spawned_rank(rank, world, port, argv):
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     sys.argv = argv
     main()
+
+
+def _calibrate(a, model, dev, step):
+    """Start-up calibration of the split-f16 operand scales (pipeline.calibrate), as a serving process runs it after loading a
+    checkpoint: one pass of the workload itself with the operand telemetry on.  Returns what goes into `config.operand_scales`."""
+    from styletts2_amd import pipeline
+    if a.calibrate == "off":
+        return {"mode": "rule (x_scale 8 after a normalising prologue, else 1)"}
+    t = time.perf_counter()
+    rep = pipeline.calibrate(lambda: (step(), torch.cuda.synchronize()))
+    rows = rep["headroom"]
+    out = {"mode": "calibrated per conv site (st2_calibrate, margin 3 bits)", "sites_set": rep["sites_set"], "passes": rep["passes"],
+           "launches_seen": len(rows), "wall_s": round(time.perf_counter() - t, 2)}
+    if rows:  # by rule, as recorded during the calibration pass: the two ends of the f16 range this checkpoint uses
+        out["by_rule"] = {"top_frac_of_65504": round(max(r["frac"] for r in rows), 5),
+                          "worst_split_rel_err": float("%.3g" % max(r["rel_err"] for r in rows)),
+                          "launches_rel_err_above_3e-7": sum(r["rel_err"] > 3e-7 for r in rows)}
+    log("operand scales calibrated: %d sites, %d pass(es), %.2f s" % (rep["sites_set"], rep["passes"], out["wall_s"]))
+    return out
+
+
+def _dominant_of(by_class):
+    rows = _all_classes(by_class)
+    if not rows:
+        return None
+    r = rows[0]
+    return {"kernel": "st2_conv1d_xs k%d C%d->%d L%d B%d" % (r["ks"], r["C_in"], r["C_out"], r["L"], r["B"]),
+            "avg_launch_ms": r["avg_launch_ms"], "launches": r["launches"], "frac": r["frac"],
+            "share_of_xs_conv_time": round(r["total_ms"] / max(sum(x["total_ms"] for x in rows), 1e-9), 3)}
+
+
+def _leg(name, a, dev, n_warm=3, n_steps=5):
+    """One short leg of another BASELINE.json configuration on this process's GPU: build + seeded weights, operand-scale
+    calibration, autotuned set-up step, schedule calibration (single vs two-stream, 2 steps each), `n_steps` timed steps with
+    the per-launch conv events on.  Same step definition as the headline (tokens -> waveform over the per-GPU batch)."""
+    from benchdata import manifest, synth
+    from styletts2_amd import _lib, models, ops, pipeline
+    cfg = CONFIGS[name]
+    longform = bool(cfg.get("longform"))
+    t_leg = time.perf_counter()
+    man = manifest(cfg["manifest"])
+    model = build(man)
+    for i, k in enumerate(KEYS):
+        synth.init_synthetic_(model[k], 10 + i)
+        model[k].eval().to(dev)
+    sampler = models.make_sampler(model, graph=longform)
+    tokens, lengths, noise, durations, ref_s = synthetic_inputs(PER_GPU_BATCH, 1000)
+    tokens, noise, durations_dev = tokens.to(dev), noise.to(dev), durations.to(dev)
+    ref_s = ref_s.to(dev) if cfg["multispeaker"] else None
+    front = None if a.eager_front else pipeline.GraphedFront(model, sampler)
+    steps_d, frames = cfg["steps"], N_PHONEMES * FRAMES_PER_PHONEME
+    sched = {"single": None, "two-stream": torch.cuda.Stream(dev, priority=a.front_priority)}
+    active = {"name": "two-stream"}
+    first_chunk = []
+    if longform:
+        sents = [tokens[i % PER_GPU_BATCH, :n].clone() for i, n in enumerate(LONGFORM_SENTENCES)]
+        durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
+        audio_s = sum(LONGFORM_SENTENCES) * FRAMES_PER_PHONEME * 600 / 24000.0
+        sched = {"two-stream": None}
+
+        def step(front=front):
+            t_start = time.perf_counter()
+
+            def on_chunk(k, w):
+                if k == 0:
+                    w[-1].item()
+                    first_chunk.append((time.perf_counter() - t_start) * 1e3)
+            return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
+                                            overlap=True, bucket=16, on_chunk=on_chunk, front=front)[0]
+    else:
+        audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
+
+        def step(front=front):
+            return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
+                                      ref_s=ref_s, durations=durations_dev, total_frames=frames,
+                                      front_stream=sched[active["name"]], front=front)
+    import contextlib
+    cal = _calibrate(a, model, dev, lambda: step(front=None))  # eager: before the front's hipGraph is recorded
+    with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
+        step()
+        torch.cuda.synchronize()
+    for _ in range(n_warm):
+        step()
+    torch.cuda.synchronize()
+
+    def time_steps(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            out = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3, out
+    calib = {}
+    if len(sched) > 1:
+        for nm in sched:
+            active["name"] = nm
+            step()
+            calib[nm] = time_steps(2)[0]
+        active["name"] = min(calib, key=calib.get)
+    first_chunk.clear()
+    lib = _lib.load()
+    lib.st2_conv_timing(1)
+    ms, out = time_steps(n_steps)
+    lib.st2_conv_timing(0)
+    by_class = _read_conv_classes(lib)
+    ops.check_status()
+    finite = all(bool(torch.isfinite(w).all()) for w in out) if longform else bool(torch.isfinite(out).all())
+    res = {"workload": cfg["workload"], "baseline_config_index": cfg["baseline_config"], "ms_per_step": round(ms, 3),
+           "audio_s_per_step": audio_s, "audio_s_per_s": round(audio_s / (ms * 1e-3), 1), "steps": n_steps, "warmup": n_warm,
+           "schedule": active["name"], "schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()},
+           "decoder": man["config"]["decoder"]["type"], "diffusion_steps": steps_d, "finite": finite,
+           "operand_scales": {k: cal[k] for k in ("mode", "sites_set") if k in cal},
+           "xs_conv_ms_per_step": round(sum(sum(v) for v in by_class.values()) / n_steps, 3),
+           "dominant": _dominant_of(by_class), "wall_s": None}
+    if longform:
+        res["first_chunk_latency_ms"] = round(min(first_chunk), 2) if first_chunk else None
+        res["sentences"] = LONGFORM_SENTENCES
+    del model, sampler, front
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    res["wall_s"] = round(time.perf_counter() - t_leg, 1)
+    return res
+
+
+def _latency_b1(a, dev, model, sampler, front, n_warm=3, n_steps=10):
+    """B = 1, one 10 s utterance, tokens -> waveform, one stream, each call synchronised: the latency point of the headline
+    model (BASELINE.json configs[0]'s shape on the GPU)."""
+    from styletts2_amd import _lib, ops, pipeline
+    tokens, lengths, noise, durations, _ = synthetic_inputs(1, 77)
+    tokens, noise, dur = tokens.to(dev), noise.to(dev), durations.to(dev)
+    steps_d, frames = CONFIGS[a.config]["steps"], N_PHONEMES * FRAMES_PER_PHONEME
+
+    def step():
+        return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
+                                  durations=dur, total_frames=frames, front=front)
+    import contextlib
+    with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
+        step()
+        torch.cuda.synchronize()
+    for _ in range(n_warm):
+        step()
+    lib = _lib.load()
+    lib.st2_conv_timing(1)
+    ts = []
+    for _ in range(n_steps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    lib.st2_conv_timing(0)
+    by_class = _read_conv_classes(lib)
+    ops.check_status()
+    return {"workload": "B = 1, one 10 s utterance (100 phonemes, %d diffusion steps, %s), one stream, graph-replayed front; "
+                        "every call synchronised" % (steps_d, a.config),
+            "latency_ms": {"mean": round(sum(ts) / len(ts), 3), "min": round(min(ts), 3), "max": round(max(ts), 3)},
+            "audio_s_per_s": round(AUDIO_S_PER_UTT / (min(ts) * 1e-3), 1), "steps": n_steps, "warmup": n_warm,
+            "finite": bool(torch.isfinite(out).all()),
+            "xs_conv_ms_per_step": round(sum(sum(v) for v in by_class.values()) / n_steps, 3), "dominant": _dominant_of(by_class)}
+
+
+def other_configs(a, dev, model, sampler, front, skip):
+    """BASELINE.json configs[2..4] + the B = 1 latency point as short legs in the same process (rank 0, N = 1): a run of the
+    default command carries every workload the baseline names.  A failing leg reports its error and never costs the line."""
+    out = {}
+    for name in ("libritts_hifigan", "libritts_istftnet", "longform"):
+        if name == skip:
+            continue
+        try:
+            out[name] = _leg(name, a, dev)
+            log("other config %-18s %.1f ms/step = %.0f audio-s/s (%s, %.1f s)" % (name, out[name]["ms_per_step"],
+                                                                                  out[name]["audio_s_per_s"], out[name]["schedule"],
+                                                                                  out[name]["wall_s"]))
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+            log("other config %s failed: %r" % (name, e))
+            torch.cuda.empty_cache()
+    try:
+        out["latency_b1_10s"] = _latency_b1(a, dev, model, sampler, front)
+        log("B = 1 latency: %.2f ms (min)" % out["latency_b1_10s"]["latency_ms"]["min"])
+    except Exception as e:  # noqa: BLE001
+        out["latency_b1_10s"] = {"error": repr(e)}
+        log("B = 1 latency leg failed: %r" % (e,))
+    return out
 
 
 def main():
@@ -378,6 +565,14 @@ def main():
                     help="`auto` (default): run the CU health probe (st2_probe_cu_health); if it finds slow CUs, streams "
                          "confined to the healthy ones are calibrated beside the plain schedules and the fastest runs; `off`: "
                          "plain streams only")
+    ap.add_argument("--calibrate", choices=["on", "off"], default="on",
+                    help="`on` (default): what a serving process does after loading a checkpoint -- one pass with the operand "
+                         "telemetry on gives every split-f16 conv its own power-of-two operand scale (pipeline.calibrate; "
+                         "fp32-class precision at every input magnitude); `off`: the rule (8 after a normalising prologue, 1 "
+                         "otherwise)")
+    ap.add_argument("--other-configs", choices=["auto", "on", "off"], default="auto",
+                    help="short legs of BASELINE.json configs[2..4] + a B = 1 latency point after the timed region (`auto`: "
+                         "on for the default config at N = 1)")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
@@ -531,7 +726,7 @@ def main():
         durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
         audio_s = sum(LONGFORM_SENTENCES) * FRAMES_PER_PHONEME * 600 / 24000.0
 
-        def step():
+        def step(front=lf_front):
             t_start = time.perf_counter()
 
             def on_chunk(k, w):
@@ -541,18 +736,21 @@ def main():
             with torch.cuda.stream(healthy.main if healthy is not None else torch.cuda.current_stream(dev)):
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
-                                                    on_chunk=on_chunk, front=lf_front,
+                                                    on_chunk=on_chunk, front=front,
                                                     side_stream=healthy.front if healthy is not None else None)
             return waves
     else:
         audio_s = B * AUDIO_S_PER_UTT
 
-        def step():
+        def step(front=lf_front):
             main_s, front_s = sched[active["name"]]
             with torch.cuda.stream(main_s if main_s is not None else torch.cuda.current_stream(dev)):
                 return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
                                           embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
-                                          front_stream=front_s, front=lf_front)
+                                          front_stream=front_s, front=front)
+
+    def step_eager():
+        return step(front=None)
 
     # Set-up, not a warm-up step: (i) the xs convs are AUTOTUNED here -- the first launch of every shape class times its
     # bitwise-equivalent builds (tile shape / occupancy, dispatch-order or XCD-aware tile order) on this box and keeps the
@@ -560,6 +758,7 @@ def main():
     # build); (ii) the hipGraph of the front is recorded (one eager pass + the capture), so that --warmup 0 puts neither
     # inside the timed region.  Nothing else runs on the GPU during this step: the measurements are un-overlapped.
     import contextlib
+    calibration = _calibrate(a, model, dev, step_eager)  # before the front's hipGraph is recorded: scales are kernel arguments
     tune_ctx = contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=True)
     t_tune = time.perf_counter()
     with tune_ctx:
@@ -622,21 +821,29 @@ def main():
     # events on (reported beside the timed region's figures as `roofline.unoverlapped`; the contract's `frac` stays the one of
     # the timed region, where the front of the next batch shares the chip with the decoder's convs and stretches them).
     lib = _lib.load()
-    unoverlapped = None
+    unoverlapped, front_ms_alone = None, None
     single_name = "single/healthy-CUs" if ("healthy" in active["name"] and "single/healthy-CUs" in sched) else "single"
     if not longform and single_name in sched and active["name"] != single_name:
         chosen = active["name"]
         try:
             active["name"] = single_name
-            step()
-            lib.st2_conv_timing(1)
+            step(front=None)  # EAGER front in these steps: a graph replay hides its launches from the timing hook, and
+            lib.st2_conv_timing(1)  # the token GEMMs of the denoiser / PL-BERT (k = 1 classes) belong in "all classes"
             torch.cuda.synchronize()
             for _ in range(2):
-                step()
+                step(front=None)
             torch.cuda.synchronize()
             lib.st2_conv_timing(0)
             if rank == 0:
                 unoverlapped = _read_conv_classes(lib)
+            # the front alone (graph replay as in the timed region), nothing else on the chip
+            torch.cuda.synchronize()
+            t_f = time.perf_counter()
+            for _ in range(3):
+                pipeline.prepare(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0, ref_s=ref_s,
+                                 durations=durations_dev, total_frames=frames, front=lf_front)
+            torch.cuda.synchronize()
+            front_ms_alone = (time.perf_counter() - t_f) / 3 * 1e3
         except Exception as e:  # a measurement extra: never in the way of the timed region
             lib.st2_conv_timing(0)
             log("un-overlapped conv timing skipped: %r" % (e,))
@@ -687,6 +894,10 @@ def main():
         except Exception as e:  # a report, never in the way of the line
             log("ceiling_live unavailable: %r" % (e,))
         roof["conv_ms_per_step_all_classes"] = sum(sum(v) for v in by_class.values()) / max(a.steps, 1)
+        roof["conv_ms_note"] = ("decoder + prosody convs of the timed region; the front's token GEMMs are replayed from its "
+                                "hipGraph there and appear in `unoverlapped.classes` (eager front) only")
+        if front_ms_alone is not None:
+            roof["front_ms_alone"] = round(front_ms_alone, 3)
         name = active["name"]
         streams = {"single": "1", "two-stream": "2 (front of step k+1 overlaps decoder of step k)",
                    "partitioned": "2 on complementary CU masks (front %d CUs, decoder the rest)" % a.front_cus,
@@ -716,6 +927,7 @@ def main():
                                          [{"class": "k%d C%d->%d L%d B%d" % (r["ks"], r["C_in"], r["C_out"], r["L"], r["B"]),
                                            "chosen": r["chosen_name"],
                                            "ms": {c["name"]: c["ms"] for c in r["candidates"]}} for r in tune_table]),
+                       "operand_scales": calibration,
                        "plan": _hooks.plan, "lstm": a.lstm, "graphed_front": not a.eager_front,
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,
@@ -735,6 +947,8 @@ def main():
             res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
                                                        "min": min(first_chunk_ms) if first_chunk_ms else None}
             res["scaling"] = "weak"  # replicas only: a passage is sequential in its style vector
+        if world == 1 and (a.other_configs == "on" or (a.other_configs == "auto" and a.config == "ljspeech")):
+            res["other_configs"] = other_configs(a, dev, model, sampler, lf_front, skip=a.config)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(man, sds, cfg)
         print(json.dumps(res), flush=True)

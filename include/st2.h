@@ -51,12 +51,16 @@ int st2_device_info(int dev, char* name, int cap);
  *                            operand raises the same bit (ABI 18: the clamp maps it to -65504);
  *   ST2_STATUS_LSTM_TIMEOUT  a bounded spin of st2_lstm_bidir_coop expired (a group's workgroups were not
  *                            co-resident in time): the outputs of that call are invalid;
+ *                            (st2_lstm_bidir_coop called directly; the launch plans use st2_lstm_bidir_coop_recovering, which
+ *                            repairs the call in-stream and raises ST2_STATUS_LSTM_RECOVERED instead);
  *   ST2_STATUS_DURATION_SUM  a row of the durations handed to st2_expand_by_durations does not sum to T (caller-supplied
  *                            durations with a wrong `total_frames`): frames past the sum repeat the last phoneme.
  * st2_status(clear != 0) returns the word and atomically clears it.  Returns < 0 if no HIP device is usable. */
 #define ST2_STATUS_F16_RANGE 1
 #define ST2_STATUS_LSTM_TIMEOUT 2
 #define ST2_STATUS_DURATION_SUM 4
+#define ST2_STATUS_LSTM_RECOVERED 8  /* informational: a cooperative BiLSTM group timed out and st2_lstm_bidir_coop_recovering
+                                        re-ran the call on the single-CU kernel -- the outputs are VALID, latency was lost */
 int st2_status(int clear);
 
 /* ---- fused Conv1d (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32) ------------ *
@@ -123,6 +127,11 @@ typedef struct st2_conv_desc {
   /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
      part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) over the 128 columns of that tile */
   float* part; int32_t part_nt;
+  /* st2_conv1d_xs only (ABI v20): columns per partial-sum slot, 0 = 128.  A small-grid launch (fewer workgroups than CUs: one
+     utterance) runs 128 x 64 or 128 x 32 tiles and emits its sums per 64 / 32 columns: the caller asks
+     st2_conv1d_xs_part_cols(d) BEFORE sizing `part` (part_nt >= ceil(L_out / part_cols)) and passes the answer here; a caller
+     that leaves it 0 keeps the 128-column tiles and the 128-column slots.  st2_stats_finalize sums whatever slots there are. */
+  int32_t part_cols;
   /* st2_conv1d_f16s only, optional: workspace for split-K launches.  A layer whose grid leaves most of the chip idle and
      whose k loop is long (C_in >= 8 chunks, < 128 workgroups: the 1024 -> 2048 Linears of the denoiser over the ~100
      tokens of one utterance) runs as up to 8 K slices per tile + a fixed-order reduction that applies the epilogue; the
@@ -185,6 +194,10 @@ int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t
                   int32_t gb_seg, int32_t gamma_plus_one, const float* alpha, float x_scale,
                   void* xs, int32_t xs_cg, int32_t Lp, int32_t halo, void* stream);
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
+/* Columns per partial-sum slot (128, 64 or 32) the launch described by *d would use when its caller opts into the small-grid
+ * builds (d.part_cols): a function of the geometry alone -- every plan gets the same answer, results are reproducible bit for
+ * bit.  128 for every launch with at least as many 128 x 128 tiles as the device has CUs (y is bitwise the same either way). */
+int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *
@@ -340,6 +353,15 @@ int st2_lstm_coop_set_block(int utterances);
 int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
                         int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,
                         void* scratch, int64_t scratch_bytes, void* stream);
+/* The same launch with its safety net (ABI v20; what every launch plan issues): the single-CU kernel of st2_lstm_bidir is
+ * queued behind the cooperative launch in a CONDITIONAL form -- every workgroup reads scratch[0] and leaves when it is 0 (a
+ * few microseconds); when a group was not co-resident in time (another queue held its CUs) it re-runs the whole call into
+ * the same Y.  The outputs are then the single-CU kernel's (same results up to fp32 summation order), ST2_STATUS_LSTM_TIMEOUT
+ * is NOT raised and ST2_STATUS_LSTM_RECOVERED is.  Same refusal behaviour as st2_lstm_bidir_coop (nothing launched); legal
+ * under stream capture. */
+int st2_lstm_bidir_coop_recovering(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths,
+                                   int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs, int32_t y_cs,
+                                   void* scratch, int64_t scratch_bytes, void* stream);
 
 /* generic fused elementwise helpers used by the sampler / denoiser glue */
 /* y[b][c][n] = x[b][c][n] + v[b][c]  (x = x + mapping, modules.py:152,394) */
@@ -628,7 +650,11 @@ int st2_conv_timing_read(double* rows, int32_t cap_rows);
  * st2_conv_tune_set pins (variant >= 0: bit 0 = 128 x 256 tiles, bit 1 = XCD-aware order) or
  * erases (variant = -1) one class on the current device; st2_conv_tune_read fills rows of 24 doubles {ks, C_in, C_out,
  * L_out, B, device, chosen variant, n candidates, (variant, ms / launch) x 8} for the current device and returns the number
- * of classes (rows may be NULL to count).  Tuning synchronises the stream it measures on; the table is guarded by a mutex. */
+ * of classes (rows may be NULL to count).  Tuning synchronises the stream it measures on; the table is guarded by a mutex and
+ * the measurement runs outside it (other threads keep launching, on the rule's build for a class while it is being measured).
+ * Tuning mode allocates and waits on events: it must not overlap a stream capture anywhere in the process (a global-mode
+ * capture on another stream would be invalidated) -- tune first, record graphs afterwards.  A class is keyed without the
+ * dilation: the three dilations of a resblock share one measurement (they differ in halo columns only). */
 int st2_conv_tune(int mode);
 int st2_conv_tune_set(int32_t ks, int32_t C_in, int32_t C_out, int32_t L_out, int32_t B, int32_t variant);
 int st2_conv_tune_read(double* rows, int32_t cap_rows);

@@ -12,6 +12,8 @@ reachable from tests/ and tools/ only, through `override(...)`:
   conv_precision  "f16s" (split-f16 MFMA) or "f32" (the exact-fp32 MFMA build of the same contract: the tests' reference
                   kernel, and what the mel front-end's DFT uses explicitly).
   lstm            "coop" (cooperative BiLSTM, with the library's own refusal -> single-CU path) or "single".
+  lstm_recover    True (always, outside tests): cooperative launches carry their in-stream safety net
+                  (st2_lstm_bidir_coop_recovering); False = the bare st2_lstm_bidir_coop, whose time-out is only reported.
 """
 import contextlib
 
@@ -19,9 +21,10 @@ plan = "engine"
 conv_path = "xs"
 conv_precision = "f16s"
 lstm = "coop"
+lstm_recover = True
 
 _CHOICES = {"plan": ("engine", "python"), "conv_path": ("xs", "fused"), "conv_precision": ("f16s", "f32"),
-            "lstm": ("coop", "single")}
+            "lstm": ("coop", "single"), "lstm_recover": (True, False)}
 
 
 @contextlib.contextmanager

@@ -20,7 +20,7 @@ HEADROOM_COLS, CALIBRATION_COLS = 12, 5  # st2.h ST2_HEADROOM_COLS / ST2_CALIBRA
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 PRO_NONE, PRO_LEAKY, PRO_ADAIN_LEAKY, PRO_ADAIN_SNAKE, PRO_SNAKE, PRO_COLNORM = range(6)
-STATUS_F16_RANGE, STATUS_LSTM_TIMEOUT, STATUS_DURATION_SUM = 1, 2, 4
+STATUS_F16_RANGE, STATUS_LSTM_TIMEOUT, STATUS_DURATION_SUM, STATUS_LSTM_RECOVERED = 1, 2, 4, 8
 ACT_NONE, ACT_GELU, ACT_EXP_SIN, ACT_TANH, ACT_LEAKY, ACT_GELU_TANH = range(6)
 
 
@@ -47,7 +47,7 @@ class ConvDesc(C.Structure):
         ("x_scale", C.c_float), ("out_scale", C.c_float),
         ("w_row_scale", f32p),
         ("xs", f32p), ("xs_cg", C.c_int32), ("xs_lp", C.c_int32), ("xs_halo", C.c_int32),
-        ("part", f32p), ("part_nt", C.c_int32),
+        ("part", f32p), ("part_nt", C.c_int32), ("part_cols", C.c_int32),
         ("splitk_ws", f32p), ("splitk_ws_bytes", C.c_int64),
     ]
 
@@ -153,6 +153,8 @@ _SIGNATURES = {
     "st2_lstm_coop_set_block": (C.c_int, [C.c_int]),
     "st2_lstm_bidir_coop": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "st2_lstm_bidir_coop_recovering": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                 f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "st2_add_chanvec": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, f32p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "st2_mean_tokens": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
@@ -213,6 +215,7 @@ _SIGNATURES = {
     "st2_probe_cu_health": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_int32)]),
     "st2_debug_headroom": (C.c_int, [C.c_int]),
     "st2_debug_headroom_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
+    "st2_conv1d_xs_part_cols": (C.c_int, [C.POINTER(ConvDesc)]),
     "st2_calibrate": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "st2_calibration_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "st2_calibration_site_name": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),

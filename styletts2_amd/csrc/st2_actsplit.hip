@@ -210,6 +210,13 @@ thread_local int t_site = -1;
 
 void headroom_record(int kind, const ActArgs& a, int B, hipStream_t s) {
   if ((int)g_hr.size() >= HR_CAP || !g_hr_dev) return;
+  // never under stream capture: a recorded probe would re-run at every replay -- and, for the fused convs, read scratch
+  // planes that st2_debug_headroom(0) has freed.  Calibrate / report on eager calls, record graphs afterwards.
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return;
+  }
   const int64_t plane = (int64_t)a.xs_cg * a.Lp;
   hipLaunchKernelGGL(xs_probe_kernel, dim3((unsigned)std::min<int64_t>((plane + 255) / 256, 1024), B), dim3(256), 0, s, a.xs, plane,
                      2 * plane, g_hr_dev + g_hr.size());
@@ -264,6 +271,13 @@ extern "C" int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t
 // Telemetry for the fused conv (st2_conv1d_f16s.hip calls this in debug mode): the same prologue into scratch planes.
 int st2_headroom_of_fused_conv(const st2_conv_desc& d, hipStream_t s) {
   if (!g_headroom || !d.x) return 0;
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;  // see headroom_record: no probes (no hipMalloc either) under capture
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return 0;
+    }
+  }
   const int cg = (d.C_in + 31) / 32 * 4, halo = 0;
   const int Lp = (d.L_in + 7) / 8 * 8;
   const size_t bytes = (size_t)d.B * 2 * cg * Lp * 16;

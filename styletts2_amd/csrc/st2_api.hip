@@ -66,7 +66,7 @@ extern "C" int st2_status(int clear) {
     return -1;
   }
   int v = 0;
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
     v |= clear ? __atomic_exchange_n(g_status_host + i, 0, __ATOMIC_SEQ_CST) : __atomic_load_n(g_status_host + i, __ATOMIC_SEQ_CST);
   return v;
 }

@@ -15,7 +15,8 @@ int* st2_status_device_ptr();  // st2_api.hip: device view of the sticky status 
 // Kernel side: raise status bit `bit` (ST2_STATUS_*).  Every bit has its own 32-bit slot in the host-mapped block so
 // that raising is a plain system-scope STORE (no read-modify-write over the host link); st2_status() ORs the slots.
 __device__ __forceinline__ void st2_raise_status(int* status, int bit) {
-  if (status) __hip_atomic_store(status + (bit == ST2_STATUS_F16_RANGE ? 0 : (bit == ST2_STATUS_LSTM_TIMEOUT ? 1 : 2)), bit,
+  if (status) __hip_atomic_store(status + (bit == ST2_STATUS_F16_RANGE ? 0 : (bit == ST2_STATUS_LSTM_TIMEOUT ? 1 :
+                                           (bit == ST2_STATUS_DURATION_SUM ? 2 : 3))), bit,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

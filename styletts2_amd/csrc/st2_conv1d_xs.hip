@@ -58,7 +58,8 @@ struct TuneEntry {
   int variant[8] = {};
   float ms[8] = {};
 };
-std::mutex g_tune_mu;
+std::mutex g_tune_mu;     // the table
+std::mutex g_measure_mu;  // one measurement at a time (they share g_scratch); never held together with a launch of another thread
 std::map<TuneKey, TuneEntry> g_tune;
 std::atomic<int> g_tune_entries{0};
 std::atomic<int> g_tune_mode{0};
@@ -171,19 +172,29 @@ int pick_variant(const st2_conv_desc& d, hipStream_t s) {
   if (!g_tune_mode.load(std::memory_order_relaxed) && !g_tune_entries.load(std::memory_order_relaxed))
     return st2xs::XS_V_RULE;
   const TuneKey key(current_device(), d.ks, d.C_in, d.C_out, d.L_out, d.B);
-  std::lock_guard<std::mutex> lock(g_tune_mu);
-  auto it = g_tune.find(key);
-  if (it != g_tune.end()) return it->second.chosen;
-  if (!g_tune_mode.load(std::memory_order_relaxed)) return st2xs::XS_V_RULE;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return st2xs::XS_V_RULE;  // a capture cannot be timed: the class stays untuned for now
+  {
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    auto it = g_tune.find(key);
+    if (it != g_tune.end()) return it->second.chosen;  // incl. a class another thread is measuring right now: the rule
+    if (!g_tune_mode.load(std::memory_order_relaxed)) return st2xs::XS_V_RULE;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return st2xs::XS_V_RULE;  // a capture cannot be timed: the class stays untuned for now
+    }
+    TuneEntry placeholder;  // chosen = XS_V_RULE, n = 0: "being measured"
+    g_tune[key] = placeholder;
+    g_tune_entries.store((int)g_tune.size(), std::memory_order_relaxed);
   }
+  // The measurement itself (hipMalloc, 1 + 3 x 2 launches per candidate, event synchronisation) runs OUTSIDE the table lock
+  // (advisor, round 4): other threads / devices keep launching, on the rule's build for this class until the result lands.
   TuneEntry e;
-  tune_launch(d, s, e);
+  {
+    std::lock_guard<std::mutex> measuring(g_measure_mu);
+    tune_launch(d, s, e);
+  }
+  std::lock_guard<std::mutex> lock(g_tune_mu);
   g_tune[key] = e;
-  g_tune_entries.store((int)g_tune.size(), std::memory_order_relaxed);
   return e.chosen;
 }
 
@@ -273,6 +284,10 @@ extern "C" int st2_conv_tune_read(double* rows, int32_t cap_rows) {
     ++n;
   }
   return n;
+}
+
+extern "C" int st2_conv1d_xs_part_cols(const st2_conv_desc* dp) {
+  return dp ? st2xs::small_grid_cols(*dp) : 128;
 }
 
 extern "C" int st2_conv1d_xs(const st2_conv_desc* dp, void* stream) {

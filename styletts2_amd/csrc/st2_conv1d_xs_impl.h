@@ -326,9 +326,15 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
   ST2_REQUIRE((int64_t)(n_tiles - 1) * BN - d.pad_left + d.xs_halo + XW <= d.xs_lp,
               "st2_conv1d_xs: xs rows of %d slots are too short for L_out=%d (tile %d, ks=%d, dil=%d, halo=%d)",
               d.xs_lp, d.L_out, BN, KS, d.dil, d.xs_halo);
-  if (d.part) ST2_REQUIRE(d.part_nt >= st2_cdiv(d.L_out, 128), "st2_conv1d_xs: part_nt=%d < %d tiles", d.part_nt,
-                          st2_cdiv(d.L_out, 128));
-  if constexpr (TN < 4) ST2_REQUIRE(!d.part, "st2_conv1d_xs: the narrow token tiles do not produce partial sums");
+  if constexpr (TN >= 4) {
+    if (d.part)
+      ST2_REQUIRE((d.part_cols == 0 || d.part_cols == 128) && d.part_nt >= st2_cdiv(d.L_out, 128),
+                  "st2_conv1d_xs: part_nt=%d / part_cols=%d for %d tiles of 128 columns", d.part_nt, d.part_cols, st2_cdiv(d.L_out, 128));
+  } else if (d.part) {  // one slot per tile (WN = 1): the caller sized `part` from st2_conv1d_xs_part_cols
+    ST2_REQUIRE(WN == 1 && d.part_cols == BN && d.part_nt >= st2_cdiv(d.L_out, BN),
+                "st2_conv1d_xs: a %d-column tile build needs part_cols=%d and part_nt >= %d (got %d / %d)", BN, BN,
+                st2_cdiv(d.L_out, BN), d.part_cols, d.part_nt);
+  }
   dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
   const int64_t total = (int64_t)grid.x * grid.y * grid.z;
   // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a tile count divisible by 8
@@ -368,7 +374,11 @@ namespace st2xs {
 //   bit 1  XS_V_SWIZZLE  XCD-aware tile order: one row block per XCD (launches with 2 / 4 / 8 row blocks)
 // Tried as further variants in round 4 and removed again (bitwise equivalent, never a winner by the tuner's 2 % margin on any
 // box: profiles/LAB_NOTES.md): 16-channel chunks at k = 3, and persistent workgroups pulling tiles from an atomic queue.
-enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2 };
+//   bit 2  XS_V_N64      128 (co) x 64 (l) tiles   } small grids (one utterance: long-form synthesis, B = 1 latency): a launch of fewer
+//   bit 3  XS_V_N32      128 (co) x 32 (l) tiles   } workgroups than CUs is paced by ONE tile's k loop, so narrower tiles (2 x / 4 x the
+//                        workgroups, each with 1/2 / 1/4 of the MFMAs per k-step) shorten it; y is bitwise the same (same products, same
+//                        order per output element), the InstanceNorm partial sums come per 64 / 32 columns (d.part_cols) instead of 128
+enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_N64 = 4, XS_V_N32 = 8 };
 
 // The build an UNTUNED process runs (tests, one-off calls; a serving process measures: st2_conv_tune).  k >= 7: 32 (co) x
 // 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU -- half the weight stream (L2 -> registers) per FLOP;
@@ -391,11 +401,31 @@ inline int rule_variant(const st2_conv_desc& d) {
   return (wide ? XS_V_WIDE : 0) | (swz ? XS_V_SWIZZLE : 0);
 }
 
+// Small grids.  A launch with fewer 128 x 128 tiles than the chip has CUs (one utterance: the long-form loop, B = 1 latency)
+// is paced by ONE workgroup's k loop.  Halving / quartering the tile width doubles / quadruples the workgroups that share the
+// same weight stream per k-step, so the loop gets shorter until the chip is full: 64-column tiles below 256 tiles of 128,
+// 32-column tiles below 128.  A function of the geometry alone (never tuned: the partial sums' slot width follows it, and a
+// measured choice would make the statistics box-dependent in their last bits).  Callers opt in through d.part_cols (with
+// statistics) or get it by rule (without): y is bitwise the same in every build.
+inline int small_grid_cols(const st2_conv_desc& d) {
+  if (d.C_out <= 64 || d.ks < 3) return 128;
+  const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
+  return wg128 >= 256 ? 128 : (wg128 >= 128 ? 64 : 32);
+}
+
 template <int KS, int CI_T>
 int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
   if (variant < 0) variant = rule_variant(d);
+  if (!(variant & (XS_V_N64 | XS_V_N32))) {  // (the micro-benchmark forces the bits; the library goes by the geometry)
+    const int cols = d.part ? (d.part_cols ? d.part_cols : 128) : small_grid_cols(d);
+    if (cols < 128) variant = (variant & XS_V_SWIZZLE) | (cols == 64 ? XS_V_N64 : XS_V_N32);
+  }
   const bool swz = (variant & XS_V_SWIZZLE) != 0;
   if (d.C_out > 64) {
+    if constexpr (KS >= 3) {
+      if (variant & XS_V_N32) return launch<KS, CI_T, 4, 1, 1, 3>(d, s, swz);
+      if (variant & XS_V_N64) return launch<KS, CI_T, 4, 1, 2, 3>(d, s, swz);
+    }
     if constexpr (KS >= 7 || KS == 3) {
       if (variant & XS_V_WIDE) return launch<KS, CI_T, 4, 1, 8, 2>(d, s, swz);
     }

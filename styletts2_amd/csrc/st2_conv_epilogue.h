@@ -43,9 +43,17 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
   // per-row weight scale: unconditional load + select (the packed weights serve as a valid address without one)
   const float* rsc = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
   const bool want_part = d.part != nullptr;
-  constexpr int NPT = TN >= 4 ? TN / 4 : 1;  // 128-column partial-sum tiles per wave tile (TN < 4: narrow token-GEMM
-  constexpr int JB = TN >= 4 ? 4 : TN;       // tiles, launched without partial sums); column blocks per residual batch
-  const int ptile = (n0 + wn * (32 * TN)) / 128;  // first 128-column tile index of this wave's partial sums
+  // 128-column partial-sum tiles per wave tile.  TN < 4 bodies are (i) the narrow token-GEMM LAUNCHES, which never carry
+  // d.part (checked by the launcher), and (ii) the row-end QUARTER bodies of a wide launch (st2_conv1d_xs_impl.h: a last
+  // tile whose valid columns fit TN / 4 blocks runs the body instantiated with TN / 4), which DO produce partial sums:
+  // write_part below closes their unfinished 128-column group.  Held against the CPU reduction of the stored output for
+  // the aligned (L = 400), unaligned (L = 777) and wide (L = 8 000) row ends in tests/test_ops_gpu.py
+  // (test_conv1d_xs_epilogue_stats; advisor, round 4).
+  constexpr int NPT = TN >= 4 ? TN / 4 : 1;
+  constexpr int JB = TN >= 4 ? 4 : TN;       // column blocks per residual batch
+  // first partial-sum slot of this wave: slots are 128 columns wide, or -- small-grid launches of 64 / 32-column tiles, whose
+  // tiles each own ONE slot (d.part_cols, checked by the launcher) -- 64 / 32
+  const int ptile = (n0 + wn * (32 * TN)) >> (d.part_cols == 64 ? 6 : (d.part_cols == 32 ? 5 : 7));
   const int co = m0 + wm * 32 + l31;       // this lane's output row (< wq_co_pad by construction of the packing)
   const int lw = n0 + wn * (32 * TN) + 4 * kg;  // first position of this lane's (j = 0, q = 0) quad
   // 16-byte accesses need every row of y / res / res2 to start 16-byte aligned (workgroup-uniform, set by the plans'

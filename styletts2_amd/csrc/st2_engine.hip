@@ -84,8 +84,11 @@ int hip_lstm(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, con
   // No sticky "refused" state: whether a cooperative launch fits depends on the device AND the batch (a refusal at B = 48
   // says nothing about the latency-critical B = 1 long-form launches, nor about another device of the process).  The
   // refusal itself is a host-side occupancy comparison -- nothing was launched -- so asking every time costs nothing.
+  // The cooperative launch carries its own safety net (round 5): the single-CU kernel is queued behind it in its conditional
+  // form and re-runs the call into the same output if a group was not co-resident in time (two queues sharing the chip) --
+  // a latency cost and ST2_STATUS_LSTM_RECOVERED instead of a batch of bad audio.
   if (scratch && scratch_bytes > 0) {
-    if (st2_lstm_bidir_coop(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream) == 0)
+    if (st2_lstm_bidir_coop_recovering(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream) == 0)
       return 0;
     const char* msg = st2_last_error();
     if (!msg || !strstr(msg, "co-resident")) return 1;
@@ -804,9 +807,11 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     float* part = nullptr;
     int nt = 0;
     if (o.stats_out) {
-      nt = (y.L + 127) / 128;
+      // small grids (one utterance) run 64 / 32-column tiles, one partial-sum slot per tile: the library says which
+      const int pc = st2_conv1d_xs_part_cols(&d);
+      nt = (y.L + pc - 1) / pc;
       part = c.a.f32((int64_t)y.B * y.C * nt * 2);
-      d.part = part; d.part_nt = nt;
+      d.part = part; d.part_nt = nt; d.part_cols = pc;
     }
     RUN(c, g_be.conv1d_xs(&d, c.stream));
     if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));

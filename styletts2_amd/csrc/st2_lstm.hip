@@ -22,11 +22,18 @@ template <int H>
 __global__ __launch_bounds__(H) void lstm_recurrence_kernel(const float* __restrict__ G, int64_t g_bs, int g_cs,
                                                             const float* __restrict__ whh_t,  // [2][H][4H]
                                                             const int* __restrict__ lengths, int N,
-                                                            float* __restrict__ Y, int64_t y_bs, int y_cs) {
+                                                            float* __restrict__ Y, int64_t y_bs, int y_cs,
+                                                            const int* cond, int* gstatus) {
   __shared__ float hs[2][H];
   const int j = threadIdx.x;
   const int b = blockIdx.x;
   const int dir = blockIdx.y;
+  // Recovery form (st2_lstm_bidir_coop_recovering): queued behind a cooperative launch, runs only if that launch left its
+  // time-out flag set -- otherwise every workgroup reads one word and leaves (a few microseconds in the stream).
+  if (cond) {
+    if (__hip_atomic_load(cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    if (j == 0 && b == 0 && dir == 0) st2_raise_status(gstatus, ST2_STATUS_LSTM_RECOVERED);
+  }
   const int len = lengths ? min(lengths[b], N) : N;
   const float* Gb = G + (int64_t)b * g_bs + (int64_t)(dir * 4 * H) * g_cs;
   const float* W = whh_t + (int64_t)dir * H * 4 * H;
@@ -89,7 +96,29 @@ extern "C" int st2_lstm_bidir(const float* G, int64_t g_bs, int32_t g_cs, const 
   ST2_REQUIRE(B <= 65535, "st2_lstm_bidir: batch too large");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((lstm_recurrence_kernel<256>), dim3(B, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t,
-                     reinterpret_cast<const int*>(lengths), N, Y, y_bs, y_cs);
+                     reinterpret_cast<const int*>(lengths), N, Y, y_bs, y_cs, nullptr, nullptr);
   ST2_CHECK_LAUNCH("st2_lstm_bidir");
+  return 0;
+}
+
+// The cooperative recurrence with its own safety net: st2_lstm_bidir_coop (time-out reported in scratch[0] only) followed, in
+// the same stream, by the single-CU kernel in its conditional form.  A group that was not co-resident in time then costs
+// the call its latency advantage, not its outputs: Y holds the single-CU kernel's results and ST2_STATUS_LSTM_RECOVERED
+// (not _TIMEOUT) is raised.  Capturable: both launches and the memset are ordinary stream work.
+int st2_lstm_coop_launch(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths, int32_t B,
+                         int32_t Hn, int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* scratch, int64_t scratch_bytes,
+                         void* stream, bool report_timeout);  // st2_lstm_coop.hip
+
+extern "C" int st2_lstm_bidir_coop_recovering(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t,
+                                              const int32_t* lengths, int32_t B, int32_t H, int32_t N, float* Y, int64_t y_bs,
+                                              int32_t y_cs, void* scratch, int64_t scratch_bytes, void* stream) {
+  ST2_REQUIRE(B <= 65535, "st2_lstm_bidir_coop_recovering: batch too large");
+  if (st2_lstm_coop_launch(G, g_bs, g_cs, whh_t, lengths, B, H, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream, false) != 0)
+    return 1;  // refused (not co-resident / bad arguments): nothing was launched, the caller takes st2_lstm_bidir
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((lstm_recurrence_kernel<256>), dim3(B, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t,
+                     reinterpret_cast<const int*>(lengths), N, Y, y_bs, y_cs, reinterpret_cast<const int*>(scratch),
+                     st2_status_device_ptr());
+  ST2_CHECK_LAUNCH("st2_lstm_bidir_coop_recovering");
   return 0;
 }

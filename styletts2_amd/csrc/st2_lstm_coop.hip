@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
 }
 
 int g_spin_limit = SPIN_LIMIT_DEFAULT;
+thread_local bool t_report_timeout = true;  // false inside st2_lstm_bidir_coop_recovering: scratch[0] alone carries the flag
 int g_xch = 2;  // st2_lstm_coop_set_exchange(): 0 fences + counter (8.1 us/step), 1 sc1 + counter (9.2 us), 2 granules
 
 size_t scratch_head(int groups) { return ((size_t)(1 + groups) * sizeof(int) + 255) / 256 * 256; }
@@ -314,7 +315,7 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
     return 1;
   }
   hipLaunchKernelGGL((lstm_coop_kernel<U, XCH>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
-                     B, N, Y, y_bs, y_cs, status, counters, hx, st2_status_device_ptr(), g_spin_limit);
+                     B, N, Y, y_bs, y_cs, status, counters, hx, t_report_timeout ? st2_status_device_ptr() : nullptr, g_spin_limit);
   ST2_CHECK_LAUNCH("st2_lstm_bidir_coop");
   return 0;
 }
@@ -371,6 +372,15 @@ extern "C" int64_t st2_lstm_coop_scratch_bytes(int32_t B) {
   const int U = block_size(B);
   if (U == 0) return 0;  // batch too large for one co-resident launch: use st2_lstm_bidir
   return (int64_t)scratch_need(2 * st2_cdiv(B, U), U);
+}
+
+int st2_lstm_coop_launch(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t, const int32_t* lengths, int32_t B,
+                         int32_t Hn, int32_t N, float* Y, int64_t y_bs, int32_t y_cs, void* scratch, int64_t scratch_bytes,
+                         void* stream, bool report_timeout) {
+  t_report_timeout = report_timeout;
+  const int rc = st2_lstm_bidir_coop(G, g_bs, g_cs, whh_t, lengths, B, Hn, N, Y, y_bs, y_cs, scratch, scratch_bytes, stream);
+  t_report_timeout = true;
+  return rc;
 }
 
 extern "C" int st2_lstm_bidir_coop(const float* G, int64_t g_bs, int32_t g_cs, const float* whh_t,

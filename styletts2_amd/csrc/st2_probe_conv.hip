@@ -139,7 +139,11 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
     r_first = std::min(r_first, h[i * 8 + 4]);
     r_last = std::max(r_last, h[i * 8 + 5]);
   }
-  ST2_REQUIRE(!all.empty(), "st2_probe_cu_health: the probe launch left no stamps");
+  if (all.empty()) {  // (advisor, round 4) an early return must not leak the probe's ~0.9 GB of buffers
+    st2_set_error("st2_probe_cu_health: the probe launch left no stamps");
+    cleanup();
+    return 1;
+  }
   for (int64_t i = 0; i < n_wg; ++i)
     if (h[i * 8 + 1]) {
       const int x = (int)((h[i * 8] >> 32) & 15);

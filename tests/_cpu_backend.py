@@ -109,10 +109,12 @@ def _emit_part(d, y):
     """Per-128-column (sum, sum of squares) of the stored output, the contract of d.part (st2.h)."""
     if d.part:
         nt = d.part_nt
+        cols = getattr(d, "part_cols", 0) or 128  # st2.h: 0 = 128 columns per slot; 64 / 32 on small grids (xs only)
+        assert cols in (128, 64, 32) and nt * cols >= d.L_out
         part = _t(d.part, (d.B, d.C_out, nt, 2), (d.C_out * nt * 2, nt * 2, 2, 1))
-        yd = torch.zeros(d.B, d.C_out, nt * 128, dtype=torch.float64)
+        yd = torch.zeros(d.B, d.C_out, nt * cols, dtype=torch.float64)
         yd[:, :, :d.L_out] = y.double()
-        yd = yd.reshape(d.B, d.C_out, nt, 128)
+        yd = yd.reshape(d.B, d.C_out, nt, cols)
         part[..., 0] = yd.sum(-1).float()
         part[..., 1] = (yd * yd).sum(-1).float()
 

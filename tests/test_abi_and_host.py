@@ -119,10 +119,16 @@ def test_xs_conv_hot_builds_do_not_spill(tmp_path):
         for name, priv, vgpr, spill in kernels:
             if "conv1d_xs_kernel" not in name:
                 continue
-            # The k loop of every build lives in registers (checked on the disassembly below).  Outside it a few dwords of
-            # scratch are tolerated: since the epilogue handles row ends by column-block ranges, the rare residual +
-            # MRF-accumulator epilogue modes of a 168-VGPR build park one 16-byte quad there.
-            assert int(priv) <= 64, "%s: %s B of scratch" % (name, priv)
+            # No scratch and no spill in any build on the hot path (advisor, round 4: the allowance of round 4 was wider than
+            # the regression it accommodated).  The one exception is named: the 64-row x 256-column build with 16-channel
+            # chunks at 3 workgroups / CU (<KS, 16, 2, 2, 4>: C_out in (32, 64] at k >= 3 on the xs path -- no layer of the
+            # five BASELINE configurations routes there, prefer_fused takes C <= 64) parks one quad (<= 64 B) in scratch in
+            # its residual + MRF-accumulator epilogue modes, outside the k loop (checked on the disassembly below).
+            rare = re.search(r"conv1d_xs_kernel_o3ILi\d+ELi16ELi2ELi2ELi4EE", name) is not None
+            if rare:
+                assert int(priv) <= 64 and int(spill) <= 16, "%s: %s B of scratch, %s spills" % (name, priv, spill)
+            else:
+                assert int(priv) == 0 and int(spill) == 0, "%s: %s B of scratch, %s VGPR spills" % (name, priv, spill)
             if "conv1d_xs_kernel_o3" in name:
                 seen += "conv1d_xs_kernel_o3" in name
                 assert int(vgpr) <= 168, "%s uses %s VGPRs: 2 workgroups per CU, not 3" % (name, vgpr)

@@ -191,7 +191,14 @@ def test_conv1d_f16s_warp_specialised_build_is_bitwise_the_one_role_kernel(B, C_
                                                        (2, 128, 128, 48001, 11, 1, True),
                                                        # >= 1024 workgroups at 256-column tiles: the 32 x 256 wave-tile
                                                        # builds (k = 7 / 11), two partial-sum tiles per wave
-                                                       (6, 128, 128, 48001, 11, 3, True), (16, 256, 256, 8000, 7, 1, True)])
+                                                       (6, 128, 128, 48001, 11, 3, True), (16, 256, 256, 8000, 7, 1, True),
+                                                       # row-end QUARTER bodies (a last tile whose valid columns fit a quarter
+                                                       # of the tile runs the body built with TN / 4 column blocks): their
+                                                       # partial sums against the CPU reduction, not only variant vs variant
+                                                       (4, 512, 512, 400, 3, 1, True),    # 16 of 128 columns, aligned
+                                                       (2, 256, 256, 777, 7, 1, True),    # 9 of 128, unaligned row end
+                                                       (16, 256, 256, 8000, 3, 1, True),  # 64 of 256: the wide k = 3 build
+                                                       (3, 1024, 1024, 400, 3, 1, False)])
 def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
     """want_stats: InstanceNorm statistics of the conv OUTPUT from the epilogue's per-tile partial sums
     (st2_conv1d_xs part + st2_stats_finalize) against the fp64 reduction of the stored tensor."""
@@ -207,6 +214,44 @@ def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
     assert st.shape == st_ref.shape == (B, C_out, 2)
     assert (st.cpu()[..., 0] - st_ref[..., 0]).abs().max().item() < 2e-6 * max(1.0, st_ref[..., 0].abs().max().item())
     assert ((st.cpu()[..., 1] - st_ref[..., 1]).abs() / st_ref[..., 1]).max().item() < 5e-6
+
+
+@pytest.mark.parametrize("B,C,L,ks,dil,cols", [(1, 256, 5680, 7, 1, 32),     # 90 tiles of 128 x 128 on 256 CUs -> 32-column tiles
+                                                (1, 128, 28400, 7, 3, 64),    # 222 -> 64-column tiles
+                                                (1, 256, 5680, 3, 1, 32), (2, 128, 8001, 11, 5, 64),
+                                                (1, 1024, 400, 3, 1, 32),     # 32 tiles, K = 3 072 deep (decoder front)
+                                                (1, 128, 40000, 7, 1, 128)])  # 313 tiles: the ordinary build
+def test_conv1d_xs_small_grid_builds(B, C, L, ks, dil, cols, monkeypatch):
+    """Launches with fewer 128 x 128 tiles than CUs (one utterance: long-form synthesis, BASELINE.json configs[4]) run 64- /
+    32-column tiles by a rule of the geometry (st2_conv1d_xs_part_cols): the output is BITWISE that of the 128-column build
+    (same products in the same order per element), the InstanceNorm statistics -- partial sums per 64 / 32 columns instead of
+    128 -- meet the CPU reduction of the stored tensor at the same bar, and two runs are bitwise identical."""
+    from styletts2_amd import _lib
+    monkeypatch.setattr(_hooks, "conv_path", "xs")
+    x, w, kw = make_conv_case(seed=41, B=B, C_in=C, C_out=C, L=L, ks=ks, dil=dil, pro=R.PRO_ADAIN_SNAKE, res=True)
+    wt_host = weights.pack_conv_f16s(w)
+    wt = wt_host.to(DEV)
+    kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    PRO_KEYS = ("pro", "slope", "stats", "gamma", "beta", "alpha")
+    xs = ops.activate(g(x), **{k: v for k, v in kwg.items() if k in PRO_KEYS})
+    ckw = {k: v for k, v in kwg.items() if k not in PRO_KEYS}
+    d = _lib.ConvDesc()
+    d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks = B, C, C, L, L, ks
+    assert _lib.load().st2_conv1d_xs_part_cols(d) == cols
+    out, st = ops.conv1d_xs(xs, wt, C, ks, want_stats=True, **ckw)
+    out2, st2 = ops.conv1d_xs(xs, wt, C, ks, want_stats=True, **ckw)
+    wide, st_wide = ops.conv1d_xs(xs, wt, C, ks, want_stats=True, part_cols=128, **ckw)
+    plain = ops.conv1d_xs(xs, wt, C, ks, **ckw)  # no statistics: the same rule, the same tiles
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(st, st2), "run-to-run determinism"
+    assert torch.equal(out, wide) and torch.equal(out, plain), "tile width must not change a single output bit"
+    if B * C * L <= 3_000_000:
+        assert rel_err(out, R.conv1d(x, wt_host, C, ks, **kw)) < 2e-5
+    st_ref = R.instnorm_stats(out.cpu())
+    for s in (st, st_wide):
+        assert (s.cpu()[..., 0] - st_ref[..., 0]).abs().max().item() < 2e-6 * max(1.0, st_ref[..., 0].abs().max().item())
+        assert ((s.cpu()[..., 1] - st_ref[..., 1]).abs() / st_ref[..., 1]).max().item() < 5e-6
+    assert ops.status() == 0
 
 
 @pytest.mark.parametrize("pro", [R.PRO_NONE, R.PRO_LEAKY, R.PRO_ADAIN_LEAKY, R.PRO_ADAIN_SNAKE, R.PRO_SNAKE,
@@ -704,6 +749,7 @@ def test_lstm_coop_timeout_is_reported_not_silent(monkeypatch):
     from styletts2_amd import _lib
     from styletts2_amd.text import EngineLSTM
     monkeypatch.setattr(_hooks, "lstm", "coop")
+    monkeypatch.setattr(_hooks, "lstm_recover", False)  # the bare cooperative launch (kernel-level callers)
     ops.status(clear=True)
     lib = _lib.load()
     torch.manual_seed(3)
@@ -722,6 +768,59 @@ def test_lstm_coop_timeout_is_reported_not_silent(monkeypatch):
     y = lstm.forward_cm(x)  # and the next call, with the default budget, is fine again
     torch.cuda.synchronize()
     assert ops.status() == 0 and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("plan", ["python", "engine"])
+def test_lstm_coop_timeout_is_recovered_in_stream(plan, monkeypatch):
+    """What the launch plans issue (st2_lstm_bidir_coop_recovering): with the poll budget forced to 1 every cooperative group
+    times out, the conditional single-CU kernel queued behind it re-runs the call, and the caller gets that kernel's outputs
+    -- bitwise -- with ST2_STATUS_LSTM_RECOVERED (a warning), not ST2_STATUS_LSTM_TIMEOUT (an exception) and not garbage.
+    `engine`: the same through a C++ plan (st2_text_forward: embedding -> convs -> BiLSTM)."""
+    import warnings
+    from styletts2_amd import _lib
+    lib = _lib.load()
+    ops.status(clear=True)
+    torch.manual_seed(3)
+    if plan == "python":
+        from styletts2_amd.text import EngineLSTM
+        lstm = EngineLSTM(640, 256).to(DEV)
+        x = torch.randn(8, 640, 50, device=DEV)
+        run = lambda: lstm.forward_cm(x)
+    else:
+        from _util import manifest
+        from styletts2_amd import engine, models
+        import synth
+        man = manifest("ljspeech")
+        te = models.build_model(models.recursive_munch(man["config"]), None, None, models.load_plbert(man["plbert"])).text_encoder
+        synth.init_synthetic_(te, 4)
+        eng = engine.build_text_engine(te.eval(), torch.device(DEV, torch.cuda.current_device()))
+        tokens = torch.randint(1, 178, (6, 40), device=DEV)
+        run = lambda: eng.text_forward(tokens)
+    with _hooks.override(lstm="single"):
+        lib.st2_lstm_coop_set_block(-1)  # the C++ plans follow the library hook: no cooperative launches
+        try:
+            want = run()
+            torch.cuda.synchronize()
+        finally:
+            lib.st2_lstm_coop_set_block(0)
+    assert ops.status() == 0
+    lib.st2_lstm_coop_set_spin_limit(1)
+    try:
+        got = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.st2_lstm_coop_set_spin_limit(0)
+    st = ops.status()
+    assert st & _lib.STATUS_LSTM_RECOVERED and not st & _lib.STATUS_LSTM_TIMEOUT, hex(st)
+    assert torch.equal(got, want), "the recovered call returns the single-CU kernel's outputs"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ops.check_status()  # informational: no exception
+    assert any("single-CU" in str(x.message) for x in w) and ops.status() == 0
+    again = run()  # default budget: the cooperative kernel's own outputs, nothing to recover
+    torch.cuda.synchronize()
+    assert ops.status() == 0
+    assert (again - want).abs().max().item() < 1e-5
 
 
 @pytest.mark.parametrize("xch", [0, 1, 2])

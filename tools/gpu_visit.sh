@@ -15,6 +15,10 @@
 #   stats[:SCHED]    rocprofv3 --kernel-trace --stats of a short bench on one schedule (default single): per-kernel table +
 #                    tools/trace_gaps.py (busy / idle / overlapped time of the steady-state steps)
 #   pmc              FETCH_SIZE / WRITE_SIZE / busy-cycle passes over tools/probe_dom.py (profiles/pmc_dominant.json)
+#   headroom         tools/headroom_report.py on the synthetic / trained-like / small-magnitude checkpoints (both ends of the f16 range)
+#   validate         tools/validate_checkpoint.py on the synthetic full-layout checkpoints
+#   stats_cfg:NAME   rocprofv3 --kernel-trace --stats of a short single-stream bench of configuration NAME
+#   smallgrid        tools/bin/xs_bench_0 on the B = 1 shapes: tile width 128 / 64 / 32 columns and the library's geometry rule
 #   cmd:COMMAND      anything else (spaces as '+')
 TAG=${1:?tag}; shift
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
@@ -94,6 +98,35 @@ for st in "$@"; do
         python tools/pmc_summary.py /tmp/pmcd_$n 2>/dev/null | tee $OUT/${TAG}_pmc_$n.txt | head -12
       done
       python tools/pmc_summary.py --json $OUT/${TAG}_pmc_dominant.json --kernel "conv1d_xs_kernel" /tmp/pmcd_FETCH_SIZE /tmp/pmcd_WRITE_SIZE | tail -2 ;;
+    headroom)  # two-sided operand tables by rule / calibrated: synthetic, trained-like, small-magnitude checkpoints
+      for v in "plain:" "trained:--trained-like" "small2:--trained-like+--small+1e-2" "small3:--trained-like+--small+1e-3" "libri_small2:--config+libritts+--trained-like+--small+1e-2"; do
+        n=${v%%:*}; fl=$(echo ${v#*:} | tr '+' ' ')
+        timeout 600 python tools/headroom_report.py $fl --json $OUT/${TAG}_headroom_$n.json > $OUT/${TAG}_headroom_$n.txt 2>&1
+        echo "[$n] rc=$?"; grep -E "top of the range|calibration table|status word" $OUT/${TAG}_headroom_$n.txt
+      done ;;
+    validate)  # the first-contact tool on the synthetic full-layout checkpoints (no real checkpoint exists offline)
+      for tag in ljspeech libritts; do
+        python - <<PY
+import sys, pathlib
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import test_checkpoint_layout as T
+d = pathlib.Path("/tmp/ckpt_$tag"); d.mkdir(exist_ok=True)
+print(*T._write_checkpoint(d, "$tag")[2:])
+PY
+        timeout 900 python tools/validate_checkpoint.py /tmp/ckpt_$tag/epoch_2nd_00017.pth /tmp/ckpt_$tag/config_libritts.yml --batch 2 --json $OUT/${TAG}_validate_$tag.json > $OUT/${TAG}_validate_$tag.txt 2>&1
+        echo "[$tag] rc=$?"; tail -22 $OUT/${TAG}_validate_$tag.txt
+      done ;;
+    stats_cfg)  # rocprofv3 --kernel-trace --stats of a short single-stream bench of another configuration
+      cfgname=${arg:-libritts_hifigan}
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$cfgname -o bench -- python $OLDPWD/bench.py --config $cfgname --steps 4 --warmup 2 --schedule single --calib-steps 0 --no-cpu-baseline --no-box-probe --cu-mask off > $OLDPWD/$OUT/${TAG}_bench_${cfgname}_single.json 2> $OLDPWD/$OUT/${TAG}_bench_${cfgname}_single.err )
+      f=$(find /tmp/prof_${TAG}_$cfgname -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${cfgname}_kernel_stats.csv && head -22 $f
+      rm -rf /tmp/prof_${TAG}_$cfgname ;;
+    smallgrid)  # tools/bin/xs_bench_0 at B = 1 (long-form / latency shapes): 128- / 64- / 32-column tiles and the geometry rule
+      for shp in "7 1 256 5680" "7 3 256 8000" "11 1 256 5680" "3 1 256 5680" "7 1 128 28400" "7 1 128 40000" "11 5 128 37200" "3 1 128 37200" "3 1 512 800" "3 1 1024 400"; do
+        for v in 0 4 8 -1; do
+          XS_VARIANT=$v timeout 120 tools/bin/xs_bench_0 $shp 1 1 1 ${REPS:-50} 2>&1 | grep -E "ms / launch|checksum_y|tile columns|partial sums" | tr '\n' ' ' | sed "s/^/variant $v: /"; echo
+        done
+      done | tee $OUT/${TAG}_smallgrid_xs_bench.log ;;
     cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -300 | tee $OUT/${TAG}_cmd.log ;;
     *) echo "unknown stage $st" ;;
   esac

@@ -68,8 +68,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&res, y_elems * 4));
   CK(hipMalloc(&bias, co_pad * 4));
   CK(hipMalloc(&rsc, co_pad * 4));
-  const int nt = (L + 127) / 128;
+  int nt = (L + 31) / 32;  // allocated for the narrowest slot width; set per build below
   CK(hipMalloc(&part, (int64_t)B * C * nt * 2 * 4));
+  CK(hipMemset(part, 0, (int64_t)B * C * nt * 2 * 4));
   // hi plane ~ values in +-24 (x8 scaled activations), lo plane ~ 2^-11 of that; weights hi in +-16384, lo in +-8
   const int64_t plane = (int64_t)cg * Lp * 8;
   for (int b = 0; b < B; ++b) {
@@ -92,7 +93,13 @@ int main(int argc, char** argv) {
   if (use_res) { d.res = res; d.res_bs = (int64_t)C * pitch; d.res_cs = pitch; }
   d.div = 1.0f;
   d.xs = xs; d.xs_cg = cg; d.xs_lp = Lp; d.xs_halo = halo;
-  if (use_stats) { d.part = part; d.part_nt = nt; }
+  {  // slot width of the partial sums: forced small-grid builds (XS_VARIANT bits 2 / 3) or the library's geometry rule
+    int pc = (xs_variant >= 0 && (xs_variant & 8)) ? 32 : ((xs_variant >= 0 && (xs_variant & 4)) ? 64 : 128);
+    if (xs_variant < 0) pc = st2xs::small_grid_cols(d);
+    nt = (L + pc - 1) / pc;
+    if (use_stats) { d.part = part; d.part_nt = nt; d.part_cols = pc; }
+    printf("tile columns %d (%d workgroups)\n", pc < 128 ? pc : 128, ((L + (pc < 128 ? pc : 128) - 1) / (pc < 128 ? pc : 128)) * ((C + 127) / 128) * B);
+  }
 
   unsigned long long* tl = nullptr;
   const int64_t n_wg = (int64_t)((L + 127) / 128) * ((C + 127) / 128) * B * 4;  // upper bound on workgroups
@@ -140,8 +147,13 @@ int main(int argc, char** argv) {
     auto mix = [&](float v) { unsigned u; memcpy(&u, &v, 4); hsh = (hsh ^ u) * 1099511628211ull; };
     for (int64_t r = 0; r < (int64_t)B * C; ++r)
       for (int l = 0; l < L; ++l) mix(hy[(size_t)r * pitch + l]);
-    if (use_stats)
+    printf("checksum_y %016llx\n", hsh);
+    if (use_stats) {
+      double s1 = 0, s2 = 0;
+      for (size_t i = 0; i + 1 < hp.size(); i += 2) { s1 += hp[i]; s2 += hp[i + 1]; }
       for (float v : hp) mix(v);
+      printf("partial sums: total %.9g / %.9g over %d slots per row\n", s1, s2, nt);
+    }
     printf("checksum %016llx\n", hsh);
   }
   if (ST2_XS_ABLATE & 64) {  // dump the last launch's timeline: one line per workgroup
