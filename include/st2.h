@@ -196,7 +196,7 @@ int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
 /* Columns per partial-sum slot (128, 64 or 32) the launch described by *d would use when its caller opts into the small-grid
  * builds (d.part_cols): a function of the geometry alone -- every plan gets the same answer, results are reproducible bit for
- * bit.  128 for every launch with at least as many 128 x 128 tiles as the device has CUs (y is bitwise the same either way). */
+ * bit.  32 below ~100 tiles of 128 x 128, 64 up to ~600 (k = 3: ~900), 128 beyond (y is bitwise the same either way). */
 int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, void* stream);
 

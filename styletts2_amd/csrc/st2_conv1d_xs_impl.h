@@ -401,16 +401,20 @@ inline int rule_variant(const st2_conv_desc& d) {
   return (wide ? XS_V_WIDE : 0) | (swz ? XS_V_SWIZZLE : 0);
 }
 
-// Small grids.  A launch with fewer 128 x 128 tiles than the chip has CUs (one utterance: the long-form loop, B = 1 latency)
-// is paced by ONE workgroup's k loop.  Halving / quartering the tile width doubles / quadruples the workgroups that share the
-// same weight stream per k-step, so the loop gets shorter until the chip is full: 64-column tiles below 256 tiles of 128,
-// 32-column tiles below 128.  A function of the geometry alone (never tuned: the partial sums' slot width follows it, and a
-// measured choice would make the statistics box-dependent in their last bits).  Callers opt in through d.part_cols (with
-// statistics) or get it by rule (without): y is bitwise the same in every build.
+// Small grids.  A launch of a few hundred 128 x 128 tiles (one to three utterances: the long-form loop, B = 1 latency) does
+// not fill 256 CUs x 3 workgroup slots; it is paced by ONE workgroup's k loop.  Halving / quartering the tile width doubles /
+// quadruples the workgroups that share the weight stream of a k-step, so the loop gets shorter until the chip is full.
+// Measured over 50 shapes at B = 1 ... 3 (tools/xs_bench.hip, profiles/r05a_smallgrid_*, r05b_smallgrid_*): 32-column tiles
+// win below ~100 tiles of 128 (k = 7, C = 256, L = 5 680, B = 1: 55.6 -> 28.3 us; k = 3: 39.6 -> 17.5), 64-column tiles up to ~600
+// (k = 11, C = 128, L = 37 200: 75.3 -> 55.5 us; k = 3 up to ~900: 47.1 -> 27.4), 128 beyond.  A function of the geometry alone
+// (never tuned: the partial sums' slot width follows it, and a measured choice would make the statistics box-dependent in
+// their last bits).  Callers opt in through d.part_cols (with statistics) or get it by rule (without): y is bitwise the same
+// in every build.
 inline int small_grid_cols(const st2_conv_desc& d) {
   if (d.C_out <= 64 || d.ks < 3) return 128;
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
-  return wg128 >= 256 ? 128 : (wg128 >= 128 ? 64 : 32);
+  if (wg128 < 100) return 32;
+  return wg128 < (d.ks == 3 ? 900 : 600) ? 64 : 128;
 }
 
 template <int KS, int CI_T>

@@ -255,6 +255,11 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 int g_spin_limit = SPIN_LIMIT_DEFAULT;
 thread_local bool t_report_timeout = true;  // false inside st2_lstm_bidir_coop_recovering: scratch[0] alone carries the flag
 int g_xch = 2;  // st2_lstm_coop_set_exchange(): 0 fences + counter (8.1 us/step), 1 sc1 + counter (9.2 us), 2 granules
@@ -308,11 +313,14 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
   int* status = reinterpret_cast<int*>(scratch);
   int* counters = status + 1;
   float* hx = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + head);
-  // status, counters and -- granule form -- every tag start at zero on EVERY call (a tag left by an earlier call
-  // would otherwise match); a memset node under graph capture, replayed first
-  if (hipMemsetAsync(scratch, 0, XCH == 2 ? need : head, s) != hipSuccess) {
-    st2_set_error("st2_lstm_bidir_coop: hipMemsetAsync failed");
-    return 1;
+  // status, counters and -- granule form -- every tag start at zero on EVERY call (a tag left by an earlier call would
+  // otherwise match).  A KERNEL, not hipMemsetAsync: recorded into a hipGraph, the memset node zeroes on the first replay and
+  // writes an 8-byte pointer-like pattern over the head of the buffer on every later one (ROCm 7.2, tools/debug_lstm_graph.py,
+  // profiles/r05c_lstm_graph.log) -- rounds 1-4 never looked at scratch[0] after a replay; round 5's in-stream recovery does.
+  {
+    const size_t words = (XCH == 2 ? need : head) / 16;  // both are multiples of 256 bytes; scratch is 256-byte aligned
+    hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4*>(scratch), words);
+    ST2_CHECK_LAUNCH("st2_lstm_bidir_coop (scratch clear)");
   }
   hipLaunchKernelGGL((lstm_coop_kernel<U, XCH>), dim3(NSL, nblk, 2), dim3(256), 0, s, G, g_bs, g_cs, whh_t, lengths,
                      B, N, Y, y_bs, y_cs, status, counters, hx, t_report_timeout ? st2_status_device_ptr() : nullptr, g_spin_limit);

@@ -220,7 +220,8 @@ def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
                                                 (1, 128, 28400, 7, 3, 64),    # 222 -> 64-column tiles
                                                 (1, 256, 5680, 3, 1, 32), (2, 128, 8001, 11, 5, 64),
                                                 (1, 1024, 400, 3, 1, 32),     # 32 tiles, K = 3 072 deep (decoder front)
-                                                (1, 128, 40000, 7, 1, 128)])  # 313 tiles: the ordinary build
+                                                (1, 128, 40000, 7, 1, 64),    # 313 tiles: still one partial round of the chip
+                                                (4, 128, 40000, 7, 1, 128)])  # 1 252 tiles: the ordinary build
 def test_conv1d_xs_small_grid_builds(B, C, L, ks, dil, cols, monkeypatch):
     """Launches with fewer 128 x 128 tiles than CUs (one utterance: long-form synthesis, BASELINE.json configs[4]) run 64- /
     32-column tiles by a rule of the geometry (st2_conv1d_xs_part_cols): the output is BITWISE that of the 128-column build
@@ -247,6 +248,8 @@ def test_conv1d_xs_small_grid_builds(B, C, L, ks, dil, cols, monkeypatch):
     assert torch.equal(out, wide) and torch.equal(out, plain), "tile width must not change a single output bit"
     if B * C * L <= 3_000_000:
         assert rel_err(out, R.conv1d(x, wt_host, C, ks, **kw)) < 2e-5
+    if B * C * L > 8_000_000:  # the large case rides on the bitwise equality above; statistics on a slice of the rows
+        out, st, st_wide = out[:1], st[:1], st_wide[:1]
     st_ref = R.instnorm_stats(out.cpu())
     for s in (st, st_wide):
         assert (s.cpu()[..., 0] - st_ref[..., 0]).abs().max().item() < 2e-6 * max(1.0, st_ref[..., 0].abs().max().item())
@@ -821,6 +824,48 @@ def test_lstm_coop_timeout_is_recovered_in_stream(plan, monkeypatch):
     torch.cuda.synchronize()
     assert ops.status() == 0
     assert (again - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(1, 96), (32, 100)])
+def test_lstm_coop_scratch_is_cleared_on_every_graph_replay(B, N):
+    """The cooperative launch clears its scratch (status word, counters, granule tags) at the start of EVERY call, also when the
+    call is a node sequence of a replayed hipGraph.  It used to do so with hipMemsetAsync, whose recorded node zeroes on the first
+    replay only (ROCm 7.2: later replays leave an 8-byte pointer-like pattern at the head of the buffer) -- invisible until the
+    in-stream recovery started reading scratch[0]: every replayed front then re-ran its BiLSTMs on the single-CU kernel (+27 ms
+    per long-form passage, profiles/r05d_*).  Now a kernel node: scratch[0] == 0, no status bit and bitwise the eager outputs on
+    replays 1..3 of a buffer pre-filled with garbage."""
+    from styletts2_amd import _lib
+    lib = _lib.load()
+    H = 256
+    gen = torch.Generator().manual_seed(11)
+    whh = g(torch.randn(2, H, 4 * H, generator=gen) / 16).contiguous()
+    G = g(torch.randn(B, 8 * H, N, generator=gen))
+    nbytes = lib.st2_lstm_coop_scratch_bytes(B)
+    assert nbytes > 0
+    Y = torch.empty(B, 2 * H, N, device=DEV)
+    scratch = torch.full((nbytes,), 0x5A, device=DEV, dtype=torch.uint8)
+
+    def call():
+        rc = lib.st2_lstm_bidir_coop_recovering(G.data_ptr(), G.stride(0), G.stride(1), whh.data_ptr(), 0, B, H, N, Y.data_ptr(),
+                                                Y.stride(0), Y.stride(1), scratch.data_ptr(), nbytes,
+                                                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.st2_last_error()
+    call()
+    torch.cuda.synchronize()
+    ref = Y.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for it in range(3):
+        scratch.fill_(0x5A)
+        Y.fill_(7.0)
+        ops.status(clear=True)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(scratch[:4].view(torch.int32).item()) == 0, "replay %d: scratch[0] not cleared" % it
+        assert ops.status(clear=True) == 0, "replay %d raised a status bit" % it
+        assert torch.equal(Y, ref), "replay %d differs from the eager call" % it
 
 
 @pytest.mark.parametrize("xch", [0, 1, 2])

@@ -122,10 +122,13 @@ PY
       f=$(find /tmp/prof_${TAG}_$cfgname -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${cfgname}_kernel_stats.csv && head -22 $f
       rm -rf /tmp/prof_${TAG}_$cfgname ;;
     smallgrid)  # tools/bin/xs_bench_0 at B = 1 (long-form / latency shapes): 128- / 64- / 32-column tiles and the geometry rule
+      # arg = the batch sizes to sweep (default 1): how many 128 x 128 tiles until the narrow tiles stop paying?
+      for bb in $(echo ${arg:-1} | tr ',' ' '); do
       for shp in "7 1 256 5680" "7 3 256 8000" "11 1 256 5680" "3 1 256 5680" "7 1 128 28400" "7 1 128 40000" "11 5 128 37200" "3 1 128 37200" "3 1 512 800" "3 1 1024 400"; do
         for v in 0 4 8 -1; do
-          XS_VARIANT=$v timeout 120 tools/bin/xs_bench_0 $shp 1 1 1 ${REPS:-50} 2>&1 | grep -E "ms / launch|checksum_y|tile columns|partial sums" | tr '\n' ' ' | sed "s/^/variant $v: /"; echo
+          XS_VARIANT=$v timeout 120 tools/bin/xs_bench_0 $shp $bb 1 1 ${REPS:-50} 2>&1 | grep -E "ms / launch|checksum_y|tile columns|partial sums" | tr '\n' ' ' | sed "s/^/variant $v: /"; echo
         done
+      done
       done | tee $OUT/${TAG}_smallgrid_xs_bench.log ;;
     cmd) timeout 1200 bash -c "$(echo $arg | tr '+' ' ')" 2>&1 | tail -300 | tee $OUT/${TAG}_cmd.log ;;
     *) echo "unknown stage $st" ;;
