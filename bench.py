@@ -437,8 +437,9 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     if len(sched) > 1:
         for nm in sched:
             active["name"] = nm
+            step()  # first use of this stream pair: allocator warm-up, the pipeline fills
             step()
-            calib[nm] = time_steps(2)[0]
+            calib[nm] = time_steps(3)[0]
         active["name"] = min(calib, key=calib.get)
     first_chunk.clear()
     lib = _lib.load()

@@ -79,8 +79,14 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
   // dispatch ONCE to a build with those terms as compile-time constants: no bounds tests, 32-bit offsets from scalar
   // bases, a column block's residual loads issued together ahead of its arithmetic.  Edge tiles, unaligned tensors and
   // rare combinations take the generic build (MODE < 0: run-time flags, per-element bounds, 4-byte accesses).
-  float s1 = 0.f, s2 = 0.f;              // running (sum, sum of squares) of this lane's stored values ...
-  float s1d[NPT] = {}, s2d[NPT] = {};    // ... and the finished 128-column sums: shared by the builds a tile may combine
+  // Running (sum, sum of squares) of this lane's stored values of the current slot, SHIFTED by the slot's first stored value
+  // (csh = y[b][co][first column of the slot]: lane kg = 0 owns it, its kg = 1 partner gets it by one cross-lane move): the
+  // finaliser reads that value back from y and combines the slots with Chan's formula in fp64.  Unshifted sums lose the variance
+  // of a channel whose mean dominates it -- E[x^2] - mean^2 with fp32 partial sums: |mean| / std = 100 (a bias-dominated channel of
+  // a residual stream) costs 1e-8 x 1e4 = 1e-4 of rstd, three decades above fp32 (round 5, tools/debug_stats_precision.py) --
+  // shifted ones do not: the shifted mean is within a few std of zero whatever the channel's offset.
+  float s1 = 0.f, s2 = 0.f, csh = 0.f;
+  float s1d[NPT] = {}, s2d[NPT] = {};    // the finished slots' sums: shared by the builds a tile may combine
   auto epilogue_as = [&](auto act_tag, auto mode_tag, const int j_lo, const int j_hi) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
@@ -162,8 +168,13 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
               if (use_res2) t = r2v[q][e] + t;
               t = finish(t);
               v[e] = t;
-              s1 += t;
-              s2 = fmaf(t, t, s2);
+              if ((j & 3) == 0 && q == 0 && e == 0) {  // (compile time after unrolling) first value of a slot: its shift
+                const float other = __shfl_xor(t, 32, 64);
+                csh = kg == 0 ? t : other;
+              }
+              const float dv = t - csh;
+              s1 += dv;
+              s2 = fmaf(dv, dv, s2);
             }
             *reinterpret_cast<f32x4*>(yb + yo + j * 32 + 8 * q) = v;
           }
@@ -189,10 +200,17 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
         if (use_res) t += ok ? rb[ro + (l >> d.res_shift)] : 0.f;
         if (use_res2) t = (ok ? r2b[r2o + j * 32 + 8 * q + e] : 0.f) + t;
         t = finish(t);
+        if constexpr ((j & 3) == 0 && q == 0 && e == 0) {
+          if (j >= j_lo && j < j_hi) {  // (wave-uniform) this pass starts the slot: same shift as the straight-line build takes
+            const float other = __shfl_xor(t, 32, 64);
+            csh = kg == 0 ? t : other;
+          }
+        }
         if (ok) {
           yb[yo + j * 32 + 8 * q + e] = t;
-          s1 += t;
-          s2 = fmaf(t, t, s2);
+          const float dv = t - csh;
+          s1 += dv;
+          s2 = fmaf(dv, dv, s2);
         }
         if constexpr (e == 3) asm volatile("" : "+v"(s1), "+v"(s2));
         if constexpr (idx % 64 == 63) {

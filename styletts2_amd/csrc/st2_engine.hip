@@ -814,7 +814,8 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
       d.part = part; d.part_nt = nt; d.part_cols = pc;
     }
     RUN(c, g_be.conv1d_xs(&d, c.stream));
-    if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
+    if (o.stats_out)
+      RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, y.p, y.bs, y.cs, y.C, d.part_cols, c.stream));
   } else {
     if (o.gb_seg > 0) {
       if (c.rc == 0) { st2_set_error("engine: a per-segment affine (gb_seg) needs the act_split + xs path"); c.rc = 1; }
@@ -838,7 +839,8 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
       }
     }
     RUN(c, g_be.conv1d_f16s(&d, c.stream));
-    if (o.stats_out) RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, c.stream));
+    if (o.stats_out)
+      RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, y.p, y.bs, y.cs, y.C, 128, c.stream));
   }
   c.a.off = mark;  // planes / partial sums are dead once the launches are queued (stream order protects reuse)
   if (!c.dry) st2_headroom_set_site(nullptr, -1);
@@ -1066,7 +1068,7 @@ int decoder_plan(Ctx& c, const st2_engine& e, const float* asr_p, const float* f
       float* part = c.a.f32((int64_t)B * C * nt * 2);
       RUN(c, g_be.convt_interleave_stats(Y.p, Y.bs, Y.cs, L_in + 1, e.F(g.ups_b[i]), xs_src.p, xs_src.bs, xs_src.cs,
                                          xu.p, xu.bs, xu.cs, B, C, u, pad, L_raw, reflect ? 1 : 0, part, nt, c.stream));
-      RUN(c, g_be.stats_finalize(part, B * C, nt, L_out, 1e-5f, st, c.stream));
+      RUN(c, g_be.stats_finalize(part, B * C, nt, L_out, 1e-5f, st, xu.p, xu.bs, xu.cs, C, CVT_TILE, c.stream));
       c.a.off = m;
     }
     // multi-receptive-field fusion (istftnet.py:369-375): ((r0 + r1) + r2) / n in the last convs' epilogues

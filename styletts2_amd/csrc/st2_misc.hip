@@ -99,21 +99,29 @@ __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __re
   const float* ab = add ? add + (int64_t)b * a_bs + (int64_t)co * a_cs : nullptr;
   float* ob = out + (int64_t)b * o_bs + (int64_t)co * o_cs;
   float s1 = 0.f, s2 = 0.f;
+  auto value_at = [&](int o) __attribute__((always_inline)) -> float {
+    int l = o;
+    if (reflect_left) l = (o == 0) ? 1 : o - 1;
+    const int lp = l + pad;
+    const int q = lp / stride;
+    const int r = lp - q * stride;
+    float v = cvt_tile[r * nqp + (q - q_lo)];
+    v += bj;
+    if (ab) v += ab[o];
+    return v;
+  };
+  // partial sums are taken of (v - shift), shift = the tile's first stored value (every thread recomputes it: one LDS + one
+  // global read): st2_stats_finalize reads it back from `out` -- see st2_conv_epilogue.h on why unshifted sums are not enough
+  const float shift = value_at(o0);  // o0 < L_out for every launched tile
 #pragma unroll
   for (int k = 0; k < CVT_TILE / 256; ++k) {
     const int o = o0 + k * 256 + threadIdx.x;
     if (o < L_out) {
-      int l = o;
-      if (reflect_left) l = (o == 0) ? 1 : o - 1;
-      const int lp = l + pad;
-      const int q = lp / stride;
-      const int r = lp - q * stride;
-      float v = cvt_tile[r * nqp + (q - q_lo)];
-      v += bj;
-      if (ab) v += ab[o];
+      const float v = value_at(o);
       ob[o] = v;
-      s1 += v;
-      s2 += v * v;
+      const float dv = v - shift;
+      s1 += dv;
+      s2 += dv * dv;
     }
   }
   if (part) {

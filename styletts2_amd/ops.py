@@ -284,16 +284,19 @@ def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, g
     return XsTensor(data, Cc, L, XS_HALO, xsc)
 
 
-def stats_finalize(part, L, eps=1e-5, out=None):
-    """`st2_stats_finalize`: part [B, C, nt, 2] (sum, sumsq per 128-column tile) -> stats [B, C, 2] (mean, rstd)."""
+def stats_finalize(part, y, cols=128, eps=1e-5, out=None):
+    """`st2_stats_finalize`: part [B, C, nt, 2] = per-slot (sum, sumsq) of (y - first value of the slot) written by the producer
+    of y [B, C, L] (slots of `cols` columns) -> stats [B, C, 2] (mean, rstd) of y; the finaliser reads the shifts from y."""
     lib = _lib.load()
     _chk(part, "part", 4)
+    _chk(y, "y", 3)
     B, Cc, nt, two = part.shape
-    assert two == 2 and part.is_contiguous()
+    assert two == 2 and part.is_contiguous() and y.shape[0] == B and y.shape[1] == Cc
+    L = y.shape[2]
     if out is None:
         out = torch.empty((B, Cc, 2), device=part.device, dtype=torch.float32)
-    _lib.check(lib.st2_stats_finalize(part.data_ptr(), B * Cc, nt, L, eps, out.data_ptr(), _stream()),
-               "st2_stats_finalize")
+    _lib.check(lib.st2_stats_finalize(part.data_ptr(), B * Cc, nt, L, eps, out.data_ptr(), y.data_ptr(), y.stride(0), y.stride(1),
+                                      Cc, int(cols), _stream()), "st2_stats_finalize")
     return out
 
 
@@ -331,7 +334,7 @@ def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, ou
         d.part, d.part_nt, d.part_cols = part.data_ptr(), nt, pc
     _launch_conv(lib.st2_conv1d_xs, "st2_conv1d_xs", d)
     if want_stats:
-        return out, stats_finalize(part, L_out)
+        return out, stats_finalize(part, out, cols=d.part_cols or 128)
     return out
 
 
@@ -434,7 +437,7 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
     _launch_conv(fn, fname, d)
     if want_stats:
-        return out, (stats_finalize(part, L_out) if part is not None else instnorm_stats(out))
+        return out, (stats_finalize(part, out) if part is not None else instnorm_stats(out))
     return out
 
 
@@ -537,7 +540,7 @@ def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, ref
                                               C_out, stride, pad, L_raw, 1 if reflect_left else 0, _ptr(part), nt,
                                               _stream()), "st2_convt_interleave")
     if want_stats:
-        return out, stats_finalize(part, L_out)
+        return out, stats_finalize(part, out, cols=CVT_TILE)
     return out
 
 

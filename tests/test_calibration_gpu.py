@@ -159,20 +159,31 @@ def test_calibrated_text_to_waveform_on_a_small_magnitude_checkpoint(tag):
     args = (model, sampler, tokens.to(DEV), lengths, noise.to(DEV))
     kw = dict(diffusion_steps=steps, ref_s=None if ref_s is None else ref_s.to(DEV), durations=dur,
               step_noise=step_noise.to(DEV), sine_noise=sine_noise.to(DEV))
-    rep = pipeline.calibrate(lambda: pipeline.inference(*args, **kw))
+    # the product path (one engine for the front, one for the decoder) AND the tap-point path (taps= makes every stage run on its
+    # own per-module engine, built on first use): both sets of engines are alive after the first pass and get their tables
+    rep = pipeline.calibrate(lambda: (pipeline.inference(*args, **kw), pipeline.inference(*args, taps={}, **kw)), max_passes=2)
+    rep = pipeline.calibrate(lambda: (pipeline.inference(*args, **kw), pipeline.inference(*args, taps={}, **kw)))
     assert rep["clamped_last_pass"] == 0 and rep["sites_set"] > 100
     engs = pipeline.model_engines(model, torch.device(DEV, torch.cuda.current_device()))
     assert {"front", "decoder"} <= set(engs)
     assert all(any(r["x_scale"] > 0 for r in e.calibration()) for k, e in engs.items() if k != "style")
     ops.status(clear=True)
     with ops.headroom() as h:
-        out = pipeline.inference(*args, taps=te, **kw)
+        out = pipeline.inference(*args, **kw)          # the product path
+        pipeline.inference(*args, taps=te, **kw)       # the same stages with tap points
     torch.cuda.synchronize()
     assert ops.status(clear=True) == 0
-    assert max(r["rel_err"] for r in h.rows) < 2e-7 and max(r["frac"] for r in h.rows) < 0.126
+    assert max(r["frac"] for r in h.rows) < 0.126
+    worst = sorted(h.rows, key=lambda r: -r["rel_err"])[:4]
     for k, tol in (("s_pred", 5e-5), ("asr", 5e-5), ("en", 1e-4), ("F0", 1e-4), ("N", 1e-4)):
         e = (te[k].cpu() - to[k]).abs().max().item() / max(to[k].abs().max().item(), 1e-6)
         assert e < tol, "%s rel err %g" % (k, e)
+    # the telemetry after calibration: every operand at the format's floor -- EXCEPT operands that are mostly exact zeros plus
+    # a few large entries (their few non-zero small elements carry no weight in any sum); reported if it ever fails
+    bad = [r for r in h.rows if r["rel_err"] > 2e-7]
+    assert not bad, "operands above the floor after calibration: %s" % [
+        (r["index"], r["kind"], r["pro"], r["C"], r["L"], r["x_scale"], "%.3g" % r["max_abs"], "%.2e" % r["rel_err"],
+         "%.2f" % r["sub_share"], r["site"]) for r in worst]
     ref_style = to["s_pred"][:, :128]
     if ref_s is not None:
         ref_style = 0.3 * ref_style + 0.7 * ref_s[:, :128]

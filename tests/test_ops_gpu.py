@@ -216,6 +216,47 @@ def test_conv1d_xs_epilogue_stats(B, C_in, C_out, L, ks, dil, res, monkeypatch):
     assert ((st.cpu()[..., 1] - st_ref[..., 1]).abs() / st_ref[..., 1]).max().item() < 5e-6
 
 
+@pytest.mark.parametrize("path,B,C,L", [("xs", 4, 128, 3000), ("xs", 1, 256, 1500), ("fused", 3, 64, 2100), ("fused", 2, 32, 5000),
+                                        ("interleave", 2, 64, 3001)])
+def test_epilogue_statistics_survive_offset_dominated_channels(path, B, C, L, monkeypatch):
+    """InstanceNorm statistics from the producers' per-slot partial sums on channels whose mean is 1 000 x their standard
+    deviation (a bias-dominated channel of a residual stream; found on the small-magnitude checkpoints of
+    test_calibration_gpu.py, where |mean| / std ~ 100 cost 2e-4 of rstd): the sums are taken of values SHIFTED by the slot's
+    first stored value and combined with Chan's formula, so the error stays at fp32 round-off in the units the consuming AdaIN
+    sees -- |d mean| * rstd and |d rstd| / rstd -- where E[x^2] - mean^2 from unshifted fp32 sums loses every digit."""
+    gen = torch.Generator().manual_seed(5)
+    offs = (torch.randn(1, C, 1, generator=gen).sign() * (1.0 + torch.rand(1, C, 1, generator=gen)))  # per-channel offset ~ +-1.5
+    if path == "interleave":
+        s, p = 5, 0
+        Lq = (L + s - 1) // s + 1
+        Y = torch.randn(B, s * C, Lq, generator=gen) * 1e-3
+        add = offs.expand(B, C, L).contiguous() + torch.randn(B, C, L, generator=gen) * 1e-3
+        out, st = ops.convt_interleave(g(Y), C, s, p, L, bias=None, add=g(add), want_stats=True)
+    else:
+        monkeypatch.setattr(_hooks, "conv_path", "xs" if path == "xs" else "fused")
+        ks = 7
+        x = torch.randn(B, C, L, generator=gen)
+        w = torch.randn(C, C, ks, generator=gen) / math.sqrt(C * ks) * 1e-3
+        res = offs.expand(B, C, L).contiguous()
+        wt = weights.pack_conv_f16s(w).to(DEV)
+        kw = dict(pad_left=3, bias=g(torch.zeros(C)), res=g(res), want_stats=True)
+        if path == "xs":
+            out, st = ops.conv1d_xs(ops.activate(g(x)), wt, C, ks, **kw)
+        else:
+            h = torch.randn(B, 2 * C, generator=gen) * 0.3
+            out, st = ops.conv1d(g(x), wt, C, ks, pro=ops.PRO_ADAIN_LEAKY, slope=0.2, stats=ops.instnorm_stats(g(x)), gamma=g(h)[:, :C],
+                                 beta=g(h)[:, C:], **kw)
+    torch.cuda.synchronize()
+    y = out.cpu().double()
+    mean, var = y.mean(-1), y.var(-1, unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 300.0, "the case is meant to be offset-dominated"
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    # the mean is handed on as an fp32 number (as in the reference): right to one ulp of it; rstd to fp32 round-off
+    dm = ((st.cpu()[..., 0].double() - mean).abs() / mean.abs()).max().item()
+    dr = ((st.cpu()[..., 1].double() - rstd).abs() / rstd).max().item()
+    assert dm < 1.2e-7 and dr < 1e-6, "|d mean| / |mean| = %.2e, |d rstd| / rstd = %.2e" % (dm, dr)
+
+
 @pytest.mark.parametrize("B,C,L,ks,dil,cols", [(1, 256, 5680, 7, 1, 32),     # 90 tiles of 128 x 128 on 256 CUs -> 32-column tiles
                                                 (1, 128, 28400, 7, 3, 64),    # 222 -> 64-column tiles
                                                 (1, 256, 5680, 3, 1, 32), (2, 128, 8001, 11, 5, 64),

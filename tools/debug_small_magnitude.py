@@ -52,12 +52,15 @@ def main():
     run(te)
     res["engine calibrated"] = errs(te, t64)
     dec._eng.set_calibration(None)
-    with _hooks.override(plan="python", conv_precision="f32"):
-        dec._pk = None
-        te = {}
-        run(te)
-        res["python plan, exact-fp32 convs"] = errs(te, t64)
-        dec._pk = None
+    for name, kw in (("python plan, exact-fp32 convs", dict(conv_precision="f32")),
+                     ("python plan, f16s (library routing)", dict()),
+                     ("python plan, f16s fused everywhere", dict(conv_path="fused"))):
+        with _hooks.override(plan="python", **kw):
+            dec._pk = None
+            te = {}
+            run(te)
+            res[name] = errs(te, t64)
+            dec._pk = None
     res["oracle fp32 (ATen CPU)"] = errs(to, t64)
     print("%s decoder, un-normalised stages scaled by %g: max |x - fp64 oracle| / max |fp64 oracle|" % (tag, f))
     print("%-32s" % "" + "".join("%12s" % k for k in keys))
