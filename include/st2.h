@@ -168,6 +168,10 @@ int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of t
  * the MFMAs; bitwise the same results) for AdaIN + Snake convs with k = 3, C_out <= 64 and at least 512 tiles, the one-role
  * build otherwise; 1 = one-role build always; 2 = warp-specialised for every layer it can run (k = 3 / 7 / 11, C_out <= 64). */
 void st2_conv1d_f16s_set_variant(int variant);
+/* Measurement hook (process-wide): the depth of the split-K rule -- at most `max_slices` K slices per tile (1..32), each of at
+ * least `min_chunks` input-channel chunks (1..16); out-of-range values restore the default (8, 4).  Every plan of a process sees
+ * the same rule (results stay reproducible within the process); the default is what the tests and the bench run. */
+void st2_conv1d_f16s_set_splitk(int max_slices, int min_chunks);
 /* sizeof(st2_conv_desc) as the library was compiled: lets a binding verify its struct mirror. */
 int st2_sizeof_conv_desc(void);
 
@@ -203,7 +207,8 @@ int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
 /* Columns per partial-sum slot (128, 64 or 32) the launch described by *d would use when its caller opts into the small-grid
  * builds (d.part_cols): a function of the geometry alone -- every plan gets the same answer, results are reproducible bit for
- * bit.  32 below ~100 tiles of 128 x 128, 64 up to ~600 (k = 3: ~900), 128 beyond (y is bitwise the same either way). */
+ * bit.  Launches of up to three utterances: 32 below ~100 tiles of 128 x 128, 64 up to ~600 (k = 3: ~900); 128 otherwise (y is
+ * bitwise the same either way). */
 int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats,
                        const float* y, int64_t y_bs, int32_t y_cs, int32_t C, int32_t cols, void* stream);

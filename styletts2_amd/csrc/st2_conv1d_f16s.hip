@@ -14,6 +14,11 @@ int st2f16s::g_variant = 0;
 int st2_headroom_of_fused_conv(const st2_conv_desc& d, hipStream_t s);  // st2_actsplit.hip: no-op unless st2_debug_headroom(1)
 
 extern "C" void st2_conv1d_f16s_set_variant(int v) { st2f16s::g_variant = (v == 1 || v == 2) ? v : 0; }
+int st2f16s::g_splitk_max = 8, st2f16s::g_splitk_min_chunks = 4;
+extern "C" void st2_conv1d_f16s_set_splitk(int max_slices, int min_chunks) {
+  st2f16s::g_splitk_max = max_slices >= 1 && max_slices <= 32 ? max_slices : 8;
+  st2f16s::g_splitk_min_chunks = min_chunks >= 1 && min_chunks <= 16 ? min_chunks : 4;
+}
 
 extern "C" int st2_conv1d_f16s_chunk(int ks) { return ks <= 3 ? 32 : 16; }
 

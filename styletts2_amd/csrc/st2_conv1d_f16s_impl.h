@@ -31,6 +31,10 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef st2_f32x16 f32x16;
 
+namespace st2f16s {
+extern int g_splitk_max, g_splitk_min_chunks;  // st2_conv1d_f16s_set_splitk (st2_conv1d_f16s.hip): 8 slices of >= 4 chunks by default
+}
+
 namespace {
 
 constexpr int NT = 256;
@@ -344,8 +348,8 @@ inline int ksplit_for_geometry(const st2_conv_desc& d) {
   // LibriTTS configurations (the reduction re-reads 4 x the output), with 8-16 (B = 1) an 8-way split takes the
   // long-form passage from 181 to 118 ms -- so only launches below half a round of the chip are split, up to ~256 slices
   if (nchunk < 8 || wgs >= 128) return 1;
-  int s = (int)std::min<int64_t>(8, 256 / wgs);
-  s = std::min(s, nchunk / 4);
+  int s = (int)std::min<int64_t>(st2f16s::g_splitk_max, 256 / wgs);
+  s = std::min(s, nchunk / st2f16s::g_splitk_min_chunks);
   return std::max(s, 1);
 }
 inline int pick_ksplit(const st2_conv_desc& d) {

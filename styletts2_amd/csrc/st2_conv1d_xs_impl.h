@@ -406,12 +406,15 @@ inline int rule_variant(const st2_conv_desc& d) {
 // quadruples the workgroups that share the weight stream of a k-step, so the loop gets shorter until the chip is full.
 // Measured over 50 shapes at B = 1 ... 3 (tools/xs_bench.hip, profiles/r05a_smallgrid_*, r05b_smallgrid_*): 32-column tiles
 // win below ~100 tiles of 128 (k = 7, C = 256, L = 5 680, B = 1: 55.6 -> 28.3 us; k = 3: 39.6 -> 17.5), 64-column tiles up to ~600
-// (k = 11, C = 128, L = 37 200: 75.3 -> 55.5 us; k = 3 up to ~900: 47.1 -> 27.4), 128 beyond.  A function of the geometry alone
+// (k = 11, C = 128, L = 37 200: 75.3 -> 55.5 us; k = 3 up to ~900: 47.1 -> 27.4), 128 beyond -- for launches of up to THREE
+// utterances: a batch of 8-32 short rows with the same tile count (k = 3, C = 256 ... 1024, L = 400 / 800, B = 32: the decoder
+// front of the throughput configurations) LOSES 5-20 % with the narrow tiles (every workgroup streams its row block's whole
+// weight slice, 0.4-1.6 MB there; profiles/r05g_smallgrid_b32.log), so those keep the 128-column build.  A function of the geometry alone
 // (never tuned: the partial sums' slot width follows it, and a measured choice would make the statistics box-dependent in
 // their last bits).  Callers opt in through d.part_cols (with statistics) or get it by rule (without): y is bitwise the same
 // in every build.
 inline int small_grid_cols(const st2_conv_desc& d) {
-  if (d.C_out <= 64 || d.ks < 3) return 128;
+  if (d.C_out <= 64 || d.ks < 3 || d.B > 3) return 128;
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
   if (wg128 < 100) return 32;
   return wg128 < (d.ks == 3 ? 900 : 600) ? 64 : 128;
