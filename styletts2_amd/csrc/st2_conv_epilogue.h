@@ -30,7 +30,6 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
                                                   int wm, int wn, int l31, int kg) {
   typedef st2_f32x4 f32x4;
   constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * TN * WN;
   // Interior tiles of 16-byte aligned tensors therefore store / load 16 bytes per lane and instruction -- 16 stores per
   // wave tile instead of 64 (the store tail of an MFMA kernel is bound by the number of store instructions, not by
   // their bytes: cdna_hip_programming.md T21; measured here: the epilogue cost 0.23 ms of a 1.70 ms k = 11 launch and

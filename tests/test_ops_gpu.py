@@ -257,15 +257,15 @@ def test_epilogue_statistics_survive_offset_dominated_channels(path, B, C, L, mo
     assert dm < 1.2e-7 and dr < 1e-6, "|d mean| / |mean| = %.2e, |d rstd| / rstd = %.2e" % (dm, dr)
 
 
-@pytest.mark.parametrize("B,C,L,ks,dil,cols", [(1, 256, 5680, 7, 1, 32),     # 90 tiles of 128 x 128 on 256 CUs -> 32-column tiles
-                                                (1, 128, 28400, 7, 3, 64),    # 222 -> 64-column tiles
-                                                (1, 256, 5680, 3, 1, 32), (2, 128, 8001, 11, 5, 64),
-                                                (1, 1024, 400, 3, 1, 32),     # 32 tiles, K = 3 072 deep (decoder front)
-                                                (1, 128, 40000, 7, 1, 64),    # 313 tiles: still one partial round of the chip
-                                                (4, 128, 40000, 7, 1, 128)])  # 1 252 tiles: the ordinary build
+@pytest.mark.parametrize("B,C,L,ks,dil,cols", [(1, 256, 5680, 3, 1, 32),     # 90 tiles of 128 x 128 on 256 CUs -> 32-column tiles
+                                                (1, 128, 28400, 3, 1, 64),    # 222 -> 64-column tiles
+                                                (2, 128, 8001, 3, 1, 64), (1, 1024, 400, 3, 1, 32),  # 32 tiles, K = 3 072 deep
+                                                (1, 128, 40000, 3, 1, 64),    # 313 tiles: still one partial round of the chip
+                                                (1, 256, 5680, 7, 1, 128),    # k = 7 / 11: 128-column tiles whatever the grid
+                                                (4, 128, 40000, 3, 1, 128)])  # 1 252 tiles: the ordinary build
 def test_conv1d_xs_small_grid_builds(B, C, L, ks, dil, cols, monkeypatch):
-    """Launches with fewer 128 x 128 tiles than CUs (one utterance: long-form synthesis, BASELINE.json configs[4]) run 64- /
-    32-column tiles by a rule of the geometry (st2_conv1d_xs_part_cols): the output is BITWISE that of the 128-column build
+    """k = 3 launches with few 128 x 128 tiles (one utterance: long-form synthesis, BASELINE.json configs[4]) run 64- / 32-column
+    tiles by a rule of the geometry (st2_conv1d_xs_part_cols): the output is BITWISE that of the 128-column build
     (same products in the same order per element), the InstanceNorm statistics -- partial sums per 64 / 32 columns instead of
     128 -- meet the CPU reduction of the stored tensor at the same bar, and two runs are bitwise identical."""
     from styletts2_amd import _lib
@@ -907,6 +907,38 @@ def test_lstm_coop_scratch_is_cleared_on_every_graph_replay(B, N):
         assert int(scratch[:4].view(torch.int32).item()) == 0, "replay %d: scratch[0] not cleared" % it
         assert ops.status(clear=True) == 0, "replay %d raised a status bit" % it
         assert torch.equal(Y, ref), "replay %d differs from the eager call" % it
+
+
+@pytest.mark.parametrize("mode", ["coop", "single"])
+def test_lstm_is_reproducible_next_to_one_utterance_convs_on_another_stream(mode):
+    """Canary for an open observation of round 5 (st2_conv1d_xs_impl.h `small_grid_cols`): the BiLSTM kernels returned different
+    results in 25-90 % of their calls while the k = 7 / 11 NARROW-tile conv builds ran on another queue (one 64-byte sector of a
+    W_hh load wrong for 16 lanes of one gate) -- those builds are not used.  What the product does launch next to a front's BiLSTMs
+    in the two-stream schedules of one utterance -- k = 3 convs in 32-column tiles, k = 7 / 11 convs in 128-column tiles -- must
+    leave them bit-exact."""
+    gen = torch.Generator().manual_seed(0)
+    lx = ops.activate(g(torch.randn(1, 256, 5680, generator=gen)))
+    w3 = weights.pack_conv_f16s(torch.randn(256, 256, 3, generator=gen) / 30).to(DEV)
+    w7 = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=gen) / 40).to(DEV)
+    y = torch.empty(1, 256, 5680, device=DEV)
+    G = g(torch.randn(1, 2048, 24, generator=gen))
+    whh = g(torch.randn(2, 256, 1024, generator=gen) / 16).contiguous()
+    side = torch.cuda.Stream()
+    with _hooks.override(lstm=mode):
+        ref = ops.lstm_bidir(G, whh).clone()
+        torch.cuda.synchronize()
+        for w, ks, n in ((w3, 3, 200), (w7, 7, 100)):
+            outs = []
+            side.wait_stream(torch.cuda.current_stream())
+            for _ in range(n):
+                ops.conv1d_xs(lx, w, 256, ks, pad_left=(ks - 1) // 2, out=y, want_stats=True)
+            with torch.cuda.stream(side):
+                for _ in range(30 if mode == "coop" else 10):
+                    outs.append(ops.lstm_bidir(G, whh))
+            torch.cuda.synchronize()
+            bad = sum(not torch.equal(o, ref) for o in outs)
+            assert bad == 0, "%d of %d BiLSTM calls differ next to k = %d convs" % (bad, len(outs), ks)
+    assert ops.status(clear=True) == 0
 
 
 @pytest.mark.parametrize("xch", [0, 1, 2])

@@ -16,7 +16,7 @@ g = torch.Generator().manual_seed(0)
 shapes = [(1024, 1024), (512, 1024), (1024, 512), (2048, 1024), (1024, 2048), (2304, 768), (768, 768), (2048, 768), (768, 2048), (512, 768)]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 settings = [(8, 4), (16, 2), (16, 1), (32, 1)]
-print("N = %d columns; us per launch (conv + reduction), 200 launches each" % N)
+print("N = %d columns; us per launch (conv + reduction), 4 replays of a 50-launch graph" % N)
 print("%-12s" % "M x K" + "".join("%12s" % ("%d/%d" % s) for s in settings))
 with _hooks.override(conv_path="fused"):
     for M, K in shapes:
@@ -27,13 +27,19 @@ with _hooks.override(conv_path="fused"):
         ref = None
         for mx, mc in settings:
             lib.st2_conv1d_f16s_set_splitk(mx, mc)
-            for _ in range(5):
+            for _ in range(3):
                 y = ops.conv1d(x, wt, M, 1, bias=bias)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()  # 50 launches per replay: the GPU's time, not the host's (18-23 us per eager call)
+            with torch.cuda.graph(graph):
+                for _ in range(50):
+                    y = ops.conv1d(x, wt, M, 1, bias=bias)
+            graph.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(200):
-                y = ops.conv1d(x, wt, M, 1, bias=bias)
+            for _ in range(4):
+                graph.replay()
             e1.record()
             torch.cuda.synchronize()
             if ref is None:
