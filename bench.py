@@ -343,6 +343,19 @@ def _spawned_rank(rank, world, port, argv):
     main()
 
 
+_STREAMS = {}
+
+
+def shared_stream(dev, priority):
+    """ONE second stream per (device, priority) for the whole process.  HIP multiplexes its streams onto a handful of hardware queues
+    (4 by default); every `torch.cuda.Stream()` is another stream of torch's pool, and once a process has touched more of them than
+    there are hardware queues a NEW front stream can land on the queue the decoder's stream already uses: the two then serialise --
+    the second model of a process measured two-stream 138 ms against 118 for the first (HiFi-GAN config, profiles/LAB_NOTES.md
+    round 5).  A serving process should likewise create its streams once."""
+    from styletts2_amd import ops
+    return ops.aux_stream(dev, priority)
+
+
 def _calibrate(a, model, dev, step):
     """Start-up calibration of the split-f16 operand scales (pipeline.calibrate), as a serving process runs it after loading a
     checkpoint: one pass of the workload itself with the operand telemetry on.  Returns what goes into `config.operand_scales`."""
@@ -392,7 +405,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     ref_s = ref_s.to(dev) if cfg["multispeaker"] else None
     front = None if a.eager_front else pipeline.GraphedFront(model, sampler)
     steps_d, frames = cfg["steps"], N_PHONEMES * FRAMES_PER_PHONEME
-    sched = {"single": None, "two-stream": torch.cuda.Stream(dev, priority=a.front_priority)}
+    sched = {"single": None, "two-stream": shared_stream(dev, a.front_priority)}
     active = {"name": "two-stream"}
     first_chunk = []
     if longform:
@@ -409,7 +422,8 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
                     w[-1].item()
                     first_chunk.append((time.perf_counter() - t_start) * 1e3)
             return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
-                                            overlap=True, bucket=16, on_chunk=on_chunk, front=front)[0]
+                                            overlap=True, bucket=16, on_chunk=on_chunk, front=front,
+                                            side_stream=shared_stream(dev, 0))[0]
     else:
         audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
 
@@ -692,7 +706,7 @@ def main():
         if "single" in want:
             sched["single"] = (None, None)
         if "two-stream" in want:
-            sched["two-stream"] = (None, torch.cuda.Stream(dev, priority=a.front_priority))
+            sched["two-stream"] = (None, shared_stream(dev, a.front_priority))
             if a.schedule == "auto" and a.calib_decoder_priority:
                 # the reverse assignment: the decoder's queue high, the front's normal (the front has slack: ~15 ms of
                 # latency-bound kernels per ~65 ms step)
@@ -738,7 +752,7 @@ def main():
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
                                                     on_chunk=on_chunk, front=front,
-                                                    side_stream=healthy.front if healthy is not None else None)
+                                                    side_stream=healthy.front if healthy is not None else shared_stream(dev, 0))
             return waves
     else:
         audio_s = B * AUDIO_S_PER_UTT

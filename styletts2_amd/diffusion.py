@@ -262,7 +262,7 @@ class GraphedSampler(nn.Module):
             return self.sampler(st["noise"], **kw)
 
         cur = torch.cuda.current_stream(noise.device)
-        side = torch.cuda.Stream(noise.device)
+        side = ops.aux_stream(noise.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             run()  # eager warm-up on the capture stream: weight packing, hipFuncSetAttribute, allocator warm-up

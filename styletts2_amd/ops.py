@@ -19,6 +19,22 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_AUX_STREAMS = {}
+
+
+def aux_stream(dev, priority=0):
+    """ONE auxiliary stream per (device, priority), created on first use and reused by everything that needs "a second stream"
+    (graph-capture warm-ups, the long-form front).  HIP maps its streams onto a handful of hardware queues (4 by default); a
+    process that keeps asking torch for new streams walks through torch's pool and sooner or later gets one that shares the
+    hardware queue of the stream it is meant to overlap with -- the two then serialise (measured: the second model of a process
+    138 ms two-stream against 118 for the first; profiles/LAB_NOTES.md round 5)."""
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority))
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(dev, priority=int(priority))
+    return _AUX_STREAMS[key]
+
+
 def _chk(t, name, ndim=None):
     if t is None:
         return

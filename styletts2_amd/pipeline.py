@@ -287,7 +287,7 @@ class GraphedFront:
 
         dev = tokens.device
         cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(dev)
+        side = ops.aux_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             run()  # eager warm-up on a side stream: weight packing, kernel attributes, allocator warm-up
@@ -484,7 +484,7 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         trim = 100 if multispeaker else 0
     use_streams = overlap and dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if use_streams else None
-    side = (side_stream if side_stream is not None else torch.cuda.Stream(dev)) if use_streams else None  # (a caller may
+    side = (side_stream if side_stream is not None else ops.aux_stream(dev)) if use_streams else None  # (a caller may
     #                                                  hand in a CU-masked side stream: pipeline.MaskedStreams)
     if use_streams:
         side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
