@@ -125,8 +125,9 @@ typedef struct st2_conv_desc {
   /* st2_conv1d_xs only: pre-activated, pre-split input planes written by st2_act_split (x/pro/stats/... unused) */
   const void* xs; int32_t xs_cg; int32_t xs_lp; int32_t xs_halo;
   /* st2_conv1d_xs only, optional: per-tile InstanceNorm partial sums of the STORED output,
-     part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) of (y - y[b][co][128*(l/128)]) over the 128 columns
-     of that tile (shifted by the tile's first stored value: see st2_stats_finalize) */
+     part[((b*C_out + co)*part_nt + l/128)*2 + {0,1}] = (sum, sum of squares) of (y - shift) over the 128 columns of that tile,
+     shift = the tile's first stored value y[b][co][128*(l/128)], itself stored at part[B*C_out*part_nt*2 + (b*C_out + co)*part_nt +
+     l/128]: the buffer holds B*C_out*part_nt*3 floats (see st2_stats_finalize) */
   float* part; int32_t part_nt;
   /* st2_conv1d_xs only (ABI v20): columns per partial-sum slot, 0 = 128.  A small-grid launch (fewer workgroups than CUs: one
      utterance) runs 128 x 64 or 128 x 32 tiles and emits its sums per 64 / 32 columns: the caller asks
@@ -193,10 +194,10 @@ int st2_sizeof_conv_desc(void);
  *                   epilogue also emits per-128-column partial (sum, sumsq) of the stored output so the next
  *                   layer's InstanceNorm statistics need no extra read of the tensor:
  *   st2_stats_finalize: stats[row] = (mean, 1/sqrt(var+eps)) from part[row][nt][2] (fp64, fixed order), rows = B*C.
- *                   ABI v20: the partial sums are SHIFTED -- slot i holds (sum, sum of squares) of (y - y[b][c][i * cols]) over
- *                   its columns, and the finaliser reads the shifts back from y (pointer + strides of the tensor the sums are
- *                   of, C = its channel count, cols = columns per slot: d.part_cols or 128 for the convs, 1024 for
- *                   st2_convt_interleave_stats) and combines the slots with Chan's formula.  Unshifted E[x^2] - mean^2 from fp32
+ *                   ABI v20: the partial sums are SHIFTED -- slot i holds (sum, sum of squares) of (y - shift_i) over its
+ *                   columns, shift_i = the slot's first stored value, written by the producer behind the sums (part = float2
+ *                   [rows][nt], then float [rows][nt]); the finaliser combines the slots with Chan's formula (cols = columns
+ *                   per slot: d.part_cols or 128 for the convs, 1024 for st2_convt_interleave_stats).  Unshifted E[x^2] - mean^2 from fp32
  *                   partial sums loses rstd of a channel whose mean dominates its variance (|mean| / std = 100: 1e-4 relative,
  *                   three decades above the reference's two-pass fp32 reduction).
  * Replaces the same reference call sites as st2_conv1d_f16s + st2_instnorm_stats. */
@@ -210,8 +211,7 @@ int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
  * bit.  k = 3 launches of up to three utterances: 32 below ~100 tiles of 128 x 128, 64 up to ~900; 128 otherwise (y is bitwise
  * the same either way; the k = 7 / 11 narrow builds of round 5 are not used: st2_conv1d_xs_impl.h). */
 int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
-int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats,
-                       const float* y, int64_t y_bs, int32_t y_cs, int32_t C, int32_t cols, void* stream);
+int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, int32_t cols, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *
  * y[b,co,l] = bias[co] + sum_{ci,t} w[co,ci,t] * x[b,ci, l*stride + t - pad]   (plain OIK weights)
@@ -267,7 +267,8 @@ int st2_convt_interleave(const float* phases, int64_t p_bs, int32_t p_cs, int32_
                          int32_t reflect_left, void* stream);
 
 /* Same, additionally emitting per-tile InstanceNorm partial sums of the stored output (tiles of 1024 positions):
- * part[((b*C + co)*part_nt + l/1024)*2 + {0,1}] = (sum, sum of squares) of (out - out[b][co][1024*(l/1024)]); part may be NULL.  Feed to
+ * part[((b*C + co)*part_nt + l/1024)*2 + {0,1}] = (sum, sum of squares) of (out - shift), shift = out[b][co][1024*(l/1024)] stored at
+ * part[B*C*part_nt*2 + (b*C + co)*part_nt + l/1024] (B*C*part_nt*3 floats in all); part may be NULL.  Feed to
  * st2_stats_finalize: the AdaIN that follows the up-sampling needs no pass over the tensor. */
 int st2_convt_interleave_stats(const float* phases, int64_t p_bs, int32_t p_cs, int32_t Lq,
                                const float* bias, const float* add, int64_t a_bs, int32_t a_cs,

@@ -112,8 +112,7 @@ _SIGNATURES = {
     "st2_act_split": (C.c_int, [f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                 f32p, f32p, f32p, C.c_int64, C.c_int32, C.c_int32, f32p, C.c_float, f32p, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_void_p]),
-    "st2_stats_finalize": (C.c_int, [f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, f32p, f32p, C.c_int64, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_void_p]),
+    "st2_stats_finalize": (C.c_int, [f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, f32p, C.c_int32, C.c_void_p]),
     "st2_conv1d_direct": (C.c_int, [f32p, C.c_int64, C.c_int32, f32p, f32p, f32p, C.c_int64, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p]),

@@ -117,22 +117,22 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
 }
 
 // stats[row] = (mean, rstd) from per-slot partial sums; one wave per row, fp64, fixed order.  Slot i covers columns [i * cols,
-// min((i + 1) * cols, L)) of row (b, c) and holds (sum, sum of squares) of (y - shift_i), shift_i = y[b][c][i * cols] read back
-// from the tensor (the value its producer subtracted): slot mean = shift + s1 / n, slot M2 = s2 - s1^2 / n; the row's mean is the
-// weighted mean of the slot means and its M2 = sum of slot M2 + sum n_i (mean_i - mean)^2 (Chan et al.) -- two wave reductions.
+// min((i + 1) * cols, L)) of row (b, c) and holds (sum, sum of squares) of (y - shift_i); the shifts (each slot's first stored value,
+// what its producer subtracted) follow the sums in the same buffer: part = float2 [rows][nt], then float [rows][nt].  Slot mean =
+// shift + s1 / n, slot M2 = s2 - s1^2 / n; the row's mean is the weighted mean of the slot means and its M2 = sum of slot M2 + sum
+// n_i (mean_i - mean)^2 (Chan et al.) -- two wave reductions over coalesced reads.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, int rows, int nt, int L,
-                                                             float eps, float* __restrict__ stats, const float* __restrict__ y,
-                                                             int64_t y_bs, int y_cs, int C, int cols) {
+                                                             float eps, float* __restrict__ stats, int cols) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float2* p = reinterpret_cast<const float2*>(part) + (int64_t)row * nt;
-  const float* yr = y + (int64_t)(row / C) * y_bs + (int64_t)(row % C) * y_cs;
+  const float* sh = part + (int64_t)rows * nt * 2 + (int64_t)row * nt;
   const int ns = min(nt, (L + cols - 1) / cols);  // slots that hold columns
   double wsum = 0.0;
   for (int i = lane; i < ns; i += 64) {
     const int n = min(cols, L - i * cols);
-    wsum += (double)n * (double)yr[(int64_t)i * cols] + (double)p[i].x;  // n_i * mean_i
+    wsum += (double)n * (double)sh[i] + (double)p[i].x;  // n_i * mean_i
   }
   wsum = st2_wave_sum(wsum);
   const double mean = __shfl(wsum, 0, 64) / (double)L;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   for (int i = lane; i < ns; i += 64) {
     const int n = min(cols, L - i * cols);
     const double s1 = (double)p[i].x, s2 = (double)p[i].y;
-    const double mi = (double)yr[(int64_t)i * cols] + s1 / (double)n;
+    const double mi = (double)sh[i] + s1 / (double)n;
     m2 += (s2 - s1 * s1 / (double)n) + (double)n * (mi - mean) * (mi - mean);
   }
   m2 = st2_wave_sum(m2);
@@ -362,15 +362,13 @@ extern "C" int st2_debug_headroom_read(double* rows, int32_t cap_rows) {
   return n;
 }
 
-extern "C" int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats,
-                                  const float* y, int64_t y_bs, int32_t y_cs, int32_t C, int32_t cols, void* stream) {
-  ST2_REQUIRE(part && stats && y && rows > 0 && nt > 0 && L > 0, "st2_stats_finalize: bad arguments");
-  ST2_REQUIRE(C > 0 && rows % C == 0, "st2_stats_finalize: rows=%d is not a multiple of C=%d", rows, C);
+extern "C" int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, int32_t cols,
+                                  void* stream) {
+  ST2_REQUIRE(part && stats && rows > 0 && nt > 0 && L > 0, "st2_stats_finalize: bad arguments");
   ST2_REQUIRE(cols > 0 && (int64_t)nt * cols >= L, "st2_stats_finalize: %d slots of %d columns do not cover L=%d", nt, cols, L);
   ST2_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, "st2_stats_finalize: part must be 8-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3(st2_cdiv(rows, 4)), dim3(256), 0, s, part, rows, nt, L, eps, stats, y, y_bs, y_cs,
-                     C, cols);
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(st2_cdiv(rows, 4)), dim3(256), 0, s, part, rows, nt, L, eps, stats, cols);
   ST2_CHECK_LAUNCH("st2_stats_finalize");
   return 0;
 }

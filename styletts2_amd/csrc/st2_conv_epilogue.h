@@ -80,12 +80,12 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
   // rare combinations take the generic build (MODE < 0: run-time flags, per-element bounds, 4-byte accesses).
   // Running (sum, sum of squares) of this lane's stored values of the current slot, SHIFTED by the slot's first stored value
   // (csh = y[b][co][first column of the slot]: lane kg = 0 owns it, its kg = 1 partner gets it by one cross-lane move): the
-  // finaliser reads that value back from y and combines the slots with Chan's formula in fp64.  Unshifted sums lose the variance
+  // finaliser gets that value with the sums and combines the slots with Chan's formula in fp64.  Unshifted sums lose the variance
   // of a channel whose mean dominates it -- E[x^2] - mean^2 with fp32 partial sums: |mean| / std = 100 (a bias-dominated channel of
   // a residual stream) costs 1e-8 x 1e4 = 1e-4 of rstd, three decades above fp32 (round 5, tools/debug_stats_precision.py) --
   // shifted ones do not: the shifted mean is within a few std of zero whatever the channel's offset.
   float s1 = 0.f, s2 = 0.f, csh = 0.f;
-  float s1d[NPT] = {}, s2d[NPT] = {};    // the finished slots' sums: shared by the builds a tile may combine
+  float s1d[NPT] = {}, s2d[NPT] = {}, cshd[NPT] = {};  // the finished slots' sums and shifts: shared by the builds a tile may combine
   auto epilogue_as = [&](auto act_tag, auto mode_tag, const int j_lo, const int j_hi) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;  // < 0: generic; else bit 0 = res, bit 1 = res2, bit 2 = div
@@ -184,6 +184,7 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
           if ((j & 3) == 3) {
             s1d[j >> 2] = s1;
             s2d[j >> 2] = s2;
+            cshd[j >> 2] = csh;
             s1 = 0.f;
             s2 = 0.f;
           }
@@ -216,6 +217,7 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
           if (j >= j_lo && j < j_hi) {  // this pass owns the end of the 128-column group (wave-uniform)
             s1d[j >> 2] = s1;
             s2d[j >> 2] = s2;
+            cshd[j >> 2] = csh;
             s1 = 0.f;
             s2 = 0.f;
           }
@@ -232,12 +234,16 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
         if (j_last >= 0 && (j_last & 3) != 3 && (j_last >> 2) == t) {
           s1d[t] = s1;
           s2d[t] = s2;
+          cshd[t] = csh;
         }
         const float a1 = s1d[t] + __shfl_xor(s1d[t], 32, 64);
         const float a2 = s2d[t] + __shfl_xor(s2d[t], 32, 64);
         if (kg == 0 && co < d.C_out && ptile + t < d.part_nt) {
-          float2* pp = reinterpret_cast<float2*>(d.part) + ((int64_t)b * d.C_out + co) * d.part_nt + ptile + t;
-          *pp = make_float2(a1, a2);
+          const int64_t slot = ((int64_t)b * d.C_out + co) * d.part_nt + ptile + t;
+          reinterpret_cast<float2*>(d.part)[slot] = make_float2(a1, a2);
+          // the slot's shift rides behind the sums ([B * C_out][part_nt] floats): the finaliser reads it from there, coalesced,
+          // instead of gathering one value per slot from y (59 us per launch on the 240 000-sample HiFi-GAN rows, r05n)
+          d.part[(int64_t)d.B * d.C_out * d.part_nt * 2 + slot] = cshd[t];
         }
       }
     }

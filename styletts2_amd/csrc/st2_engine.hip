@@ -810,12 +810,12 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
       // small grids (one utterance) run 64 / 32-column tiles, one partial-sum slot per tile: the library says which
       const int pc = st2_conv1d_xs_part_cols(&d);
       nt = (y.L + pc - 1) / pc;
-      part = c.a.f32((int64_t)y.B * y.C * nt * 2);
+      part = c.a.f32((int64_t)y.B * y.C * nt * 3);  // (sum, sum of squares) per slot, then the slots' shifts
       d.part = part; d.part_nt = nt; d.part_cols = pc;
     }
     RUN(c, g_be.conv1d_xs(&d, c.stream));
     if (o.stats_out)
-      RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, y.p, y.bs, y.cs, y.C, d.part_cols, c.stream));
+      RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, d.part_cols, c.stream));
   } else {
     if (o.gb_seg > 0) {
       if (c.rc == 0) { st2_set_error("engine: a per-segment affine (gb_seg) needs the act_split + xs path"); c.rc = 1; }
@@ -829,7 +829,7 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     int nt = 0;
     if (o.stats_out) {  // statistics of the output from the epilogue's per-tile partial sums
       nt = (y.L + 127) / 128;
-      part = c.a.f32((int64_t)y.B * y.C * nt * 2);
+      part = c.a.f32((int64_t)y.B * y.C * nt * 3);
       d.part = part; d.part_nt = nt;
     } else {
       const int64_t skb = st2_conv1d_f16s_splitk_bytes(&d);  // skinny layers run split-K inside the workspace
@@ -840,7 +840,7 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
     }
     RUN(c, g_be.conv1d_f16s(&d, c.stream));
     if (o.stats_out)
-      RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, y.p, y.bs, y.cs, y.C, 128, c.stream));
+      RUN(c, g_be.stats_finalize(part, y.B * y.C, nt, y.L, 1e-5f, o.stats_out, 128, c.stream));
   }
   c.a.off = mark;  // planes / partial sums are dead once the launches are queued (stream order protects reuse)
   if (!c.dry) st2_headroom_set_site(nullptr, -1);
@@ -1065,10 +1065,10 @@ int decoder_plan(Ctx& c, const st2_engine& e, const float* asr_p, const float* f
       if (ist) { o.pro = ST2_PRO_LEAKY; o.slope = 0.1f; } else { o.pro = ST2_PRO_SNAKE; o.alpha = e.F(g.alphas[i]); }
       conv(c, e, x, g.ups_wt[i], Y, o);
       const int nt = (L_out + CVT_TILE - 1) / CVT_TILE;
-      float* part = c.a.f32((int64_t)B * C * nt * 2);
+      float* part = c.a.f32((int64_t)B * C * nt * 3);
       RUN(c, g_be.convt_interleave_stats(Y.p, Y.bs, Y.cs, L_in + 1, e.F(g.ups_b[i]), xs_src.p, xs_src.bs, xs_src.cs,
                                          xu.p, xu.bs, xu.cs, B, C, u, pad, L_raw, reflect ? 1 : 0, part, nt, c.stream));
-      RUN(c, g_be.stats_finalize(part, B * C, nt, L_out, 1e-5f, st, xu.p, xu.bs, xu.cs, C, CVT_TILE, c.stream));
+      RUN(c, g_be.stats_finalize(part, B * C, nt, L_out, 1e-5f, st, CVT_TILE, c.stream));
       c.a.off = m;
     }
     // multi-receptive-field fusion (istftnet.py:369-375): ((r0 + r1) + r2) / n in the last convs' epilogues

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __re
     return v;
   };
   // partial sums are taken of (v - shift), shift = the tile's first stored value (every thread recomputes it: one LDS + one
-  // global read): st2_stats_finalize reads it back from `out` -- see st2_conv_epilogue.h on why unshifted sums are not enough
+  // global read): stored behind the sums for st2_stats_finalize -- see st2_conv_epilogue.h on why unshifted sums are not enough
   const float shift = value_at(o0);  // o0 < L_out for every launched tile
 #pragma unroll
   for (int k = 0; k < CVT_TILE / 256; ++k) {
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __re
     if (threadIdx.x == 0) {
       const float t1 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
       const float t2 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-      reinterpret_cast<float2*>(part)[((int64_t)b * C + co) * part_nt + blockIdx.x] = make_float2(t1, t2);
+      const int64_t slot = ((int64_t)b * C + co) * part_nt + blockIdx.x;
+      reinterpret_cast<float2*>(part)[slot] = make_float2(t1, t2);
+      part[(int64_t)gridDim.z * C * part_nt * 2 + slot] = shift;  // [B * C][part_nt] shifts behind the sums (st2_stats_finalize)
     }
   }
 }

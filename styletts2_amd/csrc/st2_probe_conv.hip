@@ -94,7 +94,7 @@ extern "C" int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, 
   float* y = (float*)alloc((size_t)y_elems * 4);
   float* res = (float*)alloc((size_t)y_elems * 4);
   float* vec = (float*)alloc((size_t)C * 2 * 4);
-  float* part = (float*)alloc((size_t)B * C * nt * 2 * 4);
+  float* part = (float*)alloc((size_t)B * C * nt * 3 * 4);  // sums + shifts (st2.h: d.part)
   const int64_t n_wg = (int64_t)((L + 255) / 256) * (C / 128) * B;
   unsigned long long* tl = (unsigned long long*)alloc((size_t)n_wg * 64);
   if (!xs || !wq || !y || !res || !vec || !part || !tl) {

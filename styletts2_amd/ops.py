@@ -300,19 +300,20 @@ def activate(x, *, pro=PRO_NONE, slope=0.0, stats=None, gamma=None, beta=None, g
     return XsTensor(data, Cc, L, XS_HALO, xsc)
 
 
-def stats_finalize(part, y, cols=128, eps=1e-5, out=None):
-    """`st2_stats_finalize`: part [B, C, nt, 2] = per-slot (sum, sumsq) of (y - first value of the slot) written by the producer
-    of y [B, C, L] (slots of `cols` columns) -> stats [B, C, 2] (mean, rstd) of y; the finaliser reads the shifts from y."""
+def new_part(B, C, nt, device):
+    """Buffer for a producer's per-slot partial sums: float2 [B * C][nt] (sum, sum of squares of y - shift) followed by float
+    [B * C][nt] (the shifts = each slot's first stored value), include/st2.h `d.part`."""
+    return torch.empty((B * C * nt * 3,), device=device, dtype=torch.float32)
+
+
+def stats_finalize(part, B, C, nt, L, cols=128, eps=1e-5, out=None):
+    """`st2_stats_finalize`: the buffer of `new_part` filled by the producer of a [B, C, L] tensor (slots of `cols` columns) ->
+    stats [B, C, 2] (mean, rstd) of that tensor."""
     lib = _lib.load()
-    _chk(part, "part", 4)
-    _chk(y, "y", 3)
-    B, Cc, nt, two = part.shape
-    assert two == 2 and part.is_contiguous() and y.shape[0] == B and y.shape[1] == Cc
-    L = y.shape[2]
+    assert part.numel() >= B * C * nt * 3 and part.is_contiguous()
     if out is None:
-        out = torch.empty((B, Cc, 2), device=part.device, dtype=torch.float32)
-    _lib.check(lib.st2_stats_finalize(part.data_ptr(), B * Cc, nt, L, eps, out.data_ptr(), y.data_ptr(), y.stride(0), y.stride(1),
-                                      Cc, int(cols), _stream()), "st2_stats_finalize")
+        out = torch.empty((B, C, 2), device=part.device, dtype=torch.float32)
+    _lib.check(lib.st2_stats_finalize(part.data_ptr(), B * C, nt, L, eps, out.data_ptr(), int(cols), _stream()), "st2_stats_finalize")
     return out
 
 
@@ -346,11 +347,11 @@ def conv1d_xs(xs, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, ou
         # 128, or 64 / 32 on a small grid (same rule as the C++ plans: bitwise); `part_cols=128` (tests) keeps the 128-column tiles
         pc = part_cols or lib.st2_conv1d_xs_part_cols(C.byref(d))
         nt = (L_out + pc - 1) // pc
-        part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
+        part = new_part(B, C_out, nt, out.device)
         d.part, d.part_nt, d.part_cols = part.data_ptr(), nt, pc
     _launch_conv(lib.st2_conv1d_xs, "st2_conv1d_xs", d)
     if want_stats:
-        return out, stats_finalize(part, out, cols=d.part_cols or 128)
+        return out, stats_finalize(part, B, C_out, nt, L_out, cols=d.part_cols or 128)
     return out
 
 
@@ -444,7 +445,7 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
     ws = part = None
     if split and want_stats:  # InstanceNorm statistics of the output from the epilogue's per-tile partial sums
         nt = (L_out + 127) // 128
-        part = torch.empty((B, C_out, nt, 2), device=out.device, dtype=torch.float32)
+        part = new_part(B, C_out, nt, out.device)
         d.part, d.part_nt = part.data_ptr(), nt
     elif split:  # skinny layers (few workgroups, long k loop) run split-K: the library says how much workspace it wants
         nb = lib.st2_conv1d_f16s_splitk_bytes(C.byref(d))
@@ -453,7 +454,7 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
     _launch_conv(fn, fname, d)
     if want_stats:
-        return out, (stats_finalize(part, out) if part is not None else instnorm_stats(out))
+        return out, (stats_finalize(part, B, C_out, nt, L_out) if part is not None else instnorm_stats(out))
     return out
 
 
@@ -550,13 +551,13 @@ def convt_interleave(phases, C_out, stride, pad, L_raw, bias=None, add=None, ref
     part, nt = None, 0
     if want_stats:
         nt = (L_out + CVT_TILE - 1) // CVT_TILE
-        part = torch.empty((B, C_out, nt, 2), device=phases.device, dtype=torch.float32)
+        part = new_part(B, C_out, nt, phases.device)
     _lib.check(lib.st2_convt_interleave_stats(phases.data_ptr(), phases.stride(0), phases.stride(1), Lq, _ptr(bias),
                                               _ptr(add), a_bs, a_cs, out.data_ptr(), out.stride(0), out.stride(1), B,
                                               C_out, stride, pad, L_raw, 1 if reflect_left else 0, _ptr(part), nt,
                                               _stream()), "st2_convt_interleave")
     if want_stats:
-        return out, stats_finalize(part, out, cols=CVT_TILE)
+        return out, stats_finalize(part, B, C_out, nt, L_out, cols=CVT_TILE)
     return out
 
 

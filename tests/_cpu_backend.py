@@ -111,8 +111,7 @@ def _emit_part(d, y):
         nt = d.part_nt
         cols = getattr(d, "part_cols", 0) or 128  # st2.h: 0 = 128 columns per slot; 64 / 32 on small grids (xs only)
         assert cols in (128, 64, 32) and nt * cols >= d.L_out
-        part = _t(d.part, (d.B, d.C_out, nt, 2), (d.C_out * nt * 2, nt * 2, 2, 1))
-        _shifted_sums(part, y, nt, cols)
+        _shifted_sums(d.part, y, nt, cols)
 
 
 def act_split(x, x_bs, x_cs, B, Cc, L, pro, slope, stats, gamma, beta, gb_bs, gb_seg, gamma_plus_one, alpha, x_scale, xs,
@@ -146,10 +145,12 @@ def conv1d_xs(dp, stream):
     return 0
 
 
-def _shifted_sums(part, y, nt, cols):
-    """The contract of every `part` output (st2.h, ABI v20): slot i of row (b, c) = (sum, sum of squares) of (y - y[b, c, i * cols])
-    over the slot's columns -- shifted by the slot's first stored value, which the finaliser reads back from y."""
+def _shifted_sums(part_ptr, y, nt, cols):
+    """The contract of every `part` output (st2.h, ABI v20): float2 [B * C][nt] = (sum, sum of squares) of (y - shift) over each
+    slot's columns, then float [B * C][nt] = the shifts, each slot's first stored value y[b, c, i * cols]."""
     B, Cc, L = y.shape
+    part = _t(part_ptr, (B, Cc, nt, 2), (Cc * nt * 2, nt * 2, 2, 1))
+    shifts = _t(part_ptr + B * Cc * nt * 2 * 4, (B, Cc, nt), (Cc * nt, nt, 1))
     yd = torch.zeros(B, Cc, nt * cols, dtype=torch.float64)
     yd[:, :, :L] = y.double()
     yd = yd.reshape(B, Cc, nt, cols)
@@ -157,24 +158,23 @@ def _shifted_sums(part, y, nt, cols):
     dv = (yd - yd[..., :1]) * valid
     part[..., 0] = dv.sum(-1).float()
     part[..., 1] = (dv * dv).sum(-1).float()
+    shifts.copy_(yd[..., 0].float())
 
 
-def stats_finalize(part, rows, nt, L, eps, stats, y, y_bs, y_cs, Cc, cols, stream):
+def stats_finalize(part, rows, nt, L, eps, stats, cols, stream):
     """Chan's combination of the shifted per-slot sums in fp64 (== stats_finalize_kernel)."""
-    B = rows // Cc
-    p = _t(part, (B, Cc, nt, 2), (Cc * nt * 2, nt * 2, 2, 1)).double()
-    yv = _ncl(y, y_bs, y_cs, B, Cc, L).double()
+    p = _t(part, (rows, nt, 2), (nt * 2, 2, 1)).double()
+    shift = _t(part + rows * nt * 2 * 4, (rows, nt), (nt, 1)).double()
     ns = min(nt, -(-L // cols))
-    shift = yv[:, :, 0:ns * cols:cols]                                    # [B, C, ns]
     n = torch.tensor([min(cols, L - i * cols) for i in range(ns)], dtype=torch.float64)
-    s1, s2 = p[:, :, :ns, 0], p[:, :, :ns, 1]
-    mi = shift + s1 / n
+    s1, s2 = p[:, :ns, 0], p[:, :ns, 1]
+    mi = shift[:, :ns] + s1 / n
     mean = (n * mi).sum(-1) / L
     m2 = ((s2 - s1 * s1 / n) + n * (mi - mean.unsqueeze(-1)) ** 2).sum(-1)
     var = (m2 / L).clamp(min=0.0)
-    st = _t(stats, (B, Cc, 2), (Cc * 2, 2, 1))
-    st[..., 0] = mean.float()
-    st[..., 1] = (1.0 / torch.sqrt(var + eps)).float()
+    st = _t(stats, (rows, 2), (2, 1))
+    st[:, 0] = mean.float()
+    st[:, 1] = (1.0 / torch.sqrt(var + eps)).float()
     return 0
 
 
@@ -211,8 +211,7 @@ def convt_interleave_stats(ph, p_bs, p_cs, Lq, bias, add, a_bs, a_cs, out, o_bs,
                             bias=_t(bias, (Cc,), (1,)), add=_ncl(add, a_bs, a_cs, B, Cc, L_out) if add else None,
                             reflect_left=bool(reflect_left), out=_ncl(out, o_bs, o_cs, B, Cc, L_out))
     if part:
-        pt = _t(part, (B, Cc, part_nt, 2), (Cc * part_nt * 2, part_nt * 2, 2, 1))
-        _shifted_sums(pt, y, part_nt, 1024)
+        _shifted_sums(part, y, part_nt, 1024)
     return 0
 
 

@@ -118,7 +118,7 @@ PY
       done ;;
     stats_cfg)  # rocprofv3 --kernel-trace --stats of a short single-stream bench of another configuration
       cfgname=${arg:-libritts_hifigan}
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$cfgname -o bench -- python $OLDPWD/bench.py --config $cfgname --steps 4 --warmup 2 --schedule single --calib-steps 0 --no-cpu-baseline --no-box-probe --cu-mask off > $OLDPWD/$OUT/${TAG}_bench_${cfgname}_single.json 2> $OLDPWD/$OUT/${TAG}_bench_${cfgname}_single.err )
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$cfgname -o bench -- python $OLDPWD/bench.py --config $cfgname --steps 4 --warmup 2 --schedule single --calib-steps 0 --calibrate off --other-configs off --no-cpu-baseline --no-box-probe --cu-mask off > $OLDPWD/$OUT/${TAG}_bench_${cfgname}_single.json 2> $OLDPWD/$OUT/${TAG}_bench_${cfgname}_single.err )
       f=$(find /tmp/prof_${TAG}_$cfgname -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${cfgname}_kernel_stats.csv && head -22 $f
       rm -rf /tmp/prof_${TAG}_$cfgname ;;
     smallgrid)  # tools/bin/xs_bench_0 at B = 1 (long-form / latency shapes): 128- / 64- / 32-column tiles and the geometry rule

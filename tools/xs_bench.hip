@@ -69,8 +69,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&bias, co_pad * 4));
   CK(hipMalloc(&rsc, co_pad * 4));
   int nt = (L + 31) / 32;  // allocated for the narrowest slot width; set per build below
-  CK(hipMalloc(&part, (int64_t)B * C * nt * 2 * 4));
-  CK(hipMemset(part, 0, (int64_t)B * C * nt * 2 * 4));
+  CK(hipMalloc(&part, (int64_t)B * C * nt * 3 * 4));  // (sum, sumsq) per slot, then the slots' shifts
+  CK(hipMemset(part, 0, (int64_t)B * C * nt * 3 * 4));
   // hi plane ~ values in +-24 (x8 scaled activations), lo plane ~ 2^-11 of that; weights hi in +-16384, lo in +-8
   const int64_t plane = (int64_t)cg * Lp * 8;
   for (int b = 0; b < B; ++b) {
@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
          "(%.3f of 833)\n", ST2_XS_ABLATE, ks, dil, C, L, B, use_res, use_stats, ms, flop / ms / 1e9,
          flop / ms / 1e9 / (2500.0 / 3));
   {  // FNV-1a over the bits of the valid part of y and of the partial sums: builds that claim bitwise equality print the same
-    std::vector<float> hy((size_t)B * C * pitch), hp((size_t)B * C * nt * 2);
+    std::vector<float> hy((size_t)B * C * pitch), hp((size_t)B * C * nt * 3);  // sums, then shifts
     CK(hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost));
     unsigned long long hsh = 1469598103934665603ull;
@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
     printf("checksum_y %016llx\n", hsh);
     if (use_stats) {
       double s1 = 0, s2 = 0;
-      for (size_t i = 0; i + 1 < hp.size(); i += 2) { s1 += hp[i]; s2 += hp[i + 1]; }
+      for (size_t i = 0; i + 1 < (size_t)B * C * nt * 2; i += 2) { s1 += hp[i]; s2 += hp[i + 1]; }
       for (float v : hp) mix(v);
       printf("partial sums: total %.9g / %.9g over %d slots per row\n", s1, s2, nt);
     }
