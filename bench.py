@@ -423,7 +423,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
                     first_chunk.append((time.perf_counter() - t_start) * 1e3)
             return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
                                             overlap=True, bucket=16, on_chunk=on_chunk, front=front,
-                                            side_stream=shared_stream(dev, 0))[0]
+                                            side_stream=shared_stream(dev, 0), front_batch=a.longform_front_batch)[0]
     else:
         audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
 
@@ -473,6 +473,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     if longform:
         res["first_chunk_latency_ms"] = round(min(first_chunk), 2) if first_chunk else None
         res["sentences"] = LONGFORM_SENTENCES
+        res["front_batch"] = a.longform_front_batch or len(LONGFORM_SENTENCES)
     del model, sampler, front
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -548,6 +549,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech")
+    ap.add_argument("--longform-front-batch", type=int, default=0,
+                    help="long-form: sentences per front call (0 = the whole passage in one batched front, 1 = sentence by "
+                         "sentence as the notebooks' loop; identical waveforms, pipeline.synthesize_long)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", choices=["auto", "single", "two-stream", "partitioned"], default="auto",
                     help="how consecutive steps share the GPU: `single` = everything on one stream; `two-stream` = front "
@@ -751,7 +755,7 @@ def main():
             with torch.cuda.stream(healthy.main if healthy is not None else torch.cuda.current_stream(dev)):
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
-                                                    on_chunk=on_chunk, front=front,
+                                                    on_chunk=on_chunk, front=front, front_batch=a.longform_front_batch,
                                                     side_stream=healthy.front if healthy is not None else shared_stream(dev, 0))
             return waves
     else:
@@ -959,6 +963,10 @@ def main():
         if longform:
             res["metric"] = "audio-seconds/sec (RTF^-1) end-to-end, long-form streaming passage"
             res["config"]["sentences"] = LONGFORM_SENTENCES
+            # sentences per front call: the passage is sequential in its 256-float style vector only, so the sentences' text
+            # encoder / PL-BERT / diffusion / duration stages run as one right-padded batch with the carry-over as a row scan
+            # (pipeline.synthesize_long front_batch; 1 = the notebooks' sentence-by-sentence schedule, same waveforms)
+            res["config"]["front_batch"] = a.longform_front_batch or len(LONGFORM_SENTENCES)
             res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
                                                        "min": min(first_chunk_ms) if first_chunk_ms else None}
             res["scaling"] = "weak"  # replicas only: a passage is sequential in its style vector

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 20
+#define ST2_ABI_VERSION 21
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -600,6 +600,10 @@ int st2_bert_forward(st2_engine* e, const int64_t* tokens, const int32_t* length
  * mixing, the duration encoder and (when `durations` is given) the duration head.
  *   s_pred  = sampler(noise, embedding = bert, features = ref_s)            [B][2*style_dim]
  *   s_pred  = t * s_prev + (1 - t) * s_pred                                 when s_prev != NULL
+ *             (carry != 0: the B rows are CONSECUTIVE SENTENCES of one passage and row k's s_prev is row k-1's mixed s_pred_out;
+ *             row 0 takes `s_prev` [1][2*style_dim] or nothing.  The passage is sequential in this vector only, so its text
+ *             encoder / PL-BERT / sampler / duration stages run as ONE right-padded batch and the carry-over as a row scan
+ *             of elementwise kernels between them: every row equals the sentence-by-sentence LFinference loop's)
  *   ref | s = s_pred[:, :style_dim] | s_pred[:, style_dim:]
  *   ref     = alpha * ref + (1 - alpha) * ref_s[:, :style_dim];  s = beta * s + (1 - beta) * ref_s[:, style_dim:]   (ref_s)
  * All pointers are device memory; NULL = absent where marked optional.  Needs every weight group of bits 1-4 finalized.
@@ -624,6 +628,7 @@ typedef struct st2_front_args {
   float* ref;                /* out [B][style_dim]  acoustic style (the decoder's `s`) */
   float* s_pred_out;         /* out [B][2*style_dim] = ref | s after mixing (the next sentence's s_prev), or NULL */
   int64_t* durations;        /* out [B][N], or NULL when the caller supplies its own durations */
+  int32_t carry;             /* != 0: rows = consecutive sentences, style carried from row k-1 to row k (see above); ABI v21 */
 } st2_front_args;
 int st2_sizeof_front_args(void);
 int64_t st2_front_workspace_bytes(st2_engine* e, const st2_front_args* a);

@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 HEADROOM_COLS, CALIBRATION_COLS = 12, 5  # st2.h ST2_HEADROOM_COLS / ST2_CALIBRATION_COLS
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -78,7 +78,7 @@ class FrontArgs(C.Structure):
                 ("embedding_scale", C.c_double), ("table", C.POINTER(C.c_double)), ("sigma0", C.c_double),
                 ("alpha", C.c_double), ("beta", C.c_double), ("t", C.c_double),
                 ("t_en", C.c_void_p), ("d_cm", C.c_void_p), ("s", C.c_void_p), ("ref", C.c_void_p),
-                ("s_pred_out", C.c_void_p), ("durations", C.c_void_p)]
+                ("s_pred_out", C.c_void_p), ("durations", C.c_void_p), ("carry", C.c_int32)]
 
 
 class DecoderTaps(C.Structure):

@@ -1698,6 +1698,38 @@ int front_plan(Ctx& c, const st2_engine& e, const st2_front_args& a) {
       c.rc = 1;
     c.a.off = mark;
   }
+  if (a.carry && B > 1) {
+    // the rows are consecutive sentences of one passage: row k mixes with row k-1's MIXED style (the loop of LFinference,
+    // Demo/Inference_LibriTTS.ipynb LFinference: `s_prev = s_pred` after the speaker mixing).  A scan of the same elementwise
+    // launches the one-sentence call makes, on one row each: bitwise the sentence-by-sentence results, ~5 us per launch.
+    float* mixed = a.s_pred_out ? a.s_pred_out : c.a.f32(n);
+    float* m = c.a.f32(C2);
+    float* ma = c.a.f32(C2);
+    float* mb = c.a.f32(C2);
+    for (int k = 0; k < B; ++k) {
+      const float* prev = k ? mixed + (int64_t)(k - 1) * C2 : a.s_prev;
+      const float* cur = sp + (int64_t)k * C2;
+      if (prev) {
+        RUN(c, g_be.axpbypcz(prev, (float)a.t, cur, (float)(1.0 - a.t), nullptr, 0.f, m, C2, c.stream));
+        cur = m;
+      }
+      const float* ref_src = cur;
+      const float* s_src = cur + sty;
+      if (a.ref_s) {
+        const float* rs = a.ref_s + (int64_t)k * C2;
+        RUN(c, g_be.axpbypcz(cur, (float)a.alpha, rs, (float)(1.0 - a.alpha), nullptr, 0.f, ma, C2, c.stream));
+        RUN(c, g_be.axpbypcz(cur, (float)a.beta, rs, (float)(1.0 - a.beta), nullptr, 0.f, mb, C2, c.stream));
+        ref_src = ma;
+        s_src = mb + sty;
+      }
+      RUN(c, g_be.copy_ncl(ref_src, C2, sty, mixed + (int64_t)k * C2, C2, sty, 1, 1, sty, c.stream));
+      RUN(c, g_be.copy_ncl(s_src, C2, sty, mixed + (int64_t)k * C2 + sty, C2, sty, 1, 1, sty, c.stream));
+    }
+    RUN(c, g_be.copy_ncl(mixed, C2, sty, a.ref, sty, sty, B, 1, sty, c.stream));
+    RUN(c, g_be.copy_ncl(mixed + sty, C2, sty, a.s, sty, sty, B, 1, sty, c.stream));
+    duration_plan(c, e, D, a.s, a.lengths, B, N, a.tail, a.d_cm, a.durations);
+    return c.rc;
+  }
   const float* cur = sp;
   if (a.s_prev) {  // LFinference: convex combination of the previous and the current style
     float* m = c.a.f32(n);

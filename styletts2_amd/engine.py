@@ -264,11 +264,12 @@ class Engine:
 
     # -- the whole front (tokens -> t_en, d, s, ref, durations) ---------------------------------------------------------------
     def front_forward(self, tokens, noise, step_noise, table, sigma0, *, lengths=None, ref_s=None, s_prev=None,
-                      embedding_scale=1.0, alpha=0.3, beta=0.7, t=0.7, predict=True, tail=0):
+                      embedding_scale=1.0, alpha=0.3, beta=0.7, t=0.7, predict=True, tail=0, carry=False):
         """One `st2_front_forward` call (== pipeline._front_core): tokens int64 [B, N], noise [B, 1, 256] or [B, 256],
         step_noise [steps-1, B, 1, 256]; (table, sigma0) = DiffusionSampler.step_table(steps).  Returns a dict with t_en
         [B, dim_in, N], d_cm [B, d_hid + sty, N], s, ref [B, sty], s_pred [B, 2 sty] (ref | s) and durations int64 [B, N]
-        (None unless `predict`)."""
+        (None unless `predict`).  `carry`: the rows are consecutive sentences of one passage, row k's style is mixed with row
+        k-1's mixed style (`s_prev` [1, 2 sty] or None feeds row 0): st2.h st2_front_args.carry."""
         cfg = self.cfg
         B, N = tokens.shape
         dev = tokens.device
@@ -278,6 +279,7 @@ class Engine:
         tokens = tokens.long().contiguous()
         noise, step_noise, ref_s, s_prev = f(noise), f(step_noise), f(ref_s), f(s_prev)
         assert noise.numel() == B * C2 and step_noise.numel() == (steps - 1) * B * C2 and len(table) == (steps - 1) * 11
+        assert s_prev is None or s_prev.numel() == (C2 if carry else B * C2)
         if lengths is not None:
             lengths = lengths.to(torch.int32).contiguous()
             assert lengths.device == dev and lengths.numel() == B
@@ -291,7 +293,7 @@ class Engine:
                            ref_s=ptr(ref_s), s_prev=ptr(s_prev), B=B, N=N, steps=steps, tail=int(tail),
                            embedding_scale=float(embedding_scale), table=tab, sigma0=float(sigma0), alpha=float(alpha),
                            beta=float(beta), t=float(t), t_en=ptr(out["t_en"]), d_cm=ptr(out["d_cm"]), s=ptr(out["s"]),
-                           ref=ptr(out["ref"]), s_pred_out=ptr(out["s_pred"]), durations=ptr(out["durations"]))
+                           ref=ptr(out["ref"]), s_pred_out=ptr(out["s_pred"]), durations=ptr(out["durations"]), carry=int(bool(carry)))
         nbytes = self.lib.st2_front_workspace_bytes(self.h, C.byref(a))
         if nbytes <= 0:
             raise _lib.St2Error("st2_front_workspace_bytes failed (a weight group is not finalized?)")

@@ -156,11 +156,15 @@ def _front_engine(model, dev):
 
 
 def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_noise, ref_s, s_prev, *, diffusion_steps,
-                embedding_scale, alpha, beta, t, predict, lj_tail, taps=None):
+                embedding_scale, alpha, beta, t, predict, lj_tail, carry=False, taps=None):
     """The device-only part of the front: text encoder, PL-BERT, style diffusion, style mixing, duration encoder and
     (when `predict`) the duration head.  No host read of device data, no host -> device copy, no random draw: every
     input is a device tensor (`lengths_dev` int32 [B] for a right-padded batch, else None and `lengths_host` decides on
-    the host), so the whole function is legal under stream capture (`GraphedFront`)."""
+    the host), so the whole function is legal under stream capture (`GraphedFront`).
+
+    `carry`: the B rows are consecutive sentences of ONE passage; row k's sampled style is mixed with row k-1's mixed style
+    (`s_prev` [1, 256] or None feeds row 0) -- LFinference's loop as a row scan between the batched sampler and the batched
+    duration stages (st2.h st2_front_args.carry)."""
     dev = tokens.device
     B, N = tokens.shape
     if _engine_path(dev, taps):  # ONE C-ABI call: st2_front_forward (csrc/st2_engine.hip front_plan)
@@ -173,7 +177,7 @@ def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_n
         table, sigma0 = smp.step_table(diffusion_steps)
         o = _front_engine(model, dev).front_forward(tokens, noise, step_noise, table, sigma0, lengths=lengths_dev, ref_s=ref_s,
                                                     s_prev=s_prev, embedding_scale=embedding_scale, alpha=alpha, beta=beta,
-                                                    t=t, predict=predict, tail=5 if lj_tail else 0)
+                                                    t=t, predict=predict, tail=5 if lj_tail else 0, carry=carry)
         return dict(t_en=o["t_en"], d=o["d_cm"].transpose(1, 2), s=o["s"], ref=o["ref"], durations=o["durations"],
                     s_mixed=o["s_pred"])  # [B, 2 sty] = (ref | s), written by the plan: no torch.cat on the product path
     if lengths_dev is not None:  # mask built on the device; the modules take the device copy (text.py _device_lengths)
@@ -193,13 +197,25 @@ def _front_core(model, sampler, tokens, lengths_host, lengths_dev, noise, step_n
     s_pred = sampler(noise, **kw).squeeze(1)                                          # [B, 256]
     if taps is not None:
         taps["s_pred"] = s_pred
-    if s_prev is not None:
-        s_pred = t * s_prev + (1 - t) * s_pred  # convex combination of previous and current style
-    s = s_pred[:, 128:]
-    ref = s_pred[:, :128]
-    if ref_s is not None:
-        ref = alpha * ref + (1 - alpha) * ref_s[:, :128]
-        s = beta * s + (1 - beta) * ref_s[:, 128:]
+    def mix(sp, prev, rs):
+        if prev is not None:
+            sp = t * prev + (1 - t) * sp  # convex combination of previous and current style
+        s, ref = sp[:, 128:], sp[:, :128]
+        if rs is not None:
+            ref = alpha * ref + (1 - alpha) * rs[:, :128]
+            s = beta * s + (1 - beta) * rs[:, 128:]
+        return s, ref
+
+    if carry and B > 1:  # row scan: sentence k mixes with sentence k-1's MIXED style
+        rows, prev = [], s_prev
+        for k in range(B):
+            s_k, ref_k = mix(s_pred[k:k + 1], prev, None if ref_s is None else ref_s[k:k + 1])
+            prev = torch.cat([ref_k, s_k], dim=-1)
+            rows.append(prev)
+        mixed = torch.cat(rows, dim=0)
+        s, ref = mixed[:, 128:], mixed[:, :128]
+    else:
+        s, ref = mix(s_pred, s_prev, ref_s)
     s, ref = s.contiguous(), ref.contiguous()
     d = model.predictor.text_encoder(d_en, s, len_arg, text_mask)                    # [B, N, 640]
     dur = predict_durations(model, d, lj_tail=lj_tail, input_lengths=len_arg) if predict else None
@@ -258,7 +274,7 @@ class GraphedFront:
             step_noise = torch.randn((steps - 1, B, 1, noise.shape[-1]), device=dev, dtype=torch.float32)
         key = (dev.index, B, N, steps, float(kw["embedding_scale"]), ref_s is not None, s_prev is not None,
                lengths_dev is not None, bool(kw["predict"]), bool(kw["lj_tail"]), float(kw["alpha"]), float(kw["beta"]),
-               float(kw["t"]))
+               float(kw["t"]), bool(kw.get("carry", False)))
         g = self._graphs.get(key)
         if g is not None and (g["gen"] != self._generation() or self._stale(g, dev)):  # packed weights were rebuilt
             self._graphs.clear()
@@ -306,7 +322,7 @@ class GraphedFront:
 @torch.no_grad()
 def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
             ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, lj_tail=None, s_prev=None, t=0.7,
-            taps=None, allow_ragged=False, total_frames=None, lengths_dev=None, front=None):
+            taps=None, allow_ragged=False, total_frames=None, lengths_dev=None, front=None, carry=False, group_events=False):
     """Everything in front of the decoder: text encoder, PL-BERT, style diffusion, style mixing, duration and
     prosody prediction, alignment expansion.  Returns the decoder's inputs {asr, F0, N, ref} plus the mixed style
     vector `s_pred` [B, 256] (what LFinference hands to the next sentence) and the durations.
@@ -326,7 +342,11 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     synthesises batch after batch keeps its forced durations on the device.
 
     `front` (a `GraphedFront`): the device-only part (`_front_core`) is replayed from a hipGraph instead of being issued
-    kernel by kernel."""
+    kernel by kernel.
+
+    `carry`: the rows are consecutive sentences of one passage (`_front_core`); `s_prev` is then [1, 256] or None.
+    `group_events`: every entry of `groups` also carries `ready`, an event recorded on the current stream behind that group's
+    last kernel (a consumer on another stream starts on group 0 while the later groups are still being expanded)."""
     dev = tokens.device
     B, N = tokens.shape
     ops.check_status() if dev.type == "cuda" else None  # device-side conditions raised by the previous call's kernels
@@ -345,7 +365,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     if noise is None:
         noise = torch.randn(B, 1, 256, device=dev)
     ckw = dict(diffusion_steps=diffusion_steps, embedding_scale=embedding_scale, alpha=alpha, beta=beta, t=t,
-               predict=durations is None, lj_tail=lj_tail)
+               predict=durations is None, lj_tail=lj_tail, carry=bool(carry))
     if front is not None and dev.type == "cuda" and taps is None:
         f = front(tokens, input_lengths, lengths_dev, noise, step_noise, ref_s, s_prev, **ckw)
     else:
@@ -374,7 +394,12 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     def expand(idx):
         """Alignment expansion + prosody for the utterances `idx` (all of one frame count T)."""
         T = int(tot[idx[0]])
-        sel = (lambda v: v) if len(idx) == B else (lambda v: v[torch.as_tensor(idx, device=dev)])
+        if len(idx) == B:
+            sel = lambda v: v
+        elif idx == list(range(idx[0], idx[0] + len(idx))):  # consecutive utterances: a view, no index tensor (whose pageable
+            sel = lambda v: v[idx[0]:idx[0] + len(idx)]      # host -> device copy would stall the host behind the stream)
+        else:
+            sel = lambda v: v[torch.as_tensor(idx, device=dev)]
         dur = sel(durations)
         # hifigan: one-frame right shift, Demo/Inference_LibriTTS.ipynb:306-319
         if _engine_path(dev, taps):  # alignment expansion + F0Ntrain as ONE C-ABI call (st2_prosody_forward)
@@ -386,7 +411,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
         F0_pred, N_pred = model.predictor.F0Ntrain(en, sel(s))
         return dict(asr=asr, F0=F0_pred, N=N_pred, ref=sel(ref), en=en)
 
-    if len(set(tot)) == 1:
+    if len(set(tot)) == 1 and not group_events:
         g = expand(list(range(B)))
         if taps is not None:
             taps.update(F0=g["F0"], N=g["N"], asr=g["asr"], en=g["en"])
@@ -398,7 +423,13 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
     groups = {}
     for b, T in enumerate(tot):
         groups.setdefault(int(T), []).append(b)
-    out["groups"] = [(idx, expand(idx)) for _, idx in sorted(groups.items())]
+    out["groups"] = []
+    for idx in sorted(groups.values(), key=lambda v: v[0]):  # in the order of each group's first utterance
+        g = expand(idx)
+        if group_events and dev.type == "cuda":
+            g["ready"] = torch.cuda.Event()
+            g["ready"].record(torch.cuda.current_stream(dev))
+        out["groups"].append((idx, g))
     return out
 
 
@@ -459,7 +490,7 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
 @torch.no_grad()
 def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, t=0.7, diffusion_steps=5,
                     embedding_scale=1.0, noises=None, step_noises=None, sine_noises=None, durations=None, trim=None,
-                    overlap=True, on_chunk=None, bucket=0, front=None, side_stream=None):
+                    overlap=True, on_chunk=None, bucket=0, front=None, side_stream=None, front_batch=1):
     """Long-form synthesis (BASELINE.json configs[4]; Demo/Inference_LibriTTS.ipynb LFinference + its driver loop,
     Demo/Inference_LJSpeech.ipynb "Long-form generation"): `sentences` is a list of token tensors [N_i] (id 0
     prepended); each sentence is synthesised with the previous sentence's mixed style carried over
@@ -470,8 +501,16 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     diffusion, duration / prosody prediction; its one host sync is the predicted frame count) is issued on a side
     stream while the decoder + vocoder of sentence k (>= 2/3 of the sentence's time) still occupies the main stream;
     an event hands the decoder inputs over.  Returns (list of waveforms [600*T_i - trim], final style [1, 256]);
-    `on_chunk(k, wave)` is called per sentence for streaming consumers.  `trim` samples are dropped from every
-    sentence's end as the notebooks do ("weird pulse at the end of the model": 100 multi-speaker, 0 single-speaker).
+    `on_chunk(k, wave)` is called per sentence, in sentence order, for streaming consumers.  `trim` samples are dropped from
+    every sentence's end as the notebooks do ("weird pulse at the end of the model": 100 multi-speaker, 0 single-speaker).
+
+    `front_batch`: how many consecutive sentences share ONE front call.  1 = the notebooks' schedule, sentence by sentence
+    (lowest time to the first waveform).  0 / None = the whole passage, n = groups of n: the sentences' text encoder, PL-BERT,
+    style diffusion and duration stages run as one right-padded batch (pad tokens masked everywhere: every row is the
+    sentence's own un-padded result) with the style carry-over as a row scan in between (`_front_core(carry=True)`) -- a
+    100-token sentence alone leaves its ~1 500 token GEMMs and BiLSTM steps latency-bound, ten of them fill the same
+    launches.  The alignment expansion / prosody predictor and the decoder still run per sentence (their InstanceNorm
+    spans the utterance), in sentence order, each waiting only for its own inputs.
 
     `bucket` > 0: every sentence's token row is right-padded to a multiple of `bucket` (the pad tokens are masked
     everywhere: packed-sequence BiLSTMs, key-padded attention, length-aware mean -- results are those of the un-padded
@@ -488,50 +527,65 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     #                                                  hand in a CU-masked side stream: pipeline.MaskedStreams)
     if use_streams:
         side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
-    # per-sentence inputs are prepared (padded to the bucket, moved to the device) BEFORE the streaming loop: a pageable
+    K = len(sentences)
+    fb = K if not front_batch else max(1, min(int(front_batch), K))
+    # per-call inputs are prepared (padded, stacked, moved to the device) BEFORE the streaming loop: a pageable
     # host -> device copy inside it would block the host until the issuing stream has drained
     prepped = []
-    for k, tok in enumerate(sentences):
-        n = tok.numel()
-        tokens = tok.reshape(1, -1)
-        dur_k = durations[k].reshape(1, -1).long() if durations is not None else None
-        lengths = None
-        if bucket and n % bucket:
-            npad = (n + bucket - 1) // bucket * bucket
-            tokens = torch.nn.functional.pad(tokens, (0, npad - n))  # token id 0 = pad (text_utils / ipynb:277)
-            lengths = torch.LongTensor([n])
-            if dur_k is not None:
-                dur_k = torch.nn.functional.pad(dur_k, (0, npad - n))  # pad tokens get no frames
-        frames = int(dur_k.sum()) if dur_k is not None and not dur_k.is_cuda else None
-        prepped.append((tokens.to(dev), lengths, None if dur_k is None else dur_k.to(dev), frames,
-                        None if lengths is None else lengths.to(torch.int32).to(dev)))
-    s_prev, waves = None, []
-    for k in range(len(sentences)):
-        tokens, lengths, dur_k, frames, lens_dev = prepped[k]
-        noise = noises[k] if noises is not None else None
-        kw = dict(input_lengths=lengths, noise=noise, diffusion_steps=diffusion_steps, embedding_scale=embedding_scale,
-                  ref_s=ref_s, alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
-                  step_noise=step_noises[k] if step_noises is not None else None, durations=dur_k,
-                  total_frames=frames, lengths_dev=lens_dev, front=front)
+    for i in range(0, K, fb):
+        ids = list(range(i, min(i + fb, K)))
+        ns = [sentences[k].numel() for k in ids]
+        npad = max(ns)
+        if bucket and npad % bucket:
+            npad = (npad + bucket - 1) // bucket * bucket
+        tokens = torch.zeros((len(ids), npad), dtype=sentences[i].dtype, device=dev)  # token id 0 = pad (text_utils / ipynb:277)
+        for j, k in enumerate(ids):
+            tokens[j, :ns[j]] = sentences[k].reshape(-1)
+        ragged = any(n != npad for n in ns)
+        lengths = torch.LongTensor(ns) if ragged else None
+        dur, frames = None, None
+        if durations is not None:
+            rows = [durations[k].reshape(-1).long() for k in ids]
+            if not rows[0].is_cuda:
+                frames = [int(r.sum()) for r in rows]
+            dur = torch.zeros((len(ids), npad), dtype=torch.long, device=dev)  # pad tokens get no frames
+            for j, r in enumerate(rows):
+                dur[j, :ns[j]] = r.to(dev)
+        cat = lambda seq, dim: None if seq is None else torch.cat([seq[k] for k in ids], dim=dim)
+        prepped.append(dict(ids=ids, tokens=tokens, lengths=lengths, dur=dur, frames=frames,
+                            lens_dev=None if lengths is None else lengths.to(torch.int32).to(dev),
+                            noise=cat(noises, 0), step_noise=cat(step_noises, 1),
+                            ref_s=None if ref_s is None else ref_s.reshape(1, -1).expand(len(ids), -1).contiguous()))
+    s_prev, waves, emitted = None, [None] * K, 0
+    for q in prepped:
+        ids = q["ids"]
+        kw = dict(input_lengths=q["lengths"], noise=q["noise"], diffusion_steps=diffusion_steps,
+                  embedding_scale=embedding_scale, ref_s=q["ref_s"], alpha=alpha, beta=beta, lj_tail=False, s_prev=s_prev, t=t,
+                  step_noise=q["step_noise"], durations=q["dur"], total_frames=q["frames"], lengths_dev=q["lens_dev"],
+                  front=front, carry=len(ids) > 1, allow_ragged=True, group_events=use_streams and len(ids) > 1)
         if use_streams:
             with torch.cuda.stream(side):
-                p = prepare(model, sampler, tokens, **kw)
+                p = prepare(model, sampler, q["tokens"], **kw)
                 ready = torch.cuda.Event()
                 ready.record(side)
-            main.wait_event(ready)
-            for v in (p["asr"], p["F0"], p["N"], p["ref"]):
-                v.record_stream(main)  # allocated on the side stream, consumed on the main stream
         else:
-            p = prepare(model, sampler, tokens, **kw)
-        s_prev = p["s_pred"]
-        wave = model.decoder(p["asr"], p["F0"], p["N"], p["ref"],
-                             noise=sine_noises[k] if sine_noises is not None else None)
-        wave = wave.reshape(-1)
-        if trim:
-            wave = wave[:-trim]
-        waves.append(wave)
-        if on_chunk is not None:
-            on_chunk(k, wave)
+            p = prepare(model, sampler, q["tokens"], **kw)
+        s_prev = p["s_pred"][-1:]
+        groups = p["groups"] if "groups" in p else [(list(range(len(ids))), p)]
+        for idx, g in groups:  # one decoder call per distinct frame count, in the order of each group's first sentence
+            if use_streams:
+                main.wait_event(g.get("ready", ready))
+                for v in (g["asr"], g["F0"], g["N"], g["ref"]):
+                    v.record_stream(main)  # allocated on the side stream, consumed on the main stream
+            sn = None if sine_noises is None else torch.cat([sine_noises[ids[j]] for j in idx], dim=0)
+            w = model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=sn)
+            for j, b in enumerate(idx):
+                wave = w[j].reshape(-1)
+                waves[ids[b]] = wave[:-trim] if trim else wave
+            while emitted < K and waves[emitted] is not None:
+                if on_chunk is not None:
+                    on_chunk(emitted, waves[emitted])
+                emitted += 1
     return waves, s_prev
 
 

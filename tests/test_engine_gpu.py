@@ -264,6 +264,7 @@ def test_front_plan_engine_matches_python_front(tag, ragged, carry):
             outs[mode] = pipeline._front_core(model, sampler, tokens, lengths, lens_dev, noise, step_noise, ref_s, s_prev, **kw)
     torch.cuda.synchronize()
     p, e = outs["python"], outs["engine"]
+    outs_plain_s = e["s"].clone()
     for k in ("t_en", "d", "s", "ref"):
         diff = float((p[k] - e[k]).abs().max())
         print("%s: max |diff| = %.3e of %.3e" % (k, diff, float(p[k].abs().max())))
@@ -271,3 +272,24 @@ def test_front_plan_engine_matches_python_front(tag, ragged, carry):
     for k in ("d", "s", "ref"):
         assert _close(e[k], p[k], 5e-5), k
     assert torch.equal(p["durations"], e["durations"])
+    # rows as consecutive sentences of one passage (st2_front_args.carry): the scan in the C++ plan against the scan of torch
+    # ops in the Python front, and against the engine's own sentence-by-sentence calls handing the vector over
+    first = None if s_prev is None else s_prev[:1]
+    outs = {}
+    for mode in ("python", "engine"):
+        with _hooks.override(plan=mode):
+            outs[mode] = pipeline._front_core(model, sampler, tokens, lengths, lens_dev, noise, step_noise, ref_s, first, carry=True,
+                                              **kw)
+    p, e = outs["python"], outs["engine"]
+    for k in ("d", "s", "ref"):
+        assert _close(e[k], p[k], 5e-5), k
+    assert torch.equal(p["durations"], e["durations"])
+    prev = first
+    for b in range(B):
+        one = pipeline._front_core(model, sampler, tokens[b:b + 1], lengths[b:b + 1], None if lens_dev is None else lens_dev[b:b + 1],
+                                   noise[b:b + 1], step_noise[:, b:b + 1], None if ref_s is None else ref_s[b:b + 1], prev, **kw)
+        prev = one["s_mixed"]
+        assert _close(e["s_mixed"][b:b + 1], prev, 5e-5), b
+        dd = (e["durations"][b:b + 1] - one["durations"]).abs()  # (a rounding tie of the duration head may flip one token)
+        assert int(dd.max()) <= 1 and int((dd > 0).sum()) <= 1, b
+    assert not _close(e["s"][1:], outs_plain_s[1:], 1e-3)  # the scan did mix rows 1.. with their predecessors

@@ -246,6 +246,23 @@ def test_long_form_streaming_matches_oracle_and_sequential(tag):
         assert w.shape == r.shape and bool(torch.isfinite(w).all())
         if man["config"]["decoder"]["type"] == "hifigan":
             assert rms(w.cpu() - r) < WAVE_RMS_TOL
+    # front_batch: the sentences' fronts as ONE right-padded batch (0 = the whole passage, 3 = groups of three handing the
+    # vector from call to call), style carry-over as a row scan: the sentence-by-sentence results, in sentence order
+    got = {}
+    for fb, ov in ((0, True), (0, False), (3, True)):
+        order_f = []
+        waves_f, style_f = pipeline.synthesize_long(model, sampler, d(sentences), overlap=ov, front_batch=fb,
+                                                    on_chunk=lambda k, w: order_f.append(k), **kw)
+        torch.cuda.synchronize()
+        got[(fb, ov)] = (waves_f, style_f)
+        assert order_f == list(range(len(lens))), (fb, ov, order_f)
+        assert (style_f - style).abs().max().item() < 5e-5 * max(1.0, style.abs().max().item()), (fb, ov)
+        for w, r in zip(waves_f, ref_waves):
+            assert w.shape == r.shape and bool(torch.isfinite(w).all())
+            if man["config"]["decoder"]["type"] == "hifigan":
+                assert rms(w.cpu() - r) < WAVE_RMS_TOL, (fb, ov)
+    assert torch.equal(got[(0, True)][1], got[(0, False)][1])
+    assert all(torch.equal(x, y) for x, y in zip(got[(0, True)][0], got[(0, False)][0]))  # overlapped == sequential, bitwise
 
 
 def test_two_stream_inference_is_bitwise_the_single_stream_result():
@@ -328,3 +345,15 @@ def test_graphed_front_is_bitwise_the_eager_front(tag, predict):
     torch.cuda.synchronize()
     assert torch.equal(s_r, s_e)
     assert all(front._graphs[k] is not old_graphs.get(k) for k in front._graphs)
+    # the whole passage through one graphed front call (one more signature: batch of 5, carried rows)
+    if predict:
+        torch.manual_seed(0)
+    n_graphs = len(front._graphs)
+    w_b, s_b = pipeline.synthesize_long(model, sampler, d(sentences), overlap=True, front=front, front_batch=0, **kw)
+    w_b2, s_b2 = pipeline.synthesize_long(model, sampler, d(sentences), overlap=True, front=front, front_batch=0, **kw)
+    torch.cuda.synchronize()
+    assert len(front._graphs) == n_graphs + 1
+    assert (s_b - s_e).abs().max().item() < 5e-5 * max(1.0, s_e.abs().max().item()) and torch.equal(s_b, s_b2)
+    assert [w.shape for w in w_b] == [w.shape for w in w_e]
+    if not predict:
+        assert all(torch.equal(x, y) for x, y in zip(w_b, w_b2))
