@@ -423,7 +423,8 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
                     first_chunk.append((time.perf_counter() - t_start) * 1e3)
             return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
                                             overlap=True, bucket=16, on_chunk=on_chunk, front=front,
-                                            side_stream=shared_stream(dev, 0), front_batch=a.longform_front_batch)[0]
+                                            side_stream=shared_stream(dev, 0), front_batch=a.longform_front_batch,
+                                            decode_streams=a.longform_decode_streams)[0]
     else:
         audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
 
@@ -474,6 +475,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
         res["first_chunk_latency_ms"] = round(min(first_chunk), 2) if first_chunk else None
         res["sentences"] = LONGFORM_SENTENCES
         res["front_batch"] = a.longform_front_batch or len(LONGFORM_SENTENCES)
+        res["decode_streams"] = a.longform_decode_streams
     del model, sampler, front
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -549,6 +551,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech")
+    ap.add_argument("--longform-decode-streams", type=int, default=2,
+                    help="long-form: streams the per-sentence decoder calls are dealt onto (1 = the caller's stream)")
     ap.add_argument("--longform-front-batch", type=int, default=0,
                     help="long-form: sentences per front call (0 = the whole passage in one batched front, 1 = sentence by "
                          "sentence as the notebooks' loop; identical waveforms, pipeline.synthesize_long)")
@@ -756,6 +760,7 @@ def main():
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
                                                     on_chunk=on_chunk, front=front, front_batch=a.longform_front_batch,
+                                                    decode_streams=a.longform_decode_streams,
                                                     side_stream=healthy.front if healthy is not None else shared_stream(dev, 0))
             return waves
     else:
@@ -967,6 +972,7 @@ def main():
             # encoder / PL-BERT / diffusion / duration stages run as one right-padded batch with the carry-over as a row scan
             # (pipeline.synthesize_long front_batch; 1 = the notebooks' sentence-by-sentence schedule, same waveforms)
             res["config"]["front_batch"] = a.longform_front_batch or len(LONGFORM_SENTENCES)
+            res["config"]["decode_streams"] = a.longform_decode_streams  # independent sentences' decoders on that many streams
             res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
                                                        "min": min(first_chunk_ms) if first_chunk_ms else None}
             res["scaling"] = "weak"  # replicas only: a passage is sequential in its style vector

@@ -22,14 +22,15 @@ def _stream():
 _AUX_STREAMS = {}
 
 
-def aux_stream(dev, priority=0):
-    """ONE auxiliary stream per (device, priority), created on first use and reused by everything that needs "a second stream"
+def aux_stream(dev, priority=0, index=0):
+    """ONE auxiliary stream per (device, priority, index), created on first use and reused by everything that needs "a second stream"
     (graph-capture warm-ups, the long-form front).  HIP maps its streams onto a handful of hardware queues (4 by default); a
     process that keeps asking torch for new streams walks through torch's pool and sooner or later gets one that shares the
     hardware queue of the stream it is meant to overlap with -- the two then serialise (measured: the second model of a process
-    138 ms two-stream against 118 for the first; profiles/LAB_NOTES.md round 5)."""
+    138 ms two-stream against 118 for the first; profiles/LAB_NOTES.md round 5).  `index` > 0: further streams of the same kind
+    (the long-form decoders of independent sentences, pipeline.synthesize_long decode_streams)."""
     dev = torch.device(dev)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority), int(index))
     if key not in _AUX_STREAMS:
         _AUX_STREAMS[key] = torch.cuda.Stream(dev, priority=int(priority))
     return _AUX_STREAMS[key]

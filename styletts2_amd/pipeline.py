@@ -490,7 +490,7 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
 @torch.no_grad()
 def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, t=0.7, diffusion_steps=5,
                     embedding_scale=1.0, noises=None, step_noises=None, sine_noises=None, durations=None, trim=None,
-                    overlap=True, on_chunk=None, bucket=0, front=None, side_stream=None, front_batch=1):
+                    overlap=True, on_chunk=None, bucket=0, front=None, side_stream=None, front_batch=1, decode_streams=1):
     """Long-form synthesis (BASELINE.json configs[4]; Demo/Inference_LibriTTS.ipynb LFinference + its driver loop,
     Demo/Inference_LJSpeech.ipynb "Long-form generation"): `sentences` is a list of token tensors [N_i] (id 0
     prepended); each sentence is synthesised with the previous sentence's mixed style carried over
@@ -511,6 +511,12 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     100-token sentence alone leaves its ~1 500 token GEMMs and BiLSTM steps latency-bound, ten of them fill the same
     launches.  The alignment expansion / prosody predictor and the decoder still run per sentence (their InstanceNorm
     spans the utterance), in sentence order, each waiting only for its own inputs.
+
+    `decode_streams` > 1 (with `overlap`): the decoder calls are dealt round-robin onto that many auxiliary streams instead
+    of the caller's.  One sentence's decoder is ~400 launches whose grids cover a fraction of the chip (2 x 23 tiles for 256
+    CUs); with a batched front the next sentences' inputs are ready long before, so independent sentences' decoders fill each
+    other's idle CUs.  The caller's stream waits for sentence k's decoder before `on_chunk(k, ...)` and for all of them before
+    the call returns: the waveforms are ordered on the caller's stream exactly as before.
 
     `bucket` > 0: every sentence's token row is right-padded to a multiple of `bucket` (the pad tokens are masked
     everywhere: packed-sequence BiLSTMs, key-padded attention, length-aware mean -- results are those of the un-padded
@@ -556,7 +562,12 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
                             lens_dev=None if lengths is None else lengths.to(torch.int32).to(dev),
                             noise=cat(noises, 0), step_noise=cat(step_noises, 1),
                             ref_s=None if ref_s is None else ref_s.reshape(1, -1).expand(len(ids), -1).contiguous()))
-    s_prev, waves, emitted = None, [None] * K, 0
+    dec = []
+    if use_streams and decode_streams and int(decode_streams) > 1:
+        dec = [ops.aux_stream(dev, 0, index=i + 1) for i in range(int(decode_streams))]
+        for ds in dec:
+            ds.wait_stream(main)
+    s_prev, waves, emitted, n_dec, done = None, [None] * K, 0, 0, {}
     for q in prepped:
         ids = q["ids"]
         kw = dict(input_lengths=q["lengths"], noise=q["noise"], diffusion_steps=diffusion_steps,
@@ -573,16 +584,28 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         s_prev = p["s_pred"][-1:]
         groups = p["groups"] if "groups" in p else [(list(range(len(ids))), p)]
         for idx, g in groups:  # one decoder call per distinct frame count, in the order of each group's first sentence
+            ds = dec[n_dec % len(dec)] if dec else main
+            n_dec += 1
             if use_streams:
-                main.wait_event(g.get("ready", ready))
+                ds.wait_event(g.get("ready", ready))
                 for v in (g["asr"], g["F0"], g["N"], g["ref"]):
-                    v.record_stream(main)  # allocated on the side stream, consumed on the main stream
-            sn = None if sine_noises is None else torch.cat([sine_noises[ids[j]] for j in idx], dim=0)
-            w = model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=sn)
+                    v.record_stream(ds)  # allocated on the side stream, consumed on the decoder's stream
+            stack = lambda: None if sine_noises is None else torch.cat([sine_noises[ids[j]] for j in idx], dim=0)
+            if dec:
+                with torch.cuda.stream(ds):  # (the noise rows are stacked on the stream that reads them)
+                    w = model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=stack())
+                    ev = torch.cuda.Event()
+                    ev.record(ds)
+                w.record_stream(main)  # handed to the caller's stream behind `ev`
+            else:
+                w, ev = model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=stack()), None
             for j, b in enumerate(idx):
                 wave = w[j].reshape(-1)
                 waves[ids[b]] = wave[:-trim] if trim else wave
+                done[ids[b]] = ev
             while emitted < K and waves[emitted] is not None:
+                if done[emitted] is not None:
+                    main.wait_event(done[emitted])
                 if on_chunk is not None:
                     on_chunk(emitted, waves[emitted])
                 emitted += 1

@@ -249,12 +249,12 @@ def test_long_form_streaming_matches_oracle_and_sequential(tag):
     # front_batch: the sentences' fronts as ONE right-padded batch (0 = the whole passage, 3 = groups of three handing the
     # vector from call to call), style carry-over as a row scan: the sentence-by-sentence results, in sentence order
     got = {}
-    for fb, ov in ((0, True), (0, False), (3, True)):
+    for fb, ov, nds in ((0, True, 1), (0, False, 1), (3, True, 1), (0, True, 2), (2, True, 3)):
         order_f = []
-        waves_f, style_f = pipeline.synthesize_long(model, sampler, d(sentences), overlap=ov, front_batch=fb,
+        waves_f, style_f = pipeline.synthesize_long(model, sampler, d(sentences), overlap=ov, front_batch=fb, decode_streams=nds,
                                                     on_chunk=lambda k, w: order_f.append(k), **kw)
         torch.cuda.synchronize()
-        got[(fb, ov)] = (waves_f, style_f)
+        got[(fb, ov) if nds == 1 else (fb, ov, nds)] = (waves_f, style_f)
         assert order_f == list(range(len(lens))), (fb, ov, order_f)
         assert (style_f - style).abs().max().item() < 5e-5 * max(1.0, style.abs().max().item()), (fb, ov)
         for w, r in zip(waves_f, ref_waves):
@@ -263,6 +263,8 @@ def test_long_form_streaming_matches_oracle_and_sequential(tag):
                 assert rms(w.cpu() - r) < WAVE_RMS_TOL, (fb, ov)
     assert torch.equal(got[(0, True)][1], got[(0, False)][1])
     assert all(torch.equal(x, y) for x, y in zip(got[(0, True)][0], got[(0, False)][0]))  # overlapped == sequential, bitwise
+    # independent sentences' decoders dealt onto two streams: the same waveforms, bit for bit
+    assert all(torch.equal(x, y) for x, y in zip(got[(0, True, 2)][0], got[(0, False)][0]))
 
 
 def test_two_stream_inference_is_bitwise_the_single_stream_result():
