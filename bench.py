@@ -474,7 +474,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     if longform:
         res["first_chunk_latency_ms"] = round(min(first_chunk), 2) if first_chunk else None
         res["sentences"] = LONGFORM_SENTENCES
-        res["front_batch"] = a.longform_front_batch or len(LONGFORM_SENTENCES)
+        res["front_batch"] = a.longform_front_batch
         res["decode_streams"] = a.longform_decode_streams
     del model, sampler, front
     torch.cuda.synchronize()
@@ -553,9 +553,10 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech")
     ap.add_argument("--longform-decode-streams", type=int, default=2,
                     help="long-form: streams the per-sentence decoder calls are dealt onto (1 = the caller's stream)")
-    ap.add_argument("--longform-front-batch", type=int, default=0,
+    ap.add_argument("--longform-front-batch", type=lambda v: [int(x) for x in str(v).split(",")], default=[0],
                     help="long-form: sentences per front call (0 = the whole passage in one batched front, 1 = sentence by "
-                         "sentence as the notebooks' loop; identical waveforms, pipeline.synthesize_long)")
+                         "sentence as the notebooks' loop, '2,0' = the first two, then the rest; identical waveforms, "
+                         "pipeline.synthesize_long)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", choices=["auto", "single", "two-stream", "partitioned"], default="auto",
                     help="how consecutive steps share the GPU: `single` = everything on one stream; `two-stream` = front "
@@ -971,7 +972,7 @@ def main():
             # sentences per front call: the passage is sequential in its 256-float style vector only, so the sentences' text
             # encoder / PL-BERT / diffusion / duration stages run as one right-padded batch with the carry-over as a row scan
             # (pipeline.synthesize_long front_batch; 1 = the notebooks' sentence-by-sentence schedule, same waveforms)
-            res["config"]["front_batch"] = a.longform_front_batch or len(LONGFORM_SENTENCES)
+            res["config"]["front_batch"] = a.longform_front_batch  # group sizes in turn, 0 = all that is left
             res["config"]["decode_streams"] = a.longform_decode_streams  # independent sentences' decoders on that many streams
             res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
                                                        "min": min(first_chunk_ms) if first_chunk_ms else None}

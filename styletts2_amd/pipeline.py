@@ -505,7 +505,8 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     every sentence's end as the notebooks do ("weird pulse at the end of the model": 100 multi-speaker, 0 single-speaker).
 
     `front_batch`: how many consecutive sentences share ONE front call.  1 = the notebooks' schedule, sentence by sentence
-    (lowest time to the first waveform).  0 / None = the whole passage, n = groups of n: the sentences' text encoder, PL-BERT,
+    (lowest time to the first waveform).  0 / None = the whole passage, n = groups of n, a sequence = those group sizes in turn
+    with the last one repeating ((2, 0): the first two sentences, then the rest while their decoders run): the sentences' text encoder, PL-BERT,
     style diffusion and duration stages run as one right-padded batch (pad tokens masked everywhere: every row is the
     sentence's own un-padded result) with the style carry-over as a row scan in between (`_front_core(carry=True)`) -- a
     100-token sentence alone leaves its ~1 500 token GEMMs and BiLSTM steps latency-bound, ten of them fill the same
@@ -534,12 +535,18 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     if use_streams:
         side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
     K = len(sentences)
-    fb = K if not front_batch else max(1, min(int(front_batch), K))
+    sizes = list(front_batch) if isinstance(front_batch, (list, tuple)) else [front_batch]
+    starts, i = [], 0
+    while i < K:  # chunk sizes in turn, the last one repeating; 0 / None = everything that is left
+        n = sizes[min(len(starts), len(sizes) - 1)]
+        n = K - i if not n else max(1, min(int(n), K - i))
+        starts.append((i, i + n))
+        i += n
     # per-call inputs are prepared (padded, stacked, moved to the device) BEFORE the streaming loop: a pageable
     # host -> device copy inside it would block the host until the issuing stream has drained
     prepped = []
-    for i in range(0, K, fb):
-        ids = list(range(i, min(i + fb, K)))
+    for i, i_end in starts:
+        ids = list(range(i, i_end))
         ns = [sentences[k].numel() for k in ids]
         npad = max(ns)
         if bucket and npad % bucket:
