@@ -346,6 +346,22 @@ def _spawned_rank(rank, world, port, argv):
 _STREAMS = {}
 
 
+def _calibrate_decode_streams(a, active, step, time_steps):
+    """Long-form: the independent sentences' decoders on --longform-decode-streams streams or on the caller's one, whichever is
+    faster in THIS process (whether two more streams get hardware queues of their own depends on how many the process already
+    made: `shared_stream`).  Untimed part of the warm-up; returns {label: ms per passage} for `schedules_ms_per_step`."""
+    cands = sorted({1, max(1, int(a.longform_decode_streams))})
+    calib = {}
+    for n in cands:
+        active["decode_streams"] = n
+        step()  # first use of these streams: allocator warm-up, the pipeline fills
+        step()
+        calib["decode-streams-%d" % n] = time_steps(3)
+    active["decode_streams"] = min(cands, key=lambda n: calib["decode-streams-%d" % n])
+    log("long-form decoder streams: %s -> %d" % ({k: round(v, 2) for k, v in calib.items()}, active["decode_streams"]))
+    return calib
+
+
 def shared_stream(dev, priority):
     """ONE second stream per (device, priority) for the whole process.  HIP multiplexes its streams onto a handful of hardware queues
     (4 by default); every `torch.cuda.Stream()` is another stream of torch's pool, and once a process has touched more of them than
@@ -424,7 +440,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
             return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
                                             overlap=True, bucket=16, on_chunk=on_chunk, front=front,
                                             side_stream=shared_stream(dev, 0), front_batch=a.longform_front_batch,
-                                            decode_streams=a.longform_decode_streams)[0]
+                                            decode_streams=active.get("decode_streams", 1))[0]
     else:
         audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
 
@@ -456,6 +472,8 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
             step()
             calib[nm] = time_steps(3)[0]
         active["name"] = min(calib, key=calib.get)
+    if longform:
+        calib = _calibrate_decode_streams(a, active, step, lambda n: time_steps(n)[0])
     first_chunk.clear()
     lib = _lib.load()
     lib.st2_conv_timing(1)
@@ -475,7 +493,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
         res["first_chunk_latency_ms"] = round(min(first_chunk), 2) if first_chunk else None
         res["sentences"] = LONGFORM_SENTENCES
         res["front_batch"] = a.longform_front_batch
-        res["decode_streams"] = a.longform_decode_streams
+        res["decode_streams"] = active.get("decode_streams", 1)
     del model, sampler, front
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -761,7 +779,7 @@ def main():
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
                                                     on_chunk=on_chunk, front=front, front_batch=a.longform_front_batch,
-                                                    decode_streams=a.longform_decode_streams,
+                                                    decode_streams=active.get("decode_streams", 1),
                                                     side_stream=healthy.front if healthy is not None else shared_stream(dev, 0))
             return waves
     else:
@@ -842,6 +860,8 @@ def main():
         log("schedule: %s" % active["name"])
     elif not longform:
         active["name"] = a.schedule if a.schedule != "auto" else "two-stream"
+    if longform and a.schedule != "single":
+        calib = _calibrate_decode_streams(a, active, step, time_steps)
     # The same conv launches WITHOUT the other queue's kernels on their CUs: two untimed single-stream steps with the per-launch
     # events on (reported beside the timed region's figures as `roofline.unoverlapped`; the contract's `frac` stays the one of
     # the timed region, where the front of the next batch shares the chip with the decoder's convs and stretches them).
@@ -973,7 +993,7 @@ def main():
             # encoder / PL-BERT / diffusion / duration stages run as one right-padded batch with the carry-over as a row scan
             # (pipeline.synthesize_long front_batch; 1 = the notebooks' sentence-by-sentence schedule, same waveforms)
             res["config"]["front_batch"] = a.longform_front_batch  # group sizes in turn, 0 = all that is left
-            res["config"]["decode_streams"] = a.longform_decode_streams  # independent sentences' decoders on that many streams
+            res["config"]["decode_streams"] = active.get("decode_streams", 1)  # independent sentences' decoders on that many streams
             res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
                                                        "min": min(first_chunk_ms) if first_chunk_ms else None}
             res["scaling"] = "weak"  # replicas only: a passage is sequential in its style vector
