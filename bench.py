@@ -350,15 +350,23 @@ def _calibrate_decode_streams(a, active, step, time_steps):
     """Long-form: the independent sentences' decoders on --longform-decode-streams streams or on the caller's one, whichever is
     faster in THIS process (whether two more streams get hardware queues of their own depends on how many the process already
     made: `shared_stream`).  Untimed part of the warm-up; returns {label: ms per passage} for `schedules_ms_per_step`."""
-    cands = sorted({1, max(1, int(a.longform_decode_streams))})
+    from styletts2_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = max(1, int(a.longform_decode_streams))
+    cands = {"decode-streams-1": 1}
+    if n > 1:  # n consecutive auxiliary streams starting at index 1, 2, ...: which hardware queues they land on depends on how
+        for first in range(1, 5):  # many streams the process made before -- one of the windows has queues of its own
+            cands["decode-streams-%d@%d" % (n, first)] = [ops.aux_stream(dev, 0, index=first + i) for i in range(n)]
     calib = {}
-    for n in cands:
-        active["decode_streams"] = n
+    for name, c in cands.items():
+        active["decode_streams"] = c
         step()  # first use of these streams: allocator warm-up, the pipeline fills
         step()
-        calib["decode-streams-%d" % n] = time_steps(3)
-    active["decode_streams"] = min(cands, key=lambda n: calib["decode-streams-%d" % n])
-    log("long-form decoder streams: %s -> %d" % ({k: round(v, 2) for k, v in calib.items()}, active["decode_streams"]))
+        calib[name] = time_steps(3)
+    best = min(calib, key=calib.get)
+    active["decode_streams"] = cands[best]
+    active["decode_streams_name"] = best
+    log("long-form decoder streams: %s -> %s" % ({k: round(v, 2) for k, v in calib.items()}, best))
     return calib
 
 
@@ -493,7 +501,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
         res["first_chunk_latency_ms"] = round(min(first_chunk), 2) if first_chunk else None
         res["sentences"] = LONGFORM_SENTENCES
         res["front_batch"] = a.longform_front_batch
-        res["decode_streams"] = active.get("decode_streams", 1)
+        res["decode_streams"] = active.get("decode_streams_name", "decode-streams-1")
     del model, sampler, front
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -993,7 +1001,8 @@ def main():
             # encoder / PL-BERT / diffusion / duration stages run as one right-padded batch with the carry-over as a row scan
             # (pipeline.synthesize_long front_batch; 1 = the notebooks' sentence-by-sentence schedule, same waveforms)
             res["config"]["front_batch"] = a.longform_front_batch  # group sizes in turn, 0 = all that is left
-            res["config"]["decode_streams"] = active.get("decode_streams", 1)  # independent sentences' decoders on that many streams
+            # independent sentences' decoders dealt onto that many streams (@ = index of the first auxiliary stream of the window)
+            res["config"]["decode_streams"] = active.get("decode_streams_name", "decode-streams-1")
             res["config"]["first_chunk_latency_ms"] = {"mean": sum(first_chunk_ms) / max(len(first_chunk_ms), 1),
                                                        "min": min(first_chunk_ms) if first_chunk_ms else None}
             res["scaling"] = "weak"  # replicas only: a passage is sequential in its style vector

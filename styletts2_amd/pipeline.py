@@ -517,7 +517,10 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     of the caller's.  One sentence's decoder is ~400 launches whose grids cover a fraction of the chip (2 x 23 tiles for 256
     CUs); with a batched front the next sentences' inputs are ready long before, so independent sentences' decoders fill each
     other's idle CUs.  The caller's stream waits for sentence k's decoder before `on_chunk(k, ...)` and for all of them before
-    the call returns: the waveforms are ordered on the caller's stream exactly as before.
+    the call returns: the waveforms are ordered on the caller's stream exactly as before.  A list of torch streams is used as
+    given: HIP multiplexes streams onto ~4 hardware queues in creation order, and two decoder streams that share a queue with
+    each other or with the front's stream serialise (or worse: 113 ms against 65 on one stream) -- a serving process
+    measures its candidates once at start-up, as bench.py does.
 
     `bucket` > 0: every sentence's token row is right-padded to a multiple of `bucket` (the pad tokens are masked
     everywhere: packed-sequence BiLSTMs, key-padded attention, length-aware mean -- results are those of the un-padded
@@ -570,10 +573,12 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
                             noise=cat(noises, 0), step_noise=cat(step_noises, 1),
                             ref_s=None if ref_s is None else ref_s.reshape(1, -1).expand(len(ids), -1).contiguous()))
     dec = []
-    if use_streams and decode_streams and int(decode_streams) > 1:
+    if use_streams and isinstance(decode_streams, (list, tuple)):
+        dec = list(decode_streams) if len(decode_streams) > 1 else []
+    elif use_streams and decode_streams and int(decode_streams) > 1:
         dec = [ops.aux_stream(dev, 0, index=i + 1) for i in range(int(decode_streams))]
-        for ds in dec:
-            ds.wait_stream(main)
+    for ds in dec:
+        ds.wait_stream(main)
     s_prev, waves, emitted, n_dec, done = None, [None] * K, 0, 0, {}
     for q in prepped:
         ids = q["ids"]
