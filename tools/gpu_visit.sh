@@ -18,6 +18,7 @@
 #   headroom         tools/headroom_report.py on the synthetic / trained-like / small-magnitude checkpoints (both ends of the f16 range)
 #   validate         tools/validate_checkpoint.py on the synthetic full-layout checkpoints
 #   stats_cfg:NAME   rocprofv3 --kernel-trace --stats of a short single-stream bench of configuration NAME
+#   pmc_narrow       FETCH_SIZE / WRITE_SIZE / MFMA-busy passes over tools/probe_narrow.py (fused conv, HiFi-GAN narrow stages)
 #   smallgrid        tools/bin/xs_bench_0 on the B = 1 shapes: tile width 128 / 64 / 32 columns and the library's geometry rule
 #   cmd:COMMAND      anything else (spaces as '+')
 TAG=${1:?tag}; shift
@@ -98,6 +99,12 @@ for st in "$@"; do
         python tools/pmc_summary.py /tmp/pmcd_$n 2>/dev/null | tee $OUT/${TAG}_pmc_$n.txt | head -12
       done
       python tools/pmc_summary.py --json $OUT/${TAG}_pmc_dominant.json --kernel "conv1d_xs_kernel" /tmp/pmcd_FETCH_SIZE /tmp/pmcd_WRITE_SIZE | tail -2 ;;
+    pmc_narrow)  # the same three counter passes over tools/probe_narrow.py: the fused conv on the HiFi-GAN narrow stages (C = 64 / 32) and k = 3, C = 128
+      for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        n=$(echo $ctr | tr ' ' '_')
+        ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmcn_$n -o pmc -- python $OLDPWD/tools/probe_narrow.py > $OLDPWD/$OUT/${TAG}_probe_narrow.log 2>&1 )
+        python tools/pmc_summary.py /tmp/pmcn_$n 2>/dev/null | grep -i "f16s" | tee $OUT/${TAG}_pmc_narrow_$n.txt | head -12
+      done ;;
     headroom)  # two-sided operand tables by rule / calibrated: synthetic, trained-like, small-magnitude checkpoints
       for v in "plain:" "trained:--trained-like" "small2:--trained-like+--small+1e-2" "small3:--trained-like+--small+1e-3" "libri_small2:--config+libritts+--trained-like+--small+1e-2"; do
         n=${v%%:*}; fl=$(echo ${v#*:} | tr '+' ' ')
