@@ -66,7 +66,31 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
   const int l31 = lane & 31;
   const int wm = wave / WN;
   const int wn = wave % WN;
+#ifndef ST2_F16S_DISPATCH_ORDER
+  // Workgroups are dealt to the 8 XCDs round-robin by their linear id, so in dispatch order NEIGHBOURING column tiles -- which share
+  // the tap halo, a whole 128-B line at each edge of a 1 KB row segment (counters: reads 1.25 x algorithmic at C = 64,
+  // profiles/r05w_pmc_narrow.md) -- never share an L2.  Here the column tiles one XCD receives within a row of the grid become a
+  // contiguous run: tile index = rank of (xcd, arrival) among the row's tiles.  A bijection on [0, gridDim.x) for any gridDim.x, so
+  // results are bitwise those of the dispatch order (-DST2_F16S_DISPATCH_ORDER: tools/build_f16s_xcd.sh builds that library for the
+  // A-B); measured -8 % at C = 64 / k = 7, -5 % at k = 11, -8 % at k = 3 / C = 128 with the residual (profiles/r05x_*).
+  int bx;
+  {
+    const int nx = gridDim.x;
+    const int o = (int)(((int64_t)nx * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z)) & 7);
+    const int t = blockIdx.x + o, xcd = t & 7;
+    int before = 0, first_mine = 0;
+    for (int r = 0; r < 8; ++r) {
+      const int t_first = o + ((r - o) & 7);  // first linear id of this row on XCD r
+      const int cnt = t_first < nx + o ? (nx + o - 1 - t_first) / 8 + 1 : 0;
+      if (r < xcd) before += cnt;
+      if (r == xcd) first_mine = t_first;
+    }
+    bx = before + (t - first_mine) / 8;
+  }
+  const int n0 = bx * BN;
+#else
   const int n0 = blockIdx.x * BN;
+#endif
   const int m0 = blockIdx.y * BM;
   // split-K launches (ksplit > 1): grid.z = B * ksplit, slice `ksl` accumulates the chunks [c_begin, c_end) of the input
   // channels and stores its scaled partial sums to part[ksl][b][co][l]; splitk_reduce_kernel adds the slices in a fixed
