@@ -10,8 +10,8 @@ import torch
 
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-import synth  # noqa: E402  tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root: benchdata/, oracle/
+from benchdata import synth  # noqa: E402  seeded synthetic weights / inputs (test + bench helper, not product code)
 from oracle import ref_harness as RH  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")

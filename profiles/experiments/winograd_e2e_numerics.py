@@ -20,7 +20,7 @@ import torch.nn.functional as TF
 from _util import decoder_kwargs, manifest, rms
 from oracle import st2_oracle as O
 from styletts2_amd.decoder import Decoder
-import synth
+from benchdata import synth
 
 
 def split(a):

@@ -43,7 +43,7 @@ def test_c_host_builds_against_the_header(tmp_path):
 @pytest.mark.parametrize("tag,B,T", [("ljspeech", 2, 24), ("libritts", 1, 31)])
 def test_c_host_matches_python_binding_bitwise(tmp_path, tag, B, T):
     from styletts2_amd import engine
-    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+    from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
     from styletts2_amd.decoder import Decoder
     exe = _build(tmp_path)
     dc = manifest(tag)["config"]["decoder"]
@@ -102,7 +102,7 @@ def test_c_tts_host_matches_python_bitwise(tmp_path, tag, N):
     st2_prosody_forward, st2_decoder_forward) == the same three calls through the Python binding == pipeline.inference
     (whose stages are those three calls), on the same weights, tokens and noise."""
     from styletts2_amd import engine, models, pipeline
-    import synth
+    from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
     exe = _build_tts(tmp_path)
     man = manifest(tag)
     model = models.build_model(models.recursive_munch(man["config"]), None, None, models.load_plbert(man["plbert"]))

@@ -14,7 +14,7 @@ from _util import decoder_kwargs, manifest
 from oracle import st2_oracle as O
 from styletts2_amd import _lib, engine
 from styletts2_amd.decoder import Decoder
-import synth
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 
 def test_scale_formula():

@@ -15,7 +15,7 @@ from oracle import ops_ref as R
 from oracle import st2_oracle as O
 from styletts2_amd import models, ops, pipeline
 from styletts2_amd.decoder import Decoder
-import synth
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

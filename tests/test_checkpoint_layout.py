@@ -17,7 +17,7 @@ import yaml
 
 from _util import manifest
 from styletts2_amd import models
-import synth  # benchdata/synth.py: seeded synthetic weights
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 HOT = ["bert", "bert_encoder", "predictor", "decoder", "text_encoder", "diffusion"]
 STYLE = ["predictor_encoder", "style_encoder"]

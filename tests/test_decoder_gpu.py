@@ -5,7 +5,7 @@ import torch
 
 from _util import MEL_L1_TOL, WAVE_RMS_TOL, decoder_kwargs, manifest, mel_l1, phase_err_weighted, rms
 from oracle import st2_oracle as O
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.decoder import Decoder
 
 pytestmark = pytest.mark.gpu
@@ -105,7 +105,7 @@ def test_headroom_report_on_a_trained_like_checkpoint():
     range.  On a "trained-like" synthetic checkpoint (log-normal weight-norm gains, Snake alpha log-uniform in [0.1, 10]:
     the free parameters of Modules/istftnet.py:27-62) every layer must stay inside the range -- the report and the sticky
     status word have to agree -- and the decoder must still meet the oracle at the waveform bar."""
-    import synth
+    from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
     from _util import decoder_kwargs, manifest, rms
     from oracle import st2_oracle as O
     from styletts2_amd import ops

@@ -10,7 +10,7 @@ import torch
 
 from _util import decoder_kwargs, manifest
 from styletts2_amd import _hooks, engine, models
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.decoder import Decoder
 
 pytestmark = pytest.mark.gpu

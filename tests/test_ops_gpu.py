@@ -578,7 +578,7 @@ def test_plbert_engine_matches_hf():
     from _util import manifest
     from transformers import AlbertModel
     from styletts2_amd import models
-    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+    from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
     bert = models.load_plbert(manifest("ljspeech")["plbert"]).eval()
     synth.init_synthetic_(bert, 15)
     B, N = 4, 100
@@ -833,7 +833,7 @@ def test_lstm_coop_timeout_is_recovered_in_stream(plan, monkeypatch):
     else:
         from _util import manifest
         from styletts2_amd import engine, models
-        import synth
+        from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
         man = manifest("ljspeech")
         te = models.build_model(models.recursive_munch(man["config"]), None, None, models.load_plbert(man["plbert"])).text_encoder
         synth.init_synthetic_(te, 4)

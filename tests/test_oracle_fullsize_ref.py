@@ -14,7 +14,7 @@ from _util import manifest
 from oracle import golden_vectors as GV
 from oracle import ref_harness as RH
 from oracle import st2_oracle as O
-import synth  # tests/synth.py
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.skipif(not RH.reference_available(), reason="no reference tree / bytecode on this machine")
 T_FULL, N_FULL = 400, 100  # 10 s of 24 kHz audio: 400 frames x 600 samples; 100 phonemes x 4 frames

@@ -6,7 +6,7 @@ import torch
 from _util import WAVE_RMS_TOL, manifest, rms
 from oracle import st2_oracle as O
 from styletts2_amd import models, pipeline
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -5,7 +5,7 @@ import torch
 from _util import manifest
 from oracle import st2_oracle as O
 from styletts2_amd import models
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -29,7 +29,7 @@ def test_state_dict_layout_matches_reference(tag):
 
 def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
     import torch
-    import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+    from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
     man = manifest("ljspeech")
     args = models.recursive_munch(man["config"])
     model = models.build_model(args, None, None, models.load_plbert(man["plbert"]))

@@ -15,7 +15,7 @@ from _util import GOLDEN, manifest
 from oracle import golden_mel, mel_ref
 from oracle import st2_oracle as O
 from styletts2_amd import models, style, text_utils
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 CASES = {"small": dict(dim_in=16, style_dim=32, max_conv_dim=64, B=3, T=83, seed=21),
          "libritts": dict(dim_in=64, style_dim=128, max_conv_dim=512, B=2, T=120, seed=22)}

@@ -13,7 +13,7 @@ from oracle import golden_mel, mel_ref
 from oracle import ops_ref as R
 from oracle import st2_oracle as O
 from styletts2_amd import _hooks, models, ops, style
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

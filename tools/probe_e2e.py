@@ -10,7 +10,7 @@ import torch
 
 from _util import manifest
 from styletts2_amd import models, pipeline
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.utils import length_to_mask
 
 tag = os.environ.get("PROBE_TAG", "ljspeech")

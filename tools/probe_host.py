@@ -14,7 +14,7 @@ import torch
 
 from _util import manifest
 from styletts2_amd import models, pipeline
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 
 dev = "cuda"
 B = int(os.environ.get("PROBE_B", "32"))

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from _util import decoder_kwargs, manifest, rms
 from oracle import st2_oracle as O
-import synth  # tests/synth.py: seeded synthetic weights / inputs (test + bench helper, not product code)
+from benchdata import synth  # seeded synthetic weights / inputs (test + bench helper, not product code)
 from styletts2_amd.decoder import Decoder
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "ljspeech"
