@@ -55,6 +55,57 @@ def test_broadcast_and_sharding_world2():
     assert t0 == t1 == 2.0
 
 
+def _calibration_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo")
+    from _cpu_backend import cpu_backend
+    from _util import manifest
+    from benchdata import synth
+    from styletts2_amd import models, pipeline
+    man = manifest("ljspeech")
+    model = models.build_model(models.recursive_munch(man["config"]), None, None, models.load_plbert(man["plbert"]))
+    for i, k in enumerate(["decoder", "diffusion", "predictor", "text_encoder", "bert_encoder", "bert"]):
+        synth.init_synthetic_(model[k], 10 + i)
+        model[k].eval()
+    dev = torch.device("cpu")
+    with cpu_backend():
+        engs = pipeline.model_engines(model, dev)
+        if rank == 0:  # rank 0 "calibrated": a table of distinct powers of two per engine; rank 1 still runs by rule
+            for j, k in enumerate(sorted(engs)):
+                engs[k].set_calibration([2.0 ** (1 + (i + j) % 9) for i in range(len(engs[k].calibration()))])
+        before = pipeline.calibration_state(model, dev)
+        n_sent = parallel.broadcast_calibration(model, dev)
+        after = pipeline.calibration_state(model, dev)
+        gens = {k: e.calib_gen for k, e in engs.items()}
+    parallel.barrier()
+    q.put((rank, n_sent, before, after, gens))
+    dist.destroy_process_group()
+
+
+def test_calibration_table_broadcast_world2():
+    """parallel.broadcast_calibration: the operand-scale table rank 0 measured (pipeline.calibrate) is installed on every rank --
+    one small broadcast at start-up, so that all shards compute bit-identical functions of their inputs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_calibration_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, n0, before0, after0, _), (_, n1, before1, after1, gens1) = res
+    assert n0 == n1 == sum(len(v) for v in after0.values()) > 100
+    assert {"front", "decoder"} <= set(after0) and after0 == before0   # the source keeps its table
+    assert all(x == 0.0 for v in before1.values() for x in v)          # rank 1 ran by rule ...
+    assert after1 == after0                                            # ... and now holds rank 0's table, value for value
+    assert all(g >= 1 for g in gens1.values())                         # recorded graphs of rank 1 are stale (calib_gen moved)
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 7, 256):
         for w in (1, 2, 4, 8):
