@@ -810,6 +810,9 @@ def main():
     # inside the timed region.  Nothing else runs on the GPU during this step: the measurements are un-overlapped.
     import contextlib
     calibration = _calibrate(a, model, dev, step_eager)  # before the front's hipGraph is recorded: scales are kernel arguments
+    if world > 1 and a.calibrate != "off":
+        # every rank holds rank 0's table: all shards compute the same function of their inputs (a few hundred floats, start-up only)
+        calibration["broadcast_scales"] = parallel.broadcast_calibration(model, dev)
     tune_ctx = contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=True)
     t_tune = time.perf_counter()
     with tune_ctx:
