@@ -812,7 +812,11 @@ def main():
     calibration = _calibrate(a, model, dev, step_eager)  # before the front's hipGraph is recorded: scales are kernel arguments
     if world > 1 and a.calibrate != "off":
         # every rank holds rank 0's table: all shards compute the same function of their inputs (a few hundred floats, start-up only)
-        calibration["broadcast_scales"] = parallel.broadcast_calibration(model, dev)
+        try:
+            calibration["broadcast_scales"] = parallel.broadcast_calibration(model, dev)
+        except Exception as e:  # deterministic across ranks (same model, same code path): every rank skips the collective
+            calibration["broadcast_scales"] = "skipped: %r" % (e,)
+            log("operand-scale broadcast skipped: %r" % (e,))
     tune_ctx = contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=True)
     t_tune = time.perf_counter()
     with tune_ctx:

@@ -661,8 +661,10 @@ def model_engines(model, dev):
     if getattr(dec, "_eng", None) is None or dec._eng.device != dev:
         dec._eng = engine.build_decoder_engine(dec, dev)
     out = {"front": _front_engine(model, dev), "decoder": dec._eng}
-    if isinstance(model.get("style_encoder"), style.StyleEncoder) and isinstance(model.get("predictor_encoder"), style.StyleEncoder):
-        out["style"] = style._style_engine(model, dev)
+    se, pe = model.get("style_encoder"), model.get("predictor_encoder")
+    on_dev = lambda m: all(p.device == torch.device(dev) for p in m.parameters())
+    if isinstance(se, style.StyleEncoder) and isinstance(pe, style.StyleEncoder) and on_dev(se) and on_dev(pe):
+        out["style"] = style._style_engine(model, dev)  # (a process that never moved the style encoders to `dev` has no such engine)
     return out
 
 
