@@ -11,7 +11,11 @@ Workloads (`--config`, BASELINE.json `configs`; default = the one the metric is 
   ljspeech           configs[1]  LJSpeech single-speaker, iSTFTNet, 5 diffusion steps, 32 x 10 s per GPU
   libritts_hifigan   configs[2]  LibriTTS multispeaker (ref-audio style vector), HiFi-GAN, 10 steps, 32 x 10 s per GPU
   libritts_istftnet  configs[3]  LibriTTS zero-shot with the iSTFTNet decoder, 5 steps, 32 x 10 s per GPU (256 over 8 GPUs)
-  longform           configs[4]  one >= 60 s passage as 8 sentence units with style carry-over, hipGraph-captured sampler
+  longform           configs[4]  one >= 60 s passage as 8 sentence units with style carry-over, hipGraph-captured sampler; the
+                                 sentences' fronts run as ONE right-padded batch with the carry-over as a row scan
+                                 (--longform-front-batch 0; 1 = sentence by sentence as the notebooks loop, same waveforms) and
+                                 their independent decoders on --longform-decode-streams streams picked by measurement
+                                 (`config.front_batch`, `config.decode_streams`, candidates in `schedules_ms_per_step`)
 Synthetic 100-phoneme sequences with durations forced to 4 frames / phoneme (=> exactly 10.0 s of 24 kHz audio per
 utterance), seeded random weights of the reference architecture (no checkpoints offline).  One "step" is one full pass
 token ids -> waveform over the per-GPU batch (longform: over the passage); inputs are resident in HBM, outputs stay in
