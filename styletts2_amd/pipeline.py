@@ -535,8 +535,6 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
     main = torch.cuda.current_stream(dev) if use_streams else None
     side = (side_stream if side_stream is not None else ops.aux_stream(dev)) if use_streams else None  # (a caller may
     #                                                  hand in a CU-masked side stream: pipeline.MaskedStreams)
-    if use_streams:
-        side.wait_stream(main)  # weights / inputs produced on the main stream are visible to the side stream
     K = len(sentences)
     sizes = list(front_batch) if isinstance(front_batch, (list, tuple)) else [front_batch]
     starts, i = [], 0
@@ -577,8 +575,14 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
         dec = list(decode_streams) if len(decode_streams) > 1 else []
     elif use_streams and decode_streams and int(decode_streams) > 1:
         dec = [ops.aux_stream(dev, 0, index=i + 1) for i in range(int(decode_streams))]
-    for ds in dec:
-        ds.wait_stream(main)
+    if use_streams:
+        # weights and inputs produced on the caller's stream -- including the rows stacked just above -- are visible to the other streams
+        for st in [side] + dec:
+            st.wait_stream(main)
+        for q in prepped:
+            for v in q.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(side)  # allocated on the caller's stream, read on the side stream
     s_prev, waves, emitted, n_dec, done = None, [None] * K, 0, 0, {}
     for q in prepped:
         ids = q["ids"]
