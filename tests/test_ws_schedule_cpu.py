@@ -161,3 +161,37 @@ def test_the_model_catches_a_broken_schedule():
             a = next(pr, None)
             if a is None and b is None:
                 break
+
+
+def f16s_tile_of_workgroup(bx, nx, row):
+    """Mirror of the blockIdx.x -> column tile mapping of conv1d_f16s_kernel (st2_conv1d_f16s_impl.h): `row` = blockIdx.y +
+    gridDim.y * blockIdx.z, workgroups are dealt to the 8 XCDs round-robin by their linear id."""
+    o = (nx * row) & 7
+    t = bx + o
+    xcd = t & 7
+    before, first_mine = 0, 0
+    for r in range(8):
+        t_first = o + ((r - o) & 7)
+        cnt = (nx + o - 1 - t_first) // 8 + 1 if t_first < nx + o else 0
+        if r < xcd:
+            before += cnt
+        if r == xcd:
+            first_mine = t_first
+    return before + (t - first_mine) // 8, xcd
+
+
+@pytest.mark.parametrize("nx", [1, 2, 7, 8, 9, 63, 188, 469, 938])
+def test_f16s_xcd_tile_order_is_a_bijection_with_contiguous_runs(nx):
+    """Every column tile of a grid row is computed exactly once whatever the row's offset in the dispatch order, and the tiles one
+    XCD receives form ONE contiguous run (so that neighbouring tiles, which share the tap halo's cache lines, share an L2)."""
+    for row in range(8):
+        tiles = [f16s_tile_of_workgroup(bx, nx, row) for bx in range(nx)]
+        assert sorted(t for t, _ in tiles) == list(range(nx))
+        by_xcd = {}
+        for t, x in tiles:
+            by_xcd.setdefault(x, []).append(t)
+        for x, ts in by_xcd.items():
+            ts.sort()
+            assert ts == list(range(ts[0], ts[0] + len(ts))), (nx, row, x)
+        for bx, (t, x) in enumerate(tiles):  # the XCD the mapping assumes is the one the round-robin dispatch gives the workgroup
+            assert x == (bx + nx * row) % 8
