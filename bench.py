@@ -101,6 +101,22 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
 
 
+def _emit(res, detail_out):
+    """The full result object goes to `detail_out` (tune table, every conv class, the box fingerprint: ~25 KB); stdout gets ONE
+    line of < 8 KB with the contract's fields (benchdata/line.py; the driver could not parse round 5's 25 KB line)."""
+    from benchdata import line as benchline
+    path = None
+    if detail_out:
+        try:
+            with open(detail_out, "w") as f:
+                json.dump(res, f, indent=1)
+            path = detail_out
+            log("full result object written to %s" % detail_out)
+        except OSError as e:
+            log("detail file not written: %r" % (e,))
+    print(benchline.dumps(res, path), flush=True)
+
+
 def _time_best(fn, threads, budget_s=30.0):
     """1 warm-up + best of up to 3 runs of fn() at `threads` host threads; a cold run over the budget is reported as is."""
     torch.set_num_threads(threads)
@@ -628,6 +644,8 @@ def main():
                     help="short legs of BASELINE.json configs[2..4] + a B = 1 latency point after the timed region (`auto`: "
                          "on for the default config at N = 1)")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
+    ap.add_argument("--detail-out", default="bench_detail.json",
+                    help="side file for the full result object (the printed line is its < 8 KB summary); '' = none")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
                                                            "compute): what the CPU tests use to cover the N-rank launch")
     a = ap.parse_args()
@@ -653,9 +671,12 @@ def main():
         per_rank = parallel.gather_over_ranks(mine, torch.device("cpu"))
         parallel.barrier()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": dt,
-                              "per_rank_ms_per_step": [round(v * 1e3, 4) for v in per_rank],
-                              "broadcast_s": round(bc_s, 4), "broadcast_bytes": nb}), flush=True)
+            line = json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": dt,
+                               "per_rank_ms_per_step": [round(v * 1e3, 4) for v in per_rank],
+                               "broadcast_s": round(bc_s, 4), "broadcast_bytes": nb}, allow_nan=False)
+            from benchdata import line as benchline
+            assert len(line) < benchline.LIMIT
+            print(line, flush=True)
         return
 
     from benchdata import manifest, synth  # workload definitions: model manifests, seeded synthetic weights
@@ -1021,7 +1042,7 @@ def main():
             res["other_configs"] = other_configs(a, dev, model, sampler, lf_front, skip=a.config)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(man, sds, cfg)
-        print(json.dumps(res), flush=True)
+        _emit(res, a.detail_out)
     if healthy is not None:
         torch.cuda.synchronize()
         healthy.close()

@@ -1,0 +1,153 @@
+"""The ONE JSON line bench.py prints, kept small enough for the driver to parse.
+
+Round 5's line had grown to ~25 KB (tune table, every conv class, the box fingerprint) and the driver's record came back
+`parsed: null`.  The full result object now goes to a side file (`bench_detail.json`, path in the line) and to stderr; the
+line itself carries the contract's fields -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+scaling / vs_baseline / dtype / data / config / roofline / cpu_baseline -- plus a compact `other_configs`, and `compact()`
+enforces a hard size bound by dropping optional keys in a fixed order (the contract's fields are never dropped).
+Pure Python, no torch: tests/test_bench_line.py runs it on the committed 21-25 KB lines of round 5.
+"""
+import json
+
+LIMIT = 8192  # bytes of the printed line, VERDICT round 5 item 2
+TARGET = 6000  # what compact() aims for, leaving room for fields a later edit adds
+
+_CONFIG_KEEP = ("workload", "name", "baseline_config_index", "global_batch", "per_gpu_batch", "phonemes", "diffusion_steps",
+                "decoder", "audio_s_per_step_per_gpu", "parallelism", "schedule", "schedule_requested", "schedules_ms_per_step",
+                "per_rank_ms_per_step", "broadcast_bytes", "broadcast_s", "plan", "lstm", "lstm_verify", "graphed_front",
+                "host_issue_ms_per_step", "front_batch", "decode_streams", "first_chunk_latency_ms", "bitwise_vs_single",
+                "lstm_reloads")
+_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mfma_tflops_executed", "launches_timed",
+              "avg_launch_ms", "algorithmic_flop_per_launch", "algorithmic_bytes_per_launch", "hbm_view",
+              "conv_ms_per_step_all_classes", "front_ms_alone", "ceiling_live")
+_CPU_KEEP = ("value", "unit", "cores", "kind", "sample", "host_cores", "threads_tried", "reference_modules")
+_LEG_KEEP = ("baseline_config_index", "ms_per_step", "audio_s_per_step", "audio_s_per_s", "steps", "warmup", "schedule",
+             "schedules_ms_per_step", "decoder", "diffusion_steps", "finite", "bitwise_vs_single", "latency_ms", "decode_streams",
+             "front_batch", "first_chunk_latency_ms", "padding_efficiency", "utterances", "phonemes_per_utterance", "error",
+             "lstm_reloads")
+
+
+def _round(o, nd=4):
+    if isinstance(o, float):
+        return round(o, nd) if o == o and abs(o) != float("inf") else None  # strict JSON: no NaN / Infinity tokens
+    if isinstance(o, dict):
+        return {k: _round(v, nd) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round(v, nd) for v in o]
+    return o
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "…"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _class_row(c):
+    """One conv shape class as a short string + three numbers."""
+    row = {"class": "k%s C%s->%s L%s B%s" % (c.get("ks"), c.get("C_in"), c.get("C_out"), c.get("L"), c.get("B")),
+           "ms": c.get("avg_launch_ms"), "n": c.get("launches"), "frac": c.get("frac"), "share": c.get("share")}
+    return {k: v for k, v in row.items() if v is not None}
+
+
+def _leg(v):
+    out = _pick(v, _LEG_KEEP)
+    if isinstance(v.get("workload"), str):
+        out["workload"] = _short(v["workload"], 100)
+    dom = v.get("dominant")
+    if isinstance(dom, dict):
+        out["dominant"] = {"kernel": _short(dom.get("kernel"), 60), "avg_launch_ms": dom.get("avg_launch_ms"), "frac": dom.get("frac")}
+    return out
+
+
+def compact(res, detail_path=None, limit=LIMIT):
+    """The printable subset of a full bench result `res` (not modified).  Returns a dict whose json.dumps is < `limit` bytes."""
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data") if k in res}
+    cfg = res.get("config") or {}
+    out["config"] = _pick(cfg, _CONFIG_KEEP)
+    if "workload" in out["config"]:
+        out["config"]["workload"] = _short(out["config"]["workload"], 200)
+    tune = cfg.get("conv_autotune")
+    if isinstance(tune, list):
+        out["config"]["conv_autotune"] = {"classes": len(tune),
+                                          "non_rule_winners": sum(1 for r in tune if "rule" not in str(r.get("chosen", "rule")))}
+    elif tune is not None:
+        out["config"]["conv_autotune"] = _short(str(tune), 40)
+    scales = cfg.get("operand_scales")
+    if isinstance(scales, dict):
+        out["config"]["operand_scales"] = _pick(scales, ("mode", "sites_set", "passes"))
+    roof = res.get("roofline") or {}
+    r = _pick(roof, _ROOF_KEEP)
+    if "kernel" in r:
+        r["kernel"] = _short(r["kernel"], 120)
+    if isinstance(roof.get("classes"), list):
+        r["classes"] = [_class_row(c) for c in roof["classes"][:6]]
+    un = roof.get("unoverlapped")
+    if isinstance(un, dict):
+        r["unoverlapped"] = _pick(un, ("frac", "achieved", "avg_launch_ms", "launches_timed"))
+        cls = un.get("classes")
+        if isinstance(cls, list) and cls:  # the worst classes that matter: >= 2 % of the un-overlapped conv time, lowest frac first
+            tot = sum(c.get("total_ms", 0.0) for c in cls) or 1.0
+            big = [c for c in cls if c.get("total_ms", 0.0) / tot >= 0.02]
+            big.sort(key=lambda c: c.get("frac") or 0.0)
+            r["unoverlapped"]["lowest_frac_classes"] = [_class_row(c) for c in big[:4]]
+    out["roofline"] = r
+    if "cpu_baseline" in res:
+        cb = res["cpu_baseline"] or {}
+        c = _pick(cb, _CPU_KEEP)
+        if "sample" in c:
+            c["sample"] = _short(c["sample"], 220)
+        if isinstance(cb.get("port"), dict):
+            c["port"] = _pick(cb["port"], ("value", "unit", "cores", "wall_s"))
+        out["cpu_baseline"] = c
+    oc = res.get("other_configs")
+    if isinstance(oc, dict):
+        out["other_configs"] = {k: (_leg(v) if isinstance(v, dict) else v) for k, v in oc.items()}
+    box = res.get("box")
+    if isinstance(box, dict):
+        b = {}
+        if isinstance(box.get("torch"), dict):
+            b.update(_pick(box["torch"], ("name", "gcnArchName", "multi_processor_count")))
+        if isinstance(box.get("sysfs"), dict):
+            b.update(_pick(box["sysfs"], ("vbios_version", "current_compute_partition", "cards_on_host")))
+        probe = box.get("probe") if isinstance(box.get("probe"), dict) else {}
+        mf = (probe.get("mfma") or {}).get("random") if isinstance(probe.get("mfma"), dict) else None
+        if isinstance(mf, dict):
+            b["mfma_probe"] = _pick(mf, ("tflops", "clock_ghz"))
+        if isinstance(box.get("cu_health"), dict):
+            b["cu_health"] = _pick(box["cu_health"], ("slow_cus", "n_slow", "checked"))
+        if b:
+            out["box"] = b
+    if detail_path:
+        out["detail"] = detail_path
+    out = _round(out)
+    # hard bound: optional keys go first, in this order; the contract's fields stay
+    drops = [("box",), ("roofline", "unoverlapped", "lowest_frac_classes"), ("roofline", "classes"), ("config", "schedules_ms_per_step"),
+             ("cpu_baseline", "threads_tried"), ("roofline", "ceiling_live"), ("roofline", "hbm_view"), ("roofline", "unoverlapped")]
+    for path in drops:
+        if len(json.dumps(out)) <= min(TARGET, limit - 256):
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k, {}) if isinstance(d, dict) else {}
+        if isinstance(d, dict):
+            d.pop(path[-1], None)
+    if len(json.dumps(out)) >= limit and isinstance(out.get("other_configs"), dict):
+        out["other_configs"] = {k: _pick(v, ("ms_per_step", "audio_s_per_s", "latency_ms", "schedule", "bitwise_vs_single", "finite"))
+                                for k, v in out["other_configs"].items() if isinstance(v, dict)}
+    if len(json.dumps(out)) >= limit:  # last resort: the contract's fields alone, strings cut
+        out["config"] = {k: _short(v, 80) if isinstance(v, str) else v for k, v in out["config"].items()
+                         if not isinstance(v, (dict, list))}
+        out["roofline"] = _pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic"))
+    return out
+
+
+def dumps(res, detail_path=None, limit=LIMIT):
+    """json.dumps(compact(res)); raises if the bound cannot be met (it always can: the last resort is a few hundred bytes)."""
+    line = json.dumps(compact(res, detail_path, limit), allow_nan=False)
+    if len(line.encode()) >= limit:
+        raise ValueError("bench line is %d bytes (limit %d)" % (len(line.encode()), limit))
+    return line

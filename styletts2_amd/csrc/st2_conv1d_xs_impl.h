@@ -37,6 +37,15 @@ typedef st2_f32x16 f32x16;
 #ifndef ST2_XS_NSET
 #define ST2_XS_NSET 3  // weight-fragment register sets = prefetch distance + 1
 #endif
+// Bisection switches of tools/lstm_load_repro.hip (round 6: which property of this kernel disturbs another queue's loads?):
+// ST2_XS_SETPRIO = 0 drops the raised wave priority of the k loop; ST2_XS_PRED_STAGE = 1 predicates the staging loads / LDS
+// stores of slots past the chunk image instead of re-reading slot 0 (narrow tiles: up to 70 % of the lanes).
+#ifndef ST2_XS_SETPRIO
+#define ST2_XS_SETPRIO 1
+#endif
+#ifndef ST2_XS_PRED_STAGE
+#define ST2_XS_PRED_STAGE 0
+#endif
 
 namespace {
 
@@ -93,12 +102,24 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
     const h8* src = xsb + (int64_t)c * CG * Lp;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) xr[i] = src[soff[i]];
+    for (int i = 0; i < NS; ++i) {
+      if constexpr (ST2_XS_PRED_STAGE) {
+        if (tid + i * NT < S) xr[i] = src[soff[i]];
+      } else {
+        xr[i] = src[soff[i]];
+      }
+    }
   };
   auto store_chunk = [&](int buf) __attribute__((always_inline)) {
     h8* dst = lds + (size_t)buf * LBUF;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) dst[tid + i * NT] = xr[i];
+    for (int i = 0; i < NS; ++i) {
+      if constexpr (ST2_XS_PRED_STAGE) {
+        if (tid + i * NT < S) dst[tid + i * NT] = xr[i];
+      } else {
+        dst[tid + i * NT] = xr[i];
+      }
+    }
   };
 
   f32x16 acc[TN];
@@ -147,7 +168,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int
   // (VALU + global memory).  Raised priority for the k loop keeps the matrix pipe fed first (cdna_hip_programming.md
   // T5: pays where waves have different roles); dropped again before the epilogue.
   h8 abl_bh[TN], abl_bl[TN];  // ABL & 1 only
-  __builtin_amdgcn_s_setprio(1);
+  if constexpr (ST2_XS_SETPRIO) __builtin_amdgcn_s_setprio(1);
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunk;
@@ -224,7 +245,7 @@ __device__ __forceinline__ void conv1d_xs_body(const st2_conv_desc& d, const int
     __syncthreads();
   }
 
-  __builtin_amdgcn_s_setprio(0);
+  if constexpr (ST2_XS_SETPRIO) __builtin_amdgcn_s_setprio(0);
   unsigned long long tl_t1 = 0;
   if constexpr (ABL & 64) tl_t1 = __builtin_amdgcn_s_memtime();
   auto tl_write = [&]() __attribute__((always_inline)) {
