@@ -419,6 +419,37 @@ def _calibrate(a, model, dev, step):
     return out
 
 
+def _same_bits(a, b):
+    """Bitwise equality of two step results (a waveform tensor, or long-form's list of per-sentence waveforms)."""
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+    return torch.equal(a, b)
+
+
+def _bitwise_vs_single(step_chosen, step_single, n=3):
+    """OUTSIDE the timed region: `n` steps of the schedule that was timed and one single-stream / sequential step on the same
+    inputs; True when every one of them is the single-stream result bit for bit.  The two-stream and multi-decode-stream schedules
+    reorder nothing inside a kernel, so anything but equality means a kernel computed something else because of what ran beside
+    it -- round 5's BiLSTM did (a gfx950 packed-f32 op_sel hazard next to another queue's MFMAs), and a
+    `finite` check cannot see that.  Returns {"equal": bool, "steps": n} (+ "error")."""
+    try:
+        torch.cuda.synchronize()
+        ref = step_single()
+        torch.cuda.synchronize()
+        ref = [w.clone() for w in ref] if isinstance(ref, (list, tuple)) else ref.clone()
+        ok = True
+        for _ in range(n):
+            out = step_chosen()
+            torch.cuda.synchronize()
+            ok = ok and _same_bits(out, ref)
+        if not ok:
+            log("WARNING: the timed schedule is NOT bitwise the single-stream run on the same inputs")
+        return {"equal": bool(ok), "steps": n}
+    except Exception as e:  # noqa: BLE001 -- a check, never in the way of the line
+        log("bitwise_vs_single check failed to run: %r" % (e,))
+        return {"equal": None, "steps": 0, "error": repr(e)[:160]}
+
+
 def _dominant_of(by_class):
     rows = _all_classes(by_class)
     if not rows:
@@ -458,13 +489,16 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
         audio_s = sum(LONGFORM_SENTENCES) * FRAMES_PER_PHONEME * 600 / 24000.0
         sched = {"two-stream": None}
 
-        def step(front=front):
+        def step(front=front, sequential=False):
             t_start = time.perf_counter()
 
             def on_chunk(k, w):
                 if k == 0:
                     w[-1].item()
                     first_chunk.append((time.perf_counter() - t_start) * 1e3)
+            if sequential:  # the reference of `bitwise_vs_single`: one stream, one sentence's decoder at a time
+                return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
+                                                overlap=False, bucket=16, front=front, front_batch=a.longform_front_batch)[0]
             return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
                                             overlap=True, bucket=16, on_chunk=on_chunk, front=front,
                                             side_stream=shared_stream(dev, 0), front_batch=a.longform_front_batch,
@@ -472,10 +506,10 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     else:
         audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
 
-        def step(front=front):
+        def step(front=front, sequential=False):
             return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
                                       ref_s=ref_s, durations=durations_dev, total_frames=frames,
-                                      front_stream=sched[active["name"]], front=front)
+                                      front_stream=None if sequential else sched[active["name"]], front=front)
     import contextlib
     cal = _calibrate(a, model, dev, lambda: step(front=None))  # eager: before the front's hipGraph is recorded
     with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
@@ -510,10 +544,13 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     by_class = _read_conv_classes(lib)
     ops.check_status()
     finite = all(bool(torch.isfinite(w).all()) for w in out) if longform else bool(torch.isfinite(out).all())
+    bitwise = _bitwise_vs_single(step, lambda: step(sequential=True))
+    ops.check_status()
     res = {"workload": cfg["workload"], "baseline_config_index": cfg["baseline_config"], "ms_per_step": round(ms, 3),
            "audio_s_per_step": audio_s, "audio_s_per_s": round(audio_s / (ms * 1e-3), 1), "steps": n_steps, "warmup": n_warm,
            "schedule": active["name"], "schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()},
            "decoder": man["config"]["decoder"]["type"], "diffusion_steps": steps_d, "finite": finite,
+           "bitwise_vs_single": bitwise["equal"], "bitwise_check": bitwise,
            "operand_scales": {k: cal[k] for k in ("mode", "sites_set") if k in cal},
            "xs_conv_ms_per_step": round(sum(sum(v) for v in by_class.values()) / n_steps, 3),
            "dominant": _dominant_of(by_class), "wall_s": None}
@@ -558,7 +595,8 @@ def _latency_b1(a, dev, model, sampler, front, n_warm=3, n_steps=10):
     lib.st2_conv_timing(0)
     by_class = _read_conv_classes(lib)
     ops.check_status()
-    return {"workload": "B = 1, one 10 s utterance (100 phonemes, %d diffusion steps, %s), one stream, graph-replayed front; "
+    bitwise = _bitwise_vs_single(step, step)  # one stream already: run-to-run reproducibility of the latency path
+    return {"bitwise_vs_single": bitwise["equal"], "workload": "B = 1, one 10 s utterance (100 phonemes, %d diffusion steps, %s), one stream, graph-replayed front; "
                         "every call synchronised" % (steps_d, a.config),
             "latency_ms": {"mean": round(sum(ts) / len(ts), 3), "min": round(min(ts), 3), "max": round(max(ts), 3)},
             "audio_s_per_s": round(AUDIO_S_PER_UTT / (min(ts) * 1e-3), 1), "steps": n_steps, "warmup": n_warm,
@@ -801,13 +839,16 @@ def main():
         durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
         audio_s = sum(LONGFORM_SENTENCES) * FRAMES_PER_PHONEME * 600 / 24000.0
 
-        def step(front=lf_front):
+        def step(front=lf_front, sequential=False):
             t_start = time.perf_counter()
 
             def on_chunk(k, w):
                 if k == 0:
                     w[-1].item()  # the first sentence's waveform has left the GPU queue: a streaming consumer has it
                     first_chunk_ms.append((time.perf_counter() - t_start) * 1e3)
+            if sequential:  # reference of `bitwise_vs_single`: one stream, sentence after sentence
+                return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
+                                                overlap=False, bucket=16, front=front, front_batch=a.longform_front_batch)[0]
             with torch.cuda.stream(healthy.main if healthy is not None else torch.cuda.current_stream(dev)):
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
@@ -818,8 +859,10 @@ def main():
     else:
         audio_s = B * AUDIO_S_PER_UTT
 
-        def step(front=lf_front):
+        def step(front=lf_front, sequential=False):
             main_s, front_s = sched[active["name"]]
+            if sequential:  # reference of `bitwise_vs_single`: everything on the caller's stream
+                main_s, front_s = None, None
             with torch.cuda.stream(main_s if main_s is not None else torch.cuda.current_stream(dev)):
                 return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
                                           embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
@@ -965,6 +1008,8 @@ def main():
         out = step()
         host_issue.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
+    bitwise = _bitwise_vs_single(step, lambda: step(sequential=True))
+    ops.check_status()
 
     if rank == 0:
         by_class = _read_conv_classes(lib)
@@ -1013,6 +1058,7 @@ def main():
                                            "chosen": r["chosen_name"],
                                            "ms": {c["name"]: c["ms"] for c in r["candidates"]}} for r in tune_table]),
                        "operand_scales": calibration,
+                       "bitwise_vs_single": bitwise["equal"], "bitwise_check": bitwise,
                        "plan": _hooks.plan, "lstm": a.lstm, "graphed_front": not a.eager_front,
                        "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
             "roofline": roof,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ST2_ABI_VERSION 21
+#define ST2_ABI_VERSION 22
 
 /* ---- library ---------------------------------------------------------------------- */
 int st2_abi_version(void);
@@ -743,6 +743,20 @@ int st2_probe_box(char* json, int32_t cap, int32_t level);
  * "slow CUs" of the slow box class were the row-end tiles of the launch -- since the epilogue fix it
  * reads 0 on every box seen -- and it stays as the check that finds a genuinely degraded CU.  Takes ~0.1 s. */
 int st2_probe_cu_health(char* json, int32_t cap, uint32_t* mask_out, int32_t mask_words, int32_t* n_excluded);
+
+/* Matrix-pipe load generator for the co-residency canaries (ABI v22).  Round 6 traced "the BiLSTM returns other bits while
+ * narrow-tile convs run on another queue" to the hardware: on gfx950 a packed-f32 VALU op whose op_sel takes the HIGH dword of
+ * src1 for the low result lane (`v_pk_fma_f32 ... op_sel:[0,1,0]`) returns a wrong low half in lanes 48-63 while ANOTHER wave of the
+ * CU issues MFMAs in certain cadences (tools/simd_hazard_repro.hip).  The library no longer contains that
+ * encoding (tools/check_isa.py gates every build); this entry point launches the cadences that provoked it, so that tests and a
+ * serving process's start-up check can run ANY kernel of the path next to them and demand bitwise the idle result:
+ *   kind 0  v_mfma_f32_16x16x32_f16, one dependent chain per wave (hit rate ~90-100 % on the old BiLSTM kernels)
+ *   kind 1  v_mfma_f32_32x32x16_f16 in isolated dependent groups of three with LDS reads between them (what a one-accumulator
+ *           32-column conv tile issues per k-step)
+ *   kind 2  v_mfma_f32_16x16x32_f16, four independent chains per wave
+ * `workgroups` x 4 waves, `iters` MFMA groups per wave (720 / 400: ~60-100 us per launch); nothing is read or written; asynchronous
+ * on `stream`.  Returns non-zero on bad arguments. */
+int st2_probe_mfma_stream(int32_t kind, int32_t workgroups, int32_t iters, void* stream);
 
 /* ---- CU-partitioned streams (ABI v17) ---------------------------------------------------------------------------- *
  * A HIP stream whose kernels may only be placed on the compute units whose bit is set in `mask` (n_words x 32 bits, bit i

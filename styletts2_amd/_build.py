@@ -25,6 +25,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # the v_mov shuffles that feed them) is an anti-lever there (MI355X_MICROARCH.md; profiles/r03D_probe_narrow_libs.log: one-role
 # kernel -4 % at k = 7 / C = 64, -13 % at k = 3 / C = 128 / L = 40 000, the warp-specialised k = 3 / C = 32 build +16 %: not for that one).
 EXTRA_FLAGS = {s: ["-fno-slp-vectorize"] for s in SOURCES if s.startswith("st2_conv1d_f16s_k")}
+# The BiLSTM recurrences: SLP packing of {a*h, b*h} with h an ODD element of an LDS vector load becomes `v_pk_fma_f32 ...
+# op_sel:[0,1,0]`, which on gfx950 returns a wrong low half in lanes 48-63 next to MFMA waves of another queue (round 6:
+# tools/simd_hazard_repro.hip).  No auto-packing there; the cooperative kernel packs along K by hand
+# (plain encoding).  tools/check_isa.py (run below after every link) keeps the encoding out of the WHOLE library.
+EXTRA_FLAGS.update({"st2_lstm.hip": ["-fno-slp-vectorize"], "st2_lstm_coop.hip": ["-fno-slp-vectorize"]})
 
 
 def _hipcc():
@@ -95,7 +100,24 @@ def build_lib(force=False, verbose=True):
         if verbose:
             print("[st2 build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        isa_gate(verbose)
     return LIB_PATH
+
+
+def isa_gate(verbose=True):
+    """tools/check_isa.py on the linked library: raises when a packed-f32 op with op_sel is present (see EXTRA_FLAGS above)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(HERE), "tools", "check_isa.py")
+    spec = importlib.util.spec_from_file_location("st2_check_isa", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok, report = mod.check(LIB_PATH)
+    if verbose or ok is False:
+        print("[st2 build] " + report, flush=True)
+    if ok is False:
+        os.replace(LIB_PATH, LIB_PATH + ".rejected")  # never leave a library that failed the gate where the loader finds it
+        raise RuntimeError("libst2_hip.so failed the ISA gate (tools/check_isa.py); kept as %s.rejected" % LIB_PATH)
+    return ok
 
 
 if __name__ == "__main__":

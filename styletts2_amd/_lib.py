@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402  (deliberately before the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libst2_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 HEADROOM_COLS, CALIBRATION_COLS = 12, 5  # st2.h ST2_HEADROOM_COLS / ST2_CALIBRATION_COLS
 
 f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -213,6 +213,7 @@ _SIGNATURES = {
     "st2_conv_tune_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_probe_box": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),
     "st2_probe_cu_health": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_int32)]),
+    "st2_probe_mfma_stream": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "st2_debug_headroom": (C.c_int, [C.c_int]),
     "st2_debug_headroom_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_conv1d_xs_part_cols": (C.c_int, [C.POINTER(ConvDesc)]),

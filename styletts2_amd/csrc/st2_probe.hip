@@ -458,3 +458,72 @@ extern "C" int st2_probe_box(char* json, int32_t cap, int32_t level) {
   memcpy(json, js.s.c_str(), js.s.size() + 1);
   return 0;
 }
+
+// ---- matrix-pipe load generator for the co-residency canaries (st2.h, ABI v22) ---------------------------------------------------
+namespace {
+typedef _Float16 pm_h8 __attribute__((ext_vector_type(8)));
+typedef float pm_f4 __attribute__((ext_vector_type(4)));
+typedef float pm_f16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma16x16_stream_kernel(float* sink, int iters) {
+  pm_f4 acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) acc[j] = pm_f4{0.f, 0.f, 0.f, 0.f};
+  pm_h8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (_Float16)(0.001f * (threadIdx.x + i));
+    b[i] = (_Float16)(0.002f * (threadIdx.x ^ i));
+  }
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) t += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  if (t == 12345.678f && sink) sink[threadIdx.x] = t;  // never true: keeps the chain live
+}
+
+__global__ __launch_bounds__(256) void mfma32x32_groups_kernel(float* sink, int iters) {
+  __shared__ pm_h8 pad[256];
+  pm_f16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  pm_h8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (_Float16)(0.001f * (threadIdx.x + i));
+    b[i] = (_Float16)(0.002f * (threadIdx.x ^ i));
+  }
+  pad[threadIdx.x] = a;
+  __syncthreads();
+  for (int i = 0; i < iters; ++i) {
+    a = pad[(threadIdx.x + i) & 255];
+    b = pad[(threadIdx.x + 2 * i + 1) & 255];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, acc, 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t += acc[r];
+  if (t == 12345.678f && sink) sink[threadIdx.x] = t;
+}
+}  // namespace
+
+extern "C" int st2_probe_mfma_stream(int32_t kind, int32_t workgroups, int32_t iters, void* stream) {
+  ST2_REQUIRE(kind >= 0 && kind <= 2 && workgroups > 0 && workgroups <= 65535 && iters > 0,
+              "st2_probe_mfma_stream: kind %d / workgroups %d / iters %d", kind, workgroups, iters);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* none = nullptr;
+  if (kind == 0)
+    hipLaunchKernelGGL((mfma16x16_stream_kernel<1>), dim3(workgroups), dim3(256), 0, s, none, iters);
+  else if (kind == 1)
+    hipLaunchKernelGGL(mfma32x32_groups_kernel, dim3(workgroups), dim3(256), 0, s, none, iters);
+  else
+    hipLaunchKernelGGL((mfma16x16_stream_kernel<4>), dim3(workgroups), dim3(256), 0, s, none, iters);
+  ST2_CHECK_LAUNCH("st2_probe_mfma_stream");
+  return 0;
+}

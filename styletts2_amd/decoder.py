@@ -6,7 +6,7 @@ models.py:617-633 does).
 
 The module keeps the reference's state_dict layout (layers.py) and, on first use after a load,
 folds weight-norm and packs every conv into the pre-split f16 layout of `st2_conv1d_xs` / `st2_conv1d_f16s`
-(`st2_conv1d`'s K-major fp32 layout under ST2_CONV_PRECISION=f32).  forward() is a straight-line plan of HIP
+(`st2_conv1d`'s K-major fp32 layout under the tests' `_hooks.override(conv_precision="f32")`).  forward() is a straight-line plan of HIP
 kernel launches on torch's current stream: no host synchronisation, no per-forward weight-norm, one batched
 style-FC GEMM for all AdaIN layers; every AdaIN + Snake / LeakyReLU is one HBM-bound `st2_act_split` pass that
 hands the following MFMA conv pre-split operands, and the InstanceNorm statistics it needs come out of the

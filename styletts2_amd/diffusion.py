@@ -8,8 +8,8 @@ Modules/diffusion/diffusion.py: AudioDiffusionConditional shell, re-wired by mod
     s_pred = sampler(noise[B,1,256], embedding=bert_dur[B,N,768], embedding_scale=1.0, num_steps=5[, features=ref_s])
 
 MI355X design: tokens are kept CHANNEL-MAJOR ([B, C, N]) for the whole denoiser so that every Linear is a k=1
-conv on the matrix pipe (`st2_conv1d_f16s`: split-f16 MFMA, fp32-class accuracy; `st2_conv1d` exact fp32 under
-ST2_CONV_PRECISION=f32) with LayerNorm/AdaLayerNorm applied in the conv prologue, GELU / residual in its epilogue;
+conv on the matrix pipe (`st2_conv1d_f16s`: split-f16 MFMA, fp32-class accuracy; `st2_conv1d` = the exact-fp32 build of the same
+contract, which the parity tests select through `_hooks.override(conv_precision="f32")`) with LayerNorm/AdaLayerNorm applied in the conv prologue, GELU / residual in its epilogue;
 attention is one fp32-MFMA HIP kernel; the per-utterance mapping MLP is `st2_style_fc`.  Everything the ADPM2
 loop needs from the host (sigma schedule, sigma_up/down/mid, EDM scale weights) is input-independent and is
 computed once on the host in the reference's own arithmetic (fp32 tensors + python floats), so the loop issues

@@ -99,7 +99,8 @@ def check_status():
     msgs = []
     if st & _lib.STATUS_F16_RANGE:
         msgs.append("a split-f16 conv operand exceeded the f16 range (|x * x_scale| > 65504) and was clamped: the "
-                    "result is finite but wrong; run with ST2_CONV_PRECISION=f32 or rescale the offending layer")
+                    "result is finite but wrong; calibrate the operand scales for this checkpoint (pipeline.calibrate / st2_calibrate) and "
+                    "check it with tools/validate_checkpoint.py, which names the conv site and its headroom")
     if st & _lib.STATUS_LSTM_TIMEOUT:
         msgs.append("a cooperative BiLSTM group timed out (its workgroups were not co-resident in time) on a launch without "
                     "the recovery pass: outputs of that call are invalid")
@@ -715,6 +716,14 @@ def lstm_bidir(G, whh_t, lengths=None, out=None):
     _lib.check(lib.st2_lstm_bidir(G.data_ptr(), G.stride(0), G.stride(1), whh_t.data_ptr(), lp, B, H, N,
                                   out.data_ptr(), out.stride(0), out.stride(1), _stream()), "st2_lstm_bidir")
     return out
+
+
+def mfma_load(kind=0, workgroups=720, iters=400):
+    """Queues one launch of the library's matrix-pipe load generator on the current stream (include/st2.h
+    `st2_probe_mfma_stream`: the MFMA cadences next to which round 5's BiLSTM kernels returned wrong bits).  The co-residency
+    canaries (tests/test_zz_coresidency_gpu.py, `pipeline.coresidency_selfcheck`) run product kernels on another stream
+    meanwhile and demand the idle result bit for bit."""
+    _lib.check(_lib.load().st2_probe_mfma_stream(int(kind), int(workgroups), int(iters), _stream()), "st2_probe_mfma_stream")
 
 
 def lstm_coop_status():

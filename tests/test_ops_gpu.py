@@ -909,38 +909,6 @@ def test_lstm_coop_scratch_is_cleared_on_every_graph_replay(B, N):
         assert torch.equal(Y, ref), "replay %d differs from the eager call" % it
 
 
-@pytest.mark.parametrize("mode", ["coop", "single"])
-def test_lstm_is_reproducible_next_to_one_utterance_convs_on_another_stream(mode):
-    """Canary for an open observation of round 5 (st2_conv1d_xs_impl.h `small_grid_cols`): the BiLSTM kernels returned different
-    results in 25-90 % of their calls while the k = 7 / 11 NARROW-tile conv builds ran on another queue (one 64-byte sector of a
-    W_hh load wrong for 16 lanes of one gate) -- those builds are not used.  What the product does launch next to a front's BiLSTMs
-    in the two-stream schedules of one utterance -- k = 3 convs in 32-column tiles, k = 7 / 11 convs in 128-column tiles -- must
-    leave them bit-exact."""
-    gen = torch.Generator().manual_seed(0)
-    lx = ops.activate(g(torch.randn(1, 256, 5680, generator=gen)))
-    w3 = weights.pack_conv_f16s(torch.randn(256, 256, 3, generator=gen) / 30).to(DEV)
-    w7 = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=gen) / 40).to(DEV)
-    y = torch.empty(1, 256, 5680, device=DEV)
-    G = g(torch.randn(1, 2048, 24, generator=gen))
-    whh = g(torch.randn(2, 256, 1024, generator=gen) / 16).contiguous()
-    side = torch.cuda.Stream()
-    with _hooks.override(lstm=mode):
-        ref = ops.lstm_bidir(G, whh).clone()
-        torch.cuda.synchronize()
-        for w, ks, n in ((w3, 3, 200), (w7, 7, 100)):
-            outs = []
-            side.wait_stream(torch.cuda.current_stream())
-            for _ in range(n):
-                ops.conv1d_xs(lx, w, 256, ks, pad_left=(ks - 1) // 2, out=y, want_stats=True)
-            with torch.cuda.stream(side):
-                for _ in range(30 if mode == "coop" else 10):
-                    outs.append(ops.lstm_bidir(G, whh))
-            torch.cuda.synchronize()
-            bad = sum(not torch.equal(o, ref) for o in outs)
-            assert bad == 0, "%d of %d BiLSTM calls differ next to k = %d convs" % (bad, len(outs), ks)
-    assert ops.status(clear=True) == 0
-
-
 @pytest.mark.parametrize("xch", [0, 1, 2])
 def test_lstm_coop_exchange_variants_agree(xch):
     """The three hand-off forms of st2_lstm_bidir_coop (fences + counter, sc1 + counter, tagged 8-byte granules) are
