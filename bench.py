@@ -426,6 +426,18 @@ def _same_bits(a, b):
     return torch.equal(a, b)
 
 
+def _fixed_draws(dev, steps_d, sentences, B):
+    """Keyword arguments that pin what a step otherwise draws per call (the ADPM2 ancestral noise, the SineGen noise; for a
+    passage also the initial noise of every sentence), so that two steps can be compared bit for bit.  Only the bitwise check
+    uses them: the timed steps draw as a serving call does."""
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    r = lambda *s: torch.randn(*s, generator=gen, device=dev)
+    if sentences is None:
+        return {"step_noise": r(steps_d - 1, B, 1, 256), "sine_noise": r(B, int(AUDIO_S_PER_UTT * 24000), 9)}
+    return {"noises": [r(1, 1, 256) for _ in sentences], "step_noises": [r(steps_d - 1, 1, 1, 256) for _ in sentences],
+            "sine_noises": [r(1, n * FRAMES_PER_PHONEME * 600, 9) for n in sentences]}
+
+
 def _bitwise_vs_single(step_chosen, step_single, n=3):
     """OUTSIDE the timed region: `n` steps of the schedule that was timed and one single-stream / sequential step on the same
     inputs; True when every one of them is the single-stream result bit for bit.  The two-stream and multi-decode-stream schedules
@@ -483,6 +495,7 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     sched = {"single": None, "two-stream": shared_stream(dev, a.front_priority)}
     active = {"name": "two-stream"}
     first_chunk = []
+    fixed = {}  # the per-call random draws (ADPM2 step noise, SineGen noise), pinned by _fixed_draws for the bitwise check only
     if longform:
         sents = [tokens[i % PER_GPU_BATCH, :n].clone() for i, n in enumerate(LONGFORM_SENTENCES)]
         durs = [torch.full((1, n), FRAMES_PER_PHONEME, dtype=torch.long) for n in LONGFORM_SENTENCES]
@@ -498,18 +511,18 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
                     first_chunk.append((time.perf_counter() - t_start) * 1e3)
             if sequential:  # the reference of `bitwise_vs_single`: one stream, one sentence's decoder at a time
                 return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
-                                                overlap=False, bucket=16, front=front, front_batch=a.longform_front_batch)[0]
+                                                overlap=False, bucket=16, front=front, front_batch=a.longform_front_batch, **fixed)[0]
             return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
                                             overlap=True, bucket=16, on_chunk=on_chunk, front=front,
                                             side_stream=shared_stream(dev, 0), front_batch=a.longform_front_batch,
-                                            decode_streams=active.get("decode_streams", 1))[0]
+                                            decode_streams=active.get("decode_streams", 1), **fixed)[0]
     else:
         audio_s = PER_GPU_BATCH * AUDIO_S_PER_UTT
 
         def step(front=front, sequential=False):
             return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
                                       ref_s=ref_s, durations=durations_dev, total_frames=frames,
-                                      front_stream=None if sequential else sched[active["name"]], front=front)
+                                      front_stream=None if sequential else sched[active["name"]], front=front, **fixed)
     import contextlib
     cal = _calibrate(a, model, dev, lambda: step(front=None))  # eager: before the front's hipGraph is recorded
     with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
@@ -544,7 +557,9 @@ def _leg(name, a, dev, n_warm=3, n_steps=5):
     by_class = _read_conv_classes(lib)
     ops.check_status()
     finite = all(bool(torch.isfinite(w).all()) for w in out) if longform else bool(torch.isfinite(out).all())
+    fixed.update(_fixed_draws(dev, steps_d, LONGFORM_SENTENCES if longform else None, PER_GPU_BATCH))
     bitwise = _bitwise_vs_single(step, lambda: step(sequential=True))
+    fixed.clear()
     ops.check_status()
     res = {"workload": cfg["workload"], "baseline_config_index": cfg["baseline_config"], "ms_per_step": round(ms, 3),
            "audio_s_per_step": audio_s, "audio_s_per_s": round(audio_s / (ms * 1e-3), 1), "steps": n_steps, "warmup": n_warm,
@@ -574,9 +589,11 @@ def _latency_b1(a, dev, model, sampler, front, n_warm=3, n_steps=10):
     tokens, noise, dur = tokens.to(dev), noise.to(dev), durations.to(dev)
     steps_d, frames = CONFIGS[a.config]["steps"], N_PHONEMES * FRAMES_PER_PHONEME
 
+    fixed = {}
+
     def step():
         return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
-                                  durations=dur, total_frames=frames, front=front)
+                                  durations=dur, total_frames=frames, front=front, **fixed)
     import contextlib
     with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
         step()
@@ -595,7 +612,9 @@ def _latency_b1(a, dev, model, sampler, front, n_warm=3, n_steps=10):
     lib.st2_conv_timing(0)
     by_class = _read_conv_classes(lib)
     ops.check_status()
+    fixed.update(_fixed_draws(dev, steps_d, None, 1))
     bitwise = _bitwise_vs_single(step, step)  # one stream already: run-to-run reproducibility of the latency path
+    fixed.clear()
     return {"bitwise_vs_single": bitwise["equal"], "workload": "B = 1, one 10 s utterance (100 phonemes, %d diffusion steps, %s), one stream, graph-replayed front; "
                         "every call synchronised" % (steps_d, a.config),
             "latency_ms": {"mean": round(sum(ts) / len(ts), 3), "min": round(min(ts), 3), "max": round(max(ts), 3)},
@@ -829,6 +848,7 @@ def main():
     active = {"name": a.schedule if a.schedule != "auto" else "two-stream"}
 
     first_chunk_ms = []
+    fixed = {}  # pinned random draws, for the bitwise check after the timed region only (_fixed_draws)
     # The device-only front of a step / sentence (text encoder, PL-BERT, diffusion sampler, style mixing, duration
     # encoder: ~600 launches of 5-70 us kernels) is replayed from ONE hipGraph per shape (pipeline.GraphedFront; captured
     # during the warm-up steps): host issue time per step 6.0 -> 1.8 ms, throughput +0.7-1.3 % (profiles/r02x_*).  The
@@ -848,13 +868,14 @@ def main():
                     first_chunk_ms.append((time.perf_counter() - t_start) * 1e3)
             if sequential:  # reference of `bitwise_vs_single`: one stream, sentence after sentence
                 return pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d, durations=durs,
-                                                overlap=False, bucket=16, front=front, front_batch=a.longform_front_batch)[0]
+                                                overlap=False, bucket=16, front=front, front_batch=a.longform_front_batch, **fixed)[0]
             with torch.cuda.stream(healthy.main if healthy is not None else torch.cuda.current_stream(dev)):
                 waves, _ = pipeline.synthesize_long(model, sampler, sents, ref_s=ref_s[:1], diffusion_steps=steps_d,
                                                     durations=durs, overlap=a.schedule != "single", bucket=16,
                                                     on_chunk=on_chunk, front=front, front_batch=a.longform_front_batch,
                                                     decode_streams=active.get("decode_streams", 1),
-                                                    side_stream=healthy.front if healthy is not None else shared_stream(dev, 0))
+                                                    side_stream=healthy.front if healthy is not None else shared_stream(dev, 0),
+                                                    **fixed)
             return waves
     else:
         audio_s = B * AUDIO_S_PER_UTT
@@ -866,7 +887,7 @@ def main():
             with torch.cuda.stream(main_s if main_s is not None else torch.cuda.current_stream(dev)):
                 return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d,
                                           embedding_scale=1.0, ref_s=ref_s, durations=durations_dev, total_frames=frames,
-                                          front_stream=front_s, front=front)
+                                          front_stream=front_s, front=front, **fixed)
 
     def step_eager():
         return step(front=None)
@@ -1008,7 +1029,9 @@ def main():
         out = step()
         host_issue.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
+    fixed.update(_fixed_draws(dev, steps_d, LONGFORM_SENTENCES if longform else None, B))
     bitwise = _bitwise_vs_single(step, lambda: step(sequential=True))
+    fixed.clear()
     ops.check_status()
 
     if rank == 0:

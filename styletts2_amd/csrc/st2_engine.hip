@@ -2081,17 +2081,13 @@ extern "C" int st2_finalize_weights(st2_engine* e, int32_t which) {
   if (e->wbase) g_be.dev_free(e->wbase);  // only now: the new blob is complete on the device
   e->wbase = static_cast<char*>(p);
   e->wbytes = bytes;
-  // New weights: new sites.  A calibration of the previous weights survives only when the layout is the same conv for conv
-  // (the usual reload of another checkpoint of one architecture keeps its table until the caller re-calibrates or clears it).
-  bool same = blob.sites.size() == e->sites.size();
-  for (size_t i = 0; same && i < blob.sites.size(); ++i)
-    same = blob.sites[i].name == e->sites[i].name && blob.sites[i].C_in == e->sites[i].C_in &&
-           blob.sites[i].C_out == e->sites[i].C_out && blob.sites[i].ks == e->sites[i].ks;
+  // New weights: new sites, and NO operand scales.  A table belongs to the weights it was measured on: another checkpoint of the same
+  // architecture has other activation magnitudes at every site, and scales that are too large clamp (ST2_STATUS_F16_RANGE) while
+  // scales that are too small push the lo halves into f16 subnormals without any signal (advisor, round 5).  The caller
+  // re-calibrates (st2_calibrate) or installs the table saved beside THAT checkpoint (st2_calibration_write).
   e->sites = blob.sites;
-  if (!same) {
-    e->site_scale.assign(e->sites.size(), 0.f);
-    e->site_seen.assign(e->sites.size(), 0.f);
-  }
+  e->site_scale.assign(e->sites.size(), 0.f);
+  e->site_seen.assign(e->sites.size(), 0.f);
   return 0;
 }
 

@@ -294,6 +294,10 @@ class Decoder(nn.Module):
 
     def __setattr__(self, name, value):
         if name == "_pk" and value is None:  # every invalidation of the Python-side pack drops the C++ plan's copy too
+            old = self.__dict__.get("_eng")
+            if old is not None:
+                from . import engine
+                engine.replaced(old, "decoder")  # a calibrated engine does not vanish silently (load_state_dict / .to())
             object.__setattr__(self, "_eng", None)
         super().__setattr__(name, value)
 
@@ -347,7 +351,8 @@ class Decoder(nn.Module):
         if asr.is_cuda and engine.plan_mode() == "engine" and W.conv_precision() == "f16s":
             # ONE C-ABI call: the launch plan below exists in C++ (csrc/st2_engine.hip, st2_decoder_forward)
             eng = self._eng
-            if eng is None or eng.device != dev:
+            if eng is None or not engine.same_device(eng, dev):
+                engine.replaced(eng, "decoder")
                 eng = self._eng = engine.build_decoder_engine(self, dev)
             return eng.decoder_forward(asr, F0_curve, N, s, noise=noise, har=har, taps=taps)
         pk = self._pk if (self._pk is not None and self._pk.device == dev) else self._prepare(dev)

@@ -45,6 +45,31 @@ def live_engines():
     return [e for e in _LIVE if getattr(e, "h", None)]
 
 
+def norm_device(dev):
+    """torch.device with its index filled in: 'cuda', 'cuda:0', torch.device('cuda') and a tensor's .device all name the
+    same engine (advisor, round 5: a cache keyed on the caller's spelling rebuilt the engine -- a full repack and upload --
+    and silently dropped its calibration table)."""
+    if dev is None:
+        return None
+    dev = torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def same_device(eng, dev):
+    return eng is not None and norm_device(eng.device) == norm_device(dev)
+
+
+def replaced(old, what):
+    """Called when a cached engine is about to be rebuilt (weights reloaded or moved): a calibration table belongs to the
+    weights it was measured on and does not travel -- but the caller must hear that it is gone."""
+    if old is not None and getattr(old, "h", None) and any(old.calibration_scales()):
+        import warnings
+        warnings.warn("the calibrated %s engine is being rebuilt (weights reloaded or moved): its per-layer operand scales are "
+                      "dropped; run pipeline.calibrate / load_calibration_state again" % what, RuntimeWarning, stacklevel=3)
+
+
 class Engine:
     """One st2_engine handle (packed weights of a decoder and / or a denoiser on the current device)."""
 

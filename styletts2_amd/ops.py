@@ -82,11 +82,14 @@ def status(clear=False):
 lstm_recoveries = 0  # check_status() calls that found ST2_STATUS_LSTM_RECOVERED (bench.py reports it)
 
 
-def check_status():
+def check_status(ignore=0):
     """Raises St2Error if a kernel reported a device-side condition since the last check (and clears it).  Called by
     the pipeline at its existing host synchronisation points and at the start of every call for the previous one's
-    kernels, so a failure is never silent and costs no extra synchronisation."""
+    kernels, so a failure is never silent and costs no extra synchronisation.  `ignore`: status bits the caller expects
+    (pipeline.calibrate provokes F16_RANGE on purpose); every other bit is still reported."""
     st = status(clear=True)
+    if st > 0:
+        st &= ~int(ignore)
     if st > 0 and st & _lib.STATUS_LSTM_RECOVERED:  # informational: the outputs are valid, the call lost its latency advantage
         global lstm_recoveries
         lstm_recoveries += 1

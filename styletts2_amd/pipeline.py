@@ -148,8 +148,10 @@ def _front_engine(model, dev):
     from . import engine
     mods = [model.text_encoder, model.bert, model.bert_encoder, model.diffusion.diffusion.net, model.predictor]
     stamp = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+    dev = engine.norm_device(dev)
     cached = getattr(model.predictor, "_front_engine", None)
-    if cached is None or cached[0] != stamp or cached[1].device != dev:
+    if cached is None or cached[0] != stamp or not engine.same_device(cached[1], dev):
+        engine.replaced(cached[1] if cached else None, "front")
         cached = (stamp, engine.build_front_engine(model, dev))
         model.predictor._front_engine = cached
     return cached[1]
@@ -625,6 +627,8 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
                 if on_chunk is not None:
                     on_chunk(emitted, waves[emitted])
                 emitted += 1
+    if use_streams and s_prev is not None:
+        s_prev.record_stream(main)  # allocated on the side stream, handed to the caller's
     return waves, s_prev
 
 
@@ -640,13 +644,13 @@ def calibrate(run, margin_bits=3, max_passes=3, engines=None):
     bounds those layers from below, so the recording is repeated (at most `max_passes` times).  Calibrate BEFORE recording
     hipGraphs (GraphedFront re-records by itself); results stay bitwise reproducible for a given table.  Returns
     {"passes", "sites_set", "clamped_last_pass", "headroom": rows of the last pass (ops.headroom)}."""
-    from . import engine
+    from . import _lib, engine
     rows, nset, clamped, passes = [], 0, 0, 0
+    ops.check_status()  # whatever earlier calls raised is theirs: reported now, not swallowed by the passes below
     for _ in range(max(1, int(max_passes))):
-        ops.status(clear=True)
         with ops.headroom() as h:
             run()
-        ops.status(clear=True)  # a clamp during calibration is what the pass is there to find
+        ops.check_status(ignore=_lib.STATUS_F16_RANGE)  # a clamp during calibration is what the pass is there to find
         rows, passes = h.rows, passes + 1
         nset = clamped = 0
         for eng in (engines if engines is not None else engine.live_engines()):
@@ -661,12 +665,14 @@ def model_engines(model, dev):
     """{"front": ..., "decoder": ..., "style": ...}: the st2_engine handles behind a model's product path on `dev`, built if
     they are not yet (same caches as the forward calls use)."""
     from . import engine, style
+    dev = engine.norm_device(dev)
     dec = model.decoder
-    if getattr(dec, "_eng", None) is None or dec._eng.device != dev:
+    if getattr(dec, "_eng", None) is None or not engine.same_device(dec._eng, dev):
+        engine.replaced(getattr(dec, "_eng", None), "decoder")
         dec._eng = engine.build_decoder_engine(dec, dev)
     out = {"front": _front_engine(model, dev), "decoder": dec._eng}
     se, pe = model.get("style_encoder"), model.get("predictor_encoder")
-    on_dev = lambda m: all(p.device == torch.device(dev) for p in m.parameters())
+    on_dev = lambda m: all(engine.norm_device(p.device) == dev for p in m.parameters())
     if isinstance(se, style.StyleEncoder) and isinstance(pe, style.StyleEncoder) and on_dev(se) and on_dev(pe):
         out["style"] = style._style_engine(model, dev)  # (a process that never moved the style encoders to `dev` has no such engine)
     return out

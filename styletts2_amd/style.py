@@ -284,7 +284,8 @@ def _style_engine(model, dev):
     mods = [model.style_encoder, model.predictor_encoder]
     stamp = tuple((p.data_ptr(), p._version) for m in mods for p in list(m.parameters()) + list(m.buffers()))
     cached = getattr(model.style_encoder, "_plan_engine", None)
-    if cached is None or cached[0] != stamp or cached[1].device != dev:
+    if cached is None or cached[0] != stamp or not engine.same_device(cached[1], dev):
+        engine.replaced(cached[1] if cached else None, "style")
         cached = (stamp, engine.build_style_engine(model.style_encoder, model.predictor_encoder, dev))
         model.style_encoder._plan_engine = cached
     return cached[1]

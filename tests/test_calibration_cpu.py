@@ -86,7 +86,7 @@ def test_site_table_and_written_scales_reach_every_launch(small_decoder):
         assert CB.X_SCALES_SEEN == by_rule and torch.equal(again, base)
 
 
-def test_calibration_write_validates_and_survives_a_same_layout_reload(small_decoder):
+def test_calibration_write_validates_and_is_dropped_by_a_reload(small_decoder):
     dc, dec = small_decoder
     with cpu_backend():
         eng = engine.build_decoder_engine(dec, None)
@@ -99,11 +99,13 @@ def test_calibration_write_validates_and_survives_a_same_layout_reload(small_dec
             eng.set_calibration([-2.0] + [1.0] * (n - 1))
         table = [0.0 if i % 5 == 0 else 2.0 ** (i % 4) for i in range(n)]  # 0 = this site by rule
         eng.set_calibration(table)
-        # reloading another checkpoint of the SAME architecture keeps the table (the caller re-calibrates when it wants to) ...
+        assert eng.calibration_scales() == table
+        # new weights, no table: scales belong to the checkpoint they were measured on (another checkpoint of the SAME architecture
+        # would run clamped or with subnormal lo halves, silently) -- the caller re-calibrates or writes the table saved beside it
         synth.init_synthetic_(dec, 2)
         eng.load_module("decoder.", dec)
         eng.finalize(1, None)
-        assert eng.calibration_scales() == table
+        assert eng.calibration_scales() == [0.0] * n
         # ... an engine holding another layout refuses it by size
         lib = dict(manifest("libritts")["config"]["decoder"])
         dec2 = Decoder(**decoder_kwargs(lib)).eval()
@@ -112,3 +114,26 @@ def test_calibration_write_validates_and_survives_a_same_layout_reload(small_dec
         assert len(eng2.calibration()) != n
         with pytest.raises(_lib.St2Error, match="conv sites"):
             eng2.set_calibration(table)
+
+
+def test_replacing_a_calibrated_engine_warns_and_device_spellings_agree(small_decoder):
+    """Advisor, round 5: `eng.device != dev` compared the caller's spelling ('cuda:0' vs torch.device('cuda')), rebuilt the engine
+    and lost its table without a word.  Devices are normalised before the comparison, and a calibrated engine never goes silently."""
+    import warnings
+    dc, dec = small_decoder
+    assert engine.norm_device(None) is None
+    assert engine.norm_device("cuda:1") == torch.device("cuda", 1) == engine.norm_device(torch.device("cuda:1"))
+    with cpu_backend():
+        eng = engine.build_decoder_engine(dec, None)
+        assert engine.same_device(eng, None) and not engine.same_device(None, None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            engine.replaced(eng, "decoder")  # by rule: nothing to lose, nothing said
+        n = len(eng.calibration())
+        eng.set_calibration([2.0] * n)
+        with pytest.warns(RuntimeWarning, match="operand scales are\\s+dropped"):
+            engine.replaced(eng, "decoder")
+        dec._eng = eng
+        with pytest.warns(RuntimeWarning, match="decoder engine is being rebuilt"):
+            dec._pk = None  # what load_state_dict / .to() do
+        assert dec._eng is None
