@@ -717,7 +717,10 @@ int st2_debug_headroom_read(double* rows, int32_t cap_rows);
  *   st2_calibration_write  installs a table (n = number of sites, entries 0 or a power of two; n = 0 clears): how rank 0's
  *                          calibration reaches the other ranks and how a table saved beside a checkpoint is restored;
  *   st2_calibration_scale  the formula above for one value (0 for max_abs <= 0).
- * st2_finalize_weights keeps the table when the new weights have the same conv layout, clears it otherwise. */
+ * st2_calibrate ACCUMULATES: a site's maximum is the largest over every recorded call since the table was last cleared, and sites whose
+ * operand does not come out of a normalising prologue (free-ranging: F0 in Hz, stage outputs, FFN intermediates) get two more bits
+ * of headroom than margin_bits (ABI v22).  st2_finalize_weights CLEARS the table (ABI v22; v20-21 kept it for an unchanged conv
+ * layout): scales belong to the weights they were measured on. */
 #define ST2_CALIBRATION_COLS 5
 int st2_calibrate(st2_engine* e, int32_t margin_bits, int32_t* n_clamped);
 int st2_calibration_read(st2_engine* e, double* rows, int32_t cap_rows);

@@ -2108,6 +2108,7 @@ extern "C" int st2_calibrate(st2_engine* e, int32_t margin_bits, int32_t* n_clam
   if (n > 0 && st2_debug_headroom_read(rows.data(), n) < 0) return -1;
   const double me = (double)(uintptr_t)e;
   std::vector<float> seen(e->sites.size(), 0.f);
+  std::vector<char> free_range(e->sites.size(), 0);  // the site's operand does not come out of a normalising prologue
   int clamped = 0;
   for (int i = 0; i < n; ++i) {
     const double* r = rows.data() + (size_t)i * ST2_HEADROOM_COLS;
@@ -2115,14 +2116,21 @@ extern "C" int st2_calibrate(st2_engine* e, int32_t margin_bits, int32_t* n_clam
     if (r[11] != me || site < 0 || site >= (int)seen.size() || !(r[5] > 0.0)) continue;
     if (r[6] >= 65504.0) ++clamped;  // the operand hit the clamp at the scale it ran with: this pass only bounds it from below
     seen[(size_t)site] = std::max(seen[(size_t)site], (float)(r[6] / r[5]));  // max |pro(x)| over every launch of the site
+    if (x_scale_for((int)r[1]) == 1.0f) free_range[(size_t)site] = 1;
   }
   e->site_scale.resize(e->sites.size(), 0.f);
   e->site_seen.resize(e->sites.size(), 0.f);
   int set = 0;
   for (size_t i = 0; i < seen.size(); ++i) {
     if (!(seen[i] > 0.f)) continue;  // never launched in the recorded calls (or all-zero operand): keeps what it had
-    e->site_seen[i] = seen[i];
-    e->site_scale[i] = st2_calibration_scale(seen[i], margin_bits);
+    // The maximum ACCUMULATES over calls (finalize / st2_calibration_write(n = 0) reset it): calibrating again on more utterances
+    // can only widen a site's range, never forget what an earlier pass saw.
+    e->site_seen[i] = std::max(e->site_seen[i], seen[i]);
+    // Headroom above the largest operand seen: 2^margin_bits after a normalising prologue (AdaIN / LayerNorm outputs are bounded by
+    // the affine's gain whatever the utterance), two bits more where the operand is free-ranging -- the F0 curve in Hz, generator
+    // stage outputs, FFN intermediates differ between utterances far more than between passes of one (advisor, round 5: 8 x over
+    // ONE synthetic step is thin for those; the lo half stays a normal f16 down to 2^-14 / x_scale, two bits cost nothing there).
+    e->site_scale[i] = st2_calibration_scale(e->site_seen[i], margin_bits + (free_range[i] ? 2 : 0));
     ++set;
   }
   if (n_clamped) *n_clamped = clamped;

@@ -635,18 +635,25 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
 # ---------------------------------------------------------------------------------------------------------------------
 # per-layer operand scales of the split-f16 convs (include/st2.h st2_calibrate)
 # ---------------------------------------------------------------------------------------------------------------------
-def calibrate(run, margin_bits=3, max_passes=3, engines=None):
+def calibrate(run, margin_bits=3, max_passes=3, engines=None, accumulate=False):
     """Start-up calibration of a serving process: `run()` issues one or more representative forwards through the product
     path (e.g. `lambda: inference(model, sampler, tokens, ...)`, plus `style.compute_style(model, wave)` for a zero-shot
     model); every split-f16 conv of every live engine that was launched gets its own power-of-two operand scale from the
     largest input it saw (the reference's convs are fp32 at every magnitude, Modules/istftnet.py:68-74; by rule the scale is
     8 / 1, which is fp32-class for O(1) tensors only).  A pass whose launches ran into the f16 clamp at their old scale only
     bounds those layers from below, so the recording is repeated (at most `max_passes` times).  Calibrate BEFORE recording
-    hipGraphs (GraphedFront re-records by itself); results stay bitwise reproducible for a given table.  Returns
+    hipGraphs (GraphedFront re-records by itself); results stay bitwise reproducible for a given table.  `run()` should cover the
+    spread of the traffic (several utterances, several reference styles): a site keeps 8 x headroom over the largest operand seen
+    after a normalising prologue and 32 x where its input is free-ranging (F0 in Hz, stage outputs, FFN intermediates); beyond that
+    the clamp + ST2_STATUS_F16_RANGE stay as the net.  `accumulate=True` widens the existing table with what this call sees instead
+    of starting over (more utterances later, same checkpoint).  Returns
     {"passes", "sites_set", "clamped_last_pass", "headroom": rows of the last pass (ops.headroom)}."""
     from . import _lib, engine
     rows, nset, clamped, passes = [], 0, 0, 0
     ops.check_status()  # whatever earlier calls raised is theirs: reported now, not swallowed by the passes below
+    if not accumulate:
+        for eng in (engines if engines is not None else engine.live_engines()):
+            eng.set_calibration(None)  # st2_calibrate accumulates maxima: a fresh calibration starts from the rule
     for _ in range(max(1, int(max_passes))):
         with ops.headroom() as h:
             run()

@@ -87,8 +87,11 @@ def test_calibrated_decoder_meets_the_tap_bars_at_small_magnitudes(tag, f):
     table = eng.calibration()
     launched = [r for r in table if r["seen"] > 0]
     assert len(launched) == rep["sites_set"]
-    for r in launched:  # the largest operand of every calibrated layer sits in (4096, 8192]: 3 bits below the clamp
-        assert 4096.0 <= r["seen"] * r["x_scale"] < 8192.0, r
+    # the largest operand of every calibrated layer sits 3 bits below the clamp after a normalising prologue, (4096, 8192], and 5
+    # bits below where the operand is free-ranging (asr_res / shortcut / stage inputs), (1024, 2048] -- ABI 22
+    bands = [r["seen"] * r["x_scale"] for r in launched]
+    assert all(4096.0 <= v < 8192.0 or 1024.0 <= v < 2048.0 for v in bands), sorted(bands)[:5]
+    assert any(v >= 4096.0 for v in bands) and any(v < 2048.0 for v in bands)
     with ops.headroom() as after:
         te = {}
         out = run(te)
