@@ -374,9 +374,17 @@ def _calibrate_decode_streams(a, active, step, time_steps):
     dev = torch.device("cuda", torch.cuda.current_device())
     n = max(1, int(a.longform_decode_streams))
     cands = {"decode-streams-1": 1}
-    if n > 1:  # n consecutive auxiliary streams starting at index 1, 2, ...: which hardware queues they land on depends on how
-        for first in range(1, 5):  # many streams the process made before -- one of the windows has queues of its own
-            cands["decode-streams-%d@%d" % (n, first)] = [ops.aux_stream(dev, 0, index=first + i) for i in range(n)]
+    if n > 1:
+        # Which auxiliary streams own a hardware queue is PROBED, not guessed (ops.distinct_queue_streams: two single-workgroup
+        # kernels overlap or they do not): n streams that overlap with the caller's stream, with the front's side stream and with
+        # each other.  Round 5 timed four windows of consecutive streams instead and kept the best (51.7 ... 114 ms: a 2.1 x
+        # spread decided by creation order); one verified candidate replaces them.
+        picked = ops.distinct_queue_streams(dev, n, avoid=[torch.cuda.current_stream(dev), shared_stream(dev, 0)])
+        active["decode_streams_probe"] = {"wanted": n, "found": len(picked)}
+        if len(picked) == n:
+            cands["decode-streams-%d/probed" % n] = picked
+        else:
+            log("long-form: only %d of %d decoder streams found a hardware queue of their own; staying on one stream" % (len(picked), n))
     calib = {}
     for name, c in cands.items():
         active["decode_streams"] = c
@@ -623,6 +631,70 @@ def _latency_b1(a, dev, model, sampler, front, n_warm=3, n_steps=10):
             "xs_conv_ms_per_step": round(sum(sum(v) for v in by_class.values()) / n_steps, 3), "dominant": _dominant_of(by_class)}
 
 
+def ragged_inputs(dev):
+    """The first 32 utterances of the reference's LJSpeech validation list (benchdata/val_phonemes_32.txt, written by
+    benchdata/make_val_phonemes.py from Data/val_list.txt) through `TextCleaner` (text_utils.py:3-26): a right-padded token batch
+    with its lengths, and forced durations of FRAMES_PER_PHONEME frames on every real token so that audio-seconds are defined
+    (Demo/Inference_LJSpeech.ipynb:268-315 with the duration head's output replaced, as in every other leg)."""
+    from styletts2_amd.text_utils import TextCleaner
+    tc = TextCleaner()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "benchdata", "val_phonemes_32.txt")
+    rows = [tc.encode(line.rstrip("\n")) for line in open(path, encoding="utf-8") if line.strip()]
+    lens = [len(r) for r in rows]
+    N = max(lens)
+    tokens = torch.zeros((len(rows), N), dtype=torch.long)
+    dur = torch.zeros((len(rows), N), dtype=torch.long)
+    for b, r in enumerate(rows):
+        tokens[b, :len(r)] = torch.tensor(r)
+        dur[b, :len(r)] = FRAMES_PER_PHONEME
+    g = torch.Generator().manual_seed(2024)
+    noise = torch.randn(len(rows), 1, 256, generator=g)
+    return tokens.to(dev), torch.LongTensor(lens), noise.to(dev), dur.to(dev), lens
+
+
+def _leg_ragged(a, dev, model, sampler, front, n_warm=2, n_steps=3):
+    """Real, ragged text through the headline model: 32 validation utterances of 47-182 tokens as ONE right-padded batch.  The
+    front runs batched (pad tokens masked everywhere); the decoder's InstanceNorm spans an utterance, so every distinct frame
+    count is its own decoder call -- 32 calls of one utterance here, which is what a serving process pays for real text unless
+    it buckets by length.  Reports audio-s/s, the padding efficiency of the token batch and the number of decoder calls."""
+    from styletts2_amd import ops, pipeline
+    tokens, lengths, noise, dur, lens = ragged_inputs(dev)
+    steps_d = CONFIGS[a.config]["steps"]
+    fixed = {}
+
+    def step():
+        return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
+                                  durations=dur, front=front, **fixed)
+    import contextlib
+    with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
+        out = step()
+        torch.cuda.synchronize()
+    for _ in range(n_warm):
+        step()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n_steps):
+        out = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / n_steps * 1e3
+    ops.check_status()
+    assert isinstance(out, list) and [w.shape[-1] for w in out] == [600 * FRAMES_PER_PHONEME * n for n in lens]
+    audio_s = sum(lens) * FRAMES_PER_PHONEME * 600 / 24000.0
+    B = len(lens)
+    fixed.update({"step_noise": torch.randn(steps_d - 1, B, 1, 256, device=dev),
+                  "sine_noise": torch.randn(B, 600 * FRAMES_PER_PHONEME * max(lens), 9, device=dev)})
+    bitwise = _bitwise_vs_single(step, step)
+    fixed.clear()
+    return {"workload": "LJSpeech validation text: %d real utterances of %d-%d tokens (Data/val_list.txt through TextCleaner), one "
+                        "right-padded batch, %d frames / token forced, iSTFTNet, %d diffusion steps" % (B, min(lens), max(lens),
+                                                                                                         FRAMES_PER_PHONEME, steps_d),
+            "ms_per_step": round(ms, 3), "audio_s_per_step": round(audio_s, 2), "audio_s_per_s": round(audio_s / (ms * 1e-3), 1),
+            "steps": n_steps, "warmup": n_warm, "utterances": B, "phonemes_per_utterance": [min(lens), max(lens)],
+            "padding_efficiency": round(sum(lens) / (B * max(lens)), 4), "decoder_calls": len(set(lens)),
+            "schedule": "single", "finite": all(bool(torch.isfinite(w).all()) for w in out),
+            "bitwise_vs_single": bitwise["equal"]}
+
+
 def other_configs(a, dev, model, sampler, front, skip):
     """BASELINE.json configs[2..4] + the B = 1 latency point as short legs in the same process (rank 0, N = 1): a run of the
     default command carries every workload the baseline names.  A failing leg reports its error and never costs the line."""
@@ -638,6 +710,16 @@ def other_configs(a, dev, model, sampler, front, skip):
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": repr(e)}
             log("other config %s failed: %r" % (name, e))
+            torch.cuda.empty_cache()
+    if a.config == "ljspeech":
+        try:
+            out["ljspeech_ragged"] = _leg_ragged(a, dev, model, sampler, front)
+            log("ragged real text: %.1f ms/step = %.0f audio-s/s (padding efficiency %.2f, %d decoder calls)" % (
+                out["ljspeech_ragged"]["ms_per_step"], out["ljspeech_ragged"]["audio_s_per_s"],
+                out["ljspeech_ragged"]["padding_efficiency"], out["ljspeech_ragged"]["decoder_calls"]))
+        except Exception as e:  # noqa: BLE001
+            out["ljspeech_ragged"] = {"error": repr(e)}
+            log("ragged leg failed: %r" % (e,))
             torch.cuda.empty_cache()
     try:
         out["latency_b1_10s"] = _latency_b1(a, dev, model, sampler, front)

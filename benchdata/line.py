@@ -23,7 +23,7 @@ _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", 
 _CPU_KEEP = ("value", "unit", "cores", "kind", "sample", "host_cores", "threads_tried", "reference_modules")
 _LEG_KEEP = ("baseline_config_index", "ms_per_step", "audio_s_per_step", "audio_s_per_s", "steps", "warmup", "schedule",
              "schedules_ms_per_step", "decoder", "diffusion_steps", "finite", "bitwise_vs_single", "latency_ms", "decode_streams",
-             "front_batch", "first_chunk_latency_ms", "padding_efficiency", "utterances", "phonemes_per_utterance", "error",
+             "front_batch", "first_chunk_latency_ms", "padding_efficiency", "utterances", "phonemes_per_utterance", "decoder_calls", "error",
              "lstm_reloads")
 
 

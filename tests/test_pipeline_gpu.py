@@ -359,3 +359,55 @@ def test_graphed_front_is_bitwise_the_eager_front(tag, predict):
     assert [w.shape for w in w_b] == [w.shape for w in w_e]
     if not predict:
         assert all(torch.equal(x, y) for x, y in zip(w_b, w_b2))
+
+
+def test_real_validation_text_ragged_batch_matches_oracle_and_solo_runs():
+    """The reference's own validation inputs (Data/val_list.txt column 2 -> TextCleaner; benchdata/val_phonemes_32.txt) instead of
+    uniform synthetic rows: six real utterances of very different lengths as one right-padded batch, forced durations as in the
+    bench's `ljspeech_ragged` leg.  One utterance is held to the oracle (front taps at their bars, the waveform at the 1e-4 bar
+    with the oracle's harmonic features injected -- the iSTFTNet tap-point protocol); every row of the batch must be the same
+    utterance synthesised alone, and the batch must return one waveform per utterance at its own length."""
+    import bench
+    man, model, sds = _model("ljspeech")
+    tokens, lengths, noise, dur, lens = bench.ragged_inputs("cpu")
+    pick = [21, 29, 3, 9, 0, 5]  # 50, 47, 84, 73, 131, 182 tokens
+    tokens, lengths, noise, dur = tokens[pick], lengths[pick], noise[pick], dur[pick]
+    lens = [lens[i] for i in pick]
+    assert lens == [50, 47, 84, 73, 131, 182] and int(tokens.max()) < 178 and bool((tokens[:, 0] == 0).all())
+    N = max(lens)
+    tokens, dur = tokens[:, :N], dur[:, :N]
+    g = torch.Generator().manual_seed(8)
+    steps, B = 5, len(pick)
+    step_noise = torch.randn(steps - 1, B, 1, 256, generator=g)
+    sine_noise = torch.randn(B, 600 * 4 * N, 9, generator=g)
+    b0, n0 = 1, lens[1]  # the 47-token utterance on the CPU oracle
+    to = {}
+    ref = O.inference(sds, man["config"], man["plbert"], tokens[b0:b0 + 1, :n0], lengths[b0:b0 + 1], noise[b0:b0 + 1],
+                      step_noise[:, b0:b0 + 1], sine_noise[b0:b0 + 1, :600 * 4 * n0], diffusion_steps=steps, durations=dur[b0:b0 + 1, :n0],
+                      taps=to)
+    for k in KEYS:
+        model[k].to(DEV)
+    sampler = models.make_sampler(model)
+    te = {}
+    waves = pipeline.inference(model, sampler, tokens.to(DEV), lengths, noise.to(DEV), diffusion_steps=steps, durations=dur.to(DEV),
+                               step_noise=step_noise.to(DEV), sine_noise=sine_noise.to(DEV), taps=te)
+    torch.cuda.synchronize()
+    assert isinstance(waves, list) and [w.shape[-1] for w in waves] == [600 * 4 * n for n in lens]
+    assert all(bool(torch.isfinite(w).all()) for w in waves)
+    e = (te["s_pred"][b0:b0 + 1].cpu() - to["s_pred"]).abs().max().item() / to["s_pred"].abs().max().item()
+    assert e < 5e-5, "s_pred of the real utterance: %g" % e
+    for b, n in enumerate(lens):  # every row == the utterance alone, un-padded
+        t1 = {}
+        solo = pipeline.inference(model, sampler, tokens[b:b + 1, :n].to(DEV), lengths[b:b + 1], noise[b:b + 1].to(DEV),
+                                  diffusion_steps=steps, durations=dur[b:b + 1, :n].to(DEV), step_noise=step_noise[:, b:b + 1].to(DEV),
+                                  sine_noise=sine_noise[b:b + 1, :600 * 4 * n].to(DEV), taps=t1)
+        assert solo.shape[-1] == waves[b].shape[-1]
+        assert (te["s_pred"][b] - t1["s_pred"][0]).abs().max().item() < 2e-5
+        if b == b0:
+            for k, tol in (("asr", 5e-5), ("en", 1e-4), ("F0", 1e-4), ("N", 1e-4)):
+                err = (t1[k].cpu() - to[k]).abs().max().item() / max(to[k].abs().max().item(), 1e-6)
+                assert err < tol, "%s rel err %g on real text" % (k, err)
+            # waveform at the 1e-4 bar: the decoder on the oracle's inputs and harmonic features (tap-point protocol, SURVEY 8c)
+            wav = model.decoder(to["asr"].to(DEV), to["F0"].to(DEV), to["N"].to(DEV), to["s_pred"][:, :128].to(DEV),
+                                noise=sine_noise[b0:b0 + 1, :600 * 4 * n0].to(DEV), har=to["har"].to(DEV))
+            assert rms(wav.cpu() - ref) < WAVE_RMS_TOL
