@@ -447,10 +447,10 @@ inline int rule_variant(const st2_conv_desc& d) {
 // k = 3 ONLY (round 5, an open hardware-level observation): while the 16-channel-chunk builds with narrow tiles (k = 7 / 11, 64 /
 // 32 columns) run on one queue, the BiLSTM kernels on ANOTHER queue -- both the single-CU and the cooperative one -- return
 // different results in 25-90 % of their calls: traced to 16 consecutive lanes of ONE gate's W_hh load carrying wrong data (one
-// 64-byte sector of a global load; tools/debug_lstm_trace.py, profiles/r05i_*).  The convs' own outputs are bit-exact under the
+// 64-byte sector of a global load; tools/stress.py lstm_trace, profiles/r05i_*).  The convs' own outputs are bit-exact under the
 // same load, guard bands around their output stay intact, capping their workgroups per CU changes nothing, and the k = 3 narrow
 // builds (32-channel chunks), the 128-column k = 7 / 11 builds and every other load tried do not do it
-// (tools/debug_lstm_under_load2.py).  Until that is understood the narrow tiles are used where they are verified harmless.
+// (tools/stress.py lstm_under_load2).  Until that is understood the narrow tiles are used where they are verified harmless.
 inline int small_grid_cols(const st2_conv_desc& d) {
   if (!ST2_XS_SMALLGRID || d.C_out <= 64 || d.ks != 3 || d.B > 3) return 128;
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;

@@ -82,7 +82,7 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
   // (csh = y[b][co][first column of the slot]: lane kg = 0 owns it, its kg = 1 partner gets it by one cross-lane move): the
   // finaliser gets that value with the sums and combines the slots with Chan's formula in fp64.  Unshifted sums lose the variance
   // of a channel whose mean dominates it -- E[x^2] - mean^2 with fp32 partial sums: |mean| / std = 100 (a bias-dominated channel of
-  // a residual stream) costs 1e-8 x 1e4 = 1e-4 of rstd, three decades above fp32 (round 5, tools/debug_stats_precision.py) --
+  // a residual stream) costs 1e-8 x 1e4 = 1e-4 of rstd, three decades above fp32 (round 5, tools/stress.py stats_precision) --
   // shifted ones do not: the shifted mean is within a few std of zero whatever the channel's offset.
   float s1 = 0.f, s2 = 0.f, csh = 0.f;
   float s1d[NPT] = {}, s2d[NPT] = {}, cshd[NPT] = {};  // the finished slots' sums and shifts: shared by the builds a tile may combine

@@ -848,1089 +848,13 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
 
 float* new_stats(Ctx& c, int B, int C) { return c.a.f32((int64_t)B * C * 2); }
 
-// ------------------------------------------------------------------------------------------------------------------
-// decoder plan == styletts2_amd/decoder.py
-// ------------------------------------------------------------------------------------------------------------------
-struct DecRun {
-  Ctx& c;
-  const st2_engine& e;
-  const float* h;  // style bank output [B][J]
-  int J;
-  const float* gamma(int off) const { return h + off; }
-  const float* beta(int off, int channels) const { return h + off + channels; }
-};
-
-// AdaINResBlock1.forward (Modules/istftnet.py:66-75); the MRF sum / division ride in the last conv's epilogue
-View run_resblock1(DecRun& r, const PResBlock1& p, View x, const float* x_stats, View mrf_acc, bool mrf_last, int n_mrf,
-                   View out) {
-  Ctx& c = r.c;
-  const int C = p.channels, ks = p.ks, B = x.B, L = x.L;
-  const float* st = x_stats;
-  if (!st) {
-    float* s0 = new_stats(c, B, C);
-    RUN(c, g_be.instnorm_stats(x.p, x.bs, x.cs, B, C, L, 1e-5f, s0, c.stream));
-    st = s0;
-  }
-  View xt = new_ncl(c, B, C, L);
-  View ping[2] = {new_ncl(c, B, C, L), new_ncl(c, B, C, L)};
-  float* st2 = new_stats(c, B, C);
-  float* stn[2] = {new_stats(c, B, C), new_stats(c, B, C)};
-  for (int i = 0; i < 3; ++i) {
-    const int d = p.dil[i];
-    ConvOpt o1;
-    o1.dil = d; o1.pad_left = (ks * d - d) / 2; o1.bias = r.e.F(p.c1[i].bias); o1.pro = ST2_PRO_ADAIN_SNAKE;
-    o1.stats = st; o1.gamma = r.gamma(p.ad1[i]); o1.beta = r.beta(p.ad1[i], C); o1.gb_bs = r.J;
-    o1.alpha = r.e.F(p.a1[i]); o1.stats_out = st2;
-    conv(c, r.e, x, p.c1[i].w, xt, o1);
-    const bool last = i == 2;
-    ConvOpt o2;
-    o2.dil = 1; o2.pad_left = (ks - 1) / 2; o2.bias = r.e.F(p.c2[i].bias); o2.pro = ST2_PRO_ADAIN_SNAKE;
-    o2.stats = st2; o2.gamma = r.gamma(p.ad2[i]); o2.beta = r.beta(p.ad2[i], C); o2.gb_bs = r.J;
-    o2.alpha = r.e.F(p.a2[i]); o2.res = x;
-    if (last) {
-      o2.res2 = mrf_acc;
-      o2.div = mrf_last ? (float)n_mrf : 1.0f;
-      conv(c, r.e, xt, p.c2[i].w, out, o2);
-      x = out;
-    } else {
-      o2.stats_out = stn[i & 1];
-      conv(c, r.e, xt, p.c2[i].w, ping[i & 1], o2);
-      x = ping[i & 1];
-      st = stn[i & 1];
-    }
-  }
-  return x;
-}
-
-// AdainResBlk1d.forward (Modules/istftnet.py:435-454): (residual(x, s) + shortcut(x)) / sqrt(2)
-void run_adain_resblk(DecRun& r, const PAdainResBlk& p, const View& x, const View& out) {
-  Ctx& c = r.c;
-  const int B = x.B, L = x.L;
-  const int64_t mark = c.a.off;
-  float* st1 = new_stats(c, B, p.dim_in);
-  RUN(c, g_be.instnorm_stats(x.p, x.bs, x.cs, B, p.dim_in, L, 1e-5f, st1, c.stream));
-  float* st2 = new_stats(c, B, p.dim_out);
-  const int Lo = p.upsample ? 2 * L : L;
-  View t1 = new_ncl(c, B, p.dim_out, Lo);
-  if (p.upsample) {
-    View u = new_ncl(c, B, p.dim_in, 2 * L);
-    RUN(c, g_be.adain_leaky_pool(x.p, x.bs, x.cs, st1, r.gamma(p.n1), r.beta(p.n1, p.dim_in), r.J, 0.2f,
-                                 r.e.F(p.pool_w), r.e.F(p.pool_b), u.p, u.bs, u.cs, B, p.dim_in, L, c.stream));
-    ConvOpt o;
-    o.pad_left = 1; o.bias = r.e.F(p.conv1.bias); o.stats_out = st2;
-    conv(c, r.e, u, p.conv1.w, t1, o);
-  } else {
-    ConvOpt o;
-    o.pad_left = 1; o.bias = r.e.F(p.conv1.bias); o.pro = ST2_PRO_ADAIN_LEAKY; o.slope = 0.2f; o.stats = st1;
-    o.gamma = r.gamma(p.n1); o.beta = r.beta(p.n1, p.dim_in); o.gb_bs = r.J; o.stats_out = st2;
-    conv(c, r.e, x, p.conv1.w, t1, o);
-  }
-  View sc = x;
-  if (p.learned_sc) {  // the 1x1 shortcut commutes with nearest x2 up-sampling: it runs at the low rate
-    sc = new_ncl(c, B, p.dim_out, L);
-    ConvOpt o;
-    conv(c, r.e, x, p.sc.w, sc, o);
-  }
-  ConvOpt o;
-  o.pad_left = 1; o.bias = r.e.F(p.conv2.bias); o.pro = ST2_PRO_ADAIN_LEAKY; o.slope = 0.2f; o.stats = st2;
-  o.gamma = r.gamma(p.n2); o.beta = r.beta(p.n2, p.dim_out); o.gb_bs = r.J; o.res = sc;
-  o.res_shift = p.upsample ? 1 : 0;
-  o.div = (float)sqrt(2.0);  // python passes math.sqrt(2) through a c_float: the same fp32 value
-  conv(c, r.e, t1, p.conv2.w, out, o);
-  c.a.off = mark;
-}
-
-void tap(Ctx& c, const View& v, float* dst) {
-  if (!dst) return;
-  RUN(c, g_be.copy_ncl(v.p, v.bs, v.cs, dst, (int64_t)v.C * v.L, v.L, v.B, v.C, v.L, c.stream));
-}
-
-int decoder_plan(Ctx& c, const st2_engine& e, const float* asr_p, const float* f0_p, const float* n_p, const float* s_p,
-                 const float* sine_noise, const float* har_inject, int B, int T, float* wave,
-                 const st2_decoder_taps* taps) {
-  const st2_model_config& cfg = e.cfg;
-  const PDecoder& d = e.dec;
-  const PGenerator& g = d.gen;
-  const bool ist = cfg.decoder_kind == 0;
-  const int Cin = cfg.dim_in, nu = cfg.n_upsamples, nk = cfg.n_resblock_kernels;
-  const int T2 = 2 * T;
-  st2_decoder_taps notaps;
-  memset(&notaps, 0, sizeof(notaps));
-  if (!taps) taps = &notaps;
-
-  float* h = c.a.f32((int64_t)B * d.J);
-  RUN(c, g_be.style_fc(s_p, B, cfg.style_dim, e.F(d.bank_wt), e.F(d.bank_b), d.J, ST2_ACT_NONE, h, c.stream));
-  DecRun r{c, e, h, d.J};
-
-  View asr = wrap(asr_p, B, Cin, T);
-  View f0 = wrap(f0_p, B, 1, T2), nn = wrap(n_p, B, 1, T2);
-  // [x(1024) | asr_res(64) | F0 | N] lives in one buffer; producers write their channel slices in place
-  View cat = new_ncl(c, B, 1024 + 64 + 2, T, false);
-  View cat0 = new_ncl(c, B, Cin + 2, T, false);
-  RUN(c, g_be.copy_ncl(asr.p, asr.bs, asr.cs, cat0.p, cat0.bs, cat0.cs, B, Cin, T, c.stream));
-  {
-    View a = cat0.rows(Cin, Cin + 1), b = cat0.rows(Cin + 1, Cin + 2);
-    RUN(c, g_be.conv1d_direct(f0.p, f0.bs, f0.cs, e.F(d.f0_w), e.F(d.f0_b), a.p, a.bs, a.cs, B, 1, 1, T2, T, 3, 2, 1, c.stream));
-    RUN(c, g_be.conv1d_direct(nn.p, nn.bs, nn.cs, e.F(d.n_w), e.F(d.n_b), b.p, b.bs, b.cs, B, 1, 1, T2, T, 3, 2, 1, c.stream));
-    View src = cat0.rows(Cin, Cin + 2), dst = cat.rows(1088, 1090);
-    RUN(c, g_be.copy_ncl(src.p, src.bs, src.cs, dst.p, dst.bs, dst.cs, B, 2, T, c.stream));
-  }
-  {
-    ConvOpt o;
-    o.bias = e.F(d.asr_res.bias);
-    conv(c, e, asr, d.asr_res.w, cat.rows(1024, 1088), o);
-  }
-  run_adain_resblk(r, d.encode, cat0, cat.rows(0, 1024));
-  tap(c, cat.rows(0, 1024), taps->encode);
-  View x = new_ncl(c, B, 512, T2);
-  for (int i = 0; i < 4; ++i) {
-    if (d.decode[i].upsample)
-      run_adain_resblk(r, d.decode[i], cat, x);
-    else
-      run_adain_resblk(r, d.decode[i], cat, cat.rows(0, 1024));
-  }
-  tap(c, x, taps->front);
-
-  // ---- generator (istftnet.py:350-380 / hifigan.py:321-347) ---------------------------------------------------------
-  int up_scale = prod_from(cfg.upsample_rates, 0, nu) * (ist ? cfg.gen_istft_hop : 1);
-  const int L = T2 * up_scale;  // samples
-  const int n_fft = cfg.gen_istft_n_fft, hop = cfg.gen_istft_hop;
-  View har;
-  if (har_inject) {
-    har = ist ? wrap(har_inject, B, n_fft + 2, L / hop + 1) : wrap(har_inject, B, 1, L);
-  } else {
-    float* scratch = c.a.f32((int64_t)B * 9 * T2);
-    float* hs = c.a.f32((int64_t)B * L);
-    RUN(c, g_be.har_source(f0_p, B, T2, up_scale, 9, sine_noise, e.F(g.lin_w), e.F(g.lin_b), 0.1f, 0.003f, 10.0f,
-                           24000.0f, scratch, hs, c.stream));
-    if (taps->har_source) RUN(c, g_be.copy_ncl(hs, L, L, taps->har_source, L, L, B, 1, L, c.stream));
-    if (ist) {
-      har = new_ncl(c, B, n_fft + 2, L / hop + 1, false);
-      RUN(c, g_be.stft_mag_phase(hs, B, L, n_fft, hop, har.p, har.bs, har.cs, c.stream));
-    } else {
-      har = wrap(hs, B, 1, L);
-    }
-  }
-  if (ist) tap(c, har, taps->har);
-
-  for (int i = 0; i < nu; ++i) {
-    const int u = cfg.upsample_rates[i], k = cfg.upsample_kernel_sizes[i], C = g.channels[i];
-    const bool last = i + 1 == nu;
-    const int L_in = x.L;
-    int pad, L_raw;
-    if (ist) {
-      pad = (k - u) / 2;
-      L_raw = (L_in - 1) * u - 2 * ((k - u) / 2) + k;
-    } else {
-      pad = u / 2 + u % 2;
-      L_raw = (L_in - 1) * u - 2 * (u / 2 + u % 2) + k + u % 2;
-    }
-    const bool reflect = ist && last;
-    const int L_out = L_raw + (reflect ? 1 : 0);
-    // persistent across the stage: the stage output and the MRF accumulators
-    View x_next = new_ncl(c, B, C, L_out);
-    const int64_t stage_mark = c.a.off;
-    // harmonic-source branch (istftnet.py:361-362 / hifigan.py:330-331)
-    View xs_src = new_ncl(c, B, C, L_out);
-    {
-      const int64_t m = c.a.off;
-      View xs0 = new_ncl(c, B, C, L_out);
-      const int stride_f0 = g.noise_stride[i];
-      ConvOpt o;
-      o.bias = e.F(g.noise_b[i]);
-      if (stride_f0 > 1) {
-        const int pad_f0 = (stride_f0 + 1) / 2;
-        const int L_ns = (har.L + 2 * pad_f0 - 2 * stride_f0) / stride_f0 + 1;
-        View harp = new_ncl(c, B, har.C * stride_f0, L_ns + 1, false);
-        RUN(c, g_be.phase_split(har.p, har.bs, har.cs, B, har.C, har.L, stride_f0, pad_f0, harp.p, harp.bs, harp.cs,
-                                L_ns + 1, c.stream));
-        if (L_ns != L_out && c.rc == 0) { st2_set_error("engine: noise conv length %d != stage length %d", L_ns, L_out); c.rc = 1; }
-        conv(c, e, harp, g.noise_wt[i], xs0, o);
-      } else {
-        conv(c, e, har, g.noise_wt[i], xs0, o);
-      }
-      View nul;
-      run_resblock1(r, g.noise_res[i], xs0, nullptr, nul, false, nk, xs_src);
-      // xs_src was allocated before m: keep it, drop the branch temporaries
-      c.a.off = m;
-    }
-    // up-sampling ConvTranspose1d as polyphase GEMM + interleave (istftnet.py:360,364-368)
-    View xu = new_ncl(c, B, C, L_out);
-    float* st = new_stats(c, B, C);
-    {
-      const int64_t m = c.a.off;
-      View Y = new_ncl(c, B, u * C, L_in + 1);
-      ConvOpt o;
-      o.pad_left = 1;
-      if (ist) { o.pro = ST2_PRO_LEAKY; o.slope = 0.1f; } else { o.pro = ST2_PRO_SNAKE; o.alpha = e.F(g.alphas[i]); }
-      conv(c, e, x, g.ups_wt[i], Y, o);
-      const int nt = (L_out + CVT_TILE - 1) / CVT_TILE;
-      float* part = c.a.f32((int64_t)B * C * nt * 3);
-      RUN(c, g_be.convt_interleave_stats(Y.p, Y.bs, Y.cs, L_in + 1, e.F(g.ups_b[i]), xs_src.p, xs_src.bs, xs_src.cs,
-                                         xu.p, xu.bs, xu.cs, B, C, u, pad, L_raw, reflect ? 1 : 0, part, nt, c.stream));
-      RUN(c, g_be.stats_finalize(part, B * C, nt, L_out, 1e-5f, st, CVT_TILE, c.stream));
-      c.a.off = m;
-    }
-    // multi-receptive-field fusion (istftnet.py:369-375): ((r0 + r1) + r2) / n in the last convs' epilogues
-    View acc[2] = {new_ncl(c, B, C, L_out), new_ncl(c, B, C, L_out)};
-    View prev;
-    for (int j = 0; j < nk; ++j) {
-      const int64_t m = c.a.off;
-      const bool lastk = j + 1 == nk;
-      View out = lastk ? x_next : acc[j & 1];
-      run_resblock1(r, g.resblocks[(size_t)i * nk + j], xu, st, prev, lastk, nk, out);
-      prev = out;
-      c.a.off = m;
-    }
-    x = x_next;
-    c.a.off = stage_mark;
-    if (i < 4) tap(c, x, taps->stage[i]);
-  }
-  if (ist) {
-    const int nb = n_fft / 2 + 1;
-    View sp = new_ncl(c, B, n_fft + 2, x.L, false);
-    ConvOpt o;
-    o.pad_left = 3; o.bias = e.F(g.post.bias); o.pro = ST2_PRO_LEAKY; o.slope = 0.01f; o.act = ST2_ACT_EXP_SIN;
-    o.act_split = nb;
-    conv(c, e, x, g.post.w, sp, o);
-    tap(c, sp, taps->spec_phase);
-    RUN(c, g_be.istft(sp.p, sp.bs, sp.cs, B, x.L, n_fft, hop, wave, (int64_t)hop * (x.L - 1), c.stream));
-  } else {
-    View w = wrap(wave, B, 1, x.L);
-    ConvOpt o;
-    o.pad_left = 3; o.bias = e.F(g.post.bias); o.pro = ST2_PRO_SNAKE; o.alpha = e.F(g.alphas[(size_t)nu]);
-    o.act = ST2_ACT_TANH;
-    conv(c, e, x, g.post.w, w, o);
-  }
-  return c.rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// sampler plan == styletts2_amd/diffusion.py (DiffusionSampler.forward + _Transformer sessions)
-// ------------------------------------------------------------------------------------------------------------------
-struct Sess {
-  Ctx& c;
-  const st2_engine& e;
-  int B, N;
-  bool merged;
-  const int32_t* key_len;
-  View bases[2];
-  int nbases;
-  const float* feat_map;  // [B][F] or null
-  const float* ada;       // [B][layers*4F] or null
-  double scale;  // embedding_scale (classifier-free guidance weight)
-};
-
-// [B][C][N] activation buffer; in the merged layout a strided view of a [C][B*N] block
-View dn_alloc(Sess& s, int C) {
-  View v;
-  v.B = s.B; v.C = C; v.L = s.N;
-  v.p = s.c.a.f32((int64_t)s.B * C * s.N);
-  if (s.merged) { v.bs = s.N; v.cs = s.B * s.N; } else { v.bs = (int64_t)C * s.N; v.cs = s.N; }
-  return v;
-}
-// the view the k=1 convs consume: [1][C][B*N] (merged) or [B][C][N]
-View dn_cv(const Sess& s, const View& t) {
-  if (!s.merged) return t;
-  View v = t;
-  v.B = 1; v.L = s.B * s.N; v.bs = (int64_t)t.C * v.L; v.cs = v.L;
-  return v;
-}
-
-const float* dn_mapping(Sess& s, float c_noise) {
-  Ctx& c = s.c;
-  const st2_engine& e = s.e;
-  const PDenoiser& d = e.dn;
-  const int F = d.features, H2 = e.cfg.dn_channels / 2;
-  float* four = c.a.f32((int64_t)s.B * (1 + 2 * H2));
-  RUN(c, g_be.time_features(c_noise, e.F(d.time_w), H2, s.B, four, c.stream));
-  float* m = c.a.f32((int64_t)s.B * F);
-  RUN(c, g_be.style_fc(four, s.B, 1 + 2 * H2, e.F(d.time_lin), e.F(d.time_b), F, ST2_ACT_GELU, m, c.stream));
-  if (s.feat_map) {
-    float* m2 = c.a.f32((int64_t)s.B * F);
-    RUN(c, g_be.axpbypcz(m, 1.0f, s.feat_map, 1.0f, nullptr, 0.0f, m2, (int64_t)s.B * F, c.stream));
-    m = m2;
-  }
-  float* m3 = c.a.f32((int64_t)s.B * F);
-  RUN(c, g_be.style_fc(m, s.B, F, e.F(d.map0), e.F(d.map0_b), F, ST2_ACT_GELU, m3, c.stream));
-  float* m4 = c.a.f32((int64_t)s.B * F);
-  RUN(c, g_be.style_fc(m3, s.B, F, e.F(d.map2), e.F(d.map2_b), F, ST2_ACT_GELU, m4, c.stream));
-  return m4;
-}
-
-// one denoiser evaluation on base buffer `base`: x [B][C] -> out [B][C]   (_Transformer._run)
-void dn_run(Sess& s, View base, const float* x, const float* m, float* out) {
-  Ctx& c = s.c;
-  const st2_engine& e = s.e;
-  const PDenoiser& d = e.dn;
-  const st2_model_config& cfg = e.cfg;
-  const int B = s.B, N = s.N, Fz = d.features, C = cfg.dn_channels;
-  const int mid = cfg.dn_heads * cfg.dn_head_features;
-  const int64_t mark = c.a.off;
-  View b0 = base.rows(0, C);
-  RUN(c, g_be.broadcast_cols(x, C, b0.p, b0.bs, b0.cs, B, C, N, c.stream));
-  View X = dn_alloc(s, Fz);
-  RUN(c, g_be.add_chanvec(base.p, base.bs, base.cs, m, Fz, X.p, X.bs, X.cs, B, Fz, N, c.stream));
-  const int nblk = (int)d.blocks.size();
-  for (int i = 0; i < nblk; ++i) {
-    const PBlock& b = d.blocks[(size_t)i];
-    float* st = c.a.f32((int64_t)B * N * 2);
-    RUN(c, g_be.colnorm_stats(X.p, X.bs, X.cs, B, Fz, N, 1e-5f, st, c.stream));
-    View qkv = dn_alloc(s, 3 * mid);
-    ConvOpt o1, o2;
-    o1.pro = o2.pro = ST2_PRO_COLNORM;
-    o1.stats = o2.stats = st;  // [B][N][2] == [1][B*N][2] in the merged view
-    if (cfg.multispeaker) {
-      const int64_t J = (int64_t)nblk * 4 * Fz;
-      const float* a = s.ada + (int64_t)4 * Fz * i;
-      o1.gamma = a;          o1.beta = a + Fz;     o1.gb_bs = J; o1.gamma_plus_one = 1;
-      o2.gamma = a + 2 * Fz; o2.beta = a + 3 * Fz; o2.gb_bs = J; o2.gamma_plus_one = 1;
-    } else {
-      o1.gamma = e.F(b.n_w);  o1.beta = e.F(b.n_b);
-      o2.gamma = e.F(b.nc_w); o2.beta = e.F(b.nc_b);
-    }
-    // The multispeaker net's AdaLayerNorm affine is per utterance.  Its q / kv convs still run as ONE GEMM over the B*N
-    // merged columns: st2_act_split picks the affine row of a column from its utterance (gb_seg = N).  That needs the xs
-    // pair (>= XS_MIN_L columns); smaller calls (one sentence of the long-form loop) keep the [B][F][N] view.  Measured
-    // at B = 32, N = 100: 2 x 99 us (fused kernel on 32 rows of 100 columns, 0.04-0.08 of the roof) -> ~65 us per layer.
-    // ... and conv()'s routing rule: nets of <= FUSED_K3_MAX_C features (small / test configurations) send k = 1 convs with
-    // a prologue to the fused kernel, which has no per-segment affine: they keep the per-utterance view (advisor, round 3).
-    const bool seg = cfg.multispeaker && s.merged && B > 1 && (int64_t)B * N >= XS_MIN_L && Fz > FUSED_K3_MAX_C;
-    if (seg) o1.gb_seg = o2.gb_seg = N;
-    const bool per_utt = cfg.multispeaker && !seg;
-    View Xv = per_utt ? X : dn_cv(s, X), qv = per_utt ? qkv : dn_cv(s, qkv);
-    conv(c, e, Xv, b.q, qv.rows(0, mid), o1);
-    conv(c, e, Xv, b.kv, qv.rows(mid, 3 * mid), o2);
-    View att = dn_alloc(s, mid);
-    View q = qkv.rows(0, mid), k = qkv.rows(mid, 2 * mid), v = qkv.rows(2 * mid, 3 * mid);
-    RUN(c, g_be.attention_keylen(q.p, k.p, v.p, q.bs, q.cs, att.p, att.bs, att.cs, B, cfg.dn_heads, cfg.dn_head_features,
-                                 N, (float)pow((double)cfg.dn_head_features, -0.5), s.key_len, c.stream));
-    View X1 = dn_alloc(s, Fz), hmid = dn_alloc(s, b.f1_out), X2 = dn_alloc(s, Fz);
-    ConvOpt oo;
-    oo.bias = e.F(b.o_b); oo.res = dn_cv(s, X);
-    conv(c, e, dn_cv(s, att), b.o, dn_cv(s, X1), oo);
-    ConvOpt of1;
-    of1.bias = e.F(b.f1_b); of1.act = ST2_ACT_GELU;
-    conv(c, e, dn_cv(s, X1), b.f1, dn_cv(s, hmid), of1);
-    ConvOpt of2;
-    of2.bias = e.F(b.f2_b); of2.res = dn_cv(s, X1);
-    conv(c, e, dn_cv(s, hmid), b.f2, dn_cv(s, X2), of2);
-    if (i + 1 < nblk) {
-      View Xn = dn_alloc(s, Fz);
-      RUN(c, g_be.add_chanvec(X2.p, X2.bs, X2.cs, m, Fz, Xn.p, Xn.bs, Xn.cs, B, Fz, N, c.stream));
-      X = Xn;
-    } else {
-      X = X2;
-    }
-  }
-  float* mean = c.a.f32((int64_t)B * Fz);
-  RUN(c, g_be.mean_tokens_len(X.p, X.bs, X.cs, mean, Fz, B, Fz, N, s.key_len, c.stream));
-  RUN(c, g_be.style_fc(mean, B, Fz, e.F(d.out_t), e.F(d.out_b), C, ST2_ACT_NONE, out, c.stream));
-  c.a.off = mark;
-}
-
-// KDiffusion.denoise_fn at one sigma (sampler.py:184-208): out = c_skip * x + c_out * net(c_in * x, c_noise)
-void dn_denoise(Sess& s, const float* x, const double* w4, float* out) {
-  Ctx& c = s.c;
-  const int C = s.e.cfg.dn_channels;
-  const int64_t n = (int64_t)s.B * C;
-  const int64_t mark = c.a.off;
-  const float c_skip = (float)w4[0], c_out = (float)w4[1], c_in = (float)w4[2], c_noise = (float)w4[3];
-  float* x_in = c.a.f32(n);
-  RUN(c, g_be.axpbypcz(x, c_in, nullptr, 0.f, nullptr, 0.f, x_in, n, c.stream));
-  const float* m = dn_mapping(s, c_noise);
-  float* pred = c.a.f32(n);
-  dn_run(s, s.bases[0], x_in, m, pred);
-  if (s.nbases > 1) {  // classifier-free guidance, modules.py:418-423
-    float* pm = c.a.f32(n);
-    dn_run(s, s.bases[1], x_in, m, pm);
-    float* mix = c.a.f32(n);
-    RUN(c, g_be.axpbypcz(pm, (float)(1.0 - s.scale), pred, (float)s.scale, nullptr, 0.f, mix, n, c.stream));
-    pred = mix;
-  }
-  RUN(c, g_be.axpbypcz(x, c_skip, pred, c_out, nullptr, 0.f, out, n, c.stream));
-  c.a.off = mark;
-}
-
-int sampler_plan(Ctx& c, const st2_engine& e, const float* noise, const float* embedding, const View* emb_cm,
-                 const float* features, const float* step_noise, const int32_t* lengths, int B, int N, int steps, double scale,
-                 const double* table, double sigma0, float* out, float* step_taps) {
-  const st2_model_config& cfg = e.cfg;
-  const PDenoiser& d = e.dn;
-  const int C = cfg.dn_channels, E = cfg.dn_embedding, Fz = d.features;
-  Sess s{c, e, B, N, true, lengths, {}, 1, nullptr, nullptr, scale};  // token-merged storage for both denoisers
-  // session: everything constant across the 2*(steps-1) net calls
-  s.bases[0] = dn_alloc(s, Fz);
-  {
-    View dst = s.bases[0].rows(C, Fz);
-    if (emb_cm)  // already channel-major on the device (front plan: PL-BERT's merged output)
-      RUN(c, g_be.copy_ncl(emb_cm->p, emb_cm->bs, emb_cm->cs, dst.p, dst.bs, dst.cs, B, E, N, c.stream));
-    else
-      RUN(c, g_be.tokens_to_channels(embedding, (int64_t)N * E, B, N, E, dst.p, dst.bs, dst.cs, c.stream));
-  }
-  if (scale != 1.0) {
-    s.nbases = 2;
-    s.bases[1] = dn_alloc(s, Fz);
-    View dst = s.bases[1].rows(C, Fz);
-    RUN(c, g_be.tokens_to_channels(e.F(d.fixed), 0, B, N, E, dst.p, dst.bs, dst.cs, c.stream));
-  }
-  if (cfg.multispeaker) {
-    if (!features) { st2_set_error("st2_sampler_run: the multispeaker denoiser needs `features`"); return 1; }
-    float* fm = c.a.f32((int64_t)B * Fz);
-    RUN(c, g_be.style_fc(features, B, cfg.dn_context_features, e.F(d.feat), e.F(d.feat_b), Fz, ST2_ACT_GELU, fm, c.stream));
-    const int J = cfg.dn_layers * 4 * Fz;
-    float* ada = c.a.f32((int64_t)B * J);
-    RUN(c, g_be.style_fc(features, B, cfg.dn_context_features, e.F(d.ada_wt), e.F(d.ada_b), J, ST2_ACT_NONE, ada, c.stream));
-    s.feat_map = fm;
-    s.ada = ada;
-  }
-  const int64_t n = (int64_t)B * C;
-  float* xa = c.a.f32(n);
-  float* xb = c.a.f32(n);
-  float* x = xa;
-  RUN(c, g_be.axpbypcz(noise, (float)sigma0, nullptr, 0.f, nullptr, 0.f, x, n, c.stream));
-  for (int i = 0; i + 1 < steps; ++i) {
-    const double* row = table + (int64_t)i * ST2_SAMPLER_TABLE_COLS;
-    const int64_t mark = c.a.off;
-    float* den = c.a.f32(n);
-    dn_denoise(s, x, row + 0, den);
-    // d = (x - den) / sigma ; x_mid = x + d * (sigma_mid - sigma)
-    const double k = row[8];
-    float* x_mid = c.a.f32(n);
-    RUN(c, g_be.axpbypcz(x, (float)(1.0 + k), den, (float)(-k), nullptr, 0.f, x_mid, n, c.stream));
-    float* den_mid = c.a.f32(n);
-    dn_denoise(s, x_mid, row + 4, den_mid);
-    // d_mid = (x_mid - den_mid) / sigma_mid ; x = x + d_mid * (sigma_down - sigma) + eps * sigma_up
-    const double k2 = row[9];
-    float* d_mid = c.a.f32(n);
-    RUN(c, g_be.axpbypcz(x_mid, (float)k2, den_mid, (float)(-k2), nullptr, 0.f, d_mid, n, c.stream));
-    float* xn = (x == xa) ? xb : xa;
-    RUN(c, g_be.axpbypcz(x, 1.0f, d_mid, 1.0f, step_noise + (int64_t)i * n, (float)row[10], xn, n, c.stream));
-    x = xn;
-    if (step_taps) RUN(c, g_be.axpbypcz(x, 1.0f, nullptr, 0.f, nullptr, 0.f, step_taps + (int64_t)i * n, n, c.stream));
-    c.a.off = mark;
-  }
-  RUN(c, g_be.axpbypcz(x, 1.0f, nullptr, 0.f, nullptr, 0.f, out, n, c.stream));
-  return c.rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// prosody plan == the notebooks' alignment expansion + ProsodyPredictor.F0Ntrain (styletts2_amd/text.py, pipeline.py)
-// ------------------------------------------------------------------------------------------------------------------
-PLstm pack_lstm(Packer& pk, const std::string& prefix) {
-  PLstm l;
-  const HostTensor* wf = pk.get(prefix + ".weight_ih_l0");
-  const HostTensor* wr = pk.get(prefix + ".weight_ih_l0_reverse");
-  const HostTensor* hf = pk.get(prefix + ".weight_hh_l0");
-  const HostTensor* hr = pk.get(prefix + ".weight_hh_l0_reverse");
-  const HostTensor* bif = pk.get(prefix + ".bias_ih_l0");
-  const HostTensor* bhf = pk.get(prefix + ".bias_hh_l0");
-  const HostTensor* bir = pk.get(prefix + ".bias_ih_l0_reverse");
-  const HostTensor* bhr = pk.get(prefix + ".bias_hh_l0_reverse");
-  if (!wf || !wr || !hf || !hr || !bif || !bhf || !bir || !bhr) return l;
-  if (wf->shape.size() != 2 || wf->shape[0] % 4 != 0) { pk.fail(prefix + ".weight_ih_l0 must be [4H, I]"); return l; }
-  const int G4 = (int)wf->shape[0], I = (int)wf->shape[1], H = G4 / 4;
-  for (const HostTensor* t : {wr})
-    if (t->shape != wf->shape) { pk.fail(prefix + ": the two directions' input weights differ in shape"); return l; }
-  for (const HostTensor* t : {hf, hr})
-    if (t->shape.size() != 2 || t->shape[0] != G4 || t->shape[1] != H) { pk.fail(prefix + ".weight_hh_l0* must be [4H, H]"); return l; }
-  for (const HostTensor* t : {bif, bhf, bir, bhr})
-    if (t->numel() != G4) { pk.fail(prefix + ".bias_* must have 4H elements"); return l; }
-  l.H = H;
-  std::vector<float> w((size_t)2 * G4 * I);  // cat([W_ih, W_ih_reverse]) as a k = 1 conv weight [8H][I][1]
-  std::copy(wf->data.begin(), wf->data.end(), w.begin());
-  std::copy(wr->data.begin(), wr->data.end(), w.begin() + (size_t)G4 * I);
-  l.w_ih = pack_split(pk.blob, prefix + ".weight_ih_l0", w.data(), 2 * G4, I, 1);
-  std::vector<float> b((size_t)2 * G4);
-  for (int i = 0; i < G4; ++i) {
-    b[(size_t)i] = bif->data[(size_t)i] + bhf->data[(size_t)i];
-    b[(size_t)G4 + i] = bir->data[(size_t)i] + bhr->data[(size_t)i];
-  }
-  l.bias = pk.blob.add_f32(b);
-  std::vector<float> t((size_t)2 * H * G4);  // stack([W_hh.t(), W_hh_reverse.t()]): [2][H][4H]
-  for (int dir = 0; dir < 2; ++dir) {
-    const HostTensor* h = dir ? hr : hf;
-    for (int r = 0; r < G4; ++r)
-      for (int k = 0; k < H; ++k) t[((size_t)dir * H + k) * G4 + r] = h->data[(size_t)r * H + k];
-  }
-  l.whh_t = pk.blob.add_f32(t);
-  return l;
-}
-
-int pack_predictor(st2_engine& e, Blob& blob, std::string* err) {
-  const st2_model_config& cfg = e.cfg;
-  Packer pk{e, blob};
-  PPredictor p;
-  Bank bank;
-  const std::string P = "predictor.";
-  const int dh = cfg.pred_hidden;
-  if (dh <= 0) { *err = "st2_model_config.pred_hidden is not set"; return 1; }
-  p.shared = pack_lstm(pk, P + "shared");
-  // registration order of text.ProsodyPredictor._prepare: F0[0..2] then N[0..2], norm1 then norm2 each
-  const int din[3] = {dh, dh, dh / 2}, dout[3] = {dh, dh / 2, dh / 2};
-  for (int path = 0; path < 2; ++path) {
-    for (int i = 0; i < 3; ++i) {
-      const std::string pre = P + (path ? "N." : "F0.") + std::to_string(i);
-      PAdainResBlk& r = path ? p.n[i] : p.f0[i];
-      r = pack_adain_resblk(pk, pre, din[i], dout[i], i == 1);
-      r.n1 = bank.add(pk, pre + ".norm1", din[i]);
-      r.n2 = bank.add(pk, pre + ".norm2", dout[i]);
-    }
-  }
-  p.f0p_w = pk.vec(P + "F0_proj.weight", dh / 2); p.f0p_b = pk.vec(P + "F0_proj.bias", 1);  // Conv1d(d_hid / 2, 1, 1)
-  p.np_w = pk.vec(P + "N_proj.weight", dh / 2);   p.np_b = pk.vec(P + "N_proj.bias", 1);
-  if (pk.ok && p.shared.H * 2 != dh) pk.fail(P + "shared: hidden size does not match st2_model_config.pred_hidden");
-  if (!pk.ok) { *err = "predictor parameter missing or malformed: " + pk.missing; return 1; }
-  p.J = bank.J;
-  bank.pack(pk, cfg.style_dim, &p.bank_wt, &p.bank_b);
-  p.ready = true;
-  e.pred = p;
-  return 0;
-}
-
-// asr[B][dim_in][T] = expand(t_en), (F0, N)[B][2T] = F0Ntrain(expand(d), s); d_cm [B][pred_hidden + style_dim][N] is the
-// duration encoder's output channel-major, dur int64 [B][N] with rows summing to T
-int prosody_plan(Ctx& c, const st2_engine& e, const float* d_cm, const float* t_en, const int64_t* dur, const float* s_p,
-                 int B, int N, int T, int shift, float* asr, float* f0, float* nn) {
-  const st2_model_config& cfg = e.cfg;
-  const PPredictor& p = e.pred;
-  const int dh = cfg.pred_hidden, Cd = dh + cfg.style_dim, Ct = cfg.dim_in;
-  View en = new_ncl(c, B, Cd, T, false);
-  RUN(c, g_be.expand_by_durations(d_cm, (int64_t)Cd * N, N, dur, B, Cd, N, T, shift, en.p, en.bs, en.cs, c.stream));
-  RUN(c, g_be.expand_by_durations(t_en, (int64_t)Ct * N, N, dur, B, Ct, N, T, shift, asr, (int64_t)Ct * T, T, c.stream));
-  // shared BiLSTM: input projection of every frame as one k = 1 conv, then the recurrence
-  const int H = p.shared.H;
-  View G = new_ncl(c, B, 8 * H, T, false);
-  {
-    ConvOpt o;
-    o.bias = e.F(p.shared.bias);
-    conv(c, e, en, p.shared.w_ih, G, o);
-  }
-  View y = new_ncl(c, B, 2 * H, T, false);
-  const int64_t sb = st2_lstm_coop_scratch_bytes(B);
-  void* scratch = sb > 0 ? c.a.alloc(sb) : nullptr;
-  RUN(c, g_be.lstm_bidir(G.p, G.bs, G.cs, e.F(p.shared.whh_t), nullptr, B, H, T, y.p, y.bs, y.cs, scratch, sb, c.stream));
-  float* h = c.a.f32((int64_t)B * p.J);
-  RUN(c, g_be.style_fc(s_p, B, cfg.style_dim, e.F(p.bank_wt), e.F(p.bank_b), p.J, ST2_ACT_NONE, h, c.stream));
-  DecRun r{c, e, h, p.J};
-  for (int path = 0; path < 2; ++path) {
-    const PAdainResBlk* blks = path ? p.n : p.f0;
-    View t = y;
-    for (int i = 0; i < 3; ++i) {
-      View out = new_ncl(c, B, blks[i].dim_out, blks[i].upsample ? 2 * t.L : t.L, false);
-      run_adain_resblk(r, blks[i], t, out);
-      t = out;
-    }
-    float* dst = path ? nn : f0;
-    RUN(c, g_be.conv1d_direct(t.p, t.bs, t.cs, e.F(path ? p.np_w : p.f0p_w), e.F(path ? p.np_b : p.f0p_b), dst,
-                              (int64_t)t.L, t.L, B, t.C, 1, t.L, t.L, 1, 1, 0, c.stream));
-  }
-  return c.rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// duration plan == DurationEncoder.forward + pipeline.predict_durations (styletts2_amd/text.py, pipeline.py)
-// ------------------------------------------------------------------------------------------------------------------
-int pack_duration(st2_engine& e, Blob& blob, std::string* err) {
-  Packer pk{e, blob};
-  PDuration d;
-  const std::string T = "predictor.text_encoder.lstms.";
-  for (int i = 0; pk.has(T + std::to_string(2 * i) + ".weight_ih_l0"); ++i) {
-    d.lstms.push_back(pack_lstm(pk, T + std::to_string(2 * i)));
-    const int dm = 2 * d.lstms.back().H;  // AdaLayerNorm(style_dim, d_model): fc = Linear(style_dim, 2 * d_model)
-    d.ada_wt.push_back(pk.lin_t(T + std::to_string(2 * i + 1) + ".fc.weight", 2 * dm, e.cfg.style_dim));
-    d.ada_b.push_back(pk.vec(T + std::to_string(2 * i + 1) + ".fc.bias", 2 * dm));
-  }
-  if (d.lstms.empty()) { *err = "missing predictor parameter predictor.text_encoder.lstms.0.weight_ih_l0"; return 1; }
-  d.dur_lstm = pack_lstm(pk, "predictor.lstm");
-  const HostTensor* pw = pk.get("predictor.duration_proj.linear_layer.weight", {-1, 2 * d.dur_lstm.H});
-  d.proj_w = pk.vec("predictor.duration_proj.linear_layer.weight");
-  if (pw) d.proj_b = pk.vec("predictor.duration_proj.linear_layer.bias", pw->shape[0]);
-  if (!pk.ok || !pw) { *err = "predictor parameter missing or malformed: " + pk.missing; return 1; }
-  d.max_dur = (int)pw->shape[0];
-  d.ready = true;
-  e.dur = d;
-  return 0;
-}
-
-View lstm_run(Ctx& c, const st2_engine& e, const PLstm& l, const View& x, const int32_t* lens) {
-  View G = new_ncl(c, x.B, 8 * l.H, x.L, false);
-  ConvOpt o;
-  o.bias = e.F(l.bias);
-  conv(c, e, x, l.w_ih, G, o);
-  View y = new_ncl(c, x.B, 2 * l.H, x.L, false);
-  const int64_t sb = st2_lstm_coop_scratch_bytes(x.B);
-  void* scratch = sb > 0 ? c.a.alloc(sb) : nullptr;
-  RUN(c, g_be.lstm_bidir(G.p, G.bs, G.cs, e.F(l.whh_t), lens, x.B, l.H, x.L, y.p, y.bs, y.cs, scratch, sb, c.stream));
-  return y;
-}
-
-int duration_plan(Ctx& c, const st2_engine& e, const View& d_en, const float* s_p, const int32_t* lens, int B, int N,
-                  int tail, float* d_cm, int64_t* durations) {
-  const st2_model_config& cfg = e.cfg;
-  const PDuration& d = e.dur;
-  const int dh = cfg.pred_hidden, sty = cfg.style_dim, Cd = dh + sty;
-  const int nl = (int)d.lstms.size();
-  View h = new_ncl(c, B, Cd, N, false);
-  {  // [x | style broadcast over the tokens], pad positions zeroed
-    View src = d_en, dst = h.rows(0, dh), st = h.rows(dh, Cd);
-    RUN(c, g_be.copy_ncl(src.p, src.bs, src.cs, dst.p, dst.bs, dst.cs, B, dh, N, c.stream));
-    RUN(c, g_be.broadcast_cols(s_p, sty, st.p, st.bs, st.cs, B, sty, N, c.stream));
-    if (lens) RUN(c, g_be.mask_tail(h.p, h.bs, h.cs, B, Cd, N, lens, c.stream));
-  }
-  for (int i = 0; i < nl; ++i) {
-    View y = lstm_run(c, e, d.lstms[(size_t)i], h, lens);  // [B][dh][N]
-    // AdaLayerNorm (models.py:418-438): (1 + gamma) * LayerNorm_c(y) + beta, gamma | beta = fc(style)
-    float* gb = c.a.f32((int64_t)B * 2 * dh);
-    RUN(c, g_be.style_fc(s_p, B, sty, e.F(d.ada_wt[(size_t)i]), e.F(d.ada_b[(size_t)i]), 2 * dh, ST2_ACT_NONE, gb, c.stream));
-    float* st = c.a.f32((int64_t)B * N * 2);
-    RUN(c, g_be.colnorm_stats(y.p, y.bs, y.cs, B, dh, N, 1e-5f, st, c.stream));
-    const bool last = i + 1 == nl;
-    View nh = last ? wrap(d_cm, B, Cd, N) : new_ncl(c, B, Cd, N, false);
-    View top = nh.rows(0, dh), bot = nh.rows(dh, Cd);
-    RUN(c, g_be.colnorm_apply(y.p, y.bs, y.cs, st, gb, gb + dh, 2 * dh, 1, ST2_ACT_NONE, 0.f, lens, top.p, top.bs, top.cs, B,
-                              dh, N, c.stream));
-    RUN(c, g_be.broadcast_cols(s_p, sty, bot.p, bot.bs, bot.cs, B, sty, N, c.stream));
-    if (lens) RUN(c, g_be.mask_tail(bot.p, bot.bs, bot.cs, B, sty, N, lens, c.stream));
-    h = nh;
-  }
-  if (durations) {
-    View x = lstm_run(c, e, d.dur_lstm, h, lens);
-    RUN(c, g_be.duration_head(x.p, x.bs, x.cs, e.F(d.proj_w), e.F(d.proj_b), B, dh, d.max_dur, N, lens, tail, durations,
-                              nullptr, c.stream));
-  }
-  return c.rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// text-encoder plan == TextEncoder.forward (styletts2_amd/text.py)
-// ------------------------------------------------------------------------------------------------------------------
-int pack_text(st2_engine& e, Blob& blob, std::string* err) {
-  Packer pk{e, blob};
-  PText t;
-  const std::string T = "text_encoder.";
-  const HostTensor* emb = pk.get(T + "embedding.weight");
-  if (!emb || emb->shape.size() != 2) { *err = "missing text-encoder parameter text_encoder.embedding.weight"; return 1; }
-  t.V = (int)emb->shape[0];
-  t.C = (int)emb->shape[1];
-  t.emb = blob.add_f32(emb->data);
-  for (int i = 0; pk.has(T + "cnn." + std::to_string(i) + ".0.weight"); ++i) {
-    const std::string p = T + "cnn." + std::to_string(i);
-    t.convs.push_back(pk.conv(p + ".0", true, t.C, t.C, -1));
-    t.ln_g.push_back(pk.vec(p + ".1.gamma", t.C));
-    t.ln_b.push_back(pk.vec(p + ".1.beta", t.C));
-  }
-  t.lstm = pack_lstm(pk, T + "lstm");
-  if (!pk.ok || t.convs.empty()) { *err = "text-encoder parameter missing or malformed: " + pk.missing; return 1; }
-  t.ready = true;
-  e.text = t;
-  return 0;
-}
-
-int text_plan(Ctx& c, const st2_engine& e, const int64_t* tokens, const int32_t* lens, int B, int N, float* t_en) {
-  const PText& t = e.text;
-  View h = new_ncl(c, B, t.C, N, false);
-  RUN(c, g_be.embed_tokens(tokens, B, N, e.F(t.emb), t.V, t.C, nullptr, nullptr, lens, h.p, h.bs, h.cs, c.stream));
-  for (size_t i = 0; i < t.convs.size(); ++i) {
-    const PConv& pc = t.convs[i];
-    View y = new_ncl(c, B, pc.c_out, N, false);
-    ConvOpt o;
-    o.pad_left = (pc.ks - 1) / 2; o.bias = e.F(pc.bias);
-    conv(c, e, h, pc.w, y, o);
-    // LayerNorm over channels + LeakyReLU(0.2) + masked_fill in one pass (models.py:270-282, 308-312)
-    float* st = c.a.f32((int64_t)B * N * 2);
-    RUN(c, g_be.colnorm_stats(y.p, y.bs, y.cs, B, pc.c_out, N, 1e-5f, st, c.stream));
-    View z = new_ncl(c, B, pc.c_out, N, false);
-    RUN(c, g_be.colnorm_apply(y.p, y.bs, y.cs, st, e.F(t.ln_g[i]), e.F(t.ln_b[i]), 0, 0, ST2_ACT_LEAKY, 0.2f, lens, z.p, z.bs,
-                              z.cs, B, pc.c_out, N, c.stream));
-    h = z;
-  }
-  View y = lstm_run(c, e, t.lstm, h, lens);  // outputs past a sequence's end are zero (packed-sequence semantics)
-  View dst = wrap(t_en, B, 2 * t.lstm.H, N);
-  RUN(c, g_be.copy_ncl(y.p, y.bs, y.cs, dst.p, dst.bs, dst.cs, B, 2 * t.lstm.H, N, c.stream));
-  return c.rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// PL-BERT plan == CustomAlbert.forward_engine (styletts2_amd/text.py); front plan == pipeline._front_core
-// ------------------------------------------------------------------------------------------------------------------
-int pack_bert(st2_engine& e, Blob& blob, std::string* err) {
-  Packer pk{e, blob};
-  PBert b;
-  const std::string R = "bert.", L = R + "encoder.albert_layer_groups.0.albert_layers.0.";
-  const HostTensor* w = pk.get(R + "embeddings.word_embeddings.weight");
-  const HostTensor* p = pk.get(R + "embeddings.position_embeddings.weight");
-  const HostTensor* tt = pk.get(R + "embeddings.token_type_embeddings.weight");
-  const HostTensor* q = pk.get(L + "attention.query.weight");
-  const HostTensor* k = pk.get(L + "attention.key.weight");
-  const HostTensor* v = pk.get(L + "attention.value.weight");
-  const HostTensor* qb = pk.get(L + "attention.query.bias");
-  const HostTensor* kb = pk.get(L + "attention.key.bias");
-  const HostTensor* vb = pk.get(L + "attention.value.bias");
-  if (!pk.ok || w->shape.size() != 2 || p->shape.size() != 2 || tt->shape.size() != 2 || q->shape.size() != 2) {
-    *err = "PL-BERT parameter missing or malformed: " + pk.missing;
-    return 1;
-  }
-  b.V = (int)w->shape[0]; b.E = (int)w->shape[1]; b.P = (int)p->shape[0]; b.H = (int)q->shape[0];
-  if (p->shape[1] != b.E || tt->shape[1] != b.E || q->shape[1] != b.H || k->numel() != q->numel() ||
-      v->numel() != q->numel() || qb->numel() != b.H || kb->numel() != b.H || vb->numel() != b.H || b.H % 64 != 0 ||
-      e.cfg.bert_layers <= 0) {
-    *err = "PL-BERT: inconsistent shapes (64-wide heads, one shared layer) or cfg.bert_layers == 0";
-    return 1;
-  }
-  b.word = blob.add_f32(w->data);
-  b.pos = blob.add_f32(p->data);
-  b.tok0 = blob.add_f32(std::vector<float>(tt->data.begin(), tt->data.begin() + b.E));  // token_type_ids == 0 everywhere
-  b.eln_w = pk.vec(R + "embeddings.LayerNorm.weight", b.E); b.eln_b = pk.vec(R + "embeddings.LayerNorm.bias", b.E);
-  b.map = pk.conv_w(R + "encoder.embedding_hidden_mapping_in.weight", b.H, b.E, 1);
-  b.map_b = pk.vec(R + "encoder.embedding_hidden_mapping_in.bias", b.H);
-  {  // q | k | v as one 3H-row Linear
-    const size_t HH = (size_t)b.H * b.H;
-    std::vector<float> cat(3 * HH), bias((size_t)3 * b.H);
-    std::copy(q->data.begin(), q->data.end(), cat.begin());
-    std::copy(k->data.begin(), k->data.end(), cat.begin() + HH);
-    std::copy(v->data.begin(), v->data.end(), cat.begin() + 2 * HH);
-    std::copy(qb->data.begin(), qb->data.end(), bias.begin());
-    std::copy(kb->data.begin(), kb->data.end(), bias.begin() + b.H);
-    std::copy(vb->data.begin(), vb->data.end(), bias.begin() + 2 * b.H);
-    b.qkv = pack_split(blob, L + "attention.query|key|value.weight", cat.data(), 3 * b.H, b.H, 1);
-    b.qkv_b = blob.add_f32(bias);
-  }
-  b.dense = pk.conv_w(L + "attention.dense.weight", b.H, b.H, 1); b.dense_b = pk.vec(L + "attention.dense.bias", b.H);
-  b.aln_w = pk.vec(L + "attention.LayerNorm.weight", b.H);        b.aln_b = pk.vec(L + "attention.LayerNorm.bias", b.H);
-  b.ffn = pk.conv_w(L + "ffn.weight", -1, b.H, 1);
-  b.I = b.ffn.C_out;
-  b.ffn_b = pk.vec(L + "ffn.bias", b.I > 0 ? b.I : -1);
-  b.out = pk.conv_w(L + "ffn_output.weight", b.H, b.I > 0 ? b.I : -1, 1); b.out_b = pk.vec(L + "ffn_output.bias", b.H);
-  b.fln_w = pk.vec(L + "full_layer_layer_norm.weight", b.H);      b.fln_b = pk.vec(L + "full_layer_layer_norm.bias", b.H);
-  if (pk.has("bert_encoder.weight")) {
-    b.enc = pk.conv_w("bert_encoder.weight", -1, b.H, 1);
-    b.enc_b = pk.vec("bert_encoder.bias", b.enc.C_out > 0 ? b.enc.C_out : -1);
-    b.has_enc = true;
-  }
-  if (!pk.ok) { *err = "PL-BERT parameter missing or malformed: " + pk.missing; return 1; }
-  b.ready = true;
-  e.bert = b;
-  return 0;
-}
-
-// -> the last hidden state as a [B][H][N] view of token-merged storage ([H][B*N]); lives in the arena
-View bert_plan(Ctx& c, const st2_engine& e, const int64_t* tokens, const int32_t* lens, int B, int N) {
-  const PBert& p = e.bert;
-  const float eps = e.cfg.bert_ln_eps;
-  const int H = p.H, heads = H / 64;
-  Sess s{c, e, B, N, true, lens, {}, 0, nullptr, nullptr, 1.0};
-  View X = dn_alloc(s, H), Xn = dn_alloc(s, H);
-  {
-    const int64_t mark = c.a.off;
-    View E = dn_alloc(s, p.E);
-    RUN(c, g_be.embed_tokens(tokens, B, N, e.F(p.word), p.V, p.E, e.F(p.tok0), e.F(p.pos), nullptr, E.p, E.bs, E.cs,
-                             c.stream));
-    float* st = c.a.f32((int64_t)B * N * 2);
-    RUN(c, g_be.colnorm_stats(E.p, E.bs, E.cs, B, p.E, N, eps, st, c.stream));
-    ConvOpt o;  // embedding LayerNorm in the prologue of the E -> H mapping
-    o.bias = e.F(p.map_b); o.pro = ST2_PRO_COLNORM; o.stats = st; o.gamma = e.F(p.eln_w); o.beta = e.F(p.eln_b);
-    conv(c, e, dn_cv(s, E), p.map, dn_cv(s, X), o);
-    c.a.off = mark;
-  }
-  for (int l = 0; l < e.cfg.bert_layers; ++l) {
-    const int64_t mark = c.a.off;
-    View qkv = dn_alloc(s, 3 * H);
-    {
-      ConvOpt o;
-      o.bias = e.F(p.qkv_b);
-      conv(c, e, dn_cv(s, X), p.qkv, dn_cv(s, qkv), o);
-    }
-    View ctx = dn_alloc(s, H);
-    View q = qkv.rows(0, H), k = qkv.rows(H, 2 * H), v = qkv.rows(2 * H, 3 * H);
-    RUN(c, g_be.attention_keylen(q.p, k.p, v.p, q.bs, q.cs, ctx.p, ctx.bs, ctx.cs, B, heads, 64, N, 0.125f, lens, c.stream));
-    View Y = dn_alloc(s, H);
-    {
-      ConvOpt o;
-      o.bias = e.F(p.dense_b); o.res = dn_cv(s, X);
-      conv(c, e, dn_cv(s, ctx), p.dense, dn_cv(s, Y), o);
-    }
-    float* st1 = c.a.f32((int64_t)B * N * 2);
-    RUN(c, g_be.colnorm_stats(Y.p, Y.bs, Y.cs, B, H, N, eps, st1, c.stream));
-    View X1 = dn_alloc(s, H);
-    RUN(c, g_be.colnorm_apply(Y.p, Y.bs, Y.cs, st1, e.F(p.aln_w), e.F(p.aln_b), 0, 0, ST2_ACT_NONE, 0.f, nullptr, X1.p, X1.bs,
-                              X1.cs, B, H, N, c.stream));
-    View Hm = dn_alloc(s, p.I);
-    {
-      ConvOpt o;
-      o.bias = e.F(p.ffn_b); o.act = ST2_ACT_GELU_TANH;
-      conv(c, e, dn_cv(s, X1), p.ffn, dn_cv(s, Hm), o);
-    }
-    View Z = dn_alloc(s, H);
-    {
-      ConvOpt o;
-      o.bias = e.F(p.out_b); o.res = dn_cv(s, X1);
-      conv(c, e, dn_cv(s, Hm), p.out, dn_cv(s, Z), o);
-    }
-    float* st2 = c.a.f32((int64_t)B * N * 2);
-    RUN(c, g_be.colnorm_stats(Z.p, Z.bs, Z.cs, B, H, N, eps, st2, c.stream));
-    RUN(c, g_be.colnorm_apply(Z.p, Z.bs, Z.cs, st2, e.F(p.fln_w), e.F(p.fln_b), 0, 0, ST2_ACT_NONE, 0.f, nullptr, Xn.p, Xn.bs,
-                              Xn.cs, B, H, N, c.stream));
-    std::swap(X, Xn);
-    c.a.off = mark;
-  }
-  return X;
-}
-
-int front_plan(Ctx& c, const st2_engine& e, const st2_front_args& a) {
-  const st2_model_config& cfg = e.cfg;
-  const int B = a.B, N = a.N, sty = cfg.style_dim, C2 = cfg.dn_channels, dh = cfg.pred_hidden;
-  text_plan(c, e, a.tokens, a.lengths, B, N, a.t_en);
-  View X = bert_plan(c, e, a.tokens, a.lengths, B, N);
-  Sess s0{c, e, B, N, true, a.lengths, {}, 0, nullptr, nullptr, 1.0};
-  View D = dn_alloc(s0, dh);  // bert_encoder: Linear(H -> hidden_dim) over the merged tokens == d_en channel-major
-  {
-    ConvOpt o;
-    o.bias = e.F(e.bert.enc_b);
-    conv(c, e, dn_cv(s0, X), e.bert.enc, dn_cv(s0, D), o);
-  }
-  const int64_t n = (int64_t)B * C2;
-  float* sp = c.a.f32(n);
-  {
-    const int64_t mark = c.a.off;
-    if (sampler_plan(c, e, a.noise, nullptr, &X, a.ref_s, a.step_noise, a.lengths, B, N, a.steps, a.embedding_scale, a.table,
-                     a.sigma0, sp, nullptr) != 0 && c.rc == 0)
-      c.rc = 1;
-    c.a.off = mark;
-  }
-  if (a.carry && B > 1) {
-    // the rows are consecutive sentences of one passage: row k mixes with row k-1's MIXED style (the loop of LFinference,
-    // Demo/Inference_LibriTTS.ipynb LFinference: `s_prev = s_pred` after the speaker mixing).  A scan of the same elementwise
-    // launches the one-sentence call makes, on one row each: bitwise the sentence-by-sentence results, ~5 us per launch.
-    float* mixed = a.s_pred_out ? a.s_pred_out : c.a.f32(n);
-    float* m = c.a.f32(C2);
-    float* ma = c.a.f32(C2);
-    float* mb = c.a.f32(C2);
-    for (int k = 0; k < B; ++k) {
-      const float* prev = k ? mixed + (int64_t)(k - 1) * C2 : a.s_prev;
-      const float* cur = sp + (int64_t)k * C2;
-      if (prev) {
-        RUN(c, g_be.axpbypcz(prev, (float)a.t, cur, (float)(1.0 - a.t), nullptr, 0.f, m, C2, c.stream));
-        cur = m;
-      }
-      const float* ref_src = cur;
-      const float* s_src = cur + sty;
-      if (a.ref_s) {
-        const float* rs = a.ref_s + (int64_t)k * C2;
-        RUN(c, g_be.axpbypcz(cur, (float)a.alpha, rs, (float)(1.0 - a.alpha), nullptr, 0.f, ma, C2, c.stream));
-        RUN(c, g_be.axpbypcz(cur, (float)a.beta, rs, (float)(1.0 - a.beta), nullptr, 0.f, mb, C2, c.stream));
-        ref_src = ma;
-        s_src = mb + sty;
-      }
-      RUN(c, g_be.copy_ncl(ref_src, C2, sty, mixed + (int64_t)k * C2, C2, sty, 1, 1, sty, c.stream));
-      RUN(c, g_be.copy_ncl(s_src, C2, sty, mixed + (int64_t)k * C2 + sty, C2, sty, 1, 1, sty, c.stream));
-    }
-    RUN(c, g_be.copy_ncl(mixed, C2, sty, a.ref, sty, sty, B, 1, sty, c.stream));
-    RUN(c, g_be.copy_ncl(mixed + sty, C2, sty, a.s, sty, sty, B, 1, sty, c.stream));
-    duration_plan(c, e, D, a.s, a.lengths, B, N, a.tail, a.d_cm, a.durations);
-    return c.rc;
-  }
-  const float* cur = sp;
-  if (a.s_prev) {  // LFinference: convex combination of the previous and the current style
-    float* m = c.a.f32(n);
-    RUN(c, g_be.axpbypcz(a.s_prev, (float)a.t, cur, (float)(1.0 - a.t), nullptr, 0.f, m, n, c.stream));
-    cur = m;
-  }
-  const float* ref_src = cur;
-  const float* s_src = cur + sty;
-  if (a.ref_s) {  // Demo/Inference_LibriTTS.ipynb:289-290
-    float* ma = c.a.f32(n);
-    float* mb = c.a.f32(n);
-    RUN(c, g_be.axpbypcz(cur, (float)a.alpha, a.ref_s, (float)(1.0 - a.alpha), nullptr, 0.f, ma, n, c.stream));
-    RUN(c, g_be.axpbypcz(cur, (float)a.beta, a.ref_s, (float)(1.0 - a.beta), nullptr, 0.f, mb, n, c.stream));
-    ref_src = ma;
-    s_src = mb + sty;
-  }
-  RUN(c, g_be.copy_ncl(ref_src, C2, sty, a.ref, sty, sty, B, 1, sty, c.stream));
-  RUN(c, g_be.copy_ncl(s_src, C2, sty, a.s, sty, sty, B, 1, sty, c.stream));
-  if (a.s_pred_out) {
-    RUN(c, g_be.copy_ncl(ref_src, C2, sty, a.s_pred_out, C2, sty, B, 1, sty, c.stream));
-    RUN(c, g_be.copy_ncl(s_src, C2, sty, a.s_pred_out + sty, C2, sty, B, 1, sty, c.stream));
-  }
-  duration_plan(c, e, D, a.s, a.lengths, B, N, a.tail, a.d_cm, a.durations);
-  return c.rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// style-encoder plan == StyleEncoder.forward (styletts2_amd/style.py): feature maps stored (h, c, w) with one zero row
-// above and below, every 3x3 Conv2d one split-f16 Conv1d over the width with 3 stacked rows as its input channels
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int STYLE_ZEROS = 4096;
-
-// Conv2d weight [Co][Ci][kh][kw] -> Conv1d weight [Co][kh*Ci][kw] on kh stacked image rows (channel index dh*Ci + ci)
-std::vector<float> rows_as_channels(const HostTensor& t) {
-  const int co = (int)t.shape[0], ci = (int)t.shape[1], kh = (int)t.shape[2], kw = (int)t.shape[3];
-  std::vector<float> v((size_t)co * kh * ci * kw);
-  for (int o = 0; o < co; ++o)
-    for (int i = 0; i < ci; ++i)
-      for (int dh = 0; dh < kh; ++dh)
-        for (int x = 0; x < kw; ++x)
-          v[(((size_t)o * kh + dh) * ci + i) * kw + x] = t.data[(((size_t)o * ci + i) * kh + dh) * kw + x];
-  return v;
-}
-
-int pack_style(st2_engine& e, Blob& blob, int which, std::string* err) {
-  Packer pk{e, blob};
-  PStyleEnc s;
-  const std::string R = which == 0 ? "style_encoder." : "predictor_encoder.";
-  auto conv2d = [&](const std::string& name) -> SplitW {  // folded Conv2d -> packed Conv1d over stacked rows
-    const HostTensor* t = pk.get(name);
-    if (!t || t->shape.size() != 4) { pk.ok = false; if (pk.missing.empty()) pk.missing = name + " (4-D expected)"; return SplitW(); }
-    const std::vector<float> v = rows_as_channels(*t);
-    return pack_split(blob, name, v.data(), (int)t->shape[0], (int)(t->shape[1] * t->shape[2]), (int)t->shape[3]);
-  };
-  const HostTensor* first = pk.get(R + "shared.0.weight");
-  if (!first || first->shape.size() != 4 || first->shape[1] != 1 || first->shape[2] != 3 || first->shape[3] != 3) {
-    *err = "missing or malformed style-encoder parameter " + R + "shared.0.weight (spectral norm folded by the caller)";
-    return 1;
-  }
-  s.c0 = (int)first->shape[0];
-  s.w0 = blob.add_f32(rows_as_channels(*first));  // [C0][3][3]: plain OIK for st2_conv1d_direct
-  s.b0 = pk.vec(R + "shared.0.bias");
-  int i = 1;
-  for (; pk.has(R + "shared." + std::to_string(i) + ".conv1.weight"); ++i) {
-    const std::string Bn = R + "shared." + std::to_string(i);
-    PStyleBlk b;
-    const HostTensor* w1 = pk.get(Bn + ".conv1.weight");
-    const HostTensor* w2 = pk.get(Bn + ".conv2.weight");
-    const HostTensor* wd = pk.get(Bn + ".downsample_res.conv.weight");
-    if (!w1 || !w2 || !wd) break;
-    if (w1->shape.size() != 4 || w2->shape.size() != 4 || w1->shape[0] != w1->shape[1] || w2->shape[1] != w1->shape[0] ||
-        wd->numel() != w1->shape[0] * 9) {
-      *err = "malformed style-encoder block " + Bn + " (ResBlk: conv1 [C, C, 3, 3], conv2 [C', C, 3, 3], depthwise [C, 1, 3, 3])";
-      return 1;
-    }
-    b.c_in = (int)w1->shape[1];
-    b.c_out = (int)w2->shape[0];
-    b.w1 = conv2d(Bn + ".conv1.weight");  b.b1 = pk.vec(Bn + ".conv1.bias");
-    b.w2 = conv2d(Bn + ".conv2.weight");  b.b2 = pk.vec(Bn + ".conv2.bias");
-    b.wd = blob.add_f32(wd->data);        b.bd = pk.vec(Bn + ".downsample_res.conv.bias");  // [C][1][3][3] == [C][3][3]
-    if (pk.has(Bn + ".conv1x1.weight")) {
-      b.wsc = conv2d(Bn + ".conv1x1.weight");
-      b.has_sc = true;
-    }
-    s.blocks.push_back(b);
-  }
-  // shared.{i} = LeakyReLU, shared.{i+1} = the 5x5 valid conv (models.py:151-153)
-  const std::string last = R + "shared." + std::to_string(i + 1);
-  s.w5 = conv2d(last + ".weight");
-  s.b5 = pk.vec(last + ".bias");
-  s.c_last = s.w5.C_out;
-  s.wl = pk.conv_w(R + "unshared.weight");
-  s.bl = pk.vec(R + "unshared.bias");
-  s.style_dim = s.wl.C_out;
-  if (!pk.ok || s.c0 > STYLE_ZEROS || s.c_last > STYLE_ZEROS) {
-    *err = "style-encoder parameter missing or malformed: " + pk.missing;
-    return 1;
-  }
-  if (s.blocks.size() != 4 || s.w5.ks != 5 || s.w5.C_in != 5 * s.blocks.back().c_out) {  // 80 mel bins -> 5 rows -> 5x5 valid conv
-    *err = "style encoder " + R + ": expected four down-sampling ResBlks and a 5x5 valid conv (models.py:139-164)";
-    return 1;
-  }
-  s.ready = true;
-  e.style[which] = s;
-  return 0;
-}
-
-int style_plan(Ctx& c, const st2_engine& e, const PStyleEnc& s, const float* mel, int B, int H, int W, float* out) {
-  // [B][h + 2][ch][w] map whose rows 0 and h + 1 are zero (the rows 1 .. h are written by the producing kernel)
-  auto new_map = [&](int h, int ch, int w) -> float* {
-    float* p = c.a.f32((int64_t)B * (h + 2) * ch * w);
-    for (int r : {0, h + 1})
-      RUN(c, g_be.broadcast_cols(e.F(e.zeros), 0, p + (int64_t)r * ch * w, (int64_t)(h + 2) * ch * w, w, B, ch, w, c.stream));
-    return p;
-  };
-  // rows r0 .. r0 + k - 1 of utterance b's padded map stacked along the channels: [h][k * ch][w] (overlapping view)
-  auto rows = [&](float* P, int b, int h, int ch, int w, int k, int r0) {
-    View v;
-    v.p = P + (int64_t)b * (h + 2) * ch * w + (int64_t)r0 * ch * w;
-    v.B = h; v.C = k * ch; v.L = w; v.bs = (int64_t)ch * w; v.cs = w;  // k = 3 from row 0 / k = 1 from row 1: h image rows
-    return v;
-  };
-  auto plain = [&](float* p, int b, int h, int ch, int w) {  // [h][ch][w] of utterance b in an unpadded [B][h][ch][w] buffer
-    View v;
-    v.p = p + (int64_t)b * h * ch * w;
-    v.B = h; v.C = ch; v.L = w; v.bs = (int64_t)ch * w; v.cs = w;
-    return v;
-  };
-  float* m0 = new_map(H, 1, W);
-  RUN(c, g_be.copy_ncl(mel, (int64_t)H * W, W, m0 + W, (int64_t)(H + 2) * W, W, B, H, W, c.stream));
-  int C = s.c0;
-  float* P = new_map(H, C, W);
-  for (int b = 0; b < B; ++b) {
-    const View x = rows(m0, b, H, 1, W, 3, 0);
-    RUN(c, g_be.conv1d_direct(x.p, x.bs, x.cs, e.F(s.w0), e.F(s.b0), P + (int64_t)b * (H + 2) * C * W + (int64_t)C * W,
-                              (int64_t)C * W, W, H, 3, C, W, W, 3, 1, 1, c.stream));
-  }
-  for (const PStyleBlk& blk : s.blocks) {
-    const int Co = blk.c_out, Ho = H / 2, Wo = (W + 1) / 2;
-    // shortcut: 1x1 conv at full resolution, then the 2x2 average (models.py:118-123)
-    float* SC = c.a.f32((int64_t)B * Ho * Co * Wo);
-    if (blk.has_sc) {
-      float* S = c.a.f32((int64_t)B * H * Co * W);
-      for (int b = 0; b < B; ++b) conv(c, e, rows(P, b, H, C, W, 1, 1), blk.wsc, plain(S, b, H, Co, W), ConvOpt());
-      RUN(c, g_be.avgpool2x2(S, (int64_t)H * Co * W, (int64_t)Co * W, W, B, Co, H, W, SC, (int64_t)Ho * Co * Wo, (int64_t)Co * Wo,
-                             Wo, c.stream));
-    } else {
-      RUN(c, g_be.avgpool2x2(P + (int64_t)C * W, (int64_t)(H + 2) * C * W, (int64_t)C * W, W, B, C, H, W, SC,
-                             (int64_t)Ho * Co * Wo, (int64_t)Co * Wo, Wo, c.stream));
-    }
-    // residual: leaky -> conv1 3x3 -> depthwise stride-2 3x3 -> leaky -> conv2 3x3 (models.py:125-135)
-    float* R1 = c.a.f32((int64_t)B * H * C * W);
-    for (int b = 0; b < B; ++b) {
-      ConvOpt o;
-      o.pad_left = 1; o.bias = e.F(blk.b1); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
-      conv(c, e, rows(P, b, H, C, W, 3, 0), blk.w1, plain(R1, b, H, C, W), o);
-    }
-    float* P2 = new_map(Ho, C, Wo);
-    RUN(c, g_be.dwconv3x3s2(R1, (int64_t)H * C * W, (int64_t)C * W, W, e.F(blk.wd), e.F(blk.bd), B, C, H, W, P2 + (int64_t)C * Wo,
-                            (int64_t)(Ho + 2) * C * Wo, (int64_t)C * Wo, Wo, c.stream));
-    float* Pn = new_map(Ho, Co, Wo);
-    for (int b = 0; b < B; ++b) {  // (shortcut + residual) / sqrt(2) in the epilogue
-      ConvOpt o;
-      o.pad_left = 1; o.bias = e.F(blk.b2); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
-      o.res = plain(SC, b, Ho, Co, Wo); o.div = (float)sqrt(2.0);
-      View y = rows(Pn, b, Ho, Co, Wo, 1, 1);
-      conv(c, e, rows(P2, b, Ho, C, Wo, 3, 0), blk.w2, y, o);
-    }
-    P = Pn; H = Ho; W = Wo; C = Co;
-  }
-  // LeakyReLU -> 5x5 valid conv -> global average -> LeakyReLU -> Linear (models.py:151-163)
-  const int Cl = s.c_last, Wf = W - 4;
-  float* Fm = c.a.f32((int64_t)B * Cl * Wf);
-  for (int b = 0; b < B; ++b) {
-    View x;
-    x.p = P + (int64_t)b * (H + 2) * C * W + (int64_t)C * W;
-    x.B = 1; x.C = 5 * C; x.L = W; x.bs = (int64_t)5 * C * W; x.cs = W;
-    View y;
-    y.p = Fm + (int64_t)b * Cl * Wf;
-    y.B = 1; y.C = Cl; y.L = Wf; y.bs = (int64_t)Cl * Wf; y.cs = Wf;
-    ConvOpt o;
-    o.bias = e.F(s.b5); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
-    conv(c, e, x, s.w5, y, o);
-  }
-  float* m = c.a.f32((int64_t)B * Cl);
-  RUN(c, g_be.mean_tokens_len(Fm, (int64_t)Cl * Wf, Wf, m, Cl, B, Cl, Wf, nullptr, c.stream));
-  {
-    View x, y;
-    x.p = m; x.B = B; x.C = Cl; x.L = 1; x.bs = Cl; x.cs = 1;
-    y.p = out; y.B = B; y.C = s.style_dim; y.L = 1; y.bs = s.style_dim; y.cs = 1;
-    ConvOpt o;
-    o.bias = e.F(s.bl); o.pro = ST2_PRO_LEAKY; o.slope = 0.2f;
-    conv(c, e, x, s.wl, y, o);
-  }
-  return c.rc;
-}
-
-bool check_cfg(const st2_model_config& c) {
-  return c.n_upsamples >= 1 && c.n_upsamples <= 4 && c.n_resblock_kernels >= 1 && c.n_resblock_kernels <= 4 &&
-         (c.decoder_kind == 0 || c.decoder_kind == 1) && c.dim_in > 0 && c.style_dim > 0 && c.dn_layers >= 0;
-}
+#include "st2_plan_decoder.inc"
+#include "st2_plan_sampler.inc"
+#include "st2_plan_prosody.inc"
+#include "st2_plan_duration.inc"
+#include "st2_plan_text.inc"
+#include "st2_plan_front.inc"
+#include "st2_plan_style.inc"
 
 }  // namespace
 

@@ -320,7 +320,7 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
   float* hx = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + head);
   // status, counters and -- granule form -- every tag start at zero on EVERY call (a tag left by an earlier call would
   // otherwise match).  A KERNEL, not hipMemsetAsync: recorded into a hipGraph, the memset node zeroes on the first replay and
-  // writes an 8-byte pointer-like pattern over the head of the buffer on every later one (ROCm 7.2, tools/debug_lstm_graph.py,
+  // writes an 8-byte pointer-like pattern over the head of the buffer on every later one (ROCm 7.2, tools/stress.py lstm_graph,
   // profiles/r05c_lstm_graph.log) -- rounds 1-4 never looked at scratch[0] after a replay; round 5's in-stream recovery does.
   {
     const size_t words = (XCH == 2 ? need : head) / 16;  // both are multiples of 256 bytes; scratch is 256-byte aligned

@@ -1,0 +1,666 @@
+#!/usr/bin/env python
+"""One entry point for the GPU stress / study probes that rounds 5-6 wrote one file at a time (`tools/debug_*.py`, folded here in
+round 6; the history keeps the originals).  `python tools/stress.py --list`, `python tools/stress.py NAME [args...]`.
+
+The co-residency family (lstm_under_load*, prosody_stress, smallgrid_stress, longform_bitwise) chased what turned out to be a gfx950
+hardware hazard -- packed-f32 `op_sel` next to MFMA waves, DESIGN.md section 9 -- and is superseded as a REPRODUCER by the torch-free
+`tools/lstm_load_repro.hip` / `tools/simd_hazard_repro.hip`; it stays because it exercises the product path (Python plans, torch streams)
+under the same loads.  The precision family (small_magnitude, fused_precision, stats_precision) is round 5's statistics study; the
+lstm_graph / lstm_recover / lstm_status trio documents the captured-hipMemsetAsync bug and the in-stream BiLSTM recovery."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cmd_fused_precision(argv):
+    """One AdaIN + Snake conv on data shaped like a small-magnitude generator stage (per-channel offsets of 5e-3, variation 8e-4:
+var << eps, rstd ~ 316), fused kernel vs xs pair vs the exact-fp32 kernel, all against an fp64 evaluation of the contract."""
+    sys.argv = ["stress.py fused_precision"] + list(argv)
+    import math
+
+    import torch  # noqa: E402
+
+    from oracle import ops_ref as R  # noqa: E402
+    from styletts2_amd import _hooks, ops, weights  # noqa: E402
+
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    for C, L, ks, dil, wscale, sig, alpha_dec in ((64, 7200, 7, 3, 1.0, 8e-4, 1.0), (64, 7200, 7, 1, 1e-3, 8e-4, 1.0), (32, 14400, 11, 5, 1.0, 8e-4, 1.0),
+                                                  (128, 2400, 7, 3, 1.0, 8e-4, 1.0), (64, 7200, 7, 3, 1.0, 1.0, 1.0), (64, 7200, 7, 3, 1.0, 8e-4, 0.0),
+                                                  (64, 7200, 7, 3, 1.0, 8e-2, 1.0)):
+        B = 2
+        x = torch.randn(B, C, 1, generator=g) * 5e-3 * (sig / 8e-4 if sig > 1e-2 else 1.0) + torch.randn(B, C, L, generator=g) * sig
+        w = torch.randn(C, C, ks, generator=g) / math.sqrt(C * ks) * wscale
+        bias = torch.randn(C, generator=g) * 0.02 * wscale
+        h = torch.randn(B, 2 * C, generator=g) * 0.5
+        alpha = 10.0 ** ((torch.rand(C, generator=g) * 2 - 1) * alpha_dec)
+        res = x.clone()
+        st = R.instnorm_stats(x)
+        kw = dict(dil=dil, pad_left=(ks - 1) * dil // 2, bias=bias, pro=R.PRO_ADAIN_SNAKE, stats=st, gamma=h[:, :C], beta=h[:, C:], alpha=alpha,
+                  res=res)
+        exact = R.conv1d(x.double(), weights.pack_conv(w).double(), C, ks, **{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
+                                                                                  for k, v in kw.items()})
+        kwg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        out = {}
+        with _hooks.override(conv_path="fused"):
+            out["fused f16s"] = ops.conv1d(x.to(dev), weights.pack_conv_f16s(w).to(dev), C, ks, **kwg)
+            out["exact f32 "] = ops.conv1d(x.to(dev), weights.pack_conv(w).to(dev), C, ks, **kwg)
+        with _hooks.override(conv_path="xs"):
+            PRO = ("pro", "stats", "gamma", "beta", "alpha")
+            xs = ops.activate(x.to(dev), **{k: v for k, v in kwg.items() if k in PRO})
+            out["xs pair   "] = ops.conv1d_xs(xs, weights.pack_conv_f16s(w).to(dev), C, ks, **{k: v for k, v in kwg.items() if k not in PRO})
+        torch.cuda.synchronize()
+        ref32 = R.conv1d(x, weights.pack_conv(w), C, ks, **kw)
+        out["ATen fp32 "] = ref32
+        # error of the conv term alone (y - res - bias), relative to ITS maximum: the residual hides it otherwise
+        conv_exact = exact - res.double() - bias.double().view(1, -1, 1)
+        line = "C %3d L %5d k %2d d %d w x%g sigma %g alpha 10^+-%g:" % (C, L, ks, dil, wscale, sig, alpha_dec)
+        for name, y in out.items():
+            e = (y.detach().cpu().double() - exact).abs().max().item()
+            line += "  %s %.2e (conv term %.2e)" % (name.strip(), e / exact.abs().max().item(), e / conv_exact.abs().max().item())
+        print(line, flush=True)
+    print("status 0x%x" % ops.status(clear=True))
+
+
+def cmd_longform_bitwise(argv):
+    """synthesize_long overlapped vs sequential: which sentences differ, by how much, and what does the status word say?"""
+    sys.argv = ["stress.py longform_bitwise"] + list(argv)
+    import torch  # noqa: E402
+
+    from test_pipeline_gpu import KEYS, _model  # noqa: E402
+    from styletts2_amd import _hooks, _lib, models, ops, pipeline  # noqa: E402
+
+    tag = sys.argv[1] if len(sys.argv) > 1 else "libritts"
+    man, model, sds = _model(tag)
+    g = torch.Generator().manual_seed(11)
+    lens, steps = [9, 6, 12, 7], 3
+    sentences = [torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, 178, (n - 1,), generator=g)]) for n in lens]
+    noises = [torch.randn(1, 1, 256, generator=g) for _ in lens]
+    step_noises = [torch.randn(steps - 1, 1, 1, 256, generator=g) for _ in lens]
+    durs = [torch.full((1, n), 2, dtype=torch.long) for n in lens]
+    sine = [torch.randn(1, 600 * 2 * n, 9, generator=g) for n in lens]
+    ref_s = torch.randn(1, 256, generator=g) if man["config"]["multispeaker"] else None
+    for k in KEYS:
+        model[k].to("cuda")
+    sampler = models.make_sampler(model)
+    d = lambda xs: [x.to("cuda") for x in xs]
+    kw = dict(ref_s=None if ref_s is None else ref_s.to("cuda"), t=0.7, diffusion_steps=steps, noises=d(noises), step_noises=d(step_noises),
+              sine_noises=d(sine), durations=durs)
+    runs = {}
+    for name, ovl in (("seq1", False), ("seq2", False), ("ovl1", True), ("ovl2", True), ("seq3", False)):
+        ops.status(clear=True)
+        waves, style = pipeline.synthesize_long(model, sampler, d(sentences), overlap=ovl, **kw)
+        torch.cuda.synchronize()
+        runs[name] = [w.clone() for w in waves]
+        print("%s: status 0x%x" % (name, ops.status(clear=True)), flush=True)
+    ref = runs["seq1"]
+    for name, ws in runs.items():
+        print(name, ["equal" if torch.equal(a, b) else "%.2e" % (a - b).abs().max().item() for a, b in zip(ws, ref)])
+    lib = _lib.load()
+    lib.st2_lstm_coop_set_block(-1)  # no cooperative launches at all
+    runs2 = {}
+    for name, ovl in (("seq/single-CU lstm", False), ("ovl/single-CU lstm", True)):
+        waves, style = pipeline.synthesize_long(model, sampler, d(sentences), overlap=ovl, **kw)
+        torch.cuda.synchronize()
+        runs2[name] = [w.clone() for w in waves]
+    lib.st2_lstm_coop_set_block(0)
+    print("single-CU lstm: ovl vs seq", ["equal" if torch.equal(a, b) else "%.2e" % (a - b).abs().max().item()
+                                        for a, b in zip(runs2["ovl/single-CU lstm"], runs2["seq/single-CU lstm"])])
+
+    # ---- where does it differ: the decoder's inputs (front affected by the concurrent decoder) or its output for equal inputs? -------
+    lib.st2_lstm_coop_set_block(-1)
+    rec = {}
+    orig = model.decoder.forward
+
+
+    def spy(asr, F0, N, s, noise=None, **k):
+        out = orig(asr, F0, N, s, noise=noise, **k)
+        rec.setdefault(mode, []).append(dict(asr=asr.clone(), F0=F0.clone(), N=N.clone(), s=s.clone(), out=out.clone()))
+        return out
+
+
+    model.decoder.forward = spy
+    for mode, ovl in (("seq", False), ("ovl", True)):
+        pipeline.synthesize_long(model, sampler, d(sentences), overlap=ovl, **kw)
+        torch.cuda.synchronize()
+    model.decoder.forward = orig
+    for k in range(len(lens)):
+        a, b = rec["seq"][k], rec["ovl"][k]
+        print("sentence %d:" % k, {n: ("equal" if torch.equal(a[n], b[n]) else "%.2e" % (a[n] - b[n]).abs().max().item()) for n in a})
+    lib.st2_lstm_coop_set_block(0)
+
+
+def cmd_lstm_graph(argv):
+    """Is the hipMemsetAsync of st2_lstm_bidir_coop replayed by a captured graph?  The cooperative launch under torch.cuda.graph on a
+scratch buffer pre-filled with 0x5A: after replay scratch[0] must be 0 (and the granule tags those of THIS run)."""
+    sys.argv = ["stress.py lstm_graph"] + list(argv)
+    import torch  # noqa: E402
+
+    from styletts2_amd import _lib, ops  # noqa: E402
+
+    lib = _lib.load()
+    dev = "cuda"
+    H = 256
+    torch.manual_seed(0)
+    whh = (torch.randn(2, H, 4 * H, device=dev) / 16).contiguous()
+    for B, N in ((1, 96), (32, 100)):
+        G = torch.randn(B, 8 * H, N, device=dev)
+        nbytes = lib.st2_lstm_coop_scratch_bytes(B)
+        Y = torch.empty(B, 2 * H, N, device=dev)
+        scratch = torch.full((nbytes,), 0x5A, device=dev, dtype=torch.uint8)
+
+        def call(fn):
+            rc = fn(G.data_ptr(), G.stride(0), G.stride(1), whh.data_ptr(), 0, B, H, N, Y.data_ptr(), Y.stride(0), Y.stride(1),
+                    scratch.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.st2_last_error()
+        for name, fn in (("coop", lib.st2_lstm_bidir_coop), ("recovering", lib.st2_lstm_bidir_coop_recovering)):
+            call(fn)  # eager once (attributes, status word)
+            torch.cuda.synchronize()
+            ref = Y.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                call(fn)
+            for it in range(3):
+                scratch.fill_(0x5A)
+                Y.fill_(7.0)
+                ops.status(clear=True)
+                torch.cuda.synchronize()
+                g.replay()
+                torch.cuda.synchronize()
+                print("B %2d %-10s replay %d: scratch[0] = 0x%x, scratch[1] = 0x%x, status 0x%x, Y equal eager: %s" % (
+                    B, name, it, int(scratch[:4].view(torch.int32).item()) & 0xffffffff, int(scratch[4:8].view(torch.int32).item()) & 0xffffffff,
+                    ops.status(clear=True), torch.equal(Y, ref)), flush=True)
+
+
+def cmd_lstm_recover(argv):
+    """Does st2_lstm_bidir_coop_recovering re-run calls that did not time out?  Per shape: scratch[0] after the call, the sticky
+status word, and the time of the pair against the bare cooperative launch."""
+    sys.argv = ["stress.py lstm_recover"] + list(argv)
+    import time
+
+    import torch  # noqa: E402
+
+    from styletts2_amd import _lib, ops  # noqa: E402
+
+    lib = _lib.load()
+    dev = "cuda"
+    torch.manual_seed(0)
+    H = 256
+    whh = (torch.randn(2, H, 4 * H, device=dev) / 16).contiguous()
+    for B, N, ragged in ((1, 100, False), (1, 400, False), (1, 96, True), (8, 50, False), (32, 100, False), (32, 400, False), (32, 100, True)):
+        G = torch.randn(B, 8 * H, N, device=dev)
+        lens = None
+        if ragged:
+            lens = torch.randint(max(1, N - 15), N + 1, (B,), dtype=torch.int32, device=dev)
+        lp = 0 if lens is None else lens.data_ptr()
+        nbytes = lib.st2_lstm_coop_scratch_bytes(B)
+        out = {}
+        for name, fn in (("coop", lib.st2_lstm_bidir_coop), ("recovering", lib.st2_lstm_bidir_coop_recovering)):
+            Y = torch.empty(B, 2 * H, N, device=dev)
+            scratch = torch.full((nbytes,), 0x5A, device=dev, dtype=torch.uint8)
+            ops.status(clear=True)
+            st0 = []
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(20):
+                rc = fn(G.data_ptr(), G.stride(0), G.stride(1), whh.data_ptr(), lp, B, H, N, Y.data_ptr(), Y.stride(0), Y.stride(1),
+                        scratch.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, lib.st2_last_error()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 20 * 1e6
+            out[name] = (int(scratch[:4].view(torch.int32).item()), ops.status(clear=True), dt, Y)
+        same = torch.equal(out["coop"][3], out["recovering"][3])
+        print("B %2d N %3d ragged %d: coop scratch[0] %d status 0x%x %.0f us | recovering scratch[0] %d status 0x%x %.0f us | outputs equal %s" % (
+            B, N, ragged, out["coop"][0], out["coop"][1], out["coop"][2], out["recovering"][0], out["recovering"][1], out["recovering"][2], same))
+
+
+def cmd_lstm_status(argv):
+    """When is ST2_STATUS_LSTM_RECOVERED raised?  Sentence-by-sentence synthesis (B = 1) and a B = 32 batch, eager front vs the
+graph-replayed front: the sticky status word after every call, and whether the two fronts agree bit for bit."""
+    sys.argv = ["stress.py lstm_status"] + list(argv)
+    import torch  # noqa: E402
+
+    import bench  # noqa: E402
+    from benchdata import manifest, synth  # noqa: E402
+    from styletts2_amd import models, ops, pipeline  # noqa: E402
+
+    dev = torch.device("cuda", 0)
+    man = manifest("ljspeech")
+    model = bench.build(man)
+    for i, k in enumerate(bench.KEYS):
+        synth.init_synthetic_(model[k], 10 + i)
+        model[k].eval().to(dev)
+    sampler = models.make_sampler(model)
+    front = pipeline.GraphedFront(model, sampler)
+    for B, N in ((1, 100), (1, 64), (32, 100)):
+        tokens, lengths, noise, durations, _ = bench.synthetic_inputs(B, 5)
+        tokens, noise, dur = tokens[:, :N].contiguous().to(dev), noise.to(dev), durations[:, :N].contiguous().to(dev)
+        lengths = lengths.clamp(max=N)
+        step_noise = torch.randn(4, B, 1, 256, device=dev)
+        outs = {}
+        for mode, fr in (("eager", None), ("graph", front), ("graph", front), ("eager", None), ("graph", front)):
+            ops.status(clear=True)
+            p = pipeline.prepare(model, sampler, tokens, lengths, noise, diffusion_steps=5, durations=dur, total_frames=4 * N,
+                                 step_noise=step_noise, front=fr)
+            torch.cuda.synchronize()
+            st = ops.status(clear=True)
+            key = (mode,)
+            same = ""
+            if "ref" in outs:
+                same = " F0 equal to first run: %s, asr equal: %s" % (torch.equal(outs["ref"]["F0"], p["F0"]), torch.equal(outs["ref"]["asr"], p["asr"]))
+            else:
+                outs["ref"] = {k: p[k].clone() for k in ("F0", "asr")}
+            print("B %2d N %3d %-5s front: status 0x%x%s" % (B, N, mode, st, same), flush=True)
+
+
+def cmd_lstm_under_load(argv):
+    """LSTM outputs that differ under a small-grid conv load: WHERE do they differ (isolated elements = somebody else's stray store;
+from some time step on in one direction = the recurrence itself took a wrong input)?  Also: guard bands around the conv's output."""
+    sys.argv = ["stress.py lstm_under_load"] + list(argv)
+    import torch  # noqa: E402
+
+    from styletts2_amd import _hooks, ops, weights  # noqa: E402
+
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    lx = ops.activate(torch.randn(1, 256, 5680, generator=g).to(dev))
+    lw = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=g) / 40).to(dev)
+    T = 24
+    G = torch.randn(1, 2048, T, generator=g).to(dev)
+    whh = (torch.randn(2, 256, 1024, generator=g) / 16).to(dev).contiguous()
+    side = torch.cuda.Stream()
+    # guard bands around the conv output
+    buf = torch.full((256 * 5680 + 2 * 65536,), 1234.5, device=dev)
+    yv = buf[65536:65536 + 256 * 5680].view(1, 256, 5680)
+    ops.conv1d_xs(lx, lw, 256, 7, pad_left=3, out=yv)
+    torch.cuda.synchronize()
+    print("guards around the small-grid conv output intact:", bool((buf[:65536] == 1234.5).all()) and bool((buf[-65536:] == 1234.5).all()))
+    for mode in ("single", "coop"):
+        with _hooks.override(lstm=mode):
+            ref = ops.lstm_bidir(G, whh).clone()
+            torch.cuda.synchronize()
+            for trial in range(3):
+                outs = []
+                side.wait_stream(torch.cuda.current_stream())
+                for _ in range(150):
+                    ops.conv1d_xs(lx, lw, 256, 7, pad_left=3, out=yv)
+                with torch.cuda.stream(side):
+                    for _ in range(40):
+                        outs.append(ops.lstm_bidir(G, whh))
+                torch.cuda.synchronize()
+                for i, o in enumerate(outs):
+                    if not torch.equal(o, ref):
+                        dmask = (o != ref)[0]                      # [2H, T]
+                        fwd, rev = dmask[:256], dmask[256:]
+                        tf = fwd.any(0).nonzero().flatten().tolist()
+                        tr = rev.any(0).nonzero().flatten().tolist()
+                        print("%s trial %d call %2d: %5d elements differ, max %.2e; forward rows differ at t = %s (units %d), reverse at t = %s (units %d)" % (
+                            mode, trial, i, int(dmask.sum()), (o - ref).abs().max().item(), tf[:6] + (["..."] if len(tf) > 6 else []),
+                            int(fwd.any(1).sum()), tr[:6] + (["..."] if len(tr) > 6 else []), int(rev.any(1).sum())), flush=True)
+                        break
+    print("guards still intact:", bool((buf[:65536] == 1234.5).all()) and bool((buf[-65536:] == 1234.5).all()))
+
+
+def cmd_lstm_under_load2(argv):
+    """Which property of the other queue's work makes the BiLSTM kernels irreproducible?  Loads: the same small conv in 32- / 64- / 128-column
+tiles (want_stats + part_cols forces the width), many small activation passes, many small fused convs, a big conv.
+The k = 7 / 11 narrow builds are compiled only with -DST2_XS_NARROW_ALL=1 (profiles/LAB_NOTES.md round 5): build the library with that flag
+(styletts2_amd/_build.py FLAGS) to reproduce the finding; with the product library those loads are reported as "not built"."""
+    sys.argv = ["stress.py lstm_under_load2"] + list(argv)
+    import torch  # noqa: E402
+
+    from styletts2_amd import _hooks, ops, weights  # noqa: E402
+
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    x_small = torch.randn(1, 256, 5680, generator=g).to(dev)
+    lx = ops.activate(x_small)
+    lw = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=g) / 40).to(dev)
+    lw11 = weights.pack_conv_f16s(torch.randn(256, 256, 11, generator=g) / 50).to(dev)
+    lw3 = weights.pack_conv_f16s(torch.randn(256, 256, 3, generator=g) / 30).to(dev)
+    bigx = ops.activate(torch.randn(8, 128, 48000, generator=g).to(dev))
+    bigw = weights.pack_conv_f16s(torch.randn(128, 128, 7, generator=g) / 30).to(dev)
+    xf = torch.randn(1, 64, 5680, generator=g).to(dev)
+    wf = weights.pack_conv_f16s(torch.randn(64, 64, 7, generator=g) / 20).to(dev)
+    T = 24
+    G = torch.randn(1, 2048, T, generator=g).to(dev)
+    whh = (torch.randn(2, 256, 1024, generator=g) / 16).to(dev).contiguous()
+    side = torch.cuda.Stream()
+    y = torch.empty(1, 256, 5680, device=dev)
+
+
+    def conv_cols(cols, n=150, w=lw, ks=7):
+        return lambda: [ops.conv1d_xs(lx, w, 256, ks, pad_left=(ks - 1) // 2, out=y, want_stats=True, part_cols=cols) for _ in range(n)]
+
+
+    loads = {
+        "idle": lambda: None,
+        "k7 conv, 32-column tiles x150": conv_cols(32),
+        "k7 conv, 64-column tiles x150": conv_cols(64),
+        "k7 conv, 128-column tiles x100": conv_cols(128, 100),
+        "k3 conv, 32-column tiles x200": conv_cols(32, 200, lw3, 3),
+        "k11 conv, 32-column tiles x120": conv_cols(32, 120, lw11, 11),
+        "k11 conv, 128-column tiles x80": conv_cols(128, 80, lw11, 11),
+        "small activation passes x400": lambda: [ops.activate(x_small) for _ in range(400)],
+        "small fused convs (C = 64) x150": lambda: [ops.conv1d(xf, wf, 64, 7, pad_left=3) for _ in range(150)],
+        "big conv x6": lambda: [ops.conv1d_xs(bigx, bigw, 128, 7, pad_left=3) for _ in range(6)],
+    }
+    for mode in ("coop", "single"):
+        with _hooks.override(lstm=mode, conv_path="fused"):
+            ref = ops.lstm_bidir(G, whh).clone()
+            torch.cuda.synchronize()
+            for name, load in loads.items():
+                bad = tot = 0
+                for trial in range(3):
+                    outs = []
+                    side.wait_stream(torch.cuda.current_stream())
+                    try:
+                        load()
+                    except Exception as e:  # the product library refuses part_cols = 32 / 64 at k = 7 / 11
+                        print("%-7s lstm under %-34s: not built (%s)" % (mode, name, str(e)[:60]))
+                        tot = -1
+                        break
+                    with torch.cuda.stream(side):
+                        for _ in range(30 if mode == "coop" else 10):
+                            outs.append(ops.lstm_bidir(G, whh))
+                    torch.cuda.synchronize()
+                    bad += sum(not torch.equal(o, ref) for o in outs)
+                    tot += len(outs)
+                if tot > 0:
+                    print("%-7s lstm under %-34s: %3d / %3d calls differ" % (mode, name, bad, tot), flush=True)
+
+
+def cmd_prosody_stress(argv):
+    """Which kernel of the prosody path is not reproducible while small-grid xs convs run on another stream?  Each candidate op runs 40 x
+on a side stream under the load and every result is compared with its idle reference."""
+    sys.argv = ["stress.py prosody_stress"] + list(argv)
+    import math
+
+    import torch  # noqa: E402
+
+    from styletts2_amd import _hooks, _lib, ops, weights  # noqa: E402
+
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    lib = _lib.load()
+    # the load: small-grid convs (B = 1, C = 256, L = 5 680: 32-column tiles) on the main stream
+    lx = ops.activate(torch.randn(1, 256, 5680, generator=g).to(dev))
+    lw = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=g) / 40).to(dev)
+    bigx = ops.activate(torch.randn(8, 128, 48000, generator=g).to(dev))
+    bigw = weights.pack_conv_f16s(torch.randn(128, 128, 7, generator=g) / 30).to(dev)
+
+
+    def load_small():
+        for _ in range(150):
+            ops.conv1d_xs(lx, lw, 256, 7, pad_left=3)
+
+
+    def load_big():
+        for _ in range(6):
+            ops.conv1d_xs(bigx, bigw, 128, 7, pad_left=3)
+
+
+    side = torch.cuda.Stream()
+    T = 24
+    C = 512
+    x = torch.randn(1, C, T, generator=g).to(dev)
+    x2 = torch.randn(1, C, 2 * T, generator=g).to(dev)
+    h = (torch.randn(1, 2 * C, generator=g) * 0.3).to(dev)
+    w3 = weights.pack_conv_f16s(torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C)).to(dev)
+    w1 = weights.pack_conv_f16s(torch.randn(2048, 640, 1, generator=g) / math.sqrt(640)).to(dev)
+    xl = torch.randn(1, 640, T, generator=g).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    st = ops.instnorm_stats(x2)
+    G = torch.randn(1, 2048, T, generator=g).to(dev)
+    whh = (torch.randn(2, 256, 1024, generator=g) / 16).to(dev).contiguous()
+    sv = torch.randn(1, 128, generator=g).to(dev)
+    fcw = torch.randn(128, 6000, generator=g).to(dev)
+    fcb = torch.randn(6000, generator=g).to(dev)
+
+    cands = {
+        "fused conv k3 + AdaIN + statistics": lambda: ops.conv1d(x2, w3, C, 3, pad_left=1, bias=bias, pro=ops.PRO_ADAIN_LEAKY, slope=0.2, stats=st,
+                                                                  gamma=h[:, :C], beta=h[:, C:], want_stats=True),
+        "fused conv k3 + AdaIN + residual": lambda: ops.conv1d(x2, w3, C, 3, pad_left=1, bias=bias, pro=ops.PRO_ADAIN_LEAKY, slope=0.2, stats=st,
+                                                                gamma=h[:, :C], beta=h[:, C:], res=x2, div=math.sqrt(2.0)),
+        "fused conv k1 split-K (LSTM input projection)": lambda: ops.conv1d(xl, w1, 2048, 1),
+        "instnorm_stats": lambda: ops.instnorm_stats(x2),
+        "lstm single-CU": None, "lstm cooperative": None,
+        "style_fc": lambda: ops.style_fc(sv, fcw, fcb),
+    }
+
+
+    def lstm(mode):
+        with _hooks.override(lstm=mode):
+            return ops.lstm_bidir(G, whh)
+
+
+    cands["lstm single-CU"] = lambda: lstm("single")
+    cands["lstm cooperative"] = lambda: lstm("coop")
+    flat = lambda r: [t for t in (r if isinstance(r, tuple) else (r,))]
+    with _hooks.override(conv_path="fused"):
+        for name, fn in cands.items():
+            ref = [t.clone() for t in flat(fn())]
+            torch.cuda.synchronize()
+            line = "%-48s" % name
+            for lname, load in (("idle", None), ("small-grid convs", load_small), ("big convs", load_big)):
+                outs = []
+                torch.cuda.synchronize()
+                side.wait_stream(torch.cuda.current_stream())
+                if load is not None:
+                    load()
+                with torch.cuda.stream(side):
+                    for _ in range(40):
+                        outs.append(flat(fn()))
+                torch.cuda.synchronize()
+                bad = sum(any(not torch.equal(a, b) for a, b in zip(o, ref)) for o in outs)
+                line += "  %s: %2d / 40 differ" % (lname, bad)
+            print(line, flush=True)
+
+
+def cmd_small_magnitude(argv):
+    """Where does the engine lose precision on a small-magnitude checkpoint?  Decoder taps vs the oracle for (a) the C++ plan by rule,
+(b) the C++ plan calibrated, (c) the per-kernel Python plan with EXACT-fp32 MFMA convs (conv_precision = "f32": no split-f16 at all):
+what (c) shares with (a) / (b) is everything that is not a conv operand -- InstanceNorm statistics, Snake, interleave, iSTFT."""
+    sys.argv = ["stress.py small_magnitude"] + list(argv)
+    import torch  # noqa: E402
+
+    from _util import decoder_kwargs, manifest, rms  # noqa: E402
+    from benchdata import synth  # noqa: E402
+    from oracle import st2_oracle as O  # noqa: E402
+    from styletts2_amd import _hooks, ops, pipeline  # noqa: E402
+    from styletts2_amd.decoder import Decoder  # noqa: E402
+
+
+    def main():
+        tag = sys.argv[1] if len(sys.argv) > 1 else "libritts"
+        f = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-3
+        dc = manifest(tag)["config"]["decoder"]
+        dec = Decoder(**decoder_kwargs(dc)).eval()
+        synth.init_trained_like_(dec, 1)
+        synth.scale_params_(dec, {"decode.3.conv2.": f, "decode.3.conv1x1.": f, "generator.ups.": 0.1, "generator.noise_convs.": f,
+                                  ".convs2.": f})
+        sd = {k: v.clone() for k, v in dec.state_dict().items()}
+        asr, F0, N, s, noise = synth.decoder_inputs(2, 24, 3)
+        asr = asr * f
+        to, t64 = {}, {}
+        with torch.no_grad():
+            O.decoder(sd, dc, asr, F0, N, s, noise=noise, taps=to)
+            O.decoder({k: v.double() for k, v in sd.items()}, dc, asr.double(), F0.double(), N.double(), s.double(), noise=noise.double(),
+                      har=to["har"].double(), taps=t64)
+        har = to["har"].cuda()  # istftnet [B, n_fft + 2, M]; hifigan [B, 1, L]
+        dec = dec.cuda()
+        a = [t.cuda() for t in (asr, F0, N, s)]
+        keys = ["encode", "front"] + ["stage%d" % i for i in range(len(dc["upsample_rates"]))]
+
+        def errs(te, ref):
+            return {k: (te[k].cpu().double() - ref[k].double()).abs().max().item() / ref[k].double().abs().max().item() for k in keys}
+
+        def run(taps=None):
+            return dec(*a, noise=noise.cuda(), har=har, taps=taps)
+        res = {}
+        te = {}
+        run(te)
+        res["engine by rule"] = errs(te, t64)
+        pipeline.calibrate(run)
+        te = {}
+        run(te)
+        res["engine calibrated"] = errs(te, t64)
+        dec._eng.set_calibration(None)
+        for name, kw in (("python plan, exact-fp32 convs", dict(conv_precision="f32")),
+                         ("python plan, f16s (library routing)", dict()),
+                         ("python plan, f16s fused everywhere", dict(conv_path="fused"))):
+            with _hooks.override(plan="python", **kw):
+                dec._pk = None
+                te = {}
+                run(te)
+                res[name] = errs(te, t64)
+                dec._pk = None
+        res["oracle fp32 (ATen CPU)"] = errs(to, t64)
+        print("%s decoder, un-normalised stages scaled by %g: max |x - fp64 oracle| / max |fp64 oracle|" % (tag, f))
+        print("%-32s" % "" + "".join("%12s" % k for k in keys))
+        for name, e in res.items():
+            print("%-32s" % name + "".join("%12.2e" % e[k] for k in keys))
+        print("status 0x%x" % ops.status(clear=True))
+
+
+    if __name__ == "__main__":
+        main()
+
+
+def cmd_smallgrid_stress(argv):
+    """Are the small-grid builds of st2_conv1d_xs bitwise reproducible when another queue keeps the chip busy?  Stream A runs one conv
+(with statistics) into a ring of outputs while stream B streams big activation passes / convs; every output and every statistics
+tensor is compared with the unloaded reference afterwards."""
+    sys.argv = ["stress.py smallgrid_stress"] + list(argv)
+    import math
+
+    import torch  # noqa: E402
+
+    from styletts2_amd import _lib, ops, weights  # noqa: E402
+
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    big = torch.randn(16, 256, 48000, generator=g).to(dev)
+    bw = weights.pack_conv_f16s(torch.randn(256, 256, 7, generator=g) / 40).to(dev)
+    side = torch.cuda.Stream()
+    for B, C, L, ks, dil in ((1, 256, 5680, 7, 1), (1, 128, 9600, 11, 5), (1, 256, 960, 3, 1), (1, 128, 14400, 7, 3), (2, 256, 2400, 7, 1)):
+        x = torch.randn(B, C, L, generator=g).to(dev)
+        w = weights.pack_conv_f16s(torch.randn(C, C, ks, generator=g) / math.sqrt(C * ks)).to(dev)
+        res = torch.randn(B, C, L, generator=g).to(dev)
+        bias = torch.randn(C, generator=g).to(dev)
+        xs = ops.activate(x)
+        kw = dict(dil=dil, pad_left=(ks - 1) * dil // 2, bias=bias, res=res, want_stats=True)
+        ref, st_ref = ops.conv1d_xs(xs, w, C, ks, **kw)
+        torch.cuda.synchronize()
+        d = _lib.ConvDesc()
+        d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks = B, C, C, L, L, ks
+        cols = _lib.load().st2_conv1d_xs_part_cols(d)
+        for load in ("idle", "act passes on a second stream", "convs on a second stream"):
+            outs = []
+            torch.cuda.synchronize()
+            if load != "idle":
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(30 if load.startswith("act") else 12):
+                        if load.startswith("act"):
+                            ops.activate(big)
+                        else:
+                            ops.conv1d_xs(ops.activate(big[:4]), bw, 256, 7, pad_left=3)
+            for _ in range(60):
+                outs.append(ops.conv1d_xs(xs, w, C, ks, **kw))
+            torch.cuda.synchronize()
+            bad_y = sum(not torch.equal(o[0], ref) for o in outs)
+            bad_s = sum(not torch.equal(o[1], st_ref) for o in outs)
+            print("B %d C %3d L %5d k %2d d %d (tile columns %3d) %-32s: y differs in %2d / 60, statistics in %2d / 60" % (
+                B, C, L, ks, dil, cols, load, bad_y, bad_s), flush=True)
+
+
+def cmd_stats_precision(argv):
+    """Are the InstanceNorm statistics that ride in the conv epilogues (per-tile fp32 partial sums + fp64 finalize) as good as a
+direct fp64 reduction of the stored tensor, on a small-magnitude checkpoint?  Python per-kernel plan of the decoder with every
+want_stats conv / convt_interleave call checked against st2_instnorm_stats of its own output: the discrepancy is reported in
+units that matter to the consuming AdaIN, |d mean| * rstd and |d rstd| / rstd."""
+    sys.argv = ["stress.py stats_precision"] + list(argv)
+    import torch  # noqa: E402
+
+    from _util import decoder_kwargs, manifest  # noqa: E402
+    from benchdata import synth  # noqa: E402
+    from styletts2_amd import _hooks, ops  # noqa: E402
+    from styletts2_amd.decoder import Decoder  # noqa: E402
+
+    tag = sys.argv[1] if len(sys.argv) > 1 else "libritts"
+    f = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-3
+    dc = manifest(tag)["config"]["decoder"]
+    dec = Decoder(**decoder_kwargs(dc)).eval()
+    synth.init_trained_like_(dec, 1)
+    synth.scale_params_(dec, {"decode.3.conv2.": f, "decode.3.conv1x1.": f, "generator.ups.": 0.1, "generator.noise_convs.": f, ".convs2.": f})
+    asr, F0, N, s, noise = synth.decoder_inputs(2, 24, 3)
+    dec = dec.cuda()
+    rows = []
+
+
+    def check(kind, out, st):
+        ex = ops.instnorm_stats(out)
+        dm = ((st[..., 0] - ex[..., 0]).abs() * ex[..., 1]).max().item()
+        dr = ((st[..., 1] - ex[..., 1]).abs() / ex[..., 1]).max().item()
+        x = out.double()
+        ratio = (x.mean(-1).abs() / x.std(-1).clamp(min=1e-30)).max().item()
+        rows.append((kind, tuple(out.shape), dm, dr, ratio, float(ex[..., 1].max())))
+
+
+    orig_conv1d, orig_xs = ops.conv1d, ops.conv1d_xs
+
+
+    def conv1d(*a, **k):
+        r = orig_conv1d(*a, **k)
+        if k.get("want_stats"):
+            check("conv1d (fused or xs)", r[0], r[1])
+        return r
+
+
+    ops.conv1d = conv1d
+    import styletts2_amd.decoder as D  # noqa: E402
+    names = [n for n in dir(ops) if "interleave" in n]
+    print("interleave entry points:", names)
+    for n in names:
+        fn = getattr(ops, n)
+
+        def wrap(*a, _fn=fn, _n=n, **k):
+            r = _fn(*a, **k)
+            if isinstance(r, tuple) and len(r) == 2 and torch.is_tensor(r[1]) and r[1].shape[-1] == 2:
+                check(_n, r[0], r[1])
+            return r
+        setattr(ops, n, wrap)
+    with _hooks.override(plan="python"):
+        dec._pk = None
+        dec(asr.cuda() * f, F0.cuda(), N.cuda(), s.cuda(), noise=noise.cuda())
+    torch.cuda.synchronize()
+    rows.sort(key=lambda r: -max(r[2], r[3]))
+    print("%-24s %-18s %12s %12s %10s %10s" % ("producer", "tensor", "|dmean|*rstd", "|drstd|/rstd", "|mean|/std", "rstd max"))
+    for r in rows[:14]:
+        print("%-24s %-18s %12.2e %12.2e %10.1f %10.1f" % (r[0], r[1], r[2], r[3], r[4], r[5]))
+    print("%d statistics checked" % len(rows))
+
+
+COMMANDS = {"fused_precision": cmd_fused_precision, "longform_bitwise": cmd_longform_bitwise, "lstm_graph": cmd_lstm_graph, "lstm_recover": cmd_lstm_recover, "lstm_status": cmd_lstm_status, "lstm_under_load": cmd_lstm_under_load, "lstm_under_load2": cmd_lstm_under_load2, "prosody_stress": cmd_prosody_stress, "small_magnitude": cmd_small_magnitude, "smallgrid_stress": cmd_smallgrid_stress, "stats_precision": cmd_stats_precision}
+
+
+def main():
+    if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help", "--list"):
+        for n, f in COMMANDS.items():
+            print("%-22s %s" % (n, (f.__doc__ or "").strip().split("\n")[0][:150]))
+        return 0
+    name = sys.argv[1]
+    if name not in COMMANDS:
+        print("unknown probe %r; --list shows them" % name, file=sys.stderr)
+        return 2
+    COMMANDS[name](sys.argv[2:])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
