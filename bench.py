@@ -280,7 +280,7 @@ def roofline(by_class):
                             "reaches 0.585 of `peak` on random operands on MI355X -- the matrix pipe's clock is power-limited "
                             "(1.64 GHz on random operands, 2.18 GHz on zeros; `ceiling_live` = this box's probe) -- and the "
                             "kernel 72 % of that loop (epilogue 12.7 %, activation staging 5 %, weight stream 4.5 %): "
-                            "profiles/r04ac_ablations.log",
+                            "profiles/r04/r04ac_ablations.log",
             "mfma_tflops_executed": dom["achieved"] * F16S_PRODUCTS,
             "launches_timed": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
             "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
@@ -926,14 +926,14 @@ def main():
                 if st is not None:
                     st.wait_stream(torch.cuda.current_stream(dev))
     # the set-up step (autotuning) runs on the plain streams: in the throughput configurations the CU-masked schedules have
-    # lost every calibration so far (74.1 vs 69.0 ms, profiles/r04m1_*)
+    # lost every calibration so far (74.1 vs 69.0 ms, profiles/r04/r04m1_*)
     active = {"name": a.schedule if a.schedule != "auto" else "two-stream"}
 
     first_chunk_ms = []
     fixed = {}  # pinned random draws, for the bitwise check after the timed region only (_fixed_draws)
     # The device-only front of a step / sentence (text encoder, PL-BERT, diffusion sampler, style mixing, duration
     # encoder: ~600 launches of 5-70 us kernels) is replayed from ONE hipGraph per shape (pipeline.GraphedFront; captured
-    # during the warm-up steps): host issue time per step 6.0 -> 1.8 ms, throughput +0.7-1.3 % (profiles/r02x_*).  The
+    # during the warm-up steps): host issue time per step 6.0 -> 1.8 ms, throughput +0.7-1.3 % (profiles/archive/r02/r02x_*).  The
     # per-step random draws stay outside the graph.  --eager-front issues it kernel by kernel.
     lf_front = None if a.eager_front else pipeline.GraphedFront(model, sampler)
     if longform:

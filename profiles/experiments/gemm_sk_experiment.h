@@ -4,7 +4,7 @@
 //
 // Why another schedule: as 128 x 128 / 128 x 64 tiles these launches are 200-450 workgroups for 256 CUs -- 1.3-1.6 rounds, a
 // quarter of the CU-time idle -- and a 128-row tile re-reads its operands from L2 at ~60 B / clk / CU, the L2 -> CU rate, so
-// 0.20-0.33 of the matrix roof was all they reached (profiles/r03c_gemm_bench.log, r03l_gemm_ablate.log).  Here:
+// 0.20-0.33 of the matrix roof was all they reached (profiles/archive/r03/r03c_gemm_bench.log, r03l_gemm_ablate.log).  Here:
 //   * ONE persistent workgroup of 8 waves per CU computes 256 (co) x 128 (token) tiles: half the operand bytes per FLOP (the
 //     token chunk staged in LDS feeds 8 row blocks instead of 4; every wave streams its own 32 weight rows L2 -> registers);
 //   * the (tile, K-chunk) units of the launch are dealt out EVENLY: worker w takes units [U*w/W, U*(w+1)/W) in (tile,
@@ -18,7 +18,7 @@
 // Cross-CU hand-off follows MI355X_MICROARCH.md (workgroup dispatch & inter-workgroup visibility): producer = sc1 stores ->
 // s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope flag store; consumer = relaxed poll -> agent acquire -> barrier ->
 // plain loads; every spin is bounded (ST2_STATUS_GEMM_TIMEOUT).  A finisher only ever waits for LOWER-numbered workers.
-// MEASURED AND NOT ADOPTED (round 4, profiles/r04d_cmd.log): correct (7e-7 .. 1.4e-6 of the largest output vs the library's
+// MEASURED AND NOT ADOPTED (round 4, profiles/r04/r04d_cmd.log): correct (7e-7 .. 1.4e-6 of the largest output vs the library's
 // build) but no faster -- with one whole tile per worker (200 workers, no split) 2048 x 768 x 3200 takes 39.0 us against the
 // library's 39.4: the 8-wave 256 x 128 pipeline runs a 1 536-MFMA-cycle chunk in ~2 600 cycles, like the 4-wave one; with
 // 256 workers every tile is split and the 32 MB of partials written through and read back put 6 us ON TOP (45.3 us) instead of

@@ -1,5 +1,5 @@
 """tools/wino_bench.hip (the Toom-Cook F(3,3) / F(4,4) form of the split-f16 conv, an experiment
-outside the library; measured on the GPU in round 3 and NOT adopted: profiles/r03_wino_decision.md): it must keep compiling for gfx950, and its GPU-free `selftest quick` --
+outside the library; measured on the GPU in round 3 and NOT adopted: profiles/archive/r03/r03_wino_decision.md): it must keep compiling for gfx950, and its GPU-free `selftest quick` --
 Toom matrices against direct correlation, a host emulation of the data flow and thread-level host twins of both kernels
 through the fp64 checker -- must keep passing."""
 import os

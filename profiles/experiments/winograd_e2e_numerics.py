@@ -6,7 +6,7 @@ synthetic weights and inputs with `F.conv1d` intercepted for the qualifying resb
             products, fp32 accumulation
   F(M,R)    the same operand scheme in the transform domain (input transform in fp32 before the split, weights transformed in
             fp64 at pack time, inverse transform in fp32), dilated layers as stride-d subsequences
-and the waveforms are compared at the 1e-4 RMS bar of BASELINE.json's north_star.  Output: profiles/r02_winograd_e2e.txt."""
+and the waveforms are compared at the 1e-4 RMS bar of BASELINE.json's north_star.  Output: profiles/archive/r02/r02_winograd_e2e.txt."""
 import os
 import sys
 

@@ -3,7 +3,7 @@
 accumulation) -- is the rounding error compatible with the 1e-4 waveform bar?  Input transform in fp32 BEFORE the f16 split,
 weights transformed in fp64 at pack time, inverse transform on the fp32 accumulators.  F(3, 3) is the interesting member: its
 tile step (3) equals the tap-group width, so one transformed copy of the input serves all groups (F(2,3) / F(4,3) would need
-one copy per group phase).  Output: profiles/r02_winograd_numerics.txt; discussion: DESIGN.md section 7."""
+one copy per group phase).  Output: profiles/archive/r02/r02_winograd_numerics.txt; discussion: DESIGN.md section 7."""
 import numpy as np
 rng = np.random.default_rng(0)
 C, Co, L, K = 128, 128, 3072, 11

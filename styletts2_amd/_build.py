@@ -22,7 +22,7 @@ SOURCES = ["st2_api.hip", "st2_conv1d.hip", "st2_conv1d_f16s.hip", "st2_conv1d_f
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC]
 # The fused conv's prologue is VALU-bound and shares its SIMD with the MFMA stream: SLP-packed f32 (v_pk_mul / v_pk_fma with
-# the v_mov shuffles that feed them) is an anti-lever there (MI355X_MICROARCH.md; profiles/r03D_probe_narrow_libs.log: one-role
+# the v_mov shuffles that feed them) is an anti-lever there (MI355X_MICROARCH.md; profiles/archive/r03/r03D_probe_narrow_libs.log: one-role
 # kernel -4 % at k = 7 / C = 64, -13 % at k = 3 / C = 128 / L = 40 000, the warp-specialised k = 3 / C = 32 build +16 %: not for that one).
 EXTRA_FLAGS = {s: ["-fno-slp-vectorize"] for s in SOURCES if s.startswith("st2_conv1d_f16s_k")}
 # The BiLSTM recurrences: SLP packing of {a*h, b*h} with h an ODD element of an LDS vector load becomes `v_pk_fma_f32 ...

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const ActArgs a) {
   for (int e = 0; e < 8; ++e) {
     const int ci = min(cg * 8 + e, a.C - 1);
     // read once, written once: nontemporal hints on both sides (-7 % at C = 128 / L = 48 001, -15 % at C = 256 / L = 8 000
-    // alone, -0.35 ms per bench step; profiles/r04aa_nt_*.log).  The conv's own stores and staging loads LOSE with the
+    // alone, -0.35 ms per bench step; profiles/r04/r04aa_nt_*.log).  The conv's own stores and staging loads LOSE with the
     // same hint (+10 % / +2 %): its output is re-read as the next layer's residual and its tiles overlap in the halo.
 #if ST2_ACT_NT & 1
     v[e] = __builtin_nontemporal_load(&xb[(int64_t)ci * a.x_cs]);

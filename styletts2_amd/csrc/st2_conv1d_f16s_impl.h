@@ -69,10 +69,10 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
 #ifndef ST2_F16S_DISPATCH_ORDER
   // Workgroups are dealt to the 8 XCDs round-robin by their linear id, so in dispatch order NEIGHBOURING column tiles -- which share
   // the tap halo, a whole 128-B line at each edge of a 1 KB row segment (counters: reads 1.25 x algorithmic at C = 64,
-  // profiles/r05w_pmc_narrow.md) -- never share an L2.  Here the column tiles one XCD receives within a row of the grid become a
+  // profiles/r05/r05w_pmc_narrow.md) -- never share an L2.  Here the column tiles one XCD receives within a row of the grid become a
   // contiguous run: tile index = rank of (xcd, arrival) among the row's tiles.  A bijection on [0, gridDim.x) for any gridDim.x, so
   // results are bitwise those of the dispatch order (-DST2_F16S_DISPATCH_ORDER: tools/build_f16s_xcd.sh builds that library for the
-  // A-B); measured -8 % at C = 64 / k = 7, -5 % at k = 11, -8 % at k = 3 / C = 128 with the residual (profiles/r05x_*).
+  // A-B); measured -8 % at C = 64 / k = 7, -5 % at k = 11, -8 % at k = 3 / C = 128 with the residual (profiles/r05/r05x_*).
   int bx;
   {
     const int nx = gridDim.x;
@@ -368,7 +368,7 @@ inline int ksplit_for_geometry(const st2_conv_desc& d) {
   const int BN = d.C_out > 64 ? 128 : (d.C_out > 32 ? 256 : 512);
   const int nchunk = (d.C_in + CI_T - 1) / CI_T;
   const int64_t wgs = (int64_t)st2_cdiv(d.L_out, BN) * st2_cdiv(d.C_out, BM) * d.B;
-  // measured (profiles/r02v_*, r02w_*): with 256 workgroups (B = 32 x 8 co-blocks) a 4-way split LOSES 4-6 % on the
+  // measured (profiles/archive/r02/r02v_*, r02w_*): with 256 workgroups (B = 32 x 8 co-blocks) a 4-way split LOSES 4-6 % on the
   // LibriTTS configurations (the reduction re-reads 4 x the output), with 8-16 (B = 1) an 8-way split takes the
   // long-form passage from 181 to 118 ms -- so only launches below half a round of the chip are split, up to ~256 slices
   if (nchunk < 8 || wgs >= 128) return 1;
@@ -435,7 +435,7 @@ extern int g_variant;  // st2_conv1d_f16s_set_variant: 0 = rule, 1 = one role pe
 // convs with k = 3 / 7 / 11 and C_out <= 64.  BY RULE it takes the k = 3 ones whose grid gives every CU at least two tiles:
 // x1.12-1.20 there (tools/probe_ws.py; inside the HiFi-GAN configuration 0.82 against 1.01 ms at C = 32, L = 240 000).  At
 // k = 7 / 11 it is within +-7 % of the one-role kernel and loses 17 % at dilation 1, at C_out = 128 it loses 9-18 %
-// (profiles/r03A_probe_ws.log): those stay on the one-role kernel; st2_conv1d_f16s_set_variant(2) forces every eligible layer.
+// (profiles/archive/r03/r03A_probe_ws.log): those stay on the one-role kernel; st2_conv1d_f16s_set_variant(2) forces every eligible layer.
 template <int KS>
 inline bool ws_eligible(const st2_conv_desc& d) {
   if constexpr (KS != 3 && KS != 7 && KS != 11) return false;

@@ -10,15 +10,15 @@
 // Phases are separated by one workgroup barrier: a tile is nchunk MFMA phases + one epilogue phase; in every phase the
 // producers stage one chunk if a buffer is free (the epilogue phase frees the second one).
 //
-// What it buys, and what it does not (round 3, profiles/r03s..r03z): on these layers conv1d_f16s_kernel keeps the matrix pipe
+// What it buys, and what it does not (round 3, profiles/archive/r03/r03s..r03z): on these layers conv1d_f16s_kernel keeps the matrix pipe
 // busy 0.99 M cycles per SIMD and the VALU 0.90 M of a 2.56 M-cycle launch (C = 64, k = 11, L = 120 000, B = 32; counters in
-// profiles/r03u_*) and removing any one stage changes little (r03s_probe_ws_abl.log).  The phase timeline of this kernel
+// profiles/archive/r03/r03u_*) and removing any one stage changes little (r03s_probe_ws_abl.log).  The phase timeline of this kernel
 // (s_memtime stamps of all eight waves, tools/probe_ws_timeline.py, r03y_ws_timeline*.log) shows why specialisation alone
 // does not reach max(MFMA, VALU): the consumer's k loop takes 5.0 k cycles per chunk alone and 5.9 k beside a staging
 // producer, the producer 4.3-6 k alone and 8-9.7 k beside the k loop -- on one SIMD the two instruction streams nearly ADD
 // (s_setprio either way, no SLP-packed f32, eight producer waves, two workgroups per CU of 64-column wave tiles: all within
 // 5 %), and the epilogue phase (residual at HBM latency on the consumers, whose weight stream shares the in-order vmcnt) costs
-// 11 k cycles per tile.  Measured against the one-role kernel (profiles/r03A_probe_ws.log): x1.12-1.20 at k = 3 for
+// 11 k cycles per tile.  Measured against the one-role kernel (profiles/archive/r03/r03A_probe_ws.log): x1.12-1.20 at k = 3 for
 // C <= 64; x1.01-1.07 at k = 7 / 11 with dilation 3 / 5 but x0.83 at dilation 1; x0.84-0.91 at C = 128 -- hence the k = 3,
 // C_out <= 64 rule in st2f16s::ws_eligible.  Two compiler facts the
 // structure depends on: (1) the register-set parity of a staging step must be a compile-time constant at every call (a

@@ -137,7 +137,7 @@ int tune_launch(const st2_conv_desc& d, hipStream_t s, TuneEntry& e) {
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return e.chosen;
   // Round-robin over the candidates, best group per candidate: a clock / power excursion of a few milliseconds (seen once
-  // in ~25 bench runs: both builds of the dominant class read 17-24 % high and the slower one won, profiles/r04ak_bench.json)
+  // in ~25 bench runs: both builds of the dominant class read 17-24 % high and the slower one won, profiles/r04/r04ak_bench.json)
   // then hits every candidate alike or is dropped by the minimum, instead of landing on whichever build was being timed.
   constexpr int GROUPS = 3, PER = 2;
   bool ok[8];

@@ -407,10 +407,10 @@ enum { XS_V_RULE = -1, XS_V_WIDE = 1, XS_V_SWIZZLE = 2, XS_V_N64 = 4, XS_V_N32 =
 // The build an UNTUNED process runs (tests, one-off calls; a serving process measures: st2_conv_tune).  k >= 7: 32 (co) x
 // 256 (l) wave tiles, 128 accumulator registers, 2 workgroups / CU -- half the weight stream (L2 -> registers) per FLOP;
 // measured 1.59 vs 1.65 ms (k = 11) and 1.19 vs 1.23 ms (k = 7) at C = 128, L = 48 001, B = 32 (tools/xs_bench.hip,
-// profiles/r02i_xs_bench_tn8.log) -- when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a
+// profiles/archive/r02/r02i_xs_bench_tn8.log) -- when the launch still has >= 2 rounds of workgroups at that tile size (512 slots): a
 // single utterance (long-form synthesis, B = 1) keeps the 128-column tiles, which fill twice as many CUs.  Launches with
 // 2 / 4 / 8 output row blocks (C_out = 256 ... 1024: the first vocoder stage) add the XCD-aware order: every XCD keeps one
-// row block's weights in its L2 (k = 7, C = 256, L = 8 000: 0.570 vs 0.598 ms; k = 11: 0.851 vs 0.848, profiles/r04q_bench.json).
+// row block's weights in its L2 (k = 7, C = 256, L = 8 000: 0.570 vs 0.598 ms; k = 11: 0.851 vs 0.848, profiles/r04/r04q_bench.json).
 // (Between rounds 2 and 4 the wide tiles were a trap on that stage: 32 tiles per row put every row-end tile on XCD 7, where
 // the then whole-tile generic epilogue ran 3.5-12 x slower -- the "slow box class", DESIGN.md section 6 -- fixed in
 // st2_conv_epilogue.h, which treats row ends by column blocks.)
@@ -428,12 +428,12 @@ inline int rule_variant(const st2_conv_desc& d) {
 // Small grids.  A launch of a few hundred 128 x 128 tiles (one to three utterances: the long-form loop, B = 1 latency) does
 // not fill 256 CUs x 3 workgroup slots; it is paced by ONE workgroup's k loop.  Halving / quartering the tile width doubles /
 // quadruples the workgroups that share the weight stream of a k-step, so the loop gets shorter until the chip is full.
-// Measured over 50 shapes at B = 1 ... 3 (tools/xs_bench.hip, profiles/r05a_smallgrid_*, r05b_smallgrid_*): 32-column tiles
+// Measured over 50 shapes at B = 1 ... 3 (tools/xs_bench.hip, profiles/r05/r05a_smallgrid_*, r05b_smallgrid_*): 32-column tiles
 // win below ~100 tiles of 128 (k = 7, C = 256, L = 5 680, B = 1: 55.6 -> 28.3 us; k = 3: 39.6 -> 17.5), 64-column tiles up to ~600
 // (k = 11, C = 128, L = 37 200: 75.3 -> 55.5 us; k = 3 up to ~900: 47.1 -> 27.4), 128 beyond -- for launches of up to THREE
 // utterances: a batch of 8-32 short rows with the same tile count (k = 3, C = 256 ... 1024, L = 400 / 800, B = 32: the decoder
 // front of the throughput configurations) LOSES 5-20 % with the narrow tiles (every workgroup streams its row block's whole
-// weight slice, 0.4-1.6 MB there; profiles/r05g_smallgrid_b32.log), so those keep the 128-column build.  A function of the geometry alone
+// weight slice, 0.4-1.6 MB there; profiles/r05/r05g_smallgrid_b32.log), so those keep the 128-column build.  A function of the geometry alone
 // (never tuned: the partial sums' slot width follows it, and a measured choice would make the statistics box-dependent in
 // their last bits).  Callers opt in through d.part_cols (with statistics) or get it by rule (without): y is bitwise the same
 // in every build.
@@ -447,7 +447,7 @@ inline int rule_variant(const st2_conv_desc& d) {
 // k = 3 ONLY (round 5, an open hardware-level observation): while the 16-channel-chunk builds with narrow tiles (k = 7 / 11, 64 /
 // 32 columns) run on one queue, the BiLSTM kernels on ANOTHER queue -- both the single-CU and the cooperative one -- return
 // different results in 25-90 % of their calls: traced to 16 consecutive lanes of ONE gate's W_hh load carrying wrong data (one
-// 64-byte sector of a global load; tools/stress.py lstm_trace, profiles/r05i_*).  The convs' own outputs are bit-exact under the
+// 64-byte sector of a global load; tools/stress.py lstm_trace, profiles/r05/r05i_*).  The convs' own outputs are bit-exact under the
 // same load, guard bands around their output stay intact, capping their workgroups per CU changes nothing, and the k = 3 narrow
 // builds (32-channel chunks), the 128-column k = 7 / 11 builds and every other load tried do not do it
 // (tools/stress.py lstm_under_load2).  Until that is understood the narrow tiles are used where they are verified harmless.
@@ -479,7 +479,7 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
       // 128 x 128 they are < 256 workgroups -- fewer than CUs, one per CU, nothing to hide the staging latency of a
       // 768-cycle chunk behind.  128 (co) x 64 (l) tiles double the workgroup count and 64-channel chunks double the
       // work between barriers: 1024 x 1024: 35.8 -> 28.9 us, 512 x 1024: 32.7 -> 17.7, 1024 x 2048: 63.6 -> 50.4, 768 x 768:
-      // 27.9 -> 22.4 (profiles/experiments/gemm_bench.hip, profiles/r03c_gemm_bench.log); launches that already have >= 256 tiles
+      // 27.9 -> 22.4 (profiles/experiments/gemm_bench.hip, profiles/archive/r03/r03c_gemm_bench.log); launches that already have >= 256 tiles
       // (C_out >= 2048) are fastest as they are.  Same products in the same order: results are bitwise unchanged.
       if ((int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B < 256 && d.wq_cin_pad % 64 == 0 && !d.part)
         return launch<1, 64, 4, 1, 2, 3>(d, s, swz);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void st2_conv_epilogue(const st2_conv_desc& d, st2_f3
   // whole -- 4-byte predicated accesses for all TN blocks, 3.5 x the cycles of the straight-line build on every box and
   // 10-12 x on some -- and, where the tile count per row is a multiple of 8 (L = 8 000 in 256-column tiles), every such
   // tile of a launch lands on the same XCD and the same shader engine, which then finishes at twice the time of the other
-  // seven (profiles/r04h1_*, r04j_*: what rounds 1-3 knew as "the slow box class").  Now blocks [0, jn_full) take the
+  // seven (profiles/r04/r04h1_*, r04j_*: what rounds 1-3 knew as "the slow box class").  Now blocks [0, jn_full) take the
   // straight-line build, blocks past the row end are skipped, and only a block that STRADDLES the row end (none at L =
   // 8 000; one column's worth at L = 48 001) takes the generic code.  Same values, same order of the partial sums.
   const int avail = d.L_out - (n0 + wn * (32 * TN));  // valid columns of this wave's part of the tile (may be <= 0)

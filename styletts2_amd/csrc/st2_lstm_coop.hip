@@ -321,7 +321,7 @@ int launch_coop_as(const float* G, int64_t g_bs, int g_cs, const float* whh_t, c
   // status, counters and -- granule form -- every tag start at zero on EVERY call (a tag left by an earlier call would
   // otherwise match).  A KERNEL, not hipMemsetAsync: recorded into a hipGraph, the memset node zeroes on the first replay and
   // writes an 8-byte pointer-like pattern over the head of the buffer on every later one (ROCm 7.2, tools/stress.py lstm_graph,
-  // profiles/r05c_lstm_graph.log) -- rounds 1-4 never looked at scratch[0] after a replay; round 5's in-stream recovery does.
+  // profiles/r05/r05c_lstm_graph.log) -- rounds 1-4 never looked at scratch[0] after a replay; round 5's in-stream recovery does.
   {
     const size_t words = (XCH == 2 ? need : head) / 16;  // both are multiples of 256 bytes; scratch is 256-byte aligned
     hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4*>(scratch), words);
@@ -350,7 +350,7 @@ int g_block = 0;  // st2_lstm_coop_set_block(): 0 = by batch size, else 1 / 2 / 
 constexpr int MAX_COOP_WG = 256;  // workgroups of one cooperative launch (the occupancy query at launch has the last word)
 // Utterances per cooperative group.  A group's step = its mat-vec (U x 128 fmas per thread) + one cross-CU exchange, so
 // fewer utterances per group means a shorter step as long as the groups still fit the chip side by side: at B = 32 blocks
-// of 4 (128 workgroups) run 2.9 us / step against 4.35 us for blocks of 8 (64 workgroups) -- profiles/r03h_probe_lstm.log.
+// of 4 (128 workgroups) run 2.9 us / step against 4.35 us for blocks of 8 (64 workgroups) -- profiles/archive/r03/r03h_probe_lstm.log.
 int block_size(int B) {
   if (g_block < 0) return 0;  // measurement hook: no cooperative launches at all (callers take st2_lstm_bidir)
   if (g_block == 1 || g_block == 2 || g_block == 4 || g_block == 8)

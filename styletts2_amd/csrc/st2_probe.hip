@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void probe_census_kernel(unsigned long long* o
 
 // The conv epilogue's store pattern (st2_conv_epilogue.h: a lane owns one output row, a wave instruction writes 32 rows x
 // 32 bytes) on a [B][256][8000] tensor, one 128 x 256 tile per workgroup, timed per workgroup: on round 4's slow-class box
-// the 8 CUs of one shader engine took 12 x the cycles of every other CU for exactly this phase (profiles/r04h1_*).
+// the 8 CUs of one shader engine took 12 x the cycles of every other CU for exactly this phase (profiles/r04/r04h1_*).
 // `row_major` = the same 128 x 256 tile written one row per wave instruction (64 lanes x 16 bytes = 1 KB contiguous): the
 // control experiment -- is it the scatter (32 rows = 32 pages per instruction) that slow workgroups cannot take?
 __global__ __launch_bounds__(256) void probe_scatter_kernel(float* y, int pitch, int rows_per_item, int n_tiles,

@@ -5,7 +5,7 @@
 // (ST2_XS_ABLATE = 64: per-workgroup s_memtime stamps at start / k-loop end / exit + HW_ID / XCC_ID) and runs the launch that
 // separated the box classes of rounds 1-3 -- k = 7, C = 256, L = 8 000, B = 32, 128 x 256 tiles, residual + statistics
 // epilogue -- on synthetic operands.  History: on the slow class XCD 7 finished that launch at 1 082 us against ~560 for the
-// others, with 8 CUs of one shader engine at 10-12 x the epilogue cycles (profiles/r04h1_*, r04j_*); this probe then found the
+// others, with 8 CUs of one shader engine at 10-12 x the epilogue cycles (profiles/r04/r04h1_*, r04j_*); this probe then found the
 // same group at 3.5 x on EVERY box, which gave the mechanism away -- those were the row-end tiles of the launch (32 tiles per
 // row: tile 31 of every row goes to XCD 7, and to the same CUs) on a slow generic epilogue, not degraded hardware
 // (DESIGN.md section 6).  With the epilogue fixed it reads 0 slow CUs; it stays as the check for a genuinely bad CU: CUs

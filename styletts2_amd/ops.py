@@ -278,7 +278,7 @@ XS_MIN_C_PLAIN = 64  # prologue-free convs take the xs pair too from this many i
 def prefer_fused(pro, C_in, ks):
     """Layers whose xs pair is HBM-bound take the fused kernel instead (prologue arithmetic on the VALU beside the MFMAs,
     no activation pass: 12 instead of 20 bytes per element): the narrow HiFi-GAN stages (C <= 64) and the k = 3 resblock
-    convs at C = 128.  Measured per layer at B = 32 (tools/probe_conv.py, profiles/r02y_probe_conv_b32.log): fused / pair =
+    convs at C = 128.  Measured per layer at B = 32 (tools/probe_conv.py, profiles/archive/r02/r02y_probe_conv_b32.log): fused / pair =
     0.80-0.96 at C = 64, 0.86-0.91 at C = 32, 0.89-0.92 at C = 128 k = 3; 1.04-1.19 everywhere else.  The same rule lives in
     csrc/st2_engine.hip (conv())."""
     return pro != PRO_NONE and (C_in <= FUSED_MAX_C or (ks <= 3 and C_in <= FUSED_K3_MAX_C))

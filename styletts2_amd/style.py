@@ -22,7 +22,7 @@ C++ launch plan, csrc/st2_engine.hip style_plan; `mel_spectrogram_engine` = five
 There is no PyTorch forward behind any of this: the nn.Modules below are parameter holders with the reference's keys, a
 CPU tensor raises in the kernel wrappers.  The per-kernel Python plan (`StyleEncoder._forward_kernels`) is the tests' tap
 path (`_hooks.override(plan="python")`) and what the CPU plan tests step through; the C++ plan is bitwise equal to it on
-the GPU (profiles/r03a_style_plan.log).
+the GPU (profiles/archive/r03/r03a_style_plan.log).
 
 The mel front-end implements `torchaudio.transforms.MelSpectrogram(n_mels=80, n_fft=2048, win_length=1200,
 hop_length=300)` with torchaudio's defaults (power 2, periodic Hann window zero-padded to n_fft, centre + reflect

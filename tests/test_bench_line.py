@@ -22,7 +22,7 @@ def _strict(text):
 
 def _fat_lines():
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05[u-y]_bench*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "r05[u-y]_bench*.json"))):
         txt = open(f).read().strip().splitlines()[-1]
         if len(txt) > 8192:
             out.append((os.path.basename(f), json.loads(txt)))

@@ -873,7 +873,7 @@ def test_lstm_coop_scratch_is_cleared_on_every_graph_replay(B, N):
     call is a node sequence of a replayed hipGraph.  It used to do so with hipMemsetAsync, whose recorded node zeroes on the first
     replay only (ROCm 7.2: later replays leave an 8-byte pointer-like pattern at the head of the buffer) -- invisible until the
     in-stream recovery started reading scratch[0]: every replayed front then re-ran its BiLSTMs on the single-CU kernel (+27 ms
-    per long-form passage, profiles/r05d_*).  Now a kernel node: scratch[0] == 0, no status bit and bitwise the eager outputs on
+    per long-form passage, profiles/r05/r05d_*).  Now a kernel node: scratch[0] == 0, no status bit and bitwise the eager outputs on
     replays 1..3 of a buffer pre-filled with garbage."""
     from styletts2_amd import _lib
     lib = _lib.load()

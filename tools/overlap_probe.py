@@ -1,6 +1,6 @@
 """Does an HBM-bound activation pass hide under an MFMA-bound conv of ANOTHER tensor when the two are queued on two
-streams?  (The question behind the interleaved decoder schedule of round 4 -- profiles/r04y_interleaved_schedule.patch --
-which lost 98 vs 71 ms single-stream in visit r04y.  Answer, profiles/r04z2_overlap_probe.log: no -- each side slows
+streams?  (The question behind the interleaved decoder schedule of round 4 -- profiles/r04/r04y_interleaved_schedule.patch --
+which lost 98 vs 71 ms single-stream in visit r04y.  Answer, profiles/r04/r04z2_overlap_probe.log: no -- each side slows
 down by the other's share, the wall time equals back-to-back execution.)
 
 For a resblock shape: N convs (st2_conv1d_xs, residual epilogue) on stream A, alone; K activation passes (st2_act_split,
