@@ -375,16 +375,14 @@ def _calibrate_decode_streams(a, active, step, time_steps):
     n = max(1, int(a.longform_decode_streams))
     cands = {"decode-streams-1": 1}
     if n > 1:
-        # Which auxiliary streams own a hardware queue is PROBED, not guessed (ops.distinct_queue_streams: two single-workgroup
-        # kernels overlap or they do not): n streams that overlap with the caller's stream, with the front's side stream and with
-        # each other.  Round 5 timed four windows of consecutive streams instead and kept the best (51.7 ... 114 ms: a 2.1 x
-        # spread decided by creation order); one verified candidate replaces them.
-        picked = ops.distinct_queue_streams(dev, n, avoid=[torch.cuda.current_stream(dev), shared_stream(dev, 0)])
-        active["decode_streams_probe"] = {"wanted": n, "found": len(picked)}
-        if len(picked) == n:
-            cands["decode-streams-%d/probed" % n] = picked
-        else:
-            log("long-form: only %d of %d decoder streams found a hardware queue of their own; staying on one stream" % (len(picked), n))
+        # n consecutive auxiliary streams starting at index 1, 2, ...: which of them serialise behind the caller's stream (whose
+        # queue carries the per-sentence event waits) depends on how many streams the process made before.  Round 6 tried to
+        # replace the timing of these windows by a two-kernel overlap probe (are the streams on distinct hardware queues?):
+        # the probe's pick ran a passage in 78 ms against 64 on one stream and 52 for the best window -- streams that share a
+        # hardware queue still overlap small independent kernels (no barrier bit between different streams' packets), so
+        # "overlaps" is not "does not block", and only the passage itself tells (profiles/LAB_NOTES.md round 6).
+        for first in range(1, 5):
+            cands["decode-streams-%d@%d" % (n, first)] = [ops.aux_stream(dev, 0, index=first + i) for i in range(n)]
     calib = {}
     for name, c in cands.items():
         active["decode_streams"] = c
@@ -783,6 +781,8 @@ def main():
                     help="short legs of BASELINE.json configs[2..4] + a B = 1 latency point after the timed region (`auto`: "
                          "on for the default config at N = 1)")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
+    ap.add_argument("--xs-stagger", type=int, choices=[0, 1], default=1,
+                    help="diagnostic A-B: 0 turns the xs conv's phase stagger off (st2_conv1d_xs_set_stagger; bitwise the same results)")
     ap.add_argument("--detail-out", default="bench_detail.json",
                     help="side file for the full result object (the printed line is its < 8 KB summary); '' = none")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
@@ -822,6 +822,7 @@ def main():
     from styletts2_amd import _hooks, _lib, models, ops, pipeline
     _hooks.lstm = a.lstm  # the per-kernel Python plans; the C++ plans (the product path) follow the library hook below
     _lib.load().st2_lstm_coop_set_block(-1 if a.lstm == "single" else a.lstm_block)
+    _lib.load().st2_conv1d_xs_set_stagger(a.xs_stagger)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

@@ -138,8 +138,15 @@ typedef struct st2_conv_desc {
      whose k loop is long (C_in >= 8 chunks, < 128 workgroups: the 1024 -> 2048 Linears of the denoiser over the ~100
      tokens of one utterance) runs as up to 8 K slices per tile + a fixed-order reduction that applies the epilogue; the
      split is a function of the geometry alone (every plan picks the same one: results are reproducible bit for bit) and
-     needs ksplit * B * C_out * L_out * 4 bytes here.  NULL / too small = no split. */
+     needs st2_conv1d_f16s_splitk_bytes(d) bytes here.  NULL / too small = no split. */
   void* splitk_ws; int64_t splitk_ws_bytes;
+  /* ABI v22, optional: one int32 per output tile of the launch (st2_conv1d_f16s_splitk_tiles(d) of them), ZERO when the launch
+     starts.  With it the reduction happens INSIDE the launch: every K slice stores its raw accumulators, counts itself on its
+     tile's counter, and the slice that arrives last adds all slices IN SLICE ORDER (results are bit for bit those of the
+     two-launch form: the scale is a power of two) and runs the ordinary epilogue.  Without it (NULL) a second launch
+     (one thread per output element) does the reduction: ~7 us more per skinny layer, 300 of them per 10 s utterance at B = 1.
+     The launch plans keep one zeroed counter block per forward call in their workspace. */
+  int32_t* splitk_counters;
 } st2_conv_desc;
 
 int st2_conv1d(const st2_conv_desc* d, void* stream);
@@ -162,6 +169,8 @@ int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
 /* Bytes of d.splitk_ws the launch described by *d would use (0 = this geometry is not split): the caller allocates that
  * much (any alignment >= 16) and sets d.splitk_ws / d.splitk_ws_bytes before calling st2_conv1d_f16s. */
 int64_t st2_conv1d_f16s_splitk_bytes(const st2_conv_desc* d);
+/* Output tiles of that launch = int32 counters d.splitk_counters must hold, zeroed (0 = not split). */
+int32_t st2_conv1d_f16s_splitk_tiles(const st2_conv_desc* d);
 int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
 int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
 /* Measurement hook (process-wide): which build of the fused kernel a launch takes.  0 (default) = by rule: the
@@ -211,6 +220,12 @@ int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
  * bit.  k = 3 launches of up to three utterances: 32 below ~100 tiles of 128 x 128, 64 up to ~900; 128 otherwise (y is bitwise
  * the same either way; the k = 7 / 11 narrow builds of round 5 are not used: st2_conv1d_xs_impl.h). */
 int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
+/* Measurement hook (process-wide, ABI v22): phase stagger of the xs conv's first-round workgroups (default on).  All workgroups of
+ * a launch start together and, with equal tiles, stay in lock-step: every CU in its k loop (HBM idle), then every CU in its epilogue
+ * (HBM saturated) -- the epilogue's HBM time adds to the k loop although three workgroups share a CU.  With the stagger the
+ * workgroups that fill the 2nd / 3rd resident slot of a CU at launch start one / two thirds of a tile late (launches of >= 2 rounds
+ * of the chip only); timing only, results are bitwise unchanged.  0 = off (the A-B of bench.py --xs-stagger). */
+void st2_conv1d_xs_set_stagger(int on);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, int32_t cols, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *

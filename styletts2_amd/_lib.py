@@ -49,6 +49,7 @@ class ConvDesc(C.Structure):
         ("xs", f32p), ("xs_cg", C.c_int32), ("xs_lp", C.c_int32), ("xs_halo", C.c_int32),
         ("part", f32p), ("part_nt", C.c_int32), ("part_cols", C.c_int32),
         ("splitk_ws", f32p), ("splitk_ws_bytes", C.c_int64),
+        ("splitk_counters", C.c_void_p),
     ]
 
 
@@ -105,6 +106,7 @@ _SIGNATURES = {
     "st2_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s_splitk_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "st2_conv1d_f16s_splitk_tiles": (C.c_int32, [C.POINTER(ConvDesc)]),
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_set_variant": (None, [C.c_int]),
@@ -218,6 +220,7 @@ _SIGNATURES = {
     "st2_debug_headroom_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_conv1d_xs_part_cols": (C.c_int, [C.POINTER(ConvDesc)]),
     "st2_conv1d_f16s_set_splitk": (None, [C.c_int, C.c_int]),
+    "st2_conv1d_xs_set_stagger": (None, [C.c_int]),
     "st2_calibrate": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "st2_calibration_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "st2_calibration_site_name": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),

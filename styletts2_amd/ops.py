@@ -36,50 +36,6 @@ def aux_stream(dev, priority=0, index=0):
     return _AUX_STREAMS[key]
 
 
-def streams_overlap(a, b, reps=3):
-    """True when kernels on torch streams `a` and `b` run CONCURRENTLY, i.e. the two sit on different hardware queues.  HIP hands
-    its few hardware queues (4 by default) to streams in creation order and has no call that says which one a stream got; two
-    streams on one queue serialise (long-form with two decoder streams: 114 ms per passage on an aliased pair against 52 on a
-    distinct one, profiles/LAB_NOTES.md round 5).  Probe: one single-workgroup matrix-pipe kernel of ~150 us on each stream
-    (`st2_probe_mfma_stream`, nothing read or written); back to back on one stream they take 2 x, on distinct queues 1 x.
-    Synchronises the device; start-up use only."""
-    import time
-    lib = _lib.load()
-    dev = a.device
-
-    def pair(s0, s1):
-        best = None
-        for _ in range(reps):
-            torch.cuda.synchronize(dev)
-            t = time.perf_counter()
-            for s in (s0, s1):
-                _lib.check(lib.st2_probe_mfma_stream(0, 1, 20000, C.c_void_p(s.cuda_stream)), "st2_probe_mfma_stream")
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t
-            best = dt if best is None else min(best, dt)
-        return best
-    pair(a, a)  # first launch of the probe kernel: code object load
-    serial = pair(a, a)
-    both = pair(a, b)
-    return both < 0.75 * serial
-
-
-def distinct_queue_streams(dev, n, avoid=(), pool=8):
-    """`n` auxiliary streams that overlap with each other AND with every stream in `avoid` (the caller's stream, the front's side
-    stream), chosen by `streams_overlap` from the process-wide `aux_stream(dev, 0, index=1..pool)`.  Deterministic for a given
-    process history, verified instead of guessed; returns fewer than n (possibly none) when the hardware queues are used up --
-    the caller then keeps its single-stream schedule."""
-    dev = torch.device(dev)
-    chosen = []
-    for i in range(1, pool + 1):
-        if len(chosen) >= n:
-            break
-        c = aux_stream(dev, 0, index=i)
-        if all(streams_overlap(s, c) for s in list(avoid) + chosen):
-            chosen.append(c)
-    return chosen
-
-
 def _chk(t, name, ndim=None):
     if t is None:
         return
@@ -501,6 +457,10 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         if nb > 0:
             ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)  # caching allocator: stream- and capture-safe
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
+            if _hooks.splitk_in_launch:  # the reduction inside the launch (last-arriving slice): zeroed per-tile counters
+                ctr = torch.zeros((lib.st2_conv1d_f16s_splitk_tiles(C.byref(d)),), device=x.device, dtype=torch.int32)
+                d.splitk_counters = ctr.data_ptr()
+                ws = (ws, ctr)
     _launch_conv(fn, fname, d)
     if want_stats:
         return out, (stats_finalize(part, B, C_out, nt, L_out) if part is not None else instnorm_stats(out))
