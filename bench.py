@@ -659,37 +659,53 @@ def _leg_ragged(a, dev, model, sampler, front, n_warm=2, n_steps=3):
     tokens, lengths, noise, dur, lens = ragged_inputs(dev)
     steps_d = CONFIGS[a.config]["steps"]
     fixed = {}
+    active = {"streams": None}
 
-    def step():
+    def step(sequential=False):
         return pipeline.inference(model, sampler, tokens, lengths, noise, diffusion_steps=steps_d, embedding_scale=1.0,
-                                  durations=dur, front=front, **fixed)
+                                  durations=dur, front=front, decode_streams=None if sequential else active["streams"], **fixed)
     import contextlib
     with (contextlib.nullcontext() if a.no_autotune else ops.conv_autotune(reset=False)):
         out = step()
         torch.cuda.synchronize()
+
+    def time_steps(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            o = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3, o
+    # the per-utterance decoder calls on the caller's stream, or dealt onto two auxiliary streams (measured windows, as long-form)
+    cands = {"decode-streams-1": None}
+    for first in range(1, 5):
+        cands["decode-streams-2@%d" % first] = [ops.aux_stream(dev, 0, index=first + i) for i in range(2)]
+    calib = {}
+    for name, c in cands.items():
+        active["streams"] = c
+        step()
+        calib[name] = time_steps(2)[0]
+    best = min(calib, key=calib.get)
+    active["streams"] = cands[best]
     for _ in range(n_warm):
         step()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(n_steps):
-        out = step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t) / n_steps * 1e3
+    ms, out = time_steps(n_steps)
     ops.check_status()
     assert isinstance(out, list) and [w.shape[-1] for w in out] == [600 * FRAMES_PER_PHONEME * n for n in lens]
     audio_s = sum(lens) * FRAMES_PER_PHONEME * 600 / 24000.0
     B = len(lens)
     fixed.update({"step_noise": torch.randn(steps_d - 1, B, 1, 256, device=dev),
                   "sine_noise": torch.randn(B, 600 * FRAMES_PER_PHONEME * max(lens), 9, device=dev)})
-    bitwise = _bitwise_vs_single(step, step)
+    bitwise = _bitwise_vs_single(step, lambda: step(sequential=True))
     fixed.clear()
-    return {"workload": "LJSpeech validation text: %d real utterances of %d-%d tokens (Data/val_list.txt through TextCleaner), one "
+    return {"schedules_ms_per_step": {k: round(v, 3) for k, v in calib.items()},
+            "workload": "LJSpeech validation text: %d real utterances of %d-%d tokens (Data/val_list.txt through TextCleaner), one "
                         "right-padded batch, %d frames / token forced, iSTFTNet, %d diffusion steps" % (B, min(lens), max(lens),
                                                                                                          FRAMES_PER_PHONEME, steps_d),
             "ms_per_step": round(ms, 3), "audio_s_per_step": round(audio_s, 2), "audio_s_per_s": round(audio_s / (ms * 1e-3), 1),
             "steps": n_steps, "warmup": n_warm, "utterances": B, "phonemes_per_utterance": [min(lens), max(lens)],
             "padding_efficiency": round(sum(lens) / (B * max(lens)), 4), "decoder_calls": len(set(lens)),
-            "schedule": "single", "finite": all(bool(torch.isfinite(w).all()) for w in out),
+            "schedule": best, "finite": all(bool(torch.isfinite(w).all()) for w in out),
             "bitwise_vs_single": bitwise["equal"]}
 
 
@@ -781,8 +797,6 @@ def main():
                     help="short legs of BASELINE.json configs[2..4] + a B = 1 latency point after the timed region (`auto`: "
                          "on for the default config at N = 1)")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box fingerprint / micro-probe (`box` in the line)")
-    ap.add_argument("--xs-stagger", type=int, choices=[0, 1], default=1,
-                    help="diagnostic A-B: 0 turns the xs conv's phase stagger off (st2_conv1d_xs_set_stagger; bitwise the same results)")
     ap.add_argument("--detail-out", default="bench_detail.json",
                     help="side file for the full result object (the printed line is its < 8 KB summary); '' = none")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction path only (gloo on CPU, no "
@@ -822,7 +836,6 @@ def main():
     from styletts2_amd import _hooks, _lib, models, ops, pipeline
     _hooks.lstm = a.lstm  # the per-kernel Python plans; the C++ plans (the product path) follow the library hook below
     _lib.load().st2_lstm_coop_set_block(-1 if a.lstm == "single" else a.lstm_block)
-    _lib.load().st2_conv1d_xs_set_stagger(a.xs_stagger)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

@@ -220,12 +220,6 @@ int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
  * bit.  k = 3 launches of up to three utterances: 32 below ~100 tiles of 128 x 128, 64 up to ~900; 128 otherwise (y is bitwise
  * the same either way; the k = 7 / 11 narrow builds of round 5 are not used: st2_conv1d_xs_impl.h). */
 int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
-/* Measurement hook (process-wide, ABI v22): phase stagger of the xs conv's first-round workgroups (default on).  All workgroups of
- * a launch start together and, with equal tiles, stay in lock-step: every CU in its k loop (HBM idle), then every CU in its epilogue
- * (HBM saturated) -- the epilogue's HBM time adds to the k loop although three workgroups share a CU.  With the stagger the
- * workgroups that fill the 2nd / 3rd resident slot of a CU at launch start one / two thirds of a tile late (launches of >= 2 rounds
- * of the chip only); timing only, results are bitwise unchanged.  0 = off (the A-B of bench.py --xs-stagger). */
-void st2_conv1d_xs_set_stagger(int on);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, int32_t cols, void* stream);
 
 /* ---- small direct Conv1d (any stride, tiny C_in): noise convs, F0/N down-convs ------ *

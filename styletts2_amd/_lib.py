@@ -220,7 +220,6 @@ _SIGNATURES = {
     "st2_debug_headroom_read": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "st2_conv1d_xs_part_cols": (C.c_int, [C.POINTER(ConvDesc)]),
     "st2_conv1d_f16s_set_splitk": (None, [C.c_int, C.c_int]),
-    "st2_conv1d_xs_set_stagger": (None, [C.c_int]),
     "st2_calibrate": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "st2_calibration_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "st2_calibration_site_name": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
     // arrives LAST adds all of them in slice order 0 .. ksplit-1 (its own included: the order never depends on who was last) and
     // runs the ordinary epilogue below.  out_scale * w_row_scale is a power of two, so scaling the sum equals summing the scaled
     // partials of the two-launch form bit for bit (tests/test_ops_gpu.py::test_splitk_in_launch_is_bitwise_the_two_launch_form).
-    __shared__ int s_last;
+    // (the flag lives in the staging buffers, dead after the k loop's last barrier: a static __shared__ on top of the 160 KB
+    // dynamic-LDS attribute makes every launch of this kernel fail with "invalid argument")
+    volatile int* s_last = reinterpret_cast<volatile int*>(smem_raw);
     const int tile = (b * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + bx;
     typedef st2_f32x4 f32x4;
     f32x4* pw = reinterpret_cast<f32x4*>(part) + (((int64_t)ksl * d.B * gridDim.y * gridDim.x + tile) * 4 + wave) * (TN * 4 * 64) + lane;
@@ -331,9 +333,9 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
         pw[(j * 4 + q) * 64] = f32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
     __threadfence();  // this wave's partials are visible device-wide before the workgroup counts itself
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ksplit - 1;
+    if (tid == 0) *s_last = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ksplit - 1;
     __syncthreads();
-    if (!s_last) return;
+    if (!*s_last) return;
     __threadfence();
 #pragma unroll
     for (int j = 0; j < TN; ++j)

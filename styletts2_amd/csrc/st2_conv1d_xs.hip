@@ -286,9 +286,6 @@ extern "C" int st2_conv_tune_read(double* rows, int32_t cap_rows) {
   return n;
 }
 
-int st2xs::g_stagger = 1;
-extern "C" void st2_conv1d_xs_set_stagger(int on) { st2xs::g_stagger = on ? 1 : 0; }
-
 extern "C" int st2_conv1d_xs_part_cols(const st2_conv_desc* dp) {
   return dp ? st2xs::small_grid_cols(*dp) : 128;
 }

@@ -47,10 +47,6 @@ typedef st2_f32x16 f32x16;
 #define ST2_XS_PRED_STAGE 0
 #endif
 
-namespace st2xs {
-extern int g_stagger;  // st2_conv1d_xs_set_stagger (st2_conv1d_xs.hip; tools/xs_bench.hip defines its own): 0 = off
-}
-
 namespace {
 
 constexpr int NT = 256;
@@ -311,31 +307,10 @@ __device__ __forceinline__ void xs_tile_of(unsigned lin, unsigned nx, unsigned n
 #ifndef ST2_XS_ROWEND
 #define ST2_XS_ROWEND 1
 #endif
-// Phase stagger (round 6): all workgroups of a launch start together and, having the same tile size, stay in lock-step -- every
-// CU in its k loop (HBM idle) and then every CU in its epilogue (HBM saturated) -- so the epilogue's HBM time ADDS to the k loop
-// although three workgroups share a CU (tools/xs_bench.hip: C = 64, k = 7: bare MFMA loop 0.50 ms, without epilogue 0.72, full
-// 1.06).  The workgroups that fill the second / third resident slot of a CU at launch therefore start one / two thirds of a tile
-// late (bit 2 of `flags`, set by the launcher for launches of >= 2 rounds; `stagger` = that third in shader cycles): from then on a
-// third of the chip is in its epilogue while two thirds compute.  Timing only: results are bitwise unchanged.
-#ifndef ST2_XS_STAGGER
-#define ST2_XS_STAGGER 1
-#endif
 #define ST2_XS_ONE_TILE_KERNEL(NAME, WGS_PER_CU)                                                                        \
   template <int KS, int CI_T, int WM, int WN, int TN>                                                                   \
   __global__ __launch_bounds__(NT, WGS_PER_CU) void NAME(const st2_conv_desc d, const int flags) {                     \
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;                                                         \
-    if constexpr (ST2_XS_STAGGER != 0) {                                                                                \
-      if (flags & 4) {                                                                                                  \
-        const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);                                                    \
-        const unsigned ncu = (unsigned)flags >> 16; /* CUs of the device */                                             \
-        const unsigned slot = lin / ncu;                                                                                \
-        if (slot > 0 && slot < (unsigned)WGS_PER_CU) {                                                                  \
-          const unsigned long long wait = (unsigned long long)slot * (((unsigned)flags >> 3) & 0x1fff) * 64ull;         \
-          const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                   \
-          while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);                                \
-        }                                                                                                               \
-      }                                                                                                                 \
-    }                                                                                                                   \
     if (flags & 1) xs_tile_of(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x, gridDim.y, flags, bx, by, bz);         \
     const int n0 = (int)bx * (32 * TN * WN);                                                                            \
     if constexpr (ST2_XS_ROWEND && WN == 1 && TN >= 4) {                                                                \
@@ -387,22 +362,7 @@ int launch(const st2_conv_desc& d, hipStream_t s, bool swizzle = false) {
   dim3 grid(n_tiles, st2_cdiv(d.C_out, BM), d.B);
   const int64_t total = (int64_t)grid.x * grid.y * grid.z;
   // XCD-aware order only where it is a bijection: 2 / 4 / 8 row blocks and a tile count divisible by 8
-  int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && total % 8 == 0;
-  if (ST2_XS_STAGGER != 0) {
-    // stagger the first-round workgroups of launches that run at least two rounds of the chip (see the kernel wrapper): a third
-    // (half, at 2 workgroups / CU) of one tile's wall time = the MFMA time of ONE wave's tile, nsteps * 3 * TN MFMAs of 32 cycles
-    static int ncu_cached = 0;
-    if (ncu_cached == 0) {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        ncu_cached = n;
-      else
-        (void)hipGetLastError();
-    }
-    const int64_t own = (int64_t)(d.wq_cin_pad / CI_T) * (CI_T / 16) * KS * 3 * TN * 32 * ST2_XS_STAGGER / 64;  // units of 64 cycles
-    if (st2xs::g_stagger && ncu_cached > 0 && ncu_cached < 65536 && total >= (int64_t)2 * OCC * ncu_cached && own > 0 && own < 0x2000)
-      flags |= 4 | ((int)own << 3) | (ncu_cached << 16);
-  }
+  const int flags = swizzle && (grid.y == 2 || grid.y == 4 || grid.y == 8) && total % 8 == 0;
   static std::atomic<uint64_t> attr_done{0};  // one bit per device ordinal (hipFuncSetAttribute is per device)
   st2_once_per_device(attr_done, [&] {
     if constexpr (OCC == 4)

@@ -438,7 +438,7 @@ def prepare(model, sampler, tokens, input_lengths=None, noise=None, diffusion_st
 @torch.no_grad()
 def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_steps=5, embedding_scale=1.0,
               ref_s=None, alpha=0.3, beta=0.7, durations=None, step_noise=None, sine_noise=None, lj_tail=None,
-              taps=None, front_stream=None, inputs_on_main=False, total_frames=None, front=None):
+              taps=None, front_stream=None, inputs_on_main=False, total_frames=None, front=None, decode_streams=None):
     """tokens [B, N] int64 (id 0 prepended, ipynb:277) -> waveform [B, 1, 600*T] on the device.
 
     Single-speaker (LJSpeech) when `ref_s` is None, else the multi-speaker flow with style mixing
@@ -457,6 +457,12 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     nothing; inputs still being produced on the CURRENT stream (a per-call torch.randn, an async H2D copy) need
     `inputs_on_main=True`, which makes the front stream wait for the current stream first -- at the price of also
     waiting for the previous call's decoder queued there, i.e. of the overlap.
+
+    `decode_streams` (a list of torch streams; ragged batches only): the per-frame-count decoder calls -- independent of each
+    other, one utterance each for real text -- are dealt round-robin onto these streams instead of running one after the other
+    on the current one; the current stream waits for all of them before the call returns.  One utterance's decoder launches
+    grids of 2 x 23 tiles for 256 CUs: two or three of them fill each other's idle CUs (the long-form path does the same,
+    `synthesize_long(decode_streams=)`).  Bitwise the sequential result.
     """
     kw = dict(input_lengths=input_lengths, noise=noise, diffusion_steps=diffusion_steps,
               embedding_scale=embedding_scale, ref_s=ref_s, alpha=alpha, beta=beta, durations=durations,
@@ -479,13 +485,33 @@ def inference(model, sampler, tokens, input_lengths=None, noise=None, diffusion_
     if "groups" not in p:
         return model.decoder(p["asr"], p["F0"], p["N"], p["ref"], noise=sine_noise)
     waves = [None] * tokens.shape[0]
-    for idx, g in p["groups"]:
-        sn = None if sine_noise is None else [sine_noise[b] for b in idx]
-        if sn is not None:
-            sn = torch.stack([n[:g["F0"].shape[1] * 300] for n in sn])
-        w = model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=sn)
+    dec = list(decode_streams) if decode_streams else []
+    main = torch.cuda.current_stream(tokens.device) if dec else None
+    for st in dec:
+        st.wait_stream(main)  # the front's outputs (and the caller's inputs) are ordered on the current stream
+    done = []
+    for n_dec, (idx, g) in enumerate(p["groups"]):
+        def run(idx=idx, g=g):
+            sn = None if sine_noise is None else [sine_noise[b] for b in idx]
+            if sn is not None:
+                sn = torch.stack([n[:g["F0"].shape[1] * 300] for n in sn])
+            return model.decoder(g["asr"], g["F0"], g["N"], g["ref"], noise=sn)
+        if dec:
+            ds = dec[n_dec % len(dec)]
+            for v in (g["asr"], g["F0"], g["N"], g["ref"]):
+                v.record_stream(ds)  # allocated on the current / front stream, consumed on the decoder's
+            with torch.cuda.stream(ds):
+                w = run()
+                ev = torch.cuda.Event()
+                ev.record(ds)
+            w.record_stream(main)
+            done.append(ev)
+        else:
+            w = run()
         for j, b in enumerate(idx):
             waves[b] = w[j]
+    for ev in done:
+        main.wait_event(ev)
     return waves
 
 

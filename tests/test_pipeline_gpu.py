@@ -394,6 +394,14 @@ def test_real_validation_text_ragged_batch_matches_oracle_and_solo_runs():
     torch.cuda.synchronize()
     assert isinstance(waves, list) and [w.shape[-1] for w in waves] == [600 * 4 * n for n in lens]
     assert all(bool(torch.isfinite(w).all()) for w in waves)
+    # the per-utterance decoder calls dealt onto two streams (inference(decode_streams=)): bit for bit the sequential result
+    from styletts2_amd import ops
+    dev = torch.device(DEV, torch.cuda.current_device())
+    dealt = pipeline.inference(model, sampler, tokens.to(DEV), lengths, noise.to(DEV), diffusion_steps=steps, durations=dur.to(DEV),
+                               step_noise=step_noise.to(DEV), sine_noise=sine_noise.to(DEV),
+                               decode_streams=[ops.aux_stream(dev, 0, index=1), ops.aux_stream(dev, 0, index=2)])
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(dealt, waves))
     e = (te["s_pred"][b0:b0 + 1].cpu() - to["s_pred"]).abs().max().item() / to["s_pred"].abs().max().item()
     assert e < 5e-5, "s_pred of the real utterance: %g" % e
     for b, n in enumerate(lens):  # every row == the utterance alone, un-padded

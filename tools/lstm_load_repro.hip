@@ -39,7 +39,6 @@ void st2_set_error(const char* fmt, ...) {
   fputc('\n', stderr);
 }
 int* st2_status_device_ptr() { return nullptr; }
-int st2xs::g_stagger = 0;
 
 #define CK(x)                                                                                  \
   do {                                                                                         \

@@ -18,7 +18,6 @@ void st2_set_error(const char* fmt, ...) {
   fputc('\n', stderr);
 }
 int* st2_status_device_ptr() { return nullptr; }
-int st2xs::g_stagger = 1;  // XS_STAGGER=0 in the environment turns the phase stagger off (A-B in one binary)
 
 #define CK(x)                                                                  \
   do {                                                                         \
@@ -48,8 +47,7 @@ int main(int argc, char** argv) {
   auto arg = [&](int i, int def) { return argc > i ? atoi(argv[i]) : def; };
   const int ks = arg(1, 11), dil = arg(2, 1), C = arg(3, 128), L = arg(4, 48001), B = arg(5, 32);
   const int use_res = arg(6, 1), use_stats = arg(7, 1), reps = arg(8, 10);
-  const int xs_variant = getenv("XS_VARIANT") ? atoi(getenv("XS_VARIANT")) : -1;
-  if (getenv("XS_STAGGER")) st2xs::g_stagger = atoi(getenv("XS_STAGGER"));  // st2xs::XS_V_* bits, -1 = the rule
+  const int xs_variant = getenv("XS_VARIANT") ? atoi(getenv("XS_VARIANT")) : -1;  // st2xs::XS_V_* bits, -1 = the rule
   const float dscale = arg(9, 0) ? 0.f : 1.f;  // 10th argument 1: all-zero operands (what does the data cost in clock?)
   const int chunk = ks <= 3 ? 32 : 16;
   const int C_pad = (C + chunk - 1) / chunk * chunk;
