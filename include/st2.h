@@ -138,15 +138,8 @@ typedef struct st2_conv_desc {
      whose k loop is long (C_in >= 8 chunks, < 128 workgroups: the 1024 -> 2048 Linears of the denoiser over the ~100
      tokens of one utterance) runs as up to 8 K slices per tile + a fixed-order reduction that applies the epilogue; the
      split is a function of the geometry alone (every plan picks the same one: results are reproducible bit for bit) and
-     needs st2_conv1d_f16s_splitk_bytes(d) bytes here.  NULL / too small = no split. */
+     needs ksplit * B * C_out * L_out * 4 bytes here.  NULL / too small = no split. */
   void* splitk_ws; int64_t splitk_ws_bytes;
-  /* ABI v22, optional: one int32 per output tile of the launch (st2_conv1d_f16s_splitk_tiles(d) of them), ZERO when the launch
-     starts.  With it the reduction happens INSIDE the launch: every K slice stores its raw accumulators, counts itself on its
-     tile's counter, and the slice that arrives last adds all slices IN SLICE ORDER (results are bit for bit those of the
-     two-launch form: the scale is a power of two) and runs the ordinary epilogue.  Without it (NULL) a second launch
-     (one thread per output element) does the reduction: ~7 us more per skinny layer, 300 of them per 10 s utterance at B = 1.
-     The launch plans keep one zeroed counter block per forward call in their workspace. */
-  int32_t* splitk_counters;
 } st2_conv_desc;
 
 int st2_conv1d(const st2_conv_desc* d, void* stream);
@@ -169,8 +162,6 @@ int st2_conv1d_f16s(const st2_conv_desc* d, void* stream);
 /* Bytes of d.splitk_ws the launch described by *d would use (0 = this geometry is not split): the caller allocates that
  * much (any alignment >= 16) and sets d.splitk_ws / d.splitk_ws_bytes before calling st2_conv1d_f16s. */
 int64_t st2_conv1d_f16s_splitk_bytes(const st2_conv_desc* d);
-/* Output tiles of that launch = int32 counters d.splitk_counters must hold, zeroed (0 = not split). */
-int32_t st2_conv1d_f16s_splitk_tiles(const st2_conv_desc* d);
 int st2_conv1d_f16s_chunk(int ks);        /* input-channel padding granule of the packed weight */
 int st2_conv1d_f16s_co_block(int C_out);  /* output-channel padding granule of the packed weight */
 /* Measurement hook (process-wide): which build of the fused kernel a launch takes.  0 (default) = by rule: the

@@ -14,8 +14,6 @@ reachable from tests/ and tools/ only, through `override(...)`:
   lstm            "coop" (cooperative BiLSTM, with the library's own refusal -> single-CU path) or "single".
   lstm_recover    True (always, outside tests): cooperative launches carry their in-stream safety net
                   (st2_lstm_bidir_coop_recovering); False = the bare st2_lstm_bidir_coop, whose time-out is only reported.
-  splitk_in_launch  True (always, outside tests): split-K launches of the Python per-kernel path reduce inside the launch
-                  (d.splitk_counters, ABI 22) as the C++ plans do; False = the two-launch form, for the bitwise A-B test.
 """
 import contextlib
 
@@ -24,10 +22,9 @@ conv_path = "xs"
 conv_precision = "f16s"
 lstm = "coop"
 lstm_recover = True
-splitk_in_launch = True
 
 _CHOICES = {"plan": ("engine", "python"), "conv_path": ("xs", "fused"), "conv_precision": ("f16s", "f32"),
-            "lstm": ("coop", "single"), "lstm_recover": (True, False), "splitk_in_launch": (True, False)}
+            "lstm": ("coop", "single"), "lstm_recover": (True, False)}
 
 
 @contextlib.contextmanager

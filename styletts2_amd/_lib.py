@@ -49,7 +49,6 @@ class ConvDesc(C.Structure):
         ("xs", f32p), ("xs_cg", C.c_int32), ("xs_lp", C.c_int32), ("xs_halo", C.c_int32),
         ("part", f32p), ("part_nt", C.c_int32), ("part_cols", C.c_int32),
         ("splitk_ws", f32p), ("splitk_ws_bytes", C.c_int64),
-        ("splitk_counters", C.c_void_p),
     ]
 
 
@@ -106,7 +105,6 @@ _SIGNATURES = {
     "st2_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "st2_conv1d_f16s_splitk_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
-    "st2_conv1d_f16s_splitk_tiles": (C.c_int32, [C.POINTER(ConvDesc)]),
     "st2_conv1d_f16s_chunk": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_co_block": (C.c_int, [C.c_int]),
     "st2_conv1d_f16s_set_variant": (None, [C.c_int]),

@@ -47,8 +47,7 @@ template <int KS, int CI_T, int WM, int WN, int TN>
 #ifndef ST2_F16S_OCC
 #define ST2_F16S_OCC 2  // workgroups per CU the fused kernel is held to; at 3 (168 VGPRs) every instantiation spills 40-400 B / lane
 #endif
-__global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2_conv_desc d, int* status, int ksplit, float* part,
-                                                                       int* counters) {
+__global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2_conv_desc d, int* status, int ksplit, float* part) {
   constexpr int BM = 32 * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int CG = CI_T / 8;    // 8-channel groups per chunk
@@ -314,49 +313,7 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
   }
 
   __builtin_amdgcn_s_setprio(0);
-  if (ksplit > 1 && counters) {
-    // In-launch reduction (ABI v22).  Every K slice stores its RAW accumulators in the accumulator's own layout -- [slice][tile]
-    // [wave][j][q][lane] float4: consecutive lanes, consecutive 16 bytes -- counts itself on the tile's counter, and the slice that
-    // arrives LAST adds all of them in slice order 0 .. ksplit-1 (its own included: the order never depends on who was last) and
-    // runs the ordinary epilogue below.  out_scale * w_row_scale is a power of two, so scaling the sum equals summing the scaled
-    // partials of the two-launch form bit for bit (tests/test_ops_gpu.py::test_splitk_in_launch_is_bitwise_the_two_launch_form).
-    // (the flag lives in the staging buffers, dead after the k loop's last barrier: a static __shared__ on top of the 160 KB
-    // dynamic-LDS attribute makes every launch of this kernel fail with "invalid argument")
-    volatile int* s_last = reinterpret_cast<volatile int*>(smem_raw);
-    const int tile = (b * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + bx;
-    typedef st2_f32x4 f32x4;
-    f32x4* pw = reinterpret_cast<f32x4*>(part) + (((int64_t)ksl * d.B * gridDim.y * gridDim.x + tile) * 4 + wave) * (TN * 4 * 64) + lane;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        pw[(j * 4 + q) * 64] = f32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-    __threadfence();  // this wave's partials are visible device-wide before the workgroup counts itself
-    __syncthreads();
-    if (tid == 0) *s_last = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ksplit - 1;
-    __syncthreads();
-    if (!*s_last) return;
-    __threadfence();
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int s = 0; s < ksplit; ++s) {
-      const f32x4* pr = reinterpret_cast<const f32x4*>(part) + (((int64_t)s * d.B * gridDim.y * gridDim.x + tile) * 4 + wave) * (TN * 4 * 64) + lane;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // agent-scope loads: the other slices' stores were made visible by their fences, but not necessarily to this CU's L1
-          const f32x4 v = f32x4{__hip_atomic_load(&reinterpret_cast<const float*>(pr + (j * 4 + q) * 64)[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(&reinterpret_cast<const float*>(pr + (j * 4 + q) * 64)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(&reinterpret_cast<const float*>(pr + (j * 4 + q) * 64)[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(&reinterpret_cast<const float*>(pr + (j * 4 + q) * 64)[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[j][4 * q + e] += v[e];
-        }
-    }
-  } else if (ksplit > 1) {  // partial sums of this K slice, scaled, dense [ksplit][B][C_out][L_out]: splitk_reduce_kernel follows
+  if (ksplit > 1) {  // partial sums of this K slice, scaled, dense [ksplit][B][C_out][L_out]
     const float* rsc1 = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
     float* pb = part + ((int64_t)ksl * d.B + b) * d.C_out * d.L_out;
     const int row = m0 + wm * 32 + l31;  // transposed accumulator: this lane's output row
@@ -419,21 +376,9 @@ inline int ksplit_for_geometry(const st2_conv_desc& d) {
   s = std::min(s, nchunk / st2f16s::g_splitk_min_chunks);
   return std::max(s, 1);
 }
-// tiles of a launch and the workspace of its K slices: the dense [slice][B][C_out][L_out] layout of the two-launch form or the
-// accumulator-shaped [slice][tile][BM x BN] layout of the in-launch reduction, whichever is larger (the caller need not know which runs)
-inline int64_t splitk_tiles(const st2_conv_desc& d) {
-  const int BM = d.C_out > 64 ? 128 : (d.C_out > 32 ? 64 : 32);
-  const int BN = d.C_out > 64 ? 128 : (d.C_out > 32 ? 256 : 512);
-  return (int64_t)st2_cdiv(d.L_out, BN) * st2_cdiv(d.C_out, BM) * d.B;
-}
-inline int64_t splitk_bytes(const st2_conv_desc& d, int s) {
-  const int BM = d.C_out > 64 ? 128 : (d.C_out > 32 ? 64 : 32);
-  const int BN = d.C_out > 64 ? 128 : (d.C_out > 32 ? 256 : 512);
-  return (int64_t)s * 4 * std::max<int64_t>((int64_t)d.B * d.C_out * d.L_out, splitk_tiles(d) * BM * BN);
-}
 inline int pick_ksplit(const st2_conv_desc& d) {
   const int s = ksplit_for_geometry(d);
-  if (s <= 1 || !d.splitk_ws || splitk_bytes(d, s) > d.splitk_ws_bytes) return 1;
+  if (s <= 1 || !d.splitk_ws || (int64_t)s * d.B * d.C_out * d.L_out * 4 > d.splitk_ws_bytes) return 1;
   return s;
 }
 
@@ -464,11 +409,10 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
   // rows beyond C_out inside the last co block are computed on zero weights and not stored
   dim3 grid(st2_cdiv(d.L_out, BN), st2_cdiv(d.C_out, BM), d.B * ksplit);
   float* part = ksplit > 1 ? reinterpret_cast<float*>(d.splitk_ws) : nullptr;
-  int* counters = ksplit > 1 ? reinterpret_cast<int*>(d.splitk_counters) : nullptr;
   hipLaunchKernelGGL((conv1d_f16s_kernel<KS, CI_T, WM, WN, TN>), grid, dim3(NT), smem, s, d, st2_status_device_ptr(),
-                     ksplit, part, counters);
+                     ksplit, part);
   ST2_CHECK_LAUNCH("st2_conv1d_f16s");
-  if (ksplit > 1 && !counters) {
+  if (ksplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(st2_cdiv(d.L_out, 256), d.C_out, d.B), dim3(256), 0, s, d, ksplit,
                        part);
     ST2_CHECK_LAUNCH("st2_conv1d_f16s (split-K reduction)");

@@ -146,40 +146,12 @@ struct View {  // NCL view, strides in elements
 
 int pitch_of(int L) { return (L + 31) / 32 * 32; }  // rows of the big activations start 128-byte aligned
 
-constexpr int SPLITK_COUNTERS = 32768;  // per forward call: ~300 split-K launches of <= 128 tiles at B = 1 use ~8 k
-
-__global__ __launch_bounds__(256) void zero_counters_kernel(int4* p, int n16) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n16) p[i] = make_int4(0, 0, 0, 0);
-}
-
 struct Ctx {
   Arena a;
   void* stream = nullptr;
   int rc = 0;
   bool dry = false;
-  // one block of zeroed int32 counters per forward call, handed out tile by tile to the split-K launches of the plan
-  // (st2_conv_desc.splitk_counters: the K slices of a skinny layer are reduced inside the launch); see ctx_begin
-  int32_t* ctr = nullptr;
-  int ctr_used = 0, ctr_cap = 0;
 };
-
-// Called by every C entry point once the arena is set up (size queries included: the block is part of the workspace).  The counter
-// block is cleared by ONE small kernel per forward call -- a kernel, not hipMemsetAsync (a captured memset node misbehaves on
-// replay, ROCm 7.2: profiles/LAB_NOTES.md round 5) -- on the caller's stream, ahead of everything the plan queues.  The CPU
-// backend of the tests has no split-K and no device: nothing to clear.
-void ctx_begin(Ctx& c) {
-  c.ctr = static_cast<int32_t*>(c.a.alloc((int64_t)SPLITK_COUNTERS * 4));
-  c.ctr_cap = SPLITK_COUNTERS;
-  c.ctr_used = 0;
-  if (c.dry || c.a.overflow || g_be.conv1d_f16s != st2_conv1d_f16s) {
-    if (g_be.conv1d_f16s != st2_conv1d_f16s) c.ctr = nullptr;
-    return;
-  }
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(SPLITK_COUNTERS / 4 / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(c.stream),
-                     reinterpret_cast<int4*>(c.ctr), SPLITK_COUNTERS / 4);
-  if (hipGetLastError() != hipSuccess) c.ctr = nullptr;  // the two-launch reduction serves
-}
 
 View new_ncl(Ctx& c, int B, int C, int L, bool padded = true) {
   View v;
@@ -864,11 +836,6 @@ void conv(Ctx& c, const st2_engine& e, const View& x, const SplitW& w, const Vie
       if (skb > 0) {
         d.splitk_ws = c.a.alloc(skb);
         d.splitk_ws_bytes = skb;
-        const int tiles = st2_conv1d_f16s_splitk_tiles(&d);
-        if (c.ctr && tiles > 0 && c.ctr_used + tiles <= c.ctr_cap) {  // reduce inside the launch (else: the second launch)
-          d.splitk_counters = c.ctr + c.ctr_used;
-          c.ctr_used += tiles;
-        }
       }
     }
     RUN(c, g_be.conv1d_f16s(&d, c.stream));
@@ -1136,7 +1103,6 @@ extern "C" int64_t st2_decoder_workspace_bytes(st2_engine* e, int32_t B, int32_t
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   decoder_plan(c, *e, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, T, nullptr, nullptr);
   return c.a.peak + 256;
 }
@@ -1152,7 +1118,6 @@ extern "C" int st2_decoder_forward(st2_engine* e, const float* asr, const float*
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = decoder_plan(c, *e, asr, f0, n, s, sine_noise, har_inject, B, T, wave, taps);
   ST2_REQUIRE(!c.a.overflow, "st2_decoder_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_decoder_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -1164,7 +1129,6 @@ extern "C" int64_t st2_text_workspace_bytes(st2_engine* e, int32_t B, int32_t N)
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   text_plan(c, *e, nullptr, nullptr, B, N, nullptr);
   return c.a.peak + 256;
 }
@@ -1178,7 +1142,6 @@ extern "C" int st2_text_forward(st2_engine* e, const int64_t* tokens, const int3
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = text_plan(c, *e, tokens, lengths, B, N, t_en);
   ST2_REQUIRE(!c.a.overflow, "st2_text_forward: workspace of %lld B is too small (need %lld B, see st2_text_workspace_bytes)",
               (long long)workspace_bytes, (long long)c.a.peak);
@@ -1190,7 +1153,6 @@ extern "C" int64_t st2_bert_workspace_bytes(st2_engine* e, int32_t B, int32_t N)
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   bert_plan(c, *e, nullptr, nullptr, B, N);
   return c.a.peak + 256;
 }
@@ -1205,7 +1167,6 @@ extern "C" int st2_bert_forward(st2_engine* e, const int64_t* tokens, const int3
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   View X = bert_plan(c, *e, tokens, lengths, B, N);
   View dst = wrap(hidden_cm, B, e->bert.H, N);
   RUN(c, g_be.copy_ncl(X.p, X.bs, X.cs, dst.p, dst.bs, dst.cs, B, e->bert.H, N, c.stream));
@@ -1219,7 +1180,6 @@ extern "C" int64_t st2_style_workspace_bytes(st2_engine* e, int32_t which, int32
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   style_plan(c, *e, e->style[which], nullptr, B, n_mels, T, nullptr);
   return c.a.peak + 256;
 }
@@ -1235,7 +1195,6 @@ extern "C" int st2_style_forward(st2_engine* e, int32_t which, const float* mel,
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = style_plan(c, *e, e->style[which], mel, B, n_mels, T, style);
   ST2_REQUIRE(!c.a.overflow, "st2_style_forward: workspace of %lld B is too small (need %lld B, see st2_style_workspace_bytes)",
               (long long)workspace_bytes, (long long)c.a.peak);
@@ -1263,7 +1222,6 @@ extern "C" int64_t st2_front_workspace_bytes(st2_engine* e, const st2_front_args
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   std::vector<double> table((size_t)(a->steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
   static const float dummy = 0.f;
   static int64_t dummy_dur;
@@ -1289,7 +1247,6 @@ extern "C" int st2_front_forward(st2_engine* e, const st2_front_args* a, void* w
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = front_plan(c, *e, *a);
   ST2_REQUIRE(!c.a.overflow, "st2_front_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_front_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -1301,7 +1258,6 @@ extern "C" int64_t st2_duration_workspace_bytes(st2_engine* e, int32_t B, int32_
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   static int64_t dummy_dur;
   duration_plan(c, *e, wrap(nullptr, B, e->cfg.pred_hidden, N), nullptr, nullptr, B, N, 0, nullptr, &dummy_dur);
   return c.a.peak + 256;
@@ -1318,7 +1274,6 @@ extern "C" int st2_duration_forward(st2_engine* e, const float* d_en, const floa
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = duration_plan(c, *e, wrap(d_en, B, e->cfg.pred_hidden, N), s, lengths, B, N, tail, d_cm, durations);
   ST2_REQUIRE(!c.a.overflow, "st2_duration_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_duration_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -1330,7 +1285,6 @@ extern "C" int64_t st2_prosody_workspace_bytes(st2_engine* e, int32_t B, int32_t
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   prosody_plan(c, *e, nullptr, nullptr, nullptr, nullptr, B, N, T, 0, nullptr, nullptr, nullptr);
   return c.a.peak + 256;
 }
@@ -1347,7 +1301,6 @@ extern "C" int st2_prosody_forward(st2_engine* e, const float* d_cm, const float
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = prosody_plan(c, *e, d_cm, t_en, durations, s, B, N, T, shift, asr, f0, n);
   ST2_REQUIRE(!c.a.overflow, "st2_prosody_forward: workspace of %lld B is too small (need %lld B, see "
               "st2_prosody_workspace_bytes)", (long long)workspace_bytes, (long long)c.a.peak);
@@ -1392,7 +1345,6 @@ extern "C" int64_t st2_sampler_workspace_bytes(st2_engine* e, int32_t B, int32_t
   Ctx c;
   c.dry = true;
   c.a.dry = true;
-  ctx_begin(c);
   std::vector<double> table((size_t)(steps - 1) * ST2_SAMPLER_TABLE_COLS, 0.0);
   static const float dummy = 0.f;
   sampler_plan(c, *e, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, B, N, steps, embedding_scale, table.data(), 1.0, nullptr,
@@ -1414,7 +1366,6 @@ extern "C" int st2_sampler_run(st2_engine* e, const float* noise, const float* e
   c.stream = stream;
   c.a.base = static_cast<char*>(workspace);
   c.a.cap = workspace_bytes;
-  ctx_begin(c);
   const int rc = sampler_plan(c, *e, noise, embedding, nullptr, features, step_noise, lengths, B, N, steps, embedding_scale, table,
                               sigma0, out, step_taps);
   ST2_REQUIRE(!c.a.overflow, "st2_sampler_run: workspace of %lld B is too small (need %lld B, see "

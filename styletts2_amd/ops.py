@@ -457,10 +457,6 @@ def conv1d(x, wt, C_out, ks, *, dil=1, pad_left=0, L_out=None, bias=None, out=No
         if nb > 0:
             ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)  # caching allocator: stream- and capture-safe
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
-            if _hooks.splitk_in_launch:  # the reduction inside the launch (last-arriving slice): zeroed per-tile counters
-                ctr = torch.zeros((lib.st2_conv1d_f16s_splitk_tiles(C.byref(d)),), device=x.device, dtype=torch.int32)
-                d.splitk_counters = ctr.data_ptr()
-                ws = (ws, ctr)
     _launch_conv(fn, fname, d)
     if want_stats:
         return out, (stats_finalize(part, B, C_out, nt, L_out) if part is not None else instnorm_stats(out))

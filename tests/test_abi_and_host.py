@@ -166,24 +166,13 @@ def test_splitk_workspace_query_is_a_function_of_the_geometry():
         d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil = B, C_in, C_out, L, L, ks, 1
         return lib.st2_conv1d_f16s_splitk_bytes(C.byref(d))
 
-    def tiles(B, C_in, C_out, L, ks):
-        d = _lib.ConvDesc()
-        d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil = B, C_in, C_out, L, L, ks, 1
-        return lib.st2_conv1d_f16s_splitk_tiles(C.byref(d))
-
-    # bytes = slices x the larger of the dense [B][C_out][L] layout (two-launch reduction) and the accumulator-shaped
-    # [tile][128 x 128] layout (in-launch reduction, ABI 22): one workspace serves whichever form runs
-    def want(slices, B, C_out, L):
-        t = B * ((C_out + 127) // 128) * ((L + 127) // 128)
-        return slices * 4 * max(B * C_out * L, t * 128 * 128), t
-
-    assert (q(1, 1024, 2048, 100, 1), tiles(1, 1024, 2048, 100, 1)) == want(8, 1, 2048, 100)   # 16 workgroups, 32 chunks -> 8 slices
-    assert (q(1, 2048, 1024, 112, 1), tiles(1, 2048, 1024, 112, 1)) == want(8, 1, 1024, 112)
-    assert (q(4, 1024, 1024, 100, 1), tiles(4, 1024, 1024, 100, 1)) == want(8, 4, 1024, 100)   # 32 workgroups -> 256 / 32 = 8 slices
-    assert (q(8, 1024, 1024, 100, 1), tiles(8, 1024, 1024, 100, 1)) == want(4, 8, 1024, 100)   # 64 workgroups -> 4 slices
-    assert q(32, 1024, 1024, 100, 1) == 0 and tiles(32, 1024, 1024, 100, 1) == 0               # 256 workgroups: a split loses (measured)
+    assert q(1, 1024, 2048, 100, 1) == 8 * 1 * 2048 * 100 * 4        # 16 workgroups, 32 chunks -> 8 slices
+    assert q(1, 2048, 1024, 112, 1) == 8 * 1 * 1024 * 112 * 4
+    assert q(4, 1024, 1024, 100, 1) == 8 * 4 * 1024 * 100 * 4        # 32 workgroups -> 256 / 32 = 8 slices
+    assert q(8, 1024, 1024, 100, 1) == 4 * 8 * 1024 * 100 * 4        # 64 workgroups -> 4 slices
+    assert q(32, 1024, 1024, 100, 1) == 0                            # 256 workgroups: a split loses (measured)
     assert q(1, 128, 1024, 100, 1) == 0                              # 4 chunks: nothing to split
-    assert (q(1, 512, 512, 37, 5), tiles(1, 512, 512, 37, 5)) == want(8, 1, 512, 37)           # k = 5: 16-channel chunks
+    assert q(1, 512, 512, 37, 5) == 8 * 512 * 37 * 4                 # k = 5: 16-channel chunks
     assert q(0, 0, 0, 0, 1) == 0
 
 

@@ -126,35 +126,6 @@ def test_conv1d_matches_contract(case, kernel, monkeypatch):
     assert ops.status() == 0, "benign inputs must not raise a device-side status bit"
 
 
-@pytest.mark.parametrize("case", [c for c in F16S_EXTRA_CASES if c["ks"] == 1] + [
-    dict(B=1, C_in=768, C_out=768, L=100, ks=1, dil=1, pro=R.PRO_COLNORM),
-    dict(B=2, C_in=1024, C_out=512, L=58, ks=1, dil=1, pro=R.PRO_NONE, res=True),
-    dict(B=1, C_in=512, C_out=50, L=100, ks=1, dil=1, pro=R.PRO_NONE),          # the duration head: C_out <= 64 layout
-], ids=lambda c: "ci%d_co%d_L%d_B%d" % (c["C_in"], c["C_out"], c["L"], c["B"]))
-def test_splitk_in_launch_is_bitwise_the_two_launch_form(case):
-    """ABI 22: the K slices of a skinny layer are reduced INSIDE the launch (the slice that arrives last adds all slices in slice
-    order and runs the epilogue) instead of by a second launch.  Same slices, same order, a power-of-two scale: bit for bit the
-    two-launch result, run to run, with every epilogue term -- and the launch really was split (the workspace query says so)."""
-    import ctypes as C
-    from styletts2_amd import _lib
-    x, w, kw = make_conv_case(seed=77, **case)
-    wt = weights.pack_conv_f16s(w).to(DEV)
-    C_out = w.shape[0]
-    kwg = {k: (g(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
-    d = _lib.ConvDesc()
-    d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil = case["B"], case["C_in"], C_out, case["L"], case["L"], 1, 1
-    assert _lib.load().st2_conv1d_f16s_splitk_tiles(C.byref(d)) > 0, "the case is meant to be a split-K launch"
-    with _hooks.override(conv_path="fused", splitk_in_launch=False):
-        two = ops.conv1d(g(x), wt, C_out, 1, **kwg)
-    with _hooks.override(conv_path="fused", splitk_in_launch=True):
-        outs = [ops.conv1d(g(x), wt, C_out, 1, **kwg) for _ in range(5)]
-    torch.cuda.synchronize()
-    assert all(torch.equal(o, two) for o in outs)
-    ref = R.conv1d(x, weights.pack_conv_f16s(w), C_out, 1, **kw)
-    assert rel_err(two, ref) < 3e-6
-    assert ops.status() == 0
-
-
 WS_CASES = [
     # (B, C_in, C_out, L, ks, dil): the warp-specialised persistent build of st2_conv1d_f16s (C_out <= 64, AdaIN + Snake)
     (32, 64, 64, 30011, 11, 5),   # 3776 tiles, 14-15 per workgroup, the 64 x 256 layout
