@@ -88,7 +88,7 @@ for st in "$@"; do
         python tools/bench_summary.py $OUT/${TAG}_bench_$c.json
       done ;;
     stats)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule ${arg:-single} --calib-steps 0 --no-cpu-baseline --no-box-probe > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --schedule ${arg:-single} --calib-steps 0 --no-cpu-baseline --no-box-probe --other-configs off > $OLDPWD/$OUT/${TAG}_bench_single.json 2> $OLDPWD/$OUT/${TAG}_bench_single.err )
       f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_single_kernel_stats.csv && head -25 $f
       t=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/trace_gaps.py $t | tee $OUT/${TAG}_trace_gaps.txt
       rm -rf /tmp/prof_$TAG ;;
