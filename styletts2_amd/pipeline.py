@@ -612,6 +612,15 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(side)  # allocated on the caller's stream, read on the side stream
     s_prev, waves, emitted, n_dec, done = None, [None] * K, 0, 0, {}
+
+    def emit(emitted):
+        while emitted < K and waves[emitted] is not None:
+            if done[emitted] is not None:
+                main.wait_event(done[emitted])
+            if on_chunk is not None:
+                on_chunk(emitted, waves[emitted])
+            emitted += 1
+        return emitted
     for q in prepped:
         ids = q["ids"]
         kw = dict(input_lengths=q["lengths"], noise=q["noise"], diffusion_steps=diffusion_steps,
@@ -647,12 +656,15 @@ def synthesize_long(model, sampler, sentences, ref_s=None, alpha=0.3, beta=0.7, 
                 wave = w[j].reshape(-1)
                 waves[ids[b]] = wave[:-trim] if trim else wave
                 done[ids[b]] = ev
-            while emitted < K and waves[emitted] is not None:
-                if done[emitted] is not None:
-                    main.wait_event(done[emitted])
-                if on_chunk is not None:
-                    on_chunk(emitted, waves[emitted])
-                emitted += 1
+            if not dec:
+                emitted = emit(emitted)
+        # Decoders on auxiliary streams: the caller's stream takes its per-sentence waits only AFTER every decoder of this front
+        # group has been queued.  A wait packet sits at the head of the caller's hardware queue until its decoder is done, and HIP
+        # multiplexes streams onto ~4 such queues: an auxiliary stream that shares the caller's queue had its NEXT decoder queued
+        # behind that wait -- the decoders serialised, and a passage took 74-114 ms instead of 52 depending on which streams the
+        # process happened to get (rounds 5-6: "stream roulette").  Queued last, the waits block nothing.
+        if dec:
+            emitted = emit(emitted)
     if use_streams and s_prev is not None:
         s_prev.record_stream(main)  # allocated on the side stream, handed to the caller's
     return waves, s_prev
