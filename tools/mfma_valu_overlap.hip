@@ -8,6 +8,7 @@
 //   waves 4-7: `vi` iterations of 8 independent v_fma_f32 chains (or v_pk_fma_f32, plain encoding)
 // alone and together: together ~ max(alone) = the pipes overlap; together ~ sum = they serialise.
 //   ./mfma_valu_overlap [mi=4000] [vi=16000]
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

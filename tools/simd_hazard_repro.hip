@@ -18,6 +18,7 @@
 // Every victim launch is compared bitwise with an idle run of the same launch; a differing launch prints the first differing
 // checkpoint and the lanes that differ there.
 //   ./simd_hazard_repro [victims=all] [aggressors=all] [calls=200]
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/simd_hazard_repro.hip -o tools/bin/simd_hazard_repro
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
