@@ -53,23 +53,30 @@ __global__ __launch_bounds__(256) void phase_split_kernel(const float* __restric
 // wave; the per-tile (sum, sum of squares) of the stored row segment is emitted for the InstanceNorm that follows
 // (fixed-order wave + LDS reduction), so the output is not read again just to be reduced.
 constexpr int CVT_TILE = 1024;
+// S = the stride as a compile-time constant (2, 3, 5, 6, 10: the up-sampling rates of the two vocoders; 0 = generic, run-time
+// divisions).  Round 6: the run-time form spent ~25 VALU slots per output on two integer divisions and moved 4 bytes per lane and
+// instruction -- 0.6-0.8 ms per launch where its 12 bytes per output are worth 0.07-0.27 ms at the HBM roof (3.3 ms of a 115 ms
+// HiFi-GAN step, 1.2 of the 65 ms default step).  Now every thread owns FOUR CONSECUTIVE outputs (one 16-byte store, one 16-byte load
+// of the added tensor when the rows are aligned) and the divisions are by constants.
+template <int S>
 __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __restrict__ ph, int64_t p_bs, int p_cs,
                                                                int Lq, const float* __restrict__ bias,
                                                                const float* __restrict__ add, int64_t a_bs, int a_cs,
                                                                float* __restrict__ out, int64_t o_bs, int o_cs, int C,
-                                                               int stride, int pad, int L_raw, int reflect_left,
+                                                               int stride_rt, int pad, int L_raw, int reflect_left,
                                                                float* __restrict__ part, int part_nt) {
   extern __shared__ float cvt_tile[];  // [stride][nqp]
   __shared__ float red[2][4];
+  const int stride = S ? S : stride_rt;
   const int co = blockIdx.y;
   const int b = blockIdx.z;
   const int L_out = L_raw + reflect_left;
   const int o0 = blockIdx.x * CVT_TILE;
-  const int nqp = (CVT_TILE / stride + 3) | 1;  // odd row pitch: the de-interleaving reads spread over the banks
+  const int nq = CVT_TILE / stride + 3;
+  const int nqp = nq | 1;  // odd row pitch: the de-interleaving reads spread over the banks
   // raw positions this tile touches: l in [l_lo, l_lo + CVT_TILE] (one extra on the left for the reflected sample)
   const int l_lo = max(o0 - reflect_left, 0);
   const int q_lo = (l_lo + pad) / stride;
-  const int nq = CVT_TILE / stride + 3;
   // stride x nq staged values, flattened; the loads of 8 iterations are issued together (unconditional, clamped column)
   // before the first LDS store: one load -> one store per iteration serialised `stride` L2 / HBM round trips per tile
   {
@@ -98,31 +105,52 @@ __global__ __launch_bounds__(256) void convt_interleave_kernel(const float* __re
   const float bj = bias ? bias[co] : 0.f;
   const float* ab = add ? add + (int64_t)b * a_bs + (int64_t)co * a_cs : nullptr;
   float* ob = out + (int64_t)b * o_bs + (int64_t)co * o_cs;
-  float s1 = 0.f, s2 = 0.f;
-  auto value_at = [&](int o) __attribute__((always_inline)) -> float {
+  auto staged_at = [&](int o) __attribute__((always_inline)) -> float {  // conv-transpose value of output o, + bias
     int l = o;
     if (reflect_left) l = (o == 0) ? 1 : o - 1;
     const int lp = l + pad;
     const int q = lp / stride;
     const int r = lp - q * stride;
-    float v = cvt_tile[r * nqp + (q - q_lo)];
-    v += bj;
-    if (ab) v += ab[o];
-    return v;
+    return cvt_tile[r * nqp + (q - q_lo)] + bj;
   };
   // partial sums are taken of (v - shift), shift = the tile's first stored value (every thread recomputes it: one LDS + one
   // global read): stored behind the sums for st2_stats_finalize -- see st2_conv_epilogue.h on why unshifted sums are not enough
-  const float shift = value_at(o0);  // o0 < L_out for every launched tile
+  float shift = staged_at(o0);  // o0 < L_out for every launched tile
+  if (ab) shift += ab[o0];
+  float s1 = 0.f, s2 = 0.f;
+  const int o = o0 + 4 * threadIdx.x;  // this thread's four consecutive outputs
+  if (o < L_out) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const bool full = o + 3 < L_out;
+    const bool vec = full && ((reinterpret_cast<uintptr_t>(ob + o) & 15) == 0) && (!ab || (reinterpret_cast<uintptr_t>(ab + o) & 15) == 0);
+    float v[4];
 #pragma unroll
-  for (int k = 0; k < CVT_TILE / 256; ++k) {
-    const int o = o0 + k * 256 + threadIdx.x;
-    if (o < L_out) {
-      const float v = value_at(o);
-      ob[o] = v;
-      const float dv = v - shift;
-      s1 += dv;
-      s2 += dv * dv;
+    for (int e = 0; e < 4; ++e) v[e] = (full || o + e < L_out) ? staged_at(o + e) : 0.f;
+    if (ab) {
+      if (vec) {
+        const f4 a4 = *reinterpret_cast<const f4*>(ab + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += a4[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (full || o + e < L_out) v[e] += ab[o + e];
+      }
     }
+    if (vec) {
+      *reinterpret_cast<f4*>(ob + o) = f4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (full || o + e < L_out) ob[o + e] = v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (full || o + e < L_out) {
+        const float dv = v[e] - shift;
+        s1 += dv;
+        s2 += dv * dv;
+      }
   }
   if (part) {
     s1 = st2_wave_sum(s1);
@@ -268,8 +296,18 @@ extern "C" int st2_convt_interleave_stats(const float* phases, int64_t p_bs, int
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nq = CVT_TILE / stride + 3;
   const size_t smem = (size_t)stride * (nq | 1) * sizeof(float);
-  hipLaunchKernelGGL(convt_interleave_kernel, dim3(nt, C, B), dim3(256), smem, s, phases, p_bs, p_cs, Lq, bias, add,
-                     a_bs, a_cs, out, o_bs, o_cs, C, stride, pad, L_raw, reflect_left, part, part_nt);
+#define ST2_CVT_LAUNCH(SV)                                                                                              \
+  hipLaunchKernelGGL((convt_interleave_kernel<SV>), dim3(nt, C, B), dim3(256), smem, s, phases, p_bs, p_cs, Lq, bias, add, \
+                     a_bs, a_cs, out, o_bs, o_cs, C, stride, pad, L_raw, reflect_left, part, part_nt)
+  switch (stride) {  // the up-sampling rates of the two vocoders as compile-time constants, anything else generic
+    case 2: ST2_CVT_LAUNCH(2); break;
+    case 3: ST2_CVT_LAUNCH(3); break;
+    case 5: ST2_CVT_LAUNCH(5); break;
+    case 6: ST2_CVT_LAUNCH(6); break;
+    case 10: ST2_CVT_LAUNCH(10); break;
+    default: ST2_CVT_LAUNCH(0); break;
+  }
+#undef ST2_CVT_LAUNCH
   ST2_CHECK_LAUNCH("st2_convt_interleave");
   return 0;
 }
