@@ -158,6 +158,24 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
   auto store_chunk_as = [&](int c0, int buf, auto pro_tag) __attribute__((always_inline)) {
     constexpr int PRO = decltype(pro_tag)::value;
     h8* dst = xs + (size_t)buf * 2 * plane + sg * XW;
+    // This thread's 8 channels keep their parameters in REGISTERS across its R positions (round 6): read inside the element loop
+    // they were re-read from LDS after every ds_write of a finished slot (the table and the staging buffers share smem_raw: the
+    // compiler cannot prove they do not alias) -- 1-3 LDS reads and an lgkmcnt wait per element in a loop whose VALU slots are the
+    // kernel's floor (tools/mfma_valu_overlap.hip).  56 VGPRs more (162-189 -> ~206 of 256).  Measured per layout at B = 32
+    // (profiles/r06/r06s_probe_narrow.log): the 32-row layout (WM = 1: C <= 32, L = 240 000) gains 5-9 % (k = 7 0.911 -> 0.833 ms, k = 11
+    // 0.988 -> 0.941), the 64- and 128-row layouts LOSE 3-8 % -- so only the 32-row layout hoists.
+    constexpr bool HOIST = WM == 1;
+    ChanPar pr[8];
+    if constexpr (PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE || PRO == ST2_PRO_SNAKE || PRO == ST2_PRO_COLNORM) {
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pr[e] = par[c0 + sg * 8 + e];
+      }
+    }
+    auto par_of = [&](int e, int ci) __attribute__((always_inline)) -> ChanPar {
+      if constexpr (HOIST) return pr[e];
+      else return par[ci];
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int pos = sp0 + r * TPG;
@@ -179,27 +197,27 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
         if constexpr (PRO == ST2_PRO_LEAKY) {
           v = leaky(v, d.slope);
         } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
-          const ChanPar p = par[ci];
+          const ChanPar p = par_of(e, ci);
           float u = (v - p.mean) * p.rstd;
           u = p.g * u + p.beta;
           v = leaky(u, d.slope);
         } else if constexpr (PRO == ST2_PRO_ADAIN_SNAKE) {
-          const ChanPar p = par[ci];
+          const ChanPar p = par_of(e, ci);
           float u = (v - p.mean) * p.rstd;
           u = p.g * u + p.beta;
           v = snake(u, p.alpha, p.inv_alpha);
         } else if constexpr (PRO == ST2_PRO_SNAKE) {
-          const ChanPar p = par[ci];
+          const ChanPar p = par_of(e, ci);
           v = snake(v, p.alpha, p.inv_alpha);
         } else if constexpr (PRO == ST2_PRO_COLNORM) {
-          const ChanPar p = par[ci];
+          const ChanPar p = par_of(e, ci);
           const float u = (v - cmean) * crstd;
           v = u * p.g + p.beta;
         }
         // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor; with a
         // parameter table the tail is the table's zero scale (one compare + select less per element)
         if constexpr (PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE || PRO == ST2_PRO_SNAKE || PRO == ST2_PRO_COLNORM)
-          v = lok ? v * par[ci].xs : 0.f;
+          v = lok ? v * par_of(e, ci).xs : 0.f;
         else
           v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
         const float vc = st2_clamp_f16(v);  // saturate instead of inf / NaN, reported via st2_status()
