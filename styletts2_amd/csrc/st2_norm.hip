@@ -13,10 +13,35 @@ __global__ __launch_bounds__(NT) void instnorm_stats_kernel(const float* __restr
   const int c = row % C;
   const float* xr = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
   double s = 0.0, ss = 0.0;
-  for (int l = threadIdx.x; l < L; l += NT) {
-    const double v = (double)xr[l];
-    s += v;
-    ss += v * v;
+  if ((reinterpret_cast<uintptr_t>(xr) & 15) == 0) {
+    // 16-byte loads, four independent fp64 chains per thread (round 6: one 4-byte load feeding one dependent fp64 add per iteration
+    // ran the 48 001-sample rows at 2.6 TB/s); fixed order: component chains, then ((0 + 1) + (2 + 3)), then the tail
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    const int L4 = L >> 2;
+    const f4* x4 = reinterpret_cast<const f4*>(xr);
+    for (int i = threadIdx.x; i < L4; i += NT) {
+      const f4 v = x4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = (double)v[e];
+        a[e] += d;
+        q[e] += d * d;
+      }
+    }
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+    ss = (q[0] + q[1]) + (q[2] + q[3]);
+    for (int l = 4 * L4 + threadIdx.x; l < L; l += NT) {
+      const double v = (double)xr[l];
+      s += v;
+      ss += v * v;
+    }
+  } else {
+    for (int l = threadIdx.x; l < L; l += NT) {
+      const double v = (double)xr[l];
+      s += v;
+      ss += v * v;
+    }
   }
   s = st2_wave_sum(s);
   ss = st2_wave_sum(ss);
