@@ -43,6 +43,33 @@ struct ChanPar {  // per input channel, staged once per workgroup in LDS (32 B);
   float mean, rstd, g, beta, alpha, inv_alpha, xs, pad1;
 };
 
+// The one-role kernel's table holds the parameters of channels (2i, 2i + 1) as PAIRS (64 B per pair: the same 32 B per channel), so that
+// its prologue runs the affine and the Snake polynomial as packed-f32 ops on two adjacent channels at once (round 6).  On one SIMD
+// the prologue's VALU time ADDS to the MFMA time (tools/mfma_valu_overlap.hip) and at C <= 64 it is as large; a v_pk_fma_f32 costs
+// ~1.27 x a v_fma_f32 and does the work of two.  Same IEEE operations in the same order per channel: results are bitwise those of
+// the scalar form (and of the warp-specialised build, which keeps it).  Plain encodings and low-half broadcasts only
+// (tools/check_isa.py: an op_sel on a packed-f32 op would be the gfx950 hazard of DESIGN.md section 9).
+typedef float st2_f2 __attribute__((ext_vector_type(2)));
+struct ChanPar2 {
+  st2_f2 mean, rstd, g, beta, alpha, inv_alpha, xs, pad1;
+};
+
+static __device__ __forceinline__ st2_f2 splat2(float c) { return st2_f2{c, c}; }
+// sin(x)^2 of st2_act.h's sin_sq, two lanes at a time: the same operations in the same order per component
+static __device__ __forceinline__ st2_f2 sin_sq2(st2_f2 x) {
+  const st2_f2 n = __builtin_elementwise_rint(x * splat2(0.3183098861837907f));
+  st2_f2 r = __builtin_elementwise_fma(n, splat2(-3.1415927410125732f), x);
+  r = __builtin_elementwise_fma(n, splat2(8.742277657347586e-08f), r);
+  const st2_f2 r2 = r * r;
+  st2_f2 p = splat2(2.6000539037340786e-06f);
+  p = __builtin_elementwise_fma(p, r2, splat2(-0.00019806614727713168f));
+  p = __builtin_elementwise_fma(p, r2, splat2(0.008333017118275166f));
+  p = __builtin_elementwise_fma(p, r2, splat2(-0.16666656732559204f));
+  const st2_f2 s = __builtin_elementwise_fma(r2 * r, p, r);
+  return s * s;
+}
+static __device__ __forceinline__ st2_f2 snake2(st2_f2 v, st2_f2 alpha, st2_f2 inv_alpha) { return v + inv_alpha * sin_sq2(alpha * v); }
+
 template <int KS, int CI_T, int WM, int WN, int TN>
 #ifndef ST2_F16S_OCC
 #define ST2_F16S_OCC 2  // workgroups per CU the fused kernel is held to; at 3 (168 VGPRs) every instantiation spills 40-400 B / lane
@@ -102,7 +129,7 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
   // LDS: [2 buffers][2 planes hi/lo][CG][XW] slots of 16 B, then the channel parameter table
   h8* xs = reinterpret_cast<h8*>(smem_raw);
   const int plane = CG * XW;  // slots per plane
-  ChanPar* par = reinterpret_cast<ChanPar*>(smem_raw + (size_t)4 * plane * 16);
+  ChanPar2* par2 = reinterpret_cast<ChanPar2*>(smem_raw + (size_t)4 * plane * 16);  // pair i = channels (2i, 2i + 1)
 
   const int pro = d.pro;
   const bool has_par = pro == ST2_PRO_ADAIN_LEAKY || pro == ST2_PRO_ADAIN_SNAKE || pro == ST2_PRO_SNAKE ||
@@ -129,7 +156,8 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
           p.inv_alpha = 1.0f / p.alpha;
         }
       }
-      par[ci] = p;
+      float* q = reinterpret_cast<float*>(&par2[ci >> 1]) + (ci & 1);  // component ci & 1 of every pair member
+      q[0] = p.mean; q[2] = p.rstd; q[4] = p.g; q[6] = p.beta; q[8] = p.alpha; q[10] = p.inv_alpha; q[12] = p.xs;
     }
   }
 
@@ -165,16 +193,19 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
     // (profiles/r06/r06s_probe_narrow.log): the 32-row layout (WM = 1: C <= 32, L = 240 000) gains 5-9 % (k = 7 0.911 -> 0.833 ms, k = 11
     // 0.988 -> 0.941), the 64- and 128-row layouts LOSE 3-8 % -- so only the 32-row layout hoists.
     constexpr bool HOIST = WM == 1;
-    ChanPar pr[8];
-    if constexpr (PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE || PRO == ST2_PRO_SNAKE || PRO == ST2_PRO_COLNORM) {
-      if constexpr (HOIST) {
+    // ... and only there the prologue runs packed (two adjacent channels per v_pk_* op, bitwise the scalar form): C = 32 / L = 240 000
+    // k = 7 0.924 -> 0.797 ms, k = 11 1.015 -> 0.924 with both; the 64-row layout moves by -5 ... 0 %, the 128-row k = 3 layers of the
+    // default step by -6 ... +6 % (profiles/r06/r06w_probe_narrow.log): they keep one channel at a time
+    constexpr bool PACK = WM == 1;
+    constexpr bool TABLE = PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE || PRO == ST2_PRO_SNAKE || PRO == ST2_PRO_COLNORM;
+    ChanPar2 pr[4];
+    if constexpr (TABLE && HOIST) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pr[e] = par[c0 + sg * 8 + e];
-      }
+      for (int ep = 0; ep < 4; ++ep) pr[ep] = par2[(c0 + sg * 8) / 2 + ep];
     }
-    auto par_of = [&](int e, int ci) __attribute__((always_inline)) -> ChanPar {
-      if constexpr (HOIST) return pr[e];
-      else return par[ci];
+    auto par_of = [&](int ep) __attribute__((always_inline)) -> ChanPar2 {
+      if constexpr (HOIST) return pr[ep];
+      else return par2[(c0 + sg * 8) / 2 + ep];
     };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -191,40 +222,79 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
       h8 hi, lo;
       bool sat = false;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ci = c0 + sg * 8 + e;
-        float v = xr[r][e];
-        if constexpr (PRO == ST2_PRO_LEAKY) {
-          v = leaky(v, d.slope);
-        } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
-          const ChanPar p = par_of(e, ci);
-          float u = (v - p.mean) * p.rstd;
-          u = p.g * u + p.beta;
-          v = leaky(u, d.slope);
-        } else if constexpr (PRO == ST2_PRO_ADAIN_SNAKE) {
-          const ChanPar p = par_of(e, ci);
-          float u = (v - p.mean) * p.rstd;
-          u = p.g * u + p.beta;
-          v = snake(u, p.alpha, p.inv_alpha);
-        } else if constexpr (PRO == ST2_PRO_SNAKE) {
-          const ChanPar p = par_of(e, ci);
-          v = snake(v, p.alpha, p.inv_alpha);
-        } else if constexpr (PRO == ST2_PRO_COLNORM) {
-          const ChanPar p = par_of(e, ci);
-          const float u = (v - cmean) * crstd;
-          v = u * p.g + p.beta;
+      for (int ep = 0; ep < 4; ++ep) {  // channels (2 ep, 2 ep + 1) of this thread's group of 8, as one packed pair
+        const int ci = c0 + sg * 8 + 2 * ep;
+        st2_f2 v = st2_f2{xr[r][2 * ep], xr[r][2 * ep + 1]};
+        if constexpr (PACK) {
+          if constexpr (PRO == ST2_PRO_LEAKY) {
+            v = st2_f2{leaky(v.x, d.slope), leaky(v.y, d.slope)};
+          } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
+            const ChanPar2 p = par_of(ep);
+            st2_f2 u = (v - p.mean) * p.rstd;
+            u = p.g * u + p.beta;
+            v = st2_f2{leaky(u.x, d.slope), leaky(u.y, d.slope)};
+          } else if constexpr (PRO == ST2_PRO_ADAIN_SNAKE) {
+            const ChanPar2 p = par_of(ep);
+            st2_f2 u = (v - p.mean) * p.rstd;
+            u = p.g * u + p.beta;
+            v = snake2(u, p.alpha, p.inv_alpha);
+          } else if constexpr (PRO == ST2_PRO_SNAKE) {
+            const ChanPar2 p = par_of(ep);
+            v = snake2(v, p.alpha, p.inv_alpha);
+          } else if constexpr (PRO == ST2_PRO_COLNORM) {
+            const ChanPar2 p = par_of(ep);
+            // per-position statistics stay scalar: splatting crstd -- the HIGH element of the (mean, rstd) pair its load returns --
+            // would be an op_sel'd packed op (tools/check_isa.py)
+            const st2_f2 u = st2_f2{(v.x - cmean) * crstd, (v.y - cmean) * crstd};
+            v = u * p.g + p.beta;
+          }
+          if constexpr (TABLE)
+            v = v * par_of(ep).xs;
+          else
+            v = v * splat2(d.x_scale);
+        } else {  // one channel at a time (the 64- / 128-row layouts: the packed form is neutral to slower there, r06w)
+          [[maybe_unused]] ChanPar2 p;
+          if constexpr (TABLE) p = par_of(ep);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float w = v[c];
+            if constexpr (PRO == ST2_PRO_LEAKY) {
+              w = leaky(w, d.slope);
+            } else if constexpr (PRO == ST2_PRO_ADAIN_LEAKY) {
+              float u = (w - p.mean[c]) * p.rstd[c];
+              u = p.g[c] * u + p.beta[c];
+              w = leaky(u, d.slope);
+            } else if constexpr (PRO == ST2_PRO_ADAIN_SNAKE) {
+              float u = (w - p.mean[c]) * p.rstd[c];
+              u = p.g[c] * u + p.beta[c];
+              w = snake(u, p.alpha[c], p.inv_alpha[c]);
+            } else if constexpr (PRO == ST2_PRO_SNAKE) {
+              w = snake(w, p.alpha[c], p.inv_alpha[c]);
+            } else if constexpr (PRO == ST2_PRO_COLNORM) {
+              const float u = (w - cmean) * crstd;
+              w = u * p.g[c] + p.beta[c];
+            }
+            if constexpr (TABLE)
+              w = w * p.xs[c];
+            else
+              w = w * d.x_scale;
+            v[c] = w;
+          }
         }
-        // zero padding (and channel tail) is applied AFTER the activation, as F.conv1d pads the activated tensor; with a
-        // parameter table the tail is the table's zero scale (one compare + select less per element)
-        if constexpr (PRO == ST2_PRO_ADAIN_LEAKY || PRO == ST2_PRO_ADAIN_SNAKE || PRO == ST2_PRO_SNAKE || PRO == ST2_PRO_COLNORM)
-          v = lok ? v * par_of(e, ci).xs : 0.f;
-        else
-          v = (lok && ci < d.C_in) ? v * d.x_scale : 0.f;
-        const float vc = st2_clamp_f16(v);  // saturate instead of inf / NaN, reported via st2_status()
-        sat |= vc != v;
-        const _Float16 h = (_Float16)vc;
-        hi[e] = h;
-        lo[e] = (_Float16)(vc - (float)h);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int e = 2 * ep + c;
+          float w = c ? v.y : v.x;
+          if constexpr (TABLE)
+            w = lok ? w : 0.f;
+          else
+            w = (lok && ci + c < d.C_in) ? w : 0.f;
+          const float vc = st2_clamp_f16(w);  // saturate instead of inf / NaN, reported via st2_status()
+          sat |= vc != w;
+          const _Float16 h = (_Float16)vc;
+          hi[e] = h;
+          lo[e] = (_Float16)(vc - (float)h);
+        }
       }
       if (sat) st2_raise_status(status, ST2_STATUS_F16_RANGE);
       dst[pos] = hi;
