@@ -192,6 +192,8 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
     // kernel's floor (tools/mfma_valu_overlap.hip).  56 VGPRs more (162-189 -> ~206 of 256).  Measured per layout at B = 32
     // (profiles/r06/r06s_probe_narrow.log): the 32-row layout (WM = 1: C <= 32, L = 240 000) gains 5-9 % (k = 7 0.911 -> 0.833 ms, k = 11
     // 0.988 -> 0.941), the 64- and 128-row layouts LOSE 3-8 % -- so only the 32-row layout hoists.
+    // (The warp-specialised build holds them in SGPRs -- a wave stages one channel group -- and gains 3-9 %, st2_conv1d_f16s_ws.h;
+    // here the same form spills 60-120 SGPRs next to the descriptor and measured 0 ... +5 % SLOWER on every layout, r06z.)
     constexpr bool HOIST = WM == 1;
     // ... and only there the prologue runs packed (two adjacent channels per v_pk_* op, bitwise the scalar form): C = 32 / L = 240 000
     // k = 7 0.924 -> 0.797 ms, k = 11 1.015 -> 0.924 with both; the 64-row layout moves by -5 ... 0 %, the 128-row k = 3 layers of the

@@ -78,6 +78,11 @@ struct ChanPar {  // per input channel, staged per batch item in LDS (32 B); xs 
   float mean, rstd, g, beta, alpha, inv_alpha, xs, pad1;
 };
 
+// a value every lane of the wave holds, moved to an SGPR
+static __device__ __forceinline__ float wave_uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 struct TileGeom {  // tile index -> (batch item, co block, l block); l fastest, so a workgroup's range stays in one batch item
   int tiles_n, tiles_m, ntiles;
 };
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(NTW, 2) void conv1d_f16s_ws_kernel(const st2_conv_d
   constexpr int R = (MAXXW + TPG - 1) / TPG;  // staging rounds (positions per producer thread)
   constexpr int SPC = S16 * KS;    // k-steps per chunk
   static_assert(WM * WN == 4, "4 consumer waves");
+  static_assert(TPG % 64 == 0, "a producer wave stays inside one channel group");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -192,6 +198,17 @@ __global__ __launch_bounds__(NTW, 2) void conv1d_f16s_ws_kernel(const st2_conv_d
       const int lin0 = q_lin0[SET];
       const ChanPar* tab = par + (size_t)(q_b[SET] & 1) * C_pad;
       h8* dst = xs + (size_t)buf * 2 * plane + sg * XW;
+      // A wave's 64 threads share one channel group (TPG is a multiple of 64), so the group's eight table entries are
+      // wave-uniform: read once per chunk (one broadcast LDS read each) and kept in SGPRs.  Read inside the element loop
+      // they cost two ds_read_b128 per element, re-issued after every fragment store (same LDS array): eight times the
+      // bytes the producers write.
+      ChanPar cp[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const ChanPar p = tab[c0 + sg * 8 + e];
+        cp[e] = ChanPar{wave_uniform(p.mean), wave_uniform(p.rstd), wave_uniform(p.g), wave_uniform(p.beta),
+                        wave_uniform(p.alpha), wave_uniform(p.inv_alpha), wave_uniform(p.xs), 0.f};
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int pos = sp0 + r * TPG;
@@ -201,8 +218,7 @@ __global__ __launch_bounds__(NTW, 2) void conv1d_f16s_ws_kernel(const st2_conv_d
         h8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int ci = c0 + sg * 8 + e;
-          const ChanPar p = tab[ci];
+          const ChanPar p = cp[e];
           float v = xq[SET][r][e];
           float u = (v - p.mean) * p.rstd;
           u = p.g * u + p.beta;
