@@ -208,8 +208,8 @@ int st2_act_split(const float* x, int64_t x_bs, int32_t x_cs, int32_t B, int32_t
 int st2_conv1d_xs(const st2_conv_desc* d, void* stream);
 /* Columns per partial-sum slot (128, 64 or 32) the launch described by *d would use when its caller opts into the small-grid
  * builds (d.part_cols): a function of the geometry alone -- every plan gets the same answer, results are reproducible bit for
- * bit.  k = 3 launches of up to three utterances: 32 below ~100 tiles of 128 x 128, 64 up to ~900; 128 otherwise (y is bitwise
- * the same either way; the k = 7 / 11 narrow builds of round 5 are not used: st2_conv1d_xs_impl.h). */
+ * bit.  k = 3 / 7 / 11 launches of up to three utterances: 32 below ~100 tiles of 128 x 128, 64 up to ~900 (k = 3) / 340 (k = 7,
+ * 11); 128 otherwise (y is bitwise the same either way: st2_conv1d_xs_impl.h). */
 int st2_conv1d_xs_part_cols(const st2_conv_desc* d);
 int st2_stats_finalize(const float* part, int32_t rows, int32_t nt, int32_t L, float eps, float* stats, int32_t cols, void* stream);
 

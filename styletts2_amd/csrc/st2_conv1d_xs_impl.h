@@ -435,7 +435,10 @@ inline int rule_variant(const st2_conv_desc& d) {
 // front of the throughput configurations) LOSES 5-20 % with the narrow tiles (every workgroup streams its row block's whole
 // weight slice, 0.4-1.6 MB there; profiles/r05/r05g_smallgrid_b32.log), so those keep the 128-column build.  A function of the geometry alone
 // (never tuned: the partial sums' slot width follows it, and a measured choice would make the statistics box-dependent in
-// their last bits).  Callers opt in through d.part_cols (with statistics) or get it by rule (without): y is bitwise the same
+// their last bits).  Inside the pipeline (round 6, per-class times of the long-form and B = 1 legs with and without the k = 7 / 11
+// narrow builds, profiles/r06/r06A_*): x1.25-1.46 at 90-291 tiles of 128 (k = 7, C = 128, L = 34 800: 95 -> 72 us; k = 11: 130 -> 100;
+// k = 7, C = 256, L = 5 680: 77 -> 53), x0.95 at 376 (k = 11, L = 48 001: 64 -> 67.5 us) -- hence 340 rather than the micro-benchmark's
+// 600 for k >= 7.  Callers opt in through d.part_cols (with statistics) or get it by rule (without): y is bitwise the same
 // in every build.
 #ifndef ST2_XS_NARROW_ALL
 #define ST2_XS_NARROW_ALL 0  // tools/xs_bench.hip and the A/B probes build with 1: narrow tiles for every kernel size
@@ -444,18 +447,15 @@ inline int rule_variant(const st2_conv_desc& d) {
 #define ST2_XS_SMALLGRID 1  // build-time switch for A/B runs: 0 = every launch keeps the 128-column tiles
 #endif
 //
-// k = 3 ONLY (round 5, an open hardware-level observation): while the 16-channel-chunk builds with narrow tiles (k = 7 / 11, 64 /
-// 32 columns) run on one queue, the BiLSTM kernels on ANOTHER queue -- both the single-CU and the cooperative one -- return
-// different results in 25-90 % of their calls: traced to 16 consecutive lanes of ONE gate's W_hh load carrying wrong data (one
-// 64-byte sector of a global load; tools/stress.py lstm_trace, profiles/r05/r05i_*).  The convs' own outputs are bit-exact under the
-// same load, guard bands around their output stay intact, capping their workgroups per CU changes nothing, and the k = 3 narrow
-// builds (32-channel chunks), the 128-column k = 7 / 11 builds and every other load tried do not do it
-// (tools/stress.py lstm_under_load2).  Until that is understood the narrow tiles are used where they are verified harmless.
+// k = 3 / 7 / 11.  (Round 5 held the k = 7 / 11 narrow builds back: with them on one queue the BiLSTM kernels on another returned
+// different bits in 25-90 % of their calls.  Round 6 found the cause on the VICTIM's side -- a packed-f32 encoding gfx950 gets
+// wrong next to the MFMA cadence of a one-accumulator tile, DESIGN.md section 9 -- removed it from the library and gates the
+// build on its absence (tools/check_isa.py); tests/test_zz_coresidency_gpu.py runs every kernel class beside these builds.)
 inline int small_grid_cols(const st2_conv_desc& d) {
-  if (!ST2_XS_SMALLGRID || d.C_out <= 64 || d.ks != 3 || d.B > 3) return 128;
+  if (!ST2_XS_SMALLGRID || d.C_out <= 64 || (d.ks != 3 && d.ks != 7 && d.ks != 11) || d.B > 3) return 128;
   const int64_t wg128 = (int64_t)st2_cdiv(d.L_out, 128) * st2_cdiv(d.C_out, 128) * d.B;
   if (wg128 < 100) return 32;
-  return wg128 < (d.ks == 3 ? 900 : 600) ? 64 : 128;
+  return wg128 < (d.ks == 3 ? 900 : 340) ? 64 : 128;
 }
 
 template <int KS, int CI_T>
@@ -467,7 +467,7 @@ int launch_by_cout(const st2_conv_desc& d, hipStream_t s, int variant) {
   }
   const bool swz = (variant & XS_V_SWIZZLE) != 0;
   if (d.C_out > 64) {
-    if constexpr (KS == 3 || ST2_XS_NARROW_ALL) {  // the k = 7 / 11 narrow builds exist in the micro-benchmark only (see small_grid_cols)
+    if constexpr (KS == 3 || KS == 7 || KS == 11 || ST2_XS_NARROW_ALL) {  // small grids (see small_grid_cols)
       if (variant & XS_V_N32) return launch<KS, CI_T, 4, 1, 1, 3>(d, s, swz);
       if (variant & XS_V_N64) return launch<KS, CI_T, 4, 1, 2, 3>(d, s, swz);
     }

@@ -261,10 +261,12 @@ def test_epilogue_statistics_survive_offset_dominated_channels(path, B, C, L, mo
                                                 (1, 128, 28400, 3, 1, 64),    # 222 -> 64-column tiles
                                                 (2, 128, 8001, 3, 1, 64), (1, 1024, 400, 3, 1, 32),  # 32 tiles, K = 3 072 deep
                                                 (1, 128, 40000, 3, 1, 64),    # 313 tiles: still one partial round of the chip
-                                                (1, 256, 5680, 7, 1, 128),    # k = 7 / 11: 128-column tiles whatever the grid
+                                                (1, 256, 5680, 7, 1, 32), (1, 128, 9000, 11, 5, 32),  # k = 7 / 11 follow the same rule
+                                                (1, 128, 34800, 7, 3, 64),    # ... up to 340 tiles of 128
+                                                (1, 128, 48001, 11, 1, 128),  # 376 tiles
                                                 (4, 128, 40000, 3, 1, 128)])  # 1 252 tiles: the ordinary build
 def test_conv1d_xs_small_grid_builds(B, C, L, ks, dil, cols, monkeypatch):
-    """k = 3 launches with few 128 x 128 tiles (one utterance: long-form synthesis, BASELINE.json configs[4]) run 64- / 32-column
+    """k = 3 / 7 / 11 launches with few 128 x 128 tiles (one utterance: long-form synthesis, BASELINE.json configs[4]) run 64- / 32-column
     tiles by a rule of the geometry (st2_conv1d_xs_part_cols): the output is BITWISE that of the 128-column build
     (same products in the same order per element), the InstanceNorm statistics -- partial sums per 64 / 32 columns instead of
     128 -- meet the CPU reduction of the stored tensor at the same bar, and two runs are bitwise identical."""

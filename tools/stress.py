@@ -308,8 +308,8 @@ from some time step on in one direction = the recurrence itself took a wrong inp
 def cmd_lstm_under_load2(argv):
     """Which property of the other queue's work makes the BiLSTM kernels irreproducible?  Loads: the same small conv in 32- / 64- / 128-column
 tiles (want_stats + part_cols forces the width), many small activation passes, many small fused convs, a big conv.
-The k = 7 / 11 narrow builds are compiled only with -DST2_XS_NARROW_ALL=1 (profiles/LAB_NOTES.md round 5): build the library with that flag
-(styletts2_amd/_build.py FLAGS) to reproduce the finding; with the product library those loads are reported as "not built"."""
+(Rounds 5 / 6 history: the product library of round 5 did not carry the k = 7 / 11 narrow builds; since the victim-side fix of round 6,
+DESIGN.md section 9, it does, and every load here must leave the BiLSTM bitwise alone.)"""
     sys.argv = ["stress.py lstm_under_load2"] + list(argv)
     import torch  # noqa: E402
 
@@ -360,7 +360,7 @@ The k = 7 / 11 narrow builds are compiled only with -DST2_XS_NARROW_ALL=1 (profi
                     side.wait_stream(torch.cuda.current_stream())
                     try:
                         load()
-                    except Exception as e:  # the product library refuses part_cols = 32 / 64 at k = 7 / 11
+                    except Exception as e:  # a library built without the narrow tiles refuses part_cols = 32 / 64
                         print("%-7s lstm under %-34s: not built (%s)" % (mode, name, str(e)[:60]))
                         tot = -1
                         break
