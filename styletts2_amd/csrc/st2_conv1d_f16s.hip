@@ -27,7 +27,7 @@ extern "C" int st2_conv1d_f16s_co_block(int C_out) { return C_out > 64 ? 128 : (
 extern "C" int64_t st2_conv1d_f16s_splitk_bytes(const st2_conv_desc* dp) {
   if (!dp || dp->B <= 0 || dp->C_in <= 0 || dp->C_out <= 0 || dp->L_out <= 0) return 0;
   const int s = ksplit_for_geometry(*dp);
-  return s > 1 ? (int64_t)s * dp->B * dp->C_out * dp->L_out * 4 : 0;
+  return s > 1 ? splitk_bytes_for(*dp, s) : 0;
 }
 
 extern "C" int st2_conv1d_f16s(const st2_conv_desc* dp, void* stream) {

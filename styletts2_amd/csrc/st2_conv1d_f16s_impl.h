@@ -403,19 +403,23 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
   }
 
   __builtin_amdgcn_s_setprio(0);
-  if (ksplit > 1) {  // partial sums of this K slice, scaled, dense [ksplit][B][C_out][L_out]
+  if (ksplit > 1) {
+    // Partial sums of this K slice, scaled, in the ACCUMULATOR'S OWN layout: [slice][b][tile y][tile x][q = 4 j + r / 4][thread] x
+    // float4 -- every store instruction of a wave is one contiguous KB.  (Until round 6 the slices were dense [C_out][L_out]
+    // images: with a lane per output row that is 64 four-byte stores to 64 different lines per instruction, 64 instructions per
+    // wave -- 7 of the 17 us such a launch took at one utterance.)
     const float* rsc1 = d.w_row_scale ? d.w_row_scale : reinterpret_cast<const float*>(d.wq);
-    float* pb = part + ((int64_t)ksl * d.B + b) * d.C_out * d.L_out;
     const int row = m0 + wm * 32 + l31;  // transposed accumulator: this lane's output row
     const float sraw = rsc1[row];
     const float osc_r = d.w_row_scale ? d.out_scale * sraw : d.out_scale;
+    float4* pb = reinterpret_cast<float4*>(part) +
+                 ((((int64_t)ksl * d.B + b) * gridDim.y + blockIdx.y) * gridDim.x + n0 / BN) * (TN * 4) * NT + tid;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int col = n0 + wn * (32 * TN) + j * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
-        if (row < d.C_out && col < d.L_out) pb[(int64_t)row * d.L_out + col] = acc[j][r] * osc_r;
-      }
+      for (int q = 0; q < 4; ++q)
+        pb[(j * 4 + q) * NT] = float4{acc[j][4 * q] * osc_r, acc[j][4 * q + 1] * osc_r, acc[j][4 * q + 2] * osc_r,
+                                      acc[j][4 * q + 3] * osc_r};
     }
     return;
   }
@@ -423,29 +427,45 @@ __global__ __launch_bounds__(NT, ST2_F16S_OCC) void conv1d_f16s_kernel(const st2
   st2_conv_epilogue<TN, WM, WN>(d, acc, b, m0, n0, wm, wn, l31, kg);
 }
 
-// Second half of a split-K conv: y = epi(bias + sum over the K slices, in slice order), one thread per output element.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const st2_conv_desc d, int ksplit, const float* part) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  const int co = blockIdx.y;
-  const int b = blockIdx.z;
-  if (l >= d.L_out) return;
-  const int64_t slice = (int64_t)d.B * d.C_out * d.L_out;
-  const float* p = part + ((int64_t)b * d.C_out + co) * d.L_out + l;
-  float a = p[0];
-  for (int s = 1; s < ksplit; ++s) a += p[s * slice];
-  float v = a + (d.bias ? d.bias[co] : 0.f);
-  if (d.res) v += d.res[(int64_t)b * d.res_bs + (int64_t)co * d.res_cs + (l >> d.res_shift)];
-  if (d.res2) v = d.res2[(int64_t)b * d.res2_bs + (int64_t)co * d.res2_cs + l] + v;
-  if (d.div != 1.0f) v = v / d.div;
-  switch (d.act) {
-    case ST2_ACT_GELU: v = gelu_erf(v); break;
-    case ST2_ACT_EXP_SIN: v = co < d.act_split ? expf(v) : sin_acc(v); break;
-    case ST2_ACT_TANH: v = tanhf(v); break;
-    case ST2_ACT_LEAKY: v = leaky(v, d.act_slope); break;
-    case ST2_ACT_GELU_TANH: v = gelu_tanh(v); break;
-    default: break;
+// Second half of a split-K conv: y = epi(bias + sum over the K slices, in slice order).  One thread per float4 of a slice (four
+// consecutive positions of one output row), addressed exactly as the conv kernel's thread `threadIdx.x` of tile (blockIdx.y) stored
+// its accumulator group q = blockIdx.x: WN / TN are the tile's wave grid and column tiles per wave.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const st2_conv_desc d, int ksplit, const float* part, int WN, int TN,
+                                                            int tiles_x) {
+  const int tid = threadIdx.x, q = blockIdx.x, tile = blockIdx.y, b = blockIdx.z;
+  const int wave = tid >> 6, lane = tid & 63, kg = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int by = tile / tiles_x, bx = tile - by * tiles_x;
+  const int co = by * (128 / WN) + wm * 32 + l31;  // BM = 32 * WM, WM * WN = 4
+  const int l0 = bx * (32 * TN * WN) + wn * (32 * TN) + (q >> 2) * 32 + 8 * (q & 3) + 4 * kg;
+  if (co >= d.C_out || l0 >= d.L_out) return;
+  const int64_t slice = (int64_t)d.B * gridDim.y * (TN * 4) * 256;  // float4 per slice
+  const float4* p = reinterpret_cast<const float4*>(part) + (((int64_t)b * gridDim.y + tile) * (TN * 4) + q) * 256 + tid;
+  float4 a4 = p[0];
+  for (int s = 1; s < ksplit; ++s) {
+    const float4 t = p[s * slice];
+    a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
   }
-  d.y[(int64_t)b * d.y_bs + (int64_t)co * d.y_cs + l] = v;
+  const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+  const float bias = d.bias ? d.bias[co] : 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int l = l0 + c;
+    if (l >= d.L_out) break;
+    float v = av[c] + bias;
+    if (d.res) v += d.res[(int64_t)b * d.res_bs + (int64_t)co * d.res_cs + (l >> d.res_shift)];
+    if (d.res2) v = d.res2[(int64_t)b * d.res2_bs + (int64_t)co * d.res2_cs + l] + v;
+    if (d.div != 1.0f) v = v / d.div;
+    switch (d.act) {
+      case ST2_ACT_GELU: v = gelu_erf(v); break;
+      case ST2_ACT_EXP_SIN: v = co < d.act_split ? expf(v) : sin_acc(v); break;
+      case ST2_ACT_TANH: v = tanhf(v); break;
+      case ST2_ACT_LEAKY: v = leaky(v, d.act_slope); break;
+      case ST2_ACT_GELU_TANH: v = gelu_tanh(v); break;
+      default: break;
+    }
+    d.y[(int64_t)b * d.y_bs + (int64_t)co * d.y_cs + l] = v;
+  }
 }
 
 // K slices of a launch: layers whose grid leaves most of the chip idle AND whose k loop is long run as `ksplit`
@@ -466,9 +486,15 @@ inline int ksplit_for_geometry(const st2_conv_desc& d) {
   s = std::min(s, nchunk / st2f16s::g_splitk_min_chunks);
   return std::max(s, 1);
 }
+// bytes of `s` slices: whole tiles (the slices are stored in the accumulator layout, splitk_reduce_kernel)
+inline int64_t splitk_bytes_for(const st2_conv_desc& d, int s) {
+  const int BM = d.C_out > 64 ? 128 : (d.C_out > 32 ? 64 : 32);
+  const int BN = d.C_out > 64 ? 128 : (d.C_out > 32 ? 256 : 512);
+  return (int64_t)s * d.B * st2_cdiv(d.C_out, BM) * BM * st2_cdiv(d.L_out, BN) * BN * 4;
+}
 inline int pick_ksplit(const st2_conv_desc& d) {
   const int s = ksplit_for_geometry(d);
-  if (s <= 1 || !d.splitk_ws || (int64_t)s * d.B * d.C_out * d.L_out * 4 > d.splitk_ws_bytes) return 1;
+  if (s <= 1 || !d.splitk_ws || splitk_bytes_for(d, s) > d.splitk_ws_bytes) return 1;
   return s;
 }
 
@@ -503,8 +529,9 @@ int launch(const st2_conv_desc& d, hipStream_t s) {
                      ksplit, part);
   ST2_CHECK_LAUNCH("st2_conv1d_f16s");
   if (ksplit > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(st2_cdiv(d.L_out, 256), d.C_out, d.B), dim3(256), 0, s, d, ksplit,
-                       part);
+    static_assert(NT == 256, "splitk_reduce_kernel mirrors a 256-thread tile");
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(TN * 4, grid.x * grid.y, d.B), dim3(256), 0, s, d, ksplit, part, WN, TN,
+                       (int)grid.x);
     ST2_CHECK_LAUNCH("st2_conv1d_f16s (split-K reduction)");
   }
   return 0;

@@ -166,13 +166,15 @@ def test_splitk_workspace_query_is_a_function_of_the_geometry():
         d.B, d.C_in, d.C_out, d.L_in, d.L_out, d.ks, d.dil = B, C_in, C_out, L, L, ks, 1
         return lib.st2_conv1d_f16s_splitk_bytes(C.byref(d))
 
-    assert q(1, 1024, 2048, 100, 1) == 8 * 1 * 2048 * 100 * 4        # 16 workgroups, 32 chunks -> 8 slices
-    assert q(1, 2048, 1024, 112, 1) == 8 * 1 * 1024 * 112 * 4
-    assert q(4, 1024, 1024, 100, 1) == 8 * 4 * 1024 * 100 * 4        # 32 workgroups -> 256 / 32 = 8 slices
-    assert q(8, 1024, 1024, 100, 1) == 4 * 8 * 1024 * 100 * 4        # 64 workgroups -> 4 slices
+    # slices are stored in the accumulator layout: whole 128 x 128 tiles (C_out > 64)
+    assert q(1, 1024, 2048, 100, 1) == 8 * 1 * 2048 * 128 * 4        # 16 workgroups, 32 chunks -> 8 slices
+    assert q(1, 2048, 1024, 112, 1) == 8 * 1 * 1024 * 128 * 4
+    assert q(4, 1024, 1024, 100, 1) == 8 * 4 * 1024 * 128 * 4        # 32 workgroups -> 256 / 32 = 8 slices
+    assert q(8, 1024, 1024, 100, 1) == 4 * 8 * 1024 * 128 * 4        # 64 workgroups -> 4 slices
     assert q(32, 1024, 1024, 100, 1) == 0                            # 256 workgroups: a split loses (measured)
     assert q(1, 128, 1024, 100, 1) == 0                              # 4 chunks: nothing to split
-    assert q(1, 512, 512, 37, 5) == 8 * 512 * 37 * 4                 # k = 5: 16-channel chunks
+    assert q(1, 512, 512, 37, 5) == 8 * 512 * 128 * 4                # k = 5: 16-channel chunks
+    assert q(1, 512, 40, 37, 5) == 8 * 64 * 256 * 4                  # 64 x 256 tiles for 32 < C_out <= 64
     assert q(0, 0, 0, 0, 1) == 0
 
 
