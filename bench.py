@@ -380,7 +380,11 @@ def _calibrate_decode_streams(a, active, step, time_steps):
         # replace the timing of these windows by a two-kernel overlap probe (are the streams on distinct hardware queues?):
         # the probe's pick ran a passage in 78 ms against 64 on one stream and 52 for the best window -- streams that share a
         # hardware queue still overlap small independent kernels (no barrier bit between different streams' packets), so
-        # "overlaps" is not "does not block", and only the passage itself tells (profiles/LAB_NOTES.md round 6).
+        # "overlaps" is not "does not block".  A second probe (ops.wait_blocks, tools/probe_queues.py: does an event wait or a long
+        # kernel on one stream hold up a tiny kernel on another?) maps the streams onto their hardware queues cleanly -- 4 classes by
+        # default, pairs at GPU_MAX_HW_QUEUES = 8 -- and streams it calls mutually free still ran the passage in 75 ms (the ragged
+        # batch in 266) against 48 (160) for the best window: queue sharing is not the whole story, and only the passage itself
+        # tells (profiles/LAB_NOTES.md round 6).
         for first in range(1, 5):
             cands["decode-streams-%d@%d" % (n, first)] = [ops.aux_stream(dev, 0, index=first + i) for i in range(n)]
     calib = {}

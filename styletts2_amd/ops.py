@@ -36,6 +36,42 @@ def aux_stream(dev, priority=0, index=0):
     return _AUX_STREAMS[key]
 
 
+_PROBE_BUF = {}
+
+
+def wait_blocks(waiter, victim, spin_cycles=3_000_000, mode="wait"):
+    """Does an event wait queued on `waiter` (mode "wait") -- or a long kernel running on it (mode "kernel") -- hold up kernels
+    of `victim`?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default): a `hipStreamWaitEvent`
+    is a barrier packet at the head of its stream's HARDWARE queue -- until the event fires nothing behind it in that queue runs,
+    whatever stream it belongs to.  Probe: a spin kernel (~1.5 ms) on a stream of its own, `waiter` waits for it (or runs the
+    spin itself), a tiny kernel goes to `victim`; blocked iff the tiny kernel finishes only after the spin.  Both streams are
+    warmed first (the first launch on a stream creates its queue).  Synchronises the device; start-up use only."""
+    dev = victim.device
+    key = dev.index
+    if key not in _PROBE_BUF:
+        _PROBE_BUF[key] = (torch.zeros(64, device=dev), torch.cuda.Stream(dev))
+    buf, spin = _PROBE_BUF[key]
+    for st in (waiter, victim, spin):
+        with torch.cuda.stream(st):
+            buf.add_(0.0)
+    torch.cuda.synchronize(dev)
+    e_spin, e_tiny = torch.cuda.Event(), torch.cuda.Event()
+    src = waiter if mode == "kernel" else spin
+    with torch.cuda.stream(src):
+        torch.cuda._sleep(int(spin_cycles))
+        e_spin.record(src)
+    if mode != "kernel":
+        waiter.wait_event(e_spin)
+    with torch.cuda.stream(victim):
+        buf.add_(1.0)
+        e_tiny.record(victim)
+    while not e_tiny.query():
+        pass
+    blocked = e_spin.query()  # the spin was over before the tiny kernel's completion was seen: it sat behind it
+    torch.cuda.synchronize(dev)
+    return bool(blocked)
+
+
 def _chk(t, name, ndim=None):
     if t is None:
         return
