@@ -1,6 +1,7 @@
 """GPU probe: the ragged real-text batch (bench.py `ljspeech_ragged`) with its decoder calls on one chosen pair of auxiliary
 streams -- wall time per step, and under `rocprofv3 --kernel-trace` the per-hardware-queue timeline of the steps.
-    python tools/probe_ragged.py FIRST [steps=3] [eager]   (FIRST = index of the first auxiliary stream; 0 = the caller's stream only)"""
+    python tools/probe_ragged.py FIRST [steps=3] [eager]   (FIRST = index of the first auxiliary stream; 0 = the caller's stream only)
+    PROBE_NSTREAMS=n: n consecutive auxiliary streams instead of 2"""
 import os
 import sys
 import time
@@ -28,8 +29,9 @@ front = None if "eager" in sys.argv else pipeline.GraphedFront(model, sampler)
 tokens, lengths, noise, dur, lens = bench.ragged_inputs(dev)
 # the streams the bench process would have made before this leg (same creation order: front stream first, then the windows)
 _ = ops.aux_stream(dev, -1), ops.aux_stream(dev, 0)
-pool = [ops.aux_stream(dev, 0, index=i) for i in range(1, 6)]
-streams = None if first == 0 else [ops.aux_stream(dev, 0, index=first + i) for i in range(2)]
+pool = [ops.aux_stream(dev, 0, index=i) for i in range(1, 9)]
+NS = int(os.environ.get("PROBE_NSTREAMS", "2"))
+streams = None if first == 0 else [ops.aux_stream(dev, 0, index=first + i) for i in range(NS)]
 
 
 def step():
@@ -47,5 +49,5 @@ for _ in range(steps):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t) * 1e3)
 ops.check_status()
-print("ragged batch, decoder streams %s: %s ms per step" % ("caller's" if streams is None else "aux%d, aux%d" % (first, first + 1),
+print("ragged batch, decoder streams %s: %s ms per step" % ("caller's" if streams is None else "aux%d..aux%d" % (first, first + NS - 1),
                                                             ", ".join("%.1f" % t for t in ts)))
