@@ -90,6 +90,10 @@ F16S_EXTRA_CASES = [
     dict(B=3, C_in=2048, C_out=1024, L=100, ks=1, dil=1, pro=R.PRO_NONE, res=True, res2=True, div=2.0),
     dict(B=1, C_in=1000, C_out=300, L=112, ks=1, dil=1, pro=R.PRO_COLNORM, res=True, act=R.ACT_GELU),
     dict(B=1, C_in=1024, C_out=2048, L=87, ks=1, dil=1, pro=R.PRO_COLNORM, act=R.ACT_GELU_TANH),
+    # ... the slices are stored in the accumulator layout of the tile: all three wave layouts, several column / row tiles, ragged ends
+    dict(B=2, C_in=512, C_out=300, L=301, ks=1, dil=1, pro=R.PRO_NONE, res=True, act=R.ACT_GELU),       # 128 x 128 tiles, 3 x 3 of them
+    dict(B=1, C_in=512, C_out=40, L=601, ks=1, dil=1, pro=R.PRO_LEAKY, res=True, res2=True, div=2.0),  # 64 x 256 tiles (2 x 2 waves)
+    dict(B=1, C_in=520, C_out=24, L=1100, ks=3, dil=2, pro=R.PRO_LEAKY, res=True),                    # 32 x 512 tiles (1 x 4 waves)
 ]
 
 
