@@ -385,8 +385,11 @@ def _calibrate_decode_streams(a, active, step, time_steps):
         # default, pairs at GPU_MAX_HW_QUEUES = 8 -- and streams it calls mutually free still ran the passage in 75 ms (the ragged
         # batch in 266) against 48 (160) for the best window: queue sharing is not the whole story, and only the passage itself
         # tells (profiles/LAB_NOTES.md round 6).
-        for first in range(1, 5):
-            cands["decode-streams-%d@%d" % (n, first)] = [ops.aux_stream(dev, 0, index=first + i) for i in range(n)]
+        # 2 ... n streams (round 6: a passage of 8 one-utterance decoders ran in 47.7 ms on two streams, 44.8 on three, 43.0 on four --
+        # each decoder is a chain of kernel latencies that fills a fraction of the chip; the ragged batch of 29 decoders is fastest on two)
+        for m in range(2, n + 1):
+            for first in range(1, 5):
+                cands["decode-streams-%d@%d" % (m, first)] = [ops.aux_stream(dev, 0, index=first + i) for i in range(m)]
     calib = {}
     for name, c in cands.items():
         active["decode_streams"] = c
@@ -754,8 +757,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech")
-    ap.add_argument("--longform-decode-streams", type=int, default=2,
-                    help="long-form: streams the per-sentence decoder calls are dealt onto (1 = the caller's stream)")
+    ap.add_argument("--longform-decode-streams", type=int, default=4,
+                    help="long-form: the per-sentence decoder calls are dealt onto 2 ... this many streams, whichever measures "
+                         "fastest (1 = the caller's stream)")
     ap.add_argument("--longform-front-batch", type=lambda v: [int(x) for x in str(v).split(",")], default=[0],
                     help="long-form: sentences per front call (0 = the whole passage in one batched front, 1 = sentence by "
                          "sentence as the notebooks' loop, '2,0' = the first two, then the rest; identical waveforms, "
