@@ -1133,6 +1133,23 @@ def main():
         out = step()
         host_issue.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
+    # Waveform device -> pinned host memory (reported beside `value`, never part of it -- the boundary hands over
+    # device tensors): one step's output, best of 3.
+    d2h_ms = None
+    try:
+        src = torch.cat([w.reshape(-1) for w in out]) if longform else out
+        host_buf = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        ts_d2h = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            host_buf.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            ts_d2h.append((time.perf_counter() - t1) * 1e3)
+        d2h_ms = min(ts_d2h)
+        del host_buf, src
+    except Exception as e:  # pinned allocation refused: the line goes out without the figure
+        log("D2H measurement skipped: %r" % (e,))
     fixed.update(_fixed_draws(dev, steps_d, LONGFORM_SENTENCES if longform else None, B))
     bitwise = _bitwise_vs_single(step, lambda: step(sequential=True))
     fixed.clear()
@@ -1187,7 +1204,9 @@ def main():
                        "operand_scales": calibration,
                        "bitwise_vs_single": bitwise["equal"], "bitwise_check": bitwise,
                        "plan": _hooks.plan, "lstm": a.lstm, "graphed_front": not a.eager_front,
-                       "host_issue_ms_per_step": None if longform else round(min(host_issue), 3)},
+                       "host_issue_ms_per_step": None if longform else round(min(host_issue), 3),
+                       "d2h_ms_per_step": None if d2h_ms is None else round(d2h_ms, 3),
+                       "value_with_d2h": None if d2h_ms is None else round(audio_s * world / (dt / a.steps + d2h_ms * 1e-3), 1)},
             "roofline": roof,
         }
         if cu_health is not None:

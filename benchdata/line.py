@@ -15,7 +15,7 @@ TARGET = 6000  # what compact() aims for, leaving room for fields a later edit a
 _CONFIG_KEEP = ("workload", "name", "baseline_config_index", "global_batch", "per_gpu_batch", "phonemes", "diffusion_steps",
                 "decoder", "audio_s_per_step_per_gpu", "parallelism", "schedule", "schedule_requested", "schedules_ms_per_step",
                 "per_rank_ms_per_step", "broadcast_bytes", "broadcast_s", "plan", "lstm", "lstm_verify", "graphed_front",
-                "host_issue_ms_per_step", "front_batch", "decode_streams", "first_chunk_latency_ms", "bitwise_vs_single",
+                "host_issue_ms_per_step", "d2h_ms_per_step", "value_with_d2h", "front_batch", "decode_streams", "first_chunk_latency_ms", "bitwise_vs_single",
                 "lstm_reloads")
 _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mfma_tflops_executed", "launches_timed",
               "avg_launch_ms", "algorithmic_flop_per_launch", "algorithmic_bytes_per_launch", "hbm_view",
