@@ -138,7 +138,8 @@ typedef struct st2_conv_desc {
      whose k loop is long (C_in >= 8 chunks, < 128 workgroups: the 1024 -> 2048 Linears of the denoiser over the ~100
      tokens of one utterance) runs as up to 8 K slices per tile + a fixed-order reduction that applies the epilogue; the
      split is a function of the geometry alone (every plan picks the same one: results are reproducible bit for bit) and
-     needs ksplit * B * C_out * L_out * 4 bytes here.  NULL / too small = no split. */
+     needs st2_conv1d_f16s_splitk_bytes(d) bytes here (the slices are stored in the accumulator layout of whole tiles: ksplit * B *
+     padded C_out * padded L_out * 4).  NULL / too small = no split. */
   void* splitk_ws; int64_t splitk_ws_bytes;
 } st2_conv_desc;
 
